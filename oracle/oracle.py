@@ -1,0 +1,254 @@
+"""ctypes binding of the C oracle (oracle/libj2koracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libj2koracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = C.CDLL(path)
+        _LIB.orc_mq_encode.restype = C.c_long
+        _LIB.orc_t1_encode.restype = C.c_long
+        _LIB.orc_ht_encode.restype = C.c_long
+        _LIB.orc_ht_bound.restype = C.c_size_t
+        _LIB.orc_ht_bound.argtypes = [C.c_int, C.c_int]
+        _LIB.orc_enumerate_blocks.restype = C.c_size_t
+        _LIB.orc_encode_tile_blocks.restype = C.c_long
+    return _LIB
+
+
+def _i32(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _f64(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _u8(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def _own_i32(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a.copy()
+
+
+def _own_f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64).copy()
+
+
+# ---- mct ---------------------------------------------------------------------
+def dc_shift_fwd(d, precision):
+    d = _own_i32(d); lib().orc_dc_shift_fwd(_i32(d), C.c_size_t(d.size), int(precision)); return d
+
+
+def dc_shift_inv(d, precision):
+    d = _own_i32(d); lib().orc_dc_shift_inv(_i32(d), C.c_size_t(d.size), int(precision)); return d
+
+
+def rct_fwd(r, g, b):
+    r, g, b = _own_i32(r), _own_i32(g), _own_i32(b)
+    lib().orc_rct_fwd(_i32(r), _i32(g), _i32(b), C.c_size_t(r.size)); return r, g, b
+
+
+def rct_inv(y, u, v):
+    y, u, v = _own_i32(y), _own_i32(u), _own_i32(v)
+    lib().orc_rct_inv(_i32(y), _i32(u), _i32(v), C.c_size_t(y.size)); return y, u, v
+
+
+def ict_fwd(r, g, b):
+    r, g, b = _own_f64(r), _own_f64(g), _own_f64(b)
+    lib().orc_ict_fwd(_f64(r), _f64(g), _f64(b), C.c_size_t(r.size)); return r, g, b
+
+
+def ict_inv(y, cb, cr):
+    y, cb, cr = _own_f64(y), _own_f64(cb), _own_f64(cr)
+    lib().orc_ict_inv(_f64(y), _f64(cb), _f64(cr), C.c_size_t(y.size)); return y, cb, cr
+
+
+# ---- dwt ---------------------------------------------------------------------
+def fwd53_1d(d):
+    d = _own_i32(d); lib().orc_fwd53_1d(_i32(d), int(d.size)); return d
+
+
+def inv53_1d(d):
+    d = _own_i32(d); lib().orc_inv53_1d(_i32(d), int(d.size)); return d
+
+
+def fwd97_1d(d):
+    d = _own_f64(d); lib().orc_fwd97_1d(_f64(d), int(d.size)); return d
+
+
+def inv97_1d(d):
+    d = _own_f64(d); lib().orc_inv97_1d(_f64(d), int(d.size)); return d
+
+
+def _2d(fn, d, w, h, conv, ptr, *extra):
+    d = conv(d).reshape(-1)
+    assert d.size == w * h
+    fn(ptr(d), int(w), int(h), *extra)
+    return d.reshape(h, w)
+
+
+def fwd53_2d(d, w, h): return _2d(lib().orc_fwd53_2d, d, w, h, _own_i32, _i32)
+def inv53_2d(d, w, h): return _2d(lib().orc_inv53_2d, d, w, h, _own_i32, _i32)
+def fwd97_2d(d, w, h): return _2d(lib().orc_fwd97_2d, d, w, h, _own_f64, _f64)
+def inv97_2d(d, w, h): return _2d(lib().orc_inv97_2d, d, w, h, _own_f64, _f64)
+def decompose53(d, w, h, levels): return _2d(lib().orc_decompose53, d, w, h, _own_i32, _i32, int(levels))
+def reconstruct53(d, w, h, levels): return _2d(lib().orc_reconstruct53, d, w, h, _own_i32, _i32, int(levels))
+def decompose97(d, w, h, levels): return _2d(lib().orc_decompose97, d, w, h, _own_f64, _f64, int(levels))
+def reconstruct97(d, w, h, levels): return _2d(lib().orc_reconstruct97, d, w, h, _own_f64, _f64, int(levels))
+
+
+def tcd_forward_dwt(d, w, h, levels, reversible):
+    return _2d(lib().orc_tcd_forward_dwt, d, w, h, _own_i32, _i32, int(levels), int(reversible))
+
+
+def tcd_inverse_dwt(d, w, h, levels, reversible):
+    return _2d(lib().orc_tcd_inverse_dwt, d, w, h, _own_i32, _i32, int(levels), int(reversible))
+
+
+def _plane_ptrs(planes):
+    arr = (C.POINTER(C.c_int32) * len(planes))()
+    for i, p in enumerate(planes):
+        arr[i] = _i32(p)
+    return arr
+
+
+def preprocess(planes, w, h, precision, lossless, num_resolutions, quality=0):
+    """encoder.preprocess on a list of C planes (each h*w int32). Returns new planes."""
+    planes = [_own_i32(p).reshape(-1) for p in planes]
+    lib().orc_preprocess(_plane_ptrs(planes), len(planes), int(w), int(h), int(precision),
+                         int(bool(lossless)), int(num_resolutions), int(quality))
+    return [p.reshape(h, w) for p in planes]
+
+
+def postprocess(planes, precision, reversible, mct=True, is_signed=False):
+    shape = np.asarray(planes[0]).shape
+    planes = [_own_i32(p).reshape(-1) for p in planes]
+    lib().orc_postprocess(_plane_ptrs(planes), len(planes), C.c_size_t(planes[0].size), int(precision),
+                          int(bool(reversible)), int(bool(mct)), int(bool(is_signed)))
+    return [p.reshape(shape) for p in planes]
+
+
+# ---- MQ ----------------------------------------------------------------------
+def mq_encode(ctx, dec):
+    ctx = np.ascontiguousarray(ctx, dtype=np.uint8); dec = np.ascontiguousarray(dec, dtype=np.uint8)
+    out = np.zeros(ctx.size * 2 + 64, dtype=np.uint8)
+    n = lib().orc_mq_encode(_u8(ctx), _u8(dec), C.c_size_t(ctx.size), _u8(out), C.c_size_t(out.size))
+    assert n >= 0
+    return out[:n].copy()
+
+
+def mq_decode(data, ctx):
+    data = np.ascontiguousarray(data, dtype=np.uint8); ctx = np.ascontiguousarray(ctx, dtype=np.uint8)
+    out = np.zeros(ctx.size, dtype=np.uint8)
+    lib().orc_mq_decode(_u8(data), C.c_size_t(data.size), _u8(ctx), C.c_size_t(ctx.size), _u8(out))
+    return out
+
+
+def mq_table():
+    qe = np.zeros(94, np.uint32); nm = np.zeros(94, np.uint8); nl = np.zeros(94, np.uint8)
+    lib().orc_mq_table(qe.ctypes.data_as(C.POINTER(C.c_uint32)), _u8(nm), _u8(nl))
+    return qe, nm, nl
+
+
+def t1_luts():
+    zc = np.zeros(1024, np.uint8); sc = np.zeros(256, np.uint8); sp = np.zeros(256, np.uint8)
+    lib().orc_t1_luts(_u8(zc), _u8(sc), _u8(sp))
+    return zc, sc, sp
+
+
+# ---- T1 / HT -----------------------------------------------------------------
+def t1_encode(data, w, h, band):
+    """Returns (bytes ndarray (len 0 == Go nil), numBPS)."""
+    d = _own_i32(data).reshape(-1); assert d.size == w * h
+    out = np.zeros(w * h * 2 + 16384, dtype=np.uint8)
+    nb = C.c_int(0)
+    n = lib().orc_t1_encode(_i32(d), int(w), int(h), int(band), _u8(out), C.c_size_t(out.size), C.byref(nb))
+    assert n >= 0
+    return out[:n].copy(), nb.value
+
+
+def t1_decode(data, numbps, band, w, h):
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    out = np.zeros(w * h, dtype=np.int32)
+    lib().orc_t1_decode(_u8(data), C.c_size_t(data.size), int(numbps), int(band), int(w), int(h), _i32(out))
+    return out.reshape(h, w)
+
+
+def ht_bound(w, h):
+    return int(lib().orc_ht_bound(int(w), int(h)))
+
+
+def ht_encode(data, w, h, band=0):
+    """Returns bytes ndarray (len 0 == Go nil) or raises on the Go-panic domain."""
+    d = _own_i32(data).reshape(-1); assert d.size == w * h
+    out = np.zeros(ht_bound(w, h), dtype=np.uint8)
+    n = lib().orc_ht_encode(_i32(d), int(w), int(h), int(band), _u8(out), C.c_size_t(out.size))
+    if n < 0:
+        raise ValueError("orc_ht_encode status %d" % n)
+    return out[:n].copy()
+
+
+def ht_decode(data, w, h, num_bitplanes=0, band=0):
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    out = np.zeros(w * h, dtype=np.int32)
+    r = lib().orc_ht_decode(_u8(data), C.c_size_t(data.size), int(num_bitplanes), int(band), int(w), int(h), _i32(out))
+    assert r == 0
+    return out.reshape(h, w)
+
+
+# ---- encodeTile --------------------------------------------------------------
+class Block(C.Structure):
+    _fields_ = [("comp", C.c_int32), ("res", C.c_int32), ("band", C.c_int32),
+                ("x0", C.c_int32), ("y0", C.c_int32), ("w", C.c_int32), ("h", C.c_int32)]
+
+
+BLOCK_DTYPE = np.dtype([("comp", "<i4"), ("res", "<i4"), ("band", "<i4"),
+                        ("x0", "<i4"), ("y0", "<i4"), ("w", "<i4"), ("h", "<i4")])
+
+
+def enumerate_blocks(ncomp, w, h, num_resolutions, cb_w, cb_h):
+    n = lib().orc_enumerate_blocks(int(ncomp), int(w), int(h), int(num_resolutions), int(cb_w), int(cb_h),
+                                   None, C.c_size_t(0))
+    out = np.zeros(n, dtype=BLOCK_DTYPE)
+    lib().orc_enumerate_blocks(int(ncomp), int(w), int(h), int(num_resolutions), int(cb_w), int(cb_h),
+                               out.ctypes.data_as(C.POINTER(Block)), C.c_size_t(n))
+    return out
+
+
+def encode_tile_blocks(planes, w, h, num_resolutions, cb_w, cb_h, coder):
+    """Sequential encodeTile body. Returns (bytes, lens[u32], numbps[u8])."""
+    planes = [_own_i32(p).reshape(-1) for p in planes]
+    nj = len(enumerate_blocks(len(planes), w, h, num_resolutions, cb_w, cb_h))
+    cap = 0
+    for b in enumerate_blocks(len(planes), w, h, num_resolutions, cb_w, cb_h):
+        bw, bh = int(b["w"]), int(b["h"])
+        cap += max(ht_bound(bw, bh), bw * bh * 2 + 16384)
+    out = np.zeros(max(cap, 1), dtype=np.uint8)
+    lens = np.zeros(max(nj, 1), dtype=np.uint32); nbps = np.zeros(max(nj, 1), dtype=np.uint8)
+    n = lib().orc_encode_tile_blocks(_plane_ptrs(planes), len(planes), int(w), int(h), int(num_resolutions),
+                                     int(cb_w), int(cb_h), int(coder), _u8(out), C.c_size_t(out.size),
+                                     lens.ctypes.data_as(C.POINTER(C.c_uint32)), _u8(nbps))
+    if n < 0:
+        raise ValueError("orc_encode_tile_blocks status %d" % n)
+    return out[:n].copy(), lens[:nj].copy(), nbps[:nj].copy()
