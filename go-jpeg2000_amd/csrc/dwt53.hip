@@ -1,0 +1,530 @@
+// dwt53.hip -- 5-3 reversible lifting DWT for gfx950, fused with DC shift + RCT.
+//
+// Replaces (reference, mrjoshuak/go-jpeg2000):
+//   dwt.Forward53/Inverse53            internal/dwt/dwt.go:73-147
+//   dwt.Forward2D53/Inverse2D53        internal/dwt/dwt.go:356-429
+//   one level of Decompose/ReconstructMultiLevel53  dwt.go:524-548
+//   mct.DCLevelShiftForward/Inverse, mct.ForwardRCT/InverseRCT  internal/mct/mct.go:28-38,56-66,96-118
+//
+// Design (MI355X-first, not the reference's row-pass + strided column-pass):
+//   * The 5-3 filter is local (L[n] <- x[2n-2..2n+2]), so one level is ONE streaming
+//     pass: every wavefront owns a column strip x a band of row pairs of one plane.
+//   * Each lane holds CPL (2/4/8) consecutive columns of a row in registers
+//     (16-byte global loads for CPL>=4); the horizontal lifting neighbours come from
+//     the adjacent lane by a DPP wave shift (no LDS, no barrier).
+//   * The wave then marches down its band: the vertical lifting is a 2-row sliding
+//     window kept in registers, so every sample is read from HBM once and written
+//     once -- algorithmic bytes = 2*4*w*h per level (plus a 3-row halo per band that
+//     is served by L2).  Row-contiguous loads and stores only; the reference's
+//     4-byte-strided column gather (dwt.go:375-394) does not exist here.
+//   * De-interleave happens at the store: L -> column p, H -> column ceil(w/2)+p,
+//     low rows -> row q, high rows -> row ceil(h/2)+q.
+//   * The reference's multi-level layout (level l+1 re-reads the contiguous prefix
+//     data[0 : w'*h'] as a dense matrix, dwt.go:524-531) is kept bit-exact by
+//     splitting every store on the LINEAR index: idx < n_next goes to the scratch
+//     that feeds the next level, the rest is final and goes to the coefficient plane.
+//   * Level 0 optionally loads three component planes, applies DC shift + RCT in
+//     registers and lifts the three results (NC=3): no separate elementwise pass.
+//
+// Go int32 semantics: '>>' is arithmetic, overflow wraps; all sums are done in
+// uint32 and shifted as int32.
+#include "j2k_internal.h"
+
+namespace j2k {
+
+// lane i <- lane i-1 (wave_shr:1) / lane i <- lane i+1 (wave_shl:1); lane 0 / 63 keep `self`.
+#ifndef J2K_NO_DPP_WAVE_SHIFT
+__device__ __forceinline__ int from_left(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int from_right(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false); }
+#else
+__device__ __forceinline__ int from_left(int v) { return __shfl_up(v, 1); }
+__device__ __forceinline__ int from_right(int v) { return __shfl_down(v, 1); }
+#endif
+
+__device__ __forceinline__ int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
+__device__ __forceinline__ int wsub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
+// (a + b) >> 1 and (a + b + 2) >> 2 with Go wraparound + arithmetic shift
+__device__ __forceinline__ int avg1(int a, int b) { return wadd(a, b) >> 1; }
+__device__ __forceinline__ int avg2(int a, int b) { return wadd(wadd(a, b), 2) >> 2; }
+
+template <int N> struct Vec { int v[N]; };
+
+// ---- global access helpers ------------------------------------------------------
+template <int CPL, bool VEC>
+__device__ __forceinline__ void load_cols(const int32_t *__restrict__ p, int c, int w, int (&x)[CPL]) {
+    if constexpr (VEC) {
+        if (c < w) {
+            if constexpr (CPL == 8) {
+                int4 a = *reinterpret_cast<const int4 *>(p + c);
+                int4 b = *reinterpret_cast<const int4 *>(p + c + 4);
+                x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+            } else if constexpr (CPL == 4) {
+                int4 a = *reinterpret_cast<const int4 *>(p + c);
+                x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w;
+            } else {
+                int2 a = *reinterpret_cast<const int2 *>(p + c);
+                x[0] = a.x; x[1] = a.y;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < CPL; i++) x[i] = 0;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < CPL; i++) x[i] = (c + i < w) ? p[c + i] : 0;
+    }
+}
+
+// store n = CPL/2 consecutive values at p[0..n) ; valid = number of in-range elements
+template <int H, bool VEC>
+__device__ __forceinline__ void store_half(int32_t *__restrict__ p, const int *v, int valid) {
+    if constexpr (VEC) {
+        if (valid > 0) {
+            if constexpr (H == 4) *reinterpret_cast<int4 *>(p) = make_int4(v[0], v[1], v[2], v[3]);
+            else if constexpr (H == 2) *reinterpret_cast<int2 *>(p) = make_int2(v[0], v[1]);
+            else p[0] = v[0];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < H; i++)
+            if (i < valid) p[i] = v[i];
+    }
+}
+
+// ---- horizontal forward lifting of one row held across the wave -------------------
+// in : x[CPL] = columns c..c+CPL-1 of the row.  out: lo[CPL/2], hi[CPL/2] (pair j = column c+2j).
+template <int CPL>
+__device__ __forceinline__ void hfwd(const int (&x)[CPL], int c, int w, int (&lo)[CPL / 2], int (&hi)[CPL / 2]) {
+    constexpr int H = CPL / 2;
+    if (w < 2) {  // dwt.go:74-76: length < 2 -> untouched
+#pragma unroll
+        for (int j = 0; j < H; j++) { lo[j] = x[2 * j]; hi[j] = 0; }
+        return;
+    }
+    const int e_right = from_right(x[0]);  // even sample of the lane to the right
+    int d[H];
+#pragma unroll
+    for (int j = 0; j < H; j++) {
+        const int ce = c + 2 * j;
+        const int en = (j + 1 < H) ? x[2 * j + 2] : e_right;
+        // predict: d = o - ((e + e_next) >> 1); last odd of an even-length row: d = o - e (dwt.go:89-95)
+        const int pred = (ce + 2 < w) ? avg1(x[2 * j], en) : x[2 * j];
+        d[j] = wsub(x[2 * j + 1], pred);
+    }
+    // a row of odd length ends on an even sample with no odd partner: its "d" mirrors d[n-2] (dwt.go:112-114)
+    const int d_left_lane = from_left(d[H - 1]);
+#pragma unroll
+    for (int j = 0; j < H; j++) {
+        const int ce = c + 2 * j;
+        int dp = (j > 0) ? d[j - 1] : d_left_lane;
+        int dc = d[j];
+        if (ce + 1 >= w) dc = dp;  // no odd partner
+        if (ce == 0) dp = dc;      // dwt.go:99: d[-1] mirrors d[1]
+        lo[j] = wadd(x[2 * j], avg2(dp, dc));
+        hi[j] = d[j];
+    }
+}
+
+// ---- horizontal inverse lifting ----------------------------------------------------
+// in : lo[H] = L[p0..p0+H), hi[H] = H[p0..p0+H) ; out: x[CPL] = columns 2*p0 ..
+template <int CPL>
+__device__ __forceinline__ void hinv(const int (&lo)[CPL / 2], const int (&hi)[CPL / 2], int c, int w, int (&x)[CPL]) {
+    constexpr int H = CPL / 2;
+    if (w < 2) {
+#pragma unroll
+        for (int j = 0; j < H; j++) { x[2 * j] = lo[j]; x[2 * j + 1] = 0; }
+        return;
+    }
+    const int d_left_lane = from_left(hi[H - 1]);
+    int e[H];
+#pragma unroll
+    for (int j = 0; j < H; j++) {  // undo update (dwt.go:132-138)
+        const int ce = c + 2 * j;
+        int dp = (j > 0) ? hi[j - 1] : d_left_lane;
+        int dc = hi[j];
+        if (ce + 1 >= w) dc = dp;
+        if (ce == 0) dp = dc;
+        e[j] = wsub(lo[j], avg2(dp, dc));
+    }
+    const int e_right = from_right(e[0]);
+#pragma unroll
+    for (int j = 0; j < H; j++) {  // undo predict (dwt.go:141-146)
+        const int ce = c + 2 * j;
+        const int en = (j + 1 < H) ? e[j + 1] : e_right;
+        const int pred = (ce + 2 < w) ? avg1(e[j], en) : e[j];
+        x[2 * j] = e[j];
+        x[2 * j + 1] = wadd(hi[j], pred);
+    }
+}
+
+// ================================================================================
+// forward level kernel
+// ================================================================================
+template <int CPL, int NC, bool VEC>
+struct FwdRow {
+    int lo[NC][CPL / 2];
+    int hi[NC][CPL / 2];
+};
+
+template <int CPL, int NC, bool VEC>
+__device__ __forceinline__ void fwd_load_row(const int32_t *__restrict__ src, const DwtPlane &P, int r, int c, int dc_shift,
+                                             FwdRow<CPL, NC, VEC> &R) {
+    int x[NC][CPL];
+#pragma unroll
+    for (int k = 0; k < NC; k++) {
+        load_cols<CPL, VEC>(src + P.src_off[k] + (int64_t)r * P.src_stride, c, P.w, x[k]);
+#pragma unroll
+        for (int i = 0; i < CPL; i++) x[k][i] = wsub(x[k][i], dc_shift);  // mct.go:96-101
+    }
+    if constexpr (NC == 3) {  // mct.go:28-38
+#pragma unroll
+        for (int i = 0; i < CPL; i++) {
+            const int r_ = x[0][i], g_ = x[1][i], b_ = x[2][i];
+            x[0][i] = wadd(wadd(r_, wadd(g_, g_)), b_) >> 2;
+            x[1][i] = wsub(b_, g_);
+            x[2][i] = wsub(r_, g_);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NC; k++) hfwd<CPL>(x[k], c, P.w, R.lo[k], R.hi[k]);
+}
+
+template <int CPL, int NC, bool VEC>
+__device__ __forceinline__ void fwd_store_row(int32_t *__restrict__ out, int32_t *__restrict__ nxt, const DwtPlane &P, int ro,
+                                              int p0, bool owned, const int (&lo)[NC][CPL / 2], const int (&hi)[NC][CPL / 2]) {
+    constexpr int H = CPL / 2;
+    if (!owned) return;
+    const int halfW = (P.w + 1) >> 1;
+    const int nL = halfW - p0;             // valid low columns from p0
+    const int nH = (P.w - halfW) - p0;     // valid high columns from p0
+    const int idxL = ro * P.w + p0;
+    const int idxH = idxL + halfW;
+#pragma unroll
+    for (int k = 0; k < NC; k++) {
+        if constexpr (VEC) {
+            int32_t *bl = (idxL < P.n_next) ? nxt + P.nxt_off[k] : out + P.out_off[k];
+            int32_t *bh = (idxH < P.n_next) ? nxt + P.nxt_off[k] : out + P.out_off[k];
+            store_half<H, true>(bl + idxL, lo[k], nL);
+            store_half<H, true>(bh + idxH, hi[k], nH);
+        } else {
+#pragma unroll
+            for (int j = 0; j < H; j++) {
+                if (j < nL) {
+                    int32_t *b = (idxL + j < P.n_next) ? nxt + P.nxt_off[k] : out + P.out_off[k];
+                    b[idxL + j] = lo[k][j];
+                }
+                if (j < nH) {
+                    int32_t *b = (idxH + j < P.n_next) ? nxt + P.nxt_off[k] : out + P.out_off[k];
+                    b[idxH + j] = hi[k][j];
+                }
+            }
+        }
+    }
+}
+
+template <int CPL, int NC, bool VEC>
+__global__ __launch_bounds__(256) void dwt53_fwd_kernel(const DwtJob *__restrict__ jobs, int njobs,
+                                                        const DwtPlane *__restrict__ planes,
+                                                        const int32_t *__restrict__ src, int32_t *__restrict__ out,
+                                                        int32_t *__restrict__ nxt, int dc_shift) {
+    constexpr int H = CPL / 2;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (wave >= njobs) return;
+    const int lane = threadIdx.x & 63;
+    const DwtJob job = jobs[wave];
+    const DwtPlane P = planes[job.plane];
+    const int w = P.w, h = P.h;
+    const int lane_first = (job.col0 == 0) ? 0 : 1;
+    const int c_base = job.col0 - lane_first * CPL;
+    const int c = c_base + lane * CPL;
+    const bool reach_end = (c_base + 64 * CPL >= w);
+    const bool owned = (lane >= lane_first) && (c < w) && (reach_end || lane < 63);
+    const int p0 = c >> 1;
+    const int halfH = (h + 1) >> 1;
+    const int pr_begin = job.prow0;
+    const int pr_end = min(job.prow0 + job.nprow, halfH);
+
+    typedef FwdRow<CPL, NC, VEC> Row;
+    Row ye, yo, yn;
+    int dvp_lo[NC][H], dvp_hi[NC][H];  // vertical d of the previous pair-row
+
+    fwd_load_row<CPL, NC, VEC>(src, P, 2 * pr_begin, c, dc_shift, ye);
+    if (h < 2) {  // vertical pass untouched (dwt.go:74-76)
+        if (pr_begin == 0) fwd_store_row<CPL, NC, VEC>(out, nxt, P, 0, p0, owned, ye.lo, ye.hi);
+        return;
+    }
+    if (pr_begin > 0) {
+        Row ym2, ym1;
+        fwd_load_row<CPL, NC, VEC>(src, P, 2 * pr_begin - 2, c, dc_shift, ym2);
+        fwd_load_row<CPL, NC, VEC>(src, P, 2 * pr_begin - 1, c, dc_shift, ym1);
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+#pragma unroll
+            for (int j = 0; j < H; j++) {
+                dvp_lo[k][j] = wsub(ym1.lo[k][j], avg1(ym2.lo[k][j], ye.lo[k][j]));
+                dvp_hi[k][j] = wsub(ym1.hi[k][j], avg1(ym2.hi[k][j], ye.hi[k][j]));
+            }
+    }
+    for (int pr = pr_begin; pr < pr_end; pr++) {
+        const int r1 = 2 * pr + 1, r2 = 2 * pr + 2;
+        const bool has_odd = r1 < h, has_next = r2 < h;
+        if (has_odd) fwd_load_row<CPL, NC, VEC>(src, P, r1, c, dc_shift, yo);
+        if (has_next) fwd_load_row<CPL, NC, VEC>(src, P, r2, c, dc_shift, yn);
+        int dv_lo[NC][H], dv_hi[NC][H], sv_lo[NC][H], sv_hi[NC][H];
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+#pragma unroll
+            for (int j = 0; j < H; j++) {
+                int dl, dh;
+                if (has_odd) {
+                    const int pl = has_next ? avg1(ye.lo[k][j], yn.lo[k][j]) : ye.lo[k][j];
+                    const int ph = has_next ? avg1(ye.hi[k][j], yn.hi[k][j]) : ye.hi[k][j];
+                    dl = wsub(yo.lo[k][j], pl);
+                    dh = wsub(yo.hi[k][j], ph);
+                } else {  // odd height: last even row mirrors d[n-2]
+                    dl = dvp_lo[k][j];
+                    dh = dvp_hi[k][j];
+                }
+                const int pl_ = (pr == 0) ? dl : dvp_lo[k][j];
+                const int ph_ = (pr == 0) ? dh : dvp_hi[k][j];
+                sv_lo[k][j] = wadd(ye.lo[k][j], avg2(pl_, dl));
+                sv_hi[k][j] = wadd(ye.hi[k][j], avg2(ph_, dh));
+                dv_lo[k][j] = dl;
+                dv_hi[k][j] = dh;
+            }
+        fwd_store_row<CPL, NC, VEC>(out, nxt, P, pr, p0, owned, sv_lo, sv_hi);
+        if (has_odd) fwd_store_row<CPL, NC, VEC>(out, nxt, P, halfH + pr, p0, owned, dv_lo, dv_hi);
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+#pragma unroll
+            for (int j = 0; j < H; j++) {
+                dvp_lo[k][j] = dv_lo[k][j];
+                dvp_hi[k][j] = dv_hi[k][j];
+                ye.lo[k][j] = yn.lo[k][j];
+                ye.hi[k][j] = yn.hi[k][j];
+            }
+    }
+}
+
+// ================================================================================
+// inverse level kernel
+// ================================================================================
+// Input row `ri` of the level matrix, columns [p0,p0+H) of the L part and of the H part,
+// each element taken from `prev` (output of the coarser inverse level) when its linear
+// index is below n_next, else from the coefficient plane.
+template <int CPL, int NC, bool VEC>
+__device__ __forceinline__ void inv_load_row(const int32_t *__restrict__ coef, const int32_t *__restrict__ prev,
+                                             const DwtPlane &P, int ri, int p0, int c, FwdRow<CPL, NC, VEC> &R) {
+    constexpr int H = CPL / 2;
+    const int halfW = (P.w + 1) >> 1;
+    const int nL = halfW - p0, nH = (P.w - halfW) - p0;
+    const int idxL = ri * P.w + p0, idxH = idxL + halfW;
+#pragma unroll
+    for (int k = 0; k < NC; k++) {
+        if constexpr (VEC) {
+            const int32_t *bl = (idxL < P.n_next) ? prev + P.nxt_off[k] : coef + P.src_off[k];
+            const int32_t *bh = (idxH < P.n_next) ? prev + P.nxt_off[k] : coef + P.src_off[k];
+            if (c < P.w) {
+                if constexpr (H == 4) {
+                    int4 a = *reinterpret_cast<const int4 *>(bl + idxL), b = *reinterpret_cast<const int4 *>(bh + idxH);
+                    R.lo[k][0] = a.x; R.lo[k][1] = a.y; R.lo[k][2] = a.z; R.lo[k][3] = a.w;
+                    R.hi[k][0] = b.x; R.hi[k][1] = b.y; R.hi[k][2] = b.z; R.hi[k][3] = b.w;
+                } else if constexpr (H == 2) {
+                    int2 a = *reinterpret_cast<const int2 *>(bl + idxL), b = *reinterpret_cast<const int2 *>(bh + idxH);
+                    R.lo[k][0] = a.x; R.lo[k][1] = a.y; R.hi[k][0] = b.x; R.hi[k][1] = b.y;
+                } else {
+                    R.lo[k][0] = bl[idxL]; R.hi[k][0] = bh[idxH];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < H; j++) { R.lo[k][j] = 0; R.hi[k][j] = 0; }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < H; j++) {
+                int l = 0, hh = 0;
+                if (j < nL) {
+                    const int32_t *b = (idxL + j < P.n_next) ? prev + P.nxt_off[k] : coef + P.src_off[k];
+                    l = b[idxL + j];
+                }
+                if (j < nH) {
+                    const int32_t *b = (idxH + j < P.n_next) ? prev + P.nxt_off[k] : coef + P.src_off[k];
+                    hh = b[idxH + j];
+                }
+                R.lo[k][j] = l; R.hi[k][j] = hh;
+            }
+        }
+    }
+}
+
+// horizontal inverse + optional inverse RCT + DC shift + store of one reconstructed row
+template <int CPL, int NC, bool VEC>
+__device__ __forceinline__ void inv_finish_row(int32_t *__restrict__ dst, const DwtPlane &P, int ro, int c, bool owned,
+                                               const int (&lo)[NC][CPL / 2], const int (&hi)[NC][CPL / 2], int dc_shift,
+                                               bool final_level) {
+    int x[NC][CPL];
+#pragma unroll
+    for (int k = 0; k < NC; k++) hinv<CPL>(lo[k], hi[k], c, P.w, x[k]);
+    if constexpr (NC == 3) {  // mct.go:56-66
+#pragma unroll
+        for (int i = 0; i < CPL; i++) {
+            const int y_ = x[0][i], u_ = x[1][i], v_ = x[2][i];
+            const int g_ = wsub(y_, wadd(u_, v_) >> 2);
+            x[0][i] = wadd(v_, g_);
+            x[1][i] = g_;
+            x[2][i] = wadd(u_, g_);
+        }
+    }
+    if (!owned) return;
+    const int stride = final_level ? P.out_stride : P.w;
+#pragma unroll
+    for (int k = 0; k < NC; k++) {
+        int32_t *p = dst + P.out_off[k] + (int64_t)ro * stride + c;
+        if constexpr (VEC) {
+            if constexpr (CPL == 8) {
+                *reinterpret_cast<int4 *>(p) = make_int4(wadd(x[k][0], dc_shift), wadd(x[k][1], dc_shift), wadd(x[k][2], dc_shift), wadd(x[k][3], dc_shift));
+                *reinterpret_cast<int4 *>(p + 4) = make_int4(wadd(x[k][4], dc_shift), wadd(x[k][5], dc_shift), wadd(x[k][6], dc_shift), wadd(x[k][7], dc_shift));
+            } else if constexpr (CPL == 4) {
+                *reinterpret_cast<int4 *>(p) = make_int4(wadd(x[k][0], dc_shift), wadd(x[k][1], dc_shift), wadd(x[k][2], dc_shift), wadd(x[k][3], dc_shift));
+            } else {
+                *reinterpret_cast<int2 *>(p) = make_int2(wadd(x[k][0], dc_shift), wadd(x[k][1], dc_shift));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < CPL; i++)
+                if (c + i < P.w) p[i] = wadd(x[k][i], dc_shift);
+        }
+    }
+}
+
+template <int CPL, int NC, bool VEC>
+__global__ __launch_bounds__(256) void dwt53_inv_kernel(const DwtJob *__restrict__ jobs, int njobs,
+                                                        const DwtPlane *__restrict__ planes,
+                                                        const int32_t *__restrict__ coef, const int32_t *__restrict__ prev,
+                                                        int32_t *__restrict__ dst, int dc_shift, int final_level) {
+    constexpr int H = CPL / 2;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (wave >= njobs) return;
+    const int lane = threadIdx.x & 63;
+    const DwtJob job = jobs[wave];
+    const DwtPlane P = planes[job.plane];
+    const int w = P.w, h = P.h;
+    const int lane_first = (job.col0 == 0) ? 0 : 1;
+    const int c_base = job.col0 - lane_first * CPL;
+    const int c = c_base + lane * CPL;
+    const bool reach_end = (c_base + 64 * CPL >= w);
+    const bool owned = (lane >= lane_first) && (c < w) && (reach_end || lane < 63);
+    const int p0 = c >> 1;
+    const int halfH = (h + 1) >> 1;
+    const int nhigh = h - halfH;  // rows in the vertical high band
+    const int pr_begin = job.prow0;
+    const int pr_end = min(job.prow0 + job.nprow, halfH);
+    const bool fin = final_level != 0;
+
+    typedef FwdRow<CPL, NC, VEC> Row;
+    if (h < 2) {  // columns untouched
+        if (pr_begin == 0) {
+            Row s0;
+            inv_load_row<CPL, NC, VEC>(coef, prev, P, 0, p0, c, s0);
+            inv_finish_row<CPL, NC, VEC>(dst, P, 0, c, owned, s0.lo, s0.hi, dc_shift, fin);
+        }
+        return;
+    }
+    // vertical inverse (columns first, dwt.go:412-421):
+    //   xe[q] = s[q] - ((d[q-1] + d[q] + 2) >> 2)   (d[-1] := d[0]; no d[q] (odd h, last) := d[q-1])
+    //   xo[q] = d[q] + ((xe[q] + xe[q+1]) >> 1)      (no xe[q+1] := xe[q])
+    Row s, dcur, dprev;
+    int xe_lo[NC][H], xe_hi[NC][H];
+    auto compute_xe = [&](int q, const Row &S, const Row &Dp, const Row &Dc, int (&xl)[NC][H], int (&xh)[NC][H]) {
+        const bool has_d = q < nhigh;
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+#pragma unroll
+            for (int j = 0; j < H; j++) {
+                int dpl = Dp.lo[k][j], dph = Dp.hi[k][j];
+                int dcl = has_d ? Dc.lo[k][j] : dpl, dch = has_d ? Dc.hi[k][j] : dph;
+                if (q == 0) { dpl = dcl; dph = dch; }
+                xl[k][j] = wsub(S.lo[k][j], avg2(dpl, dcl));
+                xh[k][j] = wsub(S.hi[k][j], avg2(dph, dch));
+            }
+    };
+    inv_load_row<CPL, NC, VEC>(coef, prev, P, pr_begin, p0, c, s);
+    if (pr_begin < nhigh) inv_load_row<CPL, NC, VEC>(coef, prev, P, halfH + pr_begin, p0, c, dcur);
+    if (pr_begin > 0) inv_load_row<CPL, NC, VEC>(coef, prev, P, halfH + pr_begin - 1, p0, c, dprev);
+    compute_xe(pr_begin, s, dprev, dcur, xe_lo, xe_hi);
+    for (int q = pr_begin; q < pr_end; q++) {
+        const bool has_d = q < nhigh;         // row 2q+1 exists
+        const bool has_next = (q + 1) < halfH;  // row 2q+2 exists
+        Row sn, dn;
+        int xn_lo[NC][H], xn_hi[NC][H];
+        if (has_next) {
+            inv_load_row<CPL, NC, VEC>(coef, prev, P, q + 1, p0, c, sn);
+            if (q + 1 < nhigh) inv_load_row<CPL, NC, VEC>(coef, prev, P, halfH + q + 1, p0, c, dn);
+            compute_xe(q + 1, sn, dcur, dn, xn_lo, xn_hi);
+        }
+        inv_finish_row<CPL, NC, VEC>(dst, P, 2 * q, c, owned, xe_lo, xe_hi, dc_shift, fin);
+        if (has_d) {
+            int xo_lo[NC][H], xo_hi[NC][H];
+#pragma unroll
+            for (int k = 0; k < NC; k++)
+#pragma unroll
+                for (int j = 0; j < H; j++) {
+                    const int pl = has_next ? avg1(xe_lo[k][j], xn_lo[k][j]) : xe_lo[k][j];
+                    const int ph = has_next ? avg1(xe_hi[k][j], xn_hi[k][j]) : xe_hi[k][j];
+                    xo_lo[k][j] = wadd(dcur.lo[k][j], pl);
+                    xo_hi[k][j] = wadd(dcur.hi[k][j], ph);
+                }
+            inv_finish_row<CPL, NC, VEC>(dst, P, 2 * q + 1, c, owned, xo_lo, xo_hi, dc_shift, fin);
+        }
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+#pragma unroll
+            for (int j = 0; j < H; j++) {
+                xe_lo[k][j] = xn_lo[k][j]; xe_hi[k][j] = xn_hi[k][j];
+                dcur.lo[k][j] = dn.lo[k][j]; dcur.hi[k][j] = dn.hi[k][j];
+            }
+    }
+}
+
+// ================================================================================
+// launchers
+// ================================================================================
+template <int CPL, int NC, bool VEC>
+static hipError_t fwd_go(hipStream_t s, const LevelLaunch &L, const int32_t *src, int32_t *out, int32_t *nxt, int dc) {
+    const int blocks = (L.njobs + 3) / 4;
+    hipLaunchKernelGGL((dwt53_fwd_kernel<CPL, NC, VEC>), dim3(blocks), dim3(256), 0, s, L.jobs, L.njobs, L.planes, src, out, nxt, dc);
+    return hipGetLastError();
+}
+template <int CPL, int NC, bool VEC>
+static hipError_t inv_go(hipStream_t s, const LevelLaunch &L, const int32_t *coef, const int32_t *prev, int32_t *dst, int dc, int fin) {
+    const int blocks = (L.njobs + 3) / 4;
+    hipLaunchKernelGGL((dwt53_inv_kernel<CPL, NC, VEC>), dim3(blocks), dim3(256), 0, s, L.jobs, L.njobs, L.planes, coef, prev, dst, dc, fin);
+    return hipGetLastError();
+}
+
+#define J2K_DISPATCH(FN, ...)                                                        \
+    do {                                                                             \
+        if (L.njobs <= 0) return hipSuccess;                                         \
+        if (!L.vec) {                                                                \
+            if (L.ncomp == 3) return FN<2, 3, false>(__VA_ARGS__);                   \
+            return FN<2, 1, false>(__VA_ARGS__);                                     \
+        }                                                                            \
+        if (L.ncomp == 3) {                                                          \
+            if (L.cpl == 8) return FN<8, 3, true>(__VA_ARGS__);                      \
+            if (L.cpl == 4) return FN<4, 3, true>(__VA_ARGS__);                      \
+            return FN<2, 3, true>(__VA_ARGS__);                                      \
+        }                                                                            \
+        if (L.cpl == 8) return FN<8, 1, true>(__VA_ARGS__);                          \
+        if (L.cpl == 4) return FN<4, 1, true>(__VA_ARGS__);                          \
+        return FN<2, 1, true>(__VA_ARGS__);                                          \
+    } while (0)
+
+hipError_t launch_dwt53_fwd(hipStream_t s, const LevelLaunch &L, const int32_t *src, int32_t *out, int32_t *nxt, int dc_shift) {
+    J2K_DISPATCH(fwd_go, s, L, src, out, nxt, dc_shift);
+}
+hipError_t launch_dwt53_inv(hipStream_t s, const LevelLaunch &L, const int32_t *coef, const int32_t *prev, int32_t *dst,
+                            int dc_shift, int final_level) {
+    J2K_DISPATCH(inv_go, s, L, coef, prev, dst, dc_shift, final_level);
+}
+
+}  // namespace j2k

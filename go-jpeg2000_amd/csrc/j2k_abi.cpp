@@ -1,0 +1,849 @@
+// j2k_abi.cpp -- the C ABI of libj2kgfx.so (declared in include/j2kgfx.h).
+// Host-side orchestration only: geometry -> device job tables, launches on the
+// context's HIP stream, host<->device staging for the one-call-per-reference-function
+// entry points.  All arithmetic lives in the .hip kernels; there is no CPU fallback.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "j2k_plan.h"
+
+using namespace j2k;
+
+namespace j2k {
+hipError_t launch_add_const(hipStream_t s, int32_t *d, size_t n, int delta);
+hipError_t launch_rct(hipStream_t s, int32_t *a, int32_t *b, int32_t *c, size_t n, int inverse);
+hipError_t launch_ict(hipStream_t s, double *a, double *b, double *c, size_t n, int inverse);
+hipError_t launch_dwt97_fwd(hipStream_t s, const LevelLaunch &L, const void *src, int src_is_f64, int32_t *out_i32,
+                            double *out_f64, double *nxt, int dc_shift, int quant, double step, int mct);
+hipError_t launch_dwt97_inv(hipStream_t s, const LevelLaunch &L, const void *coef, int coef_is_f64, const double *prev,
+                            void *dst, int dc_shift, int final_level, int dst_mode, int mct);
+hipError_t launch_ht_encode(hipStream_t s, const BlockJob *jobs, int njobs, const int32_t *coef, uint8_t *slots,
+                            uint32_t *lens, uint8_t *numbps, int *fault);
+hipError_t launch_ht_decode(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs,
+                            const uint32_t *lens, int32_t *decoded);
+hipError_t launch_t1_encode(hipStream_t s, const BlockJob *jobs, int njobs, const int32_t *coef, uint8_t *slots,
+                            uint32_t *lens, uint8_t *numbps, uint8_t *work, size_t work_per_job, int *fault);
+hipError_t launch_t1_decode(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs,
+                            const uint32_t *lens, const uint8_t *numbps, int32_t *decoded, uint8_t *work,
+                            size_t work_per_job);
+size_t t1_work_bytes(int w, int h);
+hipError_t launch_compact(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *slots, const uint32_t *lens,
+                          uint64_t *offs, uint8_t *stream, void *scan_tmp);
+}  // namespace j2k
+
+// ------------------------------------------------------------------------------
+// status / errors
+// ------------------------------------------------------------------------------
+static int fail(j2k_ctx *ctx, int status, const char *msg) {
+    if (ctx) ctx->last_error = msg ? msg : "";
+    return status;
+}
+static int fail_hip(j2k_ctx *ctx, hipError_t e, const char *where) {
+    char buf[256];
+    snprintf(buf, sizeof(buf), "%s: %s", where, hipGetErrorString(e));
+    if (ctx) ctx->last_error = buf;
+    return J2K_ERR_HIP;
+}
+#define HIPCHK(ctx, call)                                      \
+    do {                                                       \
+        hipError_t e_ = (call);                                \
+        if (e_ != hipSuccess) return fail_hip(ctx, e_, #call); \
+    } while (0)
+
+extern "C" const char *j2k_status_string(int s) {
+    switch (s) {
+        case J2K_OK: return "ok";
+        case J2K_ERR_INVALID_ARG: return "invalid argument";
+        case J2K_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU fallback)";
+        case J2K_ERR_HIP: return "HIP runtime error";
+        case J2K_ERR_CAPACITY: return "output capacity too small";
+        case J2K_ERR_GO_PANIC: return "input on which the reference panics or never returns";
+        case J2K_ERR_UNSUPPORTED: return "unsupported";
+    }
+    return "unknown status";
+}
+extern "C" const char *j2k_version(void) { return "j2kgfx 0.1 (gfx950)"; }
+extern "C" const char *j2k_ctx_last_error(j2k_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+// ------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------
+extern "C" int j2k_ctx_create(int device, j2k_ctx **out) {
+    if (!out) return J2K_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return J2K_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return J2K_ERR_INVALID_ARG;
+    if (hipSetDevice(device) != hipSuccess) return J2K_ERR_NO_DEVICE;
+    j2k_ctx *ctx = new j2k_ctx();
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return J2K_ERR_HIP;
+    }
+    if (const char *e = getenv("J2K_BAND_PROWS")) {
+        int v = atoi(e);
+        if (v >= 1 && v <= 4096) ctx->band_prows = v;
+    }
+    if (const char *e = getenv("J2K_FORCE_NOVEC")) ctx->force_novec = atoi(e) != 0;
+    *out = ctx;
+    return J2K_OK;
+}
+
+extern "C" void j2k_ctx_destroy(j2k_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (j2k_plan *p : ctx->cache) j2k_plan_destroy(p);
+    for (int i = 0; i < 4; i++)
+        if (ctx->stage[i]) (void)hipFree(ctx->stage[i]);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int j2k_ctx_sync(j2k_ctx *ctx) {
+    if (!ctx) return J2K_ERR_INVALID_ARG;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return J2K_OK;
+}
+extern "C" void *j2k_ctx_stream(j2k_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+static int stage_reserve(j2k_ctx *ctx, int slot, size_t bytes) {
+    if (ctx->stage_bytes[slot] >= bytes) return J2K_OK;
+    if (ctx->stage[slot]) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipFree(ctx->stage[slot]));
+        ctx->stage[slot] = nullptr;
+        ctx->stage_bytes[slot] = 0;
+    }
+    size_t cap = std::max<size_t>(bytes, 1 << 20);
+    HIPCHK(ctx, hipMalloc(&ctx->stage[slot], cap));
+    ctx->stage_bytes[slot] = cap;
+    return J2K_OK;
+}
+
+// ------------------------------------------------------------------------------
+// plan construction
+// ------------------------------------------------------------------------------
+bool PlanSpec::operator==(const PlanSpec &o) const {
+    return W == o.W && H == o.H && C == o.C && tile_w == o.tile_w && tile_h == o.tile_h && levels == o.levels &&
+           wavelet == o.wavelet && dc_shift == o.dc_shift && mct == o.mct && quant == o.quant && quality == o.quality &&
+           num_res_jobs == o.num_res_jobs && cb_w == o.cb_w && cb_h == o.cb_h && coder == o.coder &&
+           tile_first == o.tile_first && tile_count == o.tile_count && frame_is_f64 == o.frame_is_f64;
+}
+
+static inline int64_t align4(int64_t v) { return (v + 3) & ~int64_t(3); }
+static inline int pick_cpl(int maxw) { return maxw >= 384 ? 8 : (maxw >= 192 ? 4 : 2); }
+
+extern "C" size_t j2k_block_bound(int coder, int w, int h) {
+    size_t n = (size_t)std::max(w, 0) * (size_t)std::max(h, 0);
+    if (coder == J2K_CODER_HT) {               // ht.go:969-996: MagSgn + MEL + VLC buffers + SCUP
+        size_t maxSize = std::max<size_t>(n * 2, 64);
+        return maxSize / 2 + maxSize / 4 + maxSize / 2 + 2;
+    }
+    return n * 2 + 1024;                       // t1_fast5.go:47 (the reference's own bound)
+}
+
+template <typename T>
+static int upload(j2k_ctx *ctx, T **dptr, const std::vector<T> &v) {
+    *dptr = nullptr;
+    if (v.empty()) return J2K_OK;
+    HIPCHK(ctx, hipMalloc((void **)dptr, v.size() * sizeof(T)));
+    HIPCHK(ctx, hipMemcpy(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return J2K_OK;
+}
+
+static void make_jobs(std::vector<DwtJob> &jobs, int plane, int w, int h, int cpl, int band) {
+    const int halfH = (h + 1) / 2;
+    int col0 = 0;
+    for (;;) {
+        const int c_base = col0 - (col0 ? cpl : 0);
+        for (int pr = 0; pr < std::max(halfH, 1); pr += band) jobs.push_back(DwtJob{plane, col0, pr, band});
+        if (c_base + 64 * cpl >= w) break;
+        col0 = c_base + 63 * cpl;
+    }
+}
+
+static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
+    if (S.W <= 0 || S.H <= 0 || S.C <= 0 || S.levels < 0 || S.levels > 32) return fail(ctx, J2K_ERR_INVALID_ARG, "bad geometry");
+    if ((int64_t)S.W * S.H >= (int64_t)1 << 31) return fail(ctx, J2K_ERR_INVALID_ARG, "plane too large");
+    j2k_plan *P = new j2k_plan();
+    P->ctx = ctx;
+    P->spec = S;
+    const int tw = S.tile_w > 0 ? S.tile_w : S.W, th = S.tile_h > 0 ? S.tile_h : S.H;
+    P->tiles_x = (S.W + tw - 1) / tw;
+    P->tiles_y = (S.H + th - 1) / th;
+    const int ntiles_all = P->tiles_x * P->tiles_y;
+    P->tile_first = std::min(std::max(S.tile_first, 0), ntiles_all);
+    P->tile_count = S.tile_count > 0 ? std::min(S.tile_count, ntiles_all - P->tile_first) : ntiles_all - P->tile_first;
+    const int L = S.levels;
+    const bool triple = S.mct && S.C >= 3;
+    const int esz = S.wavelet == W97 ? 8 : 4;
+
+    // ---- tile-components, coefficient + scratch offsets -------------------------
+    int64_t coef = 0, sa = 0, sb = 0;
+    for (int tl = 0; tl < P->tile_count; tl++) {
+        const int t = P->tile_first + tl;
+        const int tx = t % P->tiles_x, ty = t / P->tiles_x;
+        const int x0 = tx * tw, y0 = ty * th;
+        const int w = std::min(tw, S.W - x0), h = std::min(th, S.H - y0);
+        const int w1 = (w + 1) / 2, h1 = (h + 1) / 2, w2 = (w1 + 1) / 2, h2 = (h1 + 1) / 2;
+        int c = 0;
+        while (c < S.C) {
+            Group g{};
+            g.tile = tl; g.comp0 = c; g.nc = (triple && c == 0) ? 3 : 1;
+            g.x0 = x0; g.y0 = y0; g.w = w; g.h = h;
+            for (int k = 0; k < g.nc; k++) {
+                g.coef_off[k] = coef; coef += align4((int64_t)w * h);
+                g.scrA_off[k] = sa; sa += align4((int64_t)w1 * h1);
+                g.scrB_off[k] = sb; sb += align4((int64_t)w2 * h2);
+                const int64_t d[7] = {t, c + k, x0, y0, w, h, g.coef_off[k]};
+                P->plane_desc.insert(P->plane_desc.end(), d, d + 7);
+            }
+            P->groups.push_back(g);
+            c += g.nc;
+        }
+    }
+    P->coeff_elems = coef; P->scrA_elems = sa; P->scrB_elems = sb;
+
+    // ---- per-level launch tables --------------------------------------------------
+    for (int cls = 0; cls < 2; cls++) { P->fwd[cls].resize(L); P->inv[cls].resize(L); }
+    for (int dir = 0; dir < 2; dir++) {
+        for (int l = 0; l < L; l++) {
+            for (int cls = 0; cls < 2; cls++) {
+                std::vector<DwtPlane> planes;
+                std::vector<int> pw, ph;
+                bool vec_ok = !ctx->force_novec;
+                int maxw = 0;
+                for (const Group &g : P->groups) {
+                    const bool as_triple = (g.nc == 3 && l == 0);
+                    if ((cls == 1) != as_triple) continue;
+                    int w = g.w, h = g.h;
+                    for (int i = 0; i < l; i++) { w = (w + 1) / 2; h = (h + 1) / 2; }
+                    const int wn = (w + 1) / 2, hn = (h + 1) / 2;
+                    const int nplanes_here = as_triple ? 1 : g.nc;
+                    for (int k0 = 0; k0 < nplanes_here; k0++) {
+                        DwtPlane D{};
+                        const int kn = as_triple ? 3 : 1;
+                        for (int k = 0; k < kn; k++) {
+                            const int kk = as_triple ? k : k0;
+                            const int64_t frame_off = (int64_t)(g.comp0 + kk) * S.H * S.W + (int64_t)g.y0 * S.W + g.x0;
+                            const int64_t *scr_in = (l & 1) ? g.scrA_off : g.scrB_off;    // where level l's input prefix lives
+                            const int64_t *scr_out = (l & 1) ? g.scrB_off : g.scrA_off;   // where level l's output prefix goes
+                            if (dir == 0) {  // forward
+                                D.src_off[k] = (l == 0) ? frame_off : scr_in[kk];
+                                D.out_off[k] = g.coef_off[kk];
+                                D.nxt_off[k] = scr_out[kk];
+                            } else {         // inverse: X_l lives where the forward input of level l lived
+                                D.src_off[k] = g.coef_off[kk];
+                                D.nxt_off[k] = scr_out[kk];               // X_{l+1}
+                                D.out_off[k] = (l == 0) ? frame_off : scr_in[kk];
+                            }
+                        }
+                        D.src_stride = (dir == 0 && l == 0) ? S.W : w;
+                        D.out_stride = S.W;
+                        D.w = w; D.h = h;
+                        D.n_next = (l == L - 1) ? 0 : wn * hn;
+                        planes.push_back(D);
+                        pw.push_back(w); ph.push_back(h);
+                        maxw = std::max(maxw, w);
+                    }
+                }
+                LevelTab &T = (dir == 0 ? P->fwd : P->inv)[cls][l];
+                T.ncomp = cls ? 3 : 1;
+                T.nplanes = (int)planes.size();
+                if (planes.empty()) continue;
+                int cpl = pick_cpl(maxw);
+                if (S.wavelet == W97 && cpl == 8) cpl = 4;   // 4 f64 = 32 B per lane already
+                for (size_t i = 0; i < planes.size() && vec_ok; i++) {
+                    const DwtPlane &D = planes[i];
+                    if (D.w % cpl) vec_ok = false;
+                    if (l == 0 && (S.W % cpl)) vec_ok = false;
+                    for (int k = 0; k < T.ncomp; k++)
+                        if ((D.src_off[k] % 4) || (D.out_off[k] % 4) || (D.nxt_off[k] % 4)) vec_ok = false;
+                }
+                if (!vec_ok) cpl = (S.wavelet == W97) ? 4 : 2;
+                T.cpl = cpl; T.vec = vec_ok ? 1 : 0;
+                std::vector<DwtJob> jobs;
+                for (size_t i = 0; i < planes.size(); i++) {
+                    make_jobs(jobs, (int)i, pw[i], ph[i], cpl, ctx->band_prows);
+                    T.alg_bytes += (int64_t)2 * esz * pw[i] * ph[i] * T.ncomp;
+                }
+                T.njobs = (int)jobs.size();
+                int r = upload(ctx, &T.d_planes, planes);
+                if (r == J2K_OK) r = upload(ctx, &T.d_jobs, jobs);
+                if (r != J2K_OK) { j2k_plan_destroy(P); return r; }
+                if (dir == 0) {
+                    P->dwt_bytes += T.alg_bytes;
+                    if (l == 0) P->dwt_level0_bytes += T.alg_bytes;
+                }
+            }
+        }
+    }
+    if (sa) { hipError_t e = hipMalloc(&P->d_scrA, (size_t)sa * esz); if (e != hipSuccess) { j2k_plan_destroy(P); return fail_hip(ctx, e, "hipMalloc scratch A"); } }
+    if (sb) { hipError_t e = hipMalloc(&P->d_scrB, (size_t)sb * esz); if (e != hipSuccess) { j2k_plan_destroy(P); return fail_hip(ctx, e, "hipMalloc scratch B"); } }
+
+    // ---- code-block jobs: encoder.go:616-673 per tile, top-left addressing (encoder.go:763-795) ----
+    {
+        int numRes = S.num_res_jobs;
+        if (numRes <= 0) numRes = 6;
+        const int cbw = S.cb_w > 0 ? S.cb_w : 64, cbh = S.cb_h > 0 ? S.cb_h : 64;
+        std::vector<BlockJob> bj;
+        int64_t slot = 0, dec = 0;
+        size_t gi = 0;
+        for (int tl = 0; tl < P->tile_count; tl++) {
+            // groups of this tile are contiguous; collect per-component coefficient offsets
+            std::vector<int64_t> coff(S.C);
+            int w = 0, h = 0;
+            for (; gi < P->groups.size() && P->groups[gi].tile == tl; gi++) {
+                const Group &g = P->groups[gi];
+                for (int k = 0; k < g.nc; k++) coff[g.comp0 + k] = g.coef_off[k];
+                w = g.w; h = g.h;
+            }
+            for (int c = 0; c < S.C; c++)
+                for (int r = 0; r < numRes; r++) {
+                    const int nb = r == 0 ? 1 : 3;
+                    for (int b = 0; b < nb; b++) {
+                        const int band = r == 0 ? J2K_BAND_LL : (b == 0 ? J2K_BAND_HL : (b == 1 ? J2K_BAND_LH : J2K_BAND_HH));
+                        const int64_t scale = (int64_t)1 << std::min(numRes - 1 - r, 40);
+                        int bw = (int)((w + scale - 1) / scale), bh = (int)((h + scale - 1) / scale);
+                        if (r > 0) { bw = (bw + 1) / 2; bh = (bh + 1) / 2; }
+                        for (int cby = 0; cby * cbh < bh; cby++)
+                            for (int cbx = 0; cbx * cbw < bw; cbx++) {
+                                const int sx = cbx * cbw, sy = cby * cbh;
+                                const int aw = std::min(cbw, bw - sx), ah = std::min(cbh, bh - sy);
+                                j2k_block jb{tl * S.C + c, band, sx, sy, aw, ah};
+                                P->blocks.push_back(jb);
+                                P->block_tile.push_back(tl);
+                                P->slot_off.push_back((uint64_t)slot);
+                                P->dec_off.push_back((uint64_t)dec);
+                                BlockJob J{};
+                                J.src_off = coff[c] + (int64_t)sy * w + sx;
+                                J.out_off = slot;
+                                J.stride = w; J.w = aw; J.h = ah; J.band = band;
+                                bj.push_back(J);
+                                slot += (int64_t)((j2k_block_bound(S.coder, aw, ah) + 15) & ~size_t(15));
+                                dec += align4((int64_t)aw * ah);
+                                P->block_samples += (int64_t)aw * ah;
+                            }
+                    }
+                }
+        }
+        P->bytes_cap = slot; P->decoded_elems = dec;
+        int r = upload(ctx, &P->d_bjobs, bj);
+        for (size_t i = 0; i < bj.size(); i++) bj[i].out_off = (int64_t)P->dec_off[i];   // decode table: dense decoded blocks
+        if (r == J2K_OK) r = upload(ctx, &P->d_djobs, bj);
+        if (r != J2K_OK) { j2k_plan_destroy(P); return r; }
+    }
+    *out = P;
+    return J2K_OK;
+}
+
+extern "C" void j2k_plan_destroy(j2k_plan *P) {
+    if (!P) return;
+    if (P->ctx) { (void)hipSetDevice(P->ctx->device); (void)hipStreamSynchronize(P->ctx->stream); }
+    for (int cls = 0; cls < 2; cls++) {
+        for (auto &T : P->fwd[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); }
+        for (auto &T : P->inv[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); }
+    }
+    void *ptrs[] = {P->d_scrA, P->d_scrB, P->d_bjobs, P->d_djobs, P->d_frame, P->d_coeff, P->d_slots, P->d_stream, P->d_lens, P->d_numbps, P->d_offs};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    delete P;
+}
+
+static int spec_from_params(j2k_ctx *ctx, const j2k_params *p, PlanSpec &S) {
+    if (!p) return fail(ctx, J2K_ERR_INVALID_ARG, "params == NULL");
+    if (p->precision < 1 || p->precision > 31) return fail(ctx, J2K_ERR_INVALID_ARG, "precision out of range");
+    S.W = p->width; S.H = p->height; S.C = p->ncomp;
+    S.tile_w = p->tile_w; S.tile_h = p->tile_h;
+    S.levels = p->num_resolutions - 1;
+    if (S.levels <= 0) S.levels = 5;                                  // encoder.go:249-252
+    S.wavelet = p->lossless ? W53 : W97;
+    S.dc_shift = (int)((uint32_t)1 << (p->precision - 1));            // mct.go:97
+    if (p->is_signed) S.dc_shift = 0;                                 // decoder.go:345 (decode side only skips it)
+    S.mct = p->ncomp >= 3;                                            // encoder.go:223
+    S.quant = p->lossless ? Q_NONE : Q_ENCODER;
+    S.quality = p->quality > 0 ? p->quality : 100;                    // encoder.go:265-268
+    S.num_res_jobs = p->num_resolutions > 0 ? p->num_resolutions : 6; // encoder.go:601-604
+    S.cb_w = p->cb_w > 0 ? p->cb_w : 64;                              // encoder.go:608-613
+    S.cb_h = p->cb_h > 0 ? p->cb_h : 64;
+    S.coder = p->coder;
+    S.tile_first = p->tile_first; S.tile_count = p->tile_count;
+    if (S.coder != J2K_CODER_MQ && S.coder != J2K_CODER_HT) return fail(ctx, J2K_ERR_INVALID_ARG, "coder");
+    return J2K_OK;
+}
+
+extern "C" int j2k_plan_create(j2k_ctx *ctx, const j2k_params *params, j2k_plan **out) {
+    if (!ctx || !out) return J2K_ERR_INVALID_ARG;
+    *out = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PlanSpec S;
+    int r = spec_from_params(ctx, params, S);
+    if (r != J2K_OK) return r;
+    return build_plan(ctx, S, out);
+}
+
+extern "C" int j2k_plan_get_info(const j2k_plan *P, j2k_plan_info *info) {
+    if (!P || !info) return J2K_ERR_INVALID_ARG;
+    info->tiles = P->tile_count;
+    info->planes = (int64_t)P->plane_desc.size() / 7;
+    info->blocks = (int64_t)P->blocks.size();
+    info->coeff_elems = P->coeff_elems;
+    info->bytes_cap = P->bytes_cap;
+    info->dwt_bytes = P->dwt_bytes;
+    info->dwt_level0_bytes = P->dwt_level0_bytes;
+    info->block_samples = P->block_samples;
+    info->decoded_elems = P->decoded_elems;
+    return J2K_OK;
+}
+extern "C" int j2k_plan_get_blocks(const j2k_plan *P, j2k_block *blocks, size_t cap) {
+    if (!P || (!blocks && cap)) return J2K_ERR_INVALID_ARG;
+    if (cap < P->blocks.size()) return J2K_ERR_CAPACITY;
+    if (!P->blocks.empty()) memcpy(blocks, P->blocks.data(), P->blocks.size() * sizeof(j2k_block));
+    return J2K_OK;
+}
+extern "C" int j2k_plan_get_planes(const j2k_plan *P, int64_t *desc7, size_t cap_planes) {
+    if (!P || !desc7) return J2K_ERR_INVALID_ARG;
+    if (cap_planes * 7 < P->plane_desc.size()) return J2K_ERR_CAPACITY;
+    memcpy(desc7, P->plane_desc.data(), P->plane_desc.size() * sizeof(int64_t));
+    return J2K_OK;
+}
+extern "C" int j2k_plan_get_decoded_offsets(const j2k_plan *P, uint64_t *offs, size_t cap) {
+    if (!P || !offs) return J2K_ERR_INVALID_ARG;
+    if (cap < P->dec_off.size()) return J2K_ERR_CAPACITY;
+    if (!P->dec_off.empty()) memcpy(offs, P->dec_off.data(), P->dec_off.size() * sizeof(uint64_t));
+    return J2K_OK;
+}
+
+// ------------------------------------------------------------------------------
+// transform stages on device buffers
+// ------------------------------------------------------------------------------
+static LevelLaunch mk(const LevelTab &T) { return LevelLaunch{T.d_jobs, T.njobs, T.d_planes, T.cpl, T.vec, T.ncomp}; }
+
+static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff) {
+    j2k_ctx *ctx = P->ctx;
+    const PlanSpec &S = P->spec;
+    if (((uintptr_t)d_frame & 15) || ((uintptr_t)d_coeff & 15)) return fail(ctx, J2K_ERR_INVALID_ARG, "device pointers must be 16-byte aligned");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const double step = 1.0 / (double)S.quality;   // encoder.go:269
+    for (int l = 0; l < S.levels; l++) {
+        void *in = (l == 0) ? const_cast<void *>(d_frame) : ((l & 1) ? P->d_scrA : P->d_scrB);
+        void *nx = (l & 1) ? P->d_scrB : P->d_scrA;
+        for (int cls = 0; cls < 2; cls++) {
+            const LevelTab &T = P->fwd[cls][l];
+            if (!T.njobs) continue;
+            if (S.wavelet == W53) {
+                HIPCHK(ctx, launch_dwt53_fwd(ctx->stream, mk(T), (const int32_t *)in, (int32_t *)d_coeff, (int32_t *)nx, l == 0 ? S.dc_shift : 0));
+            } else {
+                const int src_f64 = (l > 0) || S.frame_is_f64;
+                HIPCHK(ctx, launch_dwt97_fwd(ctx->stream, mk(T), in, src_f64, (int32_t *)d_coeff, (double *)d_coeff, (double *)nx,
+                                             l == 0 ? S.dc_shift : 0, S.quant, step, (cls == 1) ? 1 : 0));
+            }
+        }
+    }
+    return J2K_OK;
+}
+
+static int plan_inverse_impl(j2k_plan *P, const void *d_coeff, void *d_frame) {
+    j2k_ctx *ctx = P->ctx;
+    const PlanSpec &S = P->spec;
+    if (((uintptr_t)d_frame & 15) || ((uintptr_t)d_coeff & 15)) return fail(ctx, J2K_ERR_INVALID_ARG, "device pointers must be 16-byte aligned");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    for (int l = S.levels - 1; l >= 0; l--) {
+        void *prev = (l & 1) ? P->d_scrB : P->d_scrA;                     // X_{l+1}
+        void *dst = (l == 0) ? d_frame : ((l & 1) ? P->d_scrA : P->d_scrB);  // X_l
+        for (int cls = 0; cls < 2; cls++) {
+            const LevelTab &T = P->inv[cls][l];
+            if (!T.njobs) continue;
+            if (S.wavelet == W53) {
+                HIPCHK(ctx, launch_dwt53_inv(ctx->stream, mk(T), (const int32_t *)d_coeff, (const int32_t *)prev, (int32_t *)dst,
+                                             l == 0 ? S.dc_shift : 0, l == 0));
+            } else {
+                // dst_mode: 0 = f64 scratch (l>0), 1 = f64 frame (unit calls), 2 = int32 frame via int32(v+0.5) (tcd.go:433-435)
+                const int dst_mode = (l > 0) ? 0 : (S.frame_is_f64 ? 1 : 2);
+                HIPCHK(ctx, launch_dwt97_inv(ctx->stream, mk(T), d_coeff, S.quant == Q_NONE ? 1 : 0, (const double *)prev, dst,
+                                             l == 0 ? S.dc_shift : 0, l == 0, dst_mode, (cls == 1) ? 1 : 0));
+            }
+        }
+    }
+    return J2K_OK;
+}
+
+extern "C" int j2k_plan_forward(j2k_plan *P, const int32_t *d_frame, int32_t *d_coeff) {
+    if (!P || !d_frame || !d_coeff) return J2K_ERR_INVALID_ARG;
+    return plan_forward_impl(P, d_frame, d_coeff);
+}
+extern "C" int j2k_plan_inverse(j2k_plan *P, const int32_t *d_coeff, int32_t *d_frame) {
+    if (!P || !d_frame || !d_coeff) return J2K_ERR_INVALID_ARG;
+    return plan_inverse_impl(P, d_coeff, d_frame);
+}
+
+// ------------------------------------------------------------------------------
+// block coding stages on device buffers
+// ------------------------------------------------------------------------------
+static int ensure(j2k_ctx *ctx, void **p, size_t bytes) {
+    if (*p) return J2K_OK;
+    HIPCHK(ctx, hipMalloc(p, std::max<size_t>(bytes, 16)));
+    return J2K_OK;
+}
+
+static size_t t1_work_per_job(const j2k_plan *P) {
+    size_t m = 0;
+    for (const j2k_block &b : P->blocks) m = std::max(m, t1_work_bytes(b.w, b.h));
+    return (m + 255) & ~size_t(255);
+}
+
+extern "C" int j2k_plan_encode_blocks(j2k_plan *P, const int32_t *d_coeff, uint8_t *d_slots, uint32_t *d_lens, uint8_t *d_numbps) {
+    if (!P || !d_coeff || !d_slots || !d_lens || !d_numbps) return J2K_ERR_INVALID_ARG;
+    j2k_ctx *ctx = P->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int n = (int)P->blocks.size();
+    if (!n) return J2K_OK;
+    int r = stage_reserve(ctx, 3, 256);
+    if (r != J2K_OK) return r;
+    int *d_fault = (int *)ctx->stage[3];
+    HIPCHK(ctx, hipMemsetAsync(d_fault, 0, sizeof(int), ctx->stream));
+    if (P->spec.coder == J2K_CODER_HT) {
+        HIPCHK(ctx, launch_ht_encode(ctx->stream, P->d_bjobs, n, d_coeff, d_slots, d_lens, d_numbps, d_fault));
+    } else {
+        const size_t wpj = t1_work_per_job(P);
+        r = stage_reserve(ctx, 2, wpj * (size_t)n + 256);
+        if (r != J2K_OK) return r;
+        HIPCHK(ctx, launch_t1_encode(ctx->stream, P->d_bjobs, n, d_coeff, d_slots, d_lens, d_numbps, (uint8_t *)ctx->stage[2], wpj, d_fault));
+    }
+    return J2K_OK;
+}
+
+// reads the device fault word written by the encode kernels (after a sync)
+static int check_fault(j2k_ctx *ctx) {
+    int f = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&f, ctx->stage[3], sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (f == 1) return fail(ctx, J2K_ERR_GO_PANIC, "block coder: input on which the reference panics (stream buffer overrun / MinInt32)");
+    if (f) return fail(ctx, J2K_ERR_CAPACITY, "block coder: slot overflow");
+    return J2K_OK;
+}
+
+extern "C" int j2k_plan_compact(j2k_plan *P, const uint8_t *d_slots, const uint32_t *d_lens, uint64_t *d_offs, uint8_t *d_stream) {
+    if (!P || !d_slots || !d_lens || !d_offs || !d_stream) return J2K_ERR_INVALID_ARG;
+    j2k_ctx *ctx = P->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int n = (int)P->blocks.size();
+    int r = stage_reserve(ctx, 1, 4096);
+    if (r != J2K_OK) return r;
+    HIPCHK(ctx, launch_compact(ctx->stream, P->d_bjobs, n, d_slots, d_lens, d_offs, d_stream, ctx->stage[1]));
+    return J2K_OK;
+}
+
+extern "C" int j2k_plan_decode_blocks(j2k_plan *P, const uint8_t *d_stream, const uint64_t *d_offs, const uint32_t *d_lens,
+                                      const uint8_t *d_numbps, int32_t *d_decoded) {
+    if (!P || !d_stream || !d_offs || !d_lens || !d_numbps || !d_decoded) return J2K_ERR_INVALID_ARG;
+    j2k_ctx *ctx = P->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int n = (int)P->blocks.size();
+    if (!n) return J2K_OK;
+    if (P->spec.coder == J2K_CODER_HT) {
+        HIPCHK(ctx, launch_ht_decode(ctx->stream, P->d_djobs, n, d_stream, d_offs, d_lens, d_decoded));
+    } else {
+        const size_t wpj = t1_work_per_job(P);
+        int r = stage_reserve(ctx, 2, wpj * (size_t)n + 256);
+        if (r != J2K_OK) return r;
+        HIPCHK(ctx, launch_t1_decode(ctx->stream, P->d_djobs, n, d_stream, d_offs, d_lens, d_numbps, d_decoded,
+                                     (uint8_t *)ctx->stage[2], wpj));
+    }
+    return J2K_OK;
+}
+
+// ------------------------------------------------------------------------------
+// host (unit) calls
+// ------------------------------------------------------------------------------
+static int cached_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
+    for (j2k_plan *p : ctx->cache)
+        if (p->spec == S) { *out = p; return J2K_OK; }
+    j2k_plan *p = nullptr;
+    int r = build_plan(ctx, S, &p);
+    if (r != J2K_OK) return r;
+    if (ctx->cache.size() >= 16) { j2k_plan_destroy(ctx->cache.front()); ctx->cache.erase(ctx->cache.begin()); }
+    ctx->cache.push_back(p);
+    *out = p;
+    return J2K_OK;
+}
+
+// Runs `levels` of a single-plane transform on a host buffer, in place.
+static int host_dwt(j2k_ctx *ctx, void *data, int w, int h, int levels, int wavelet, bool inverse, int quant, bool frame_f64) {
+    if (!ctx) return J2K_ERR_INVALID_ARG;
+    if (w < 0 || h < 0 || levels < 0) return fail(ctx, J2K_ERR_INVALID_ARG, "negative size");
+    if (w == 0 || h == 0 || levels == 0) return J2K_OK;   // Go loops simply do not run
+    if (!data) return fail(ctx, J2K_ERR_INVALID_ARG, "data == NULL");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PlanSpec S;
+    S.W = w; S.H = h; S.C = 1; S.levels = levels; S.wavelet = wavelet; S.dc_shift = 0; S.mct = 0;
+    S.quant = quant; S.frame_is_f64 = frame_f64; S.num_res_jobs = 1; S.cb_w = 1 << 20; S.cb_h = 1 << 20;
+    j2k_plan *P = nullptr;
+    int r = cached_plan(ctx, S, &P);
+    if (r != J2K_OK) return r;
+    const size_t n = (size_t)w * h;
+    const size_t fsz = frame_f64 ? 8 : 4;
+    const size_t csz = (wavelet == W97 && quant == Q_NONE) ? 8 : 4;
+    r = stage_reserve(ctx, 0, n * fsz + 64);
+    if (r == J2K_OK) r = stage_reserve(ctx, 1, (size_t)P->coeff_elems * csz + 64);
+    if (r != J2K_OK) return r;
+    void *d_frame = ctx->stage[0], *d_coef = ctx->stage[1];
+    if (!inverse) {
+        HIPCHK(ctx, hipMemcpyAsync(d_frame, data, n * fsz, hipMemcpyHostToDevice, ctx->stream));
+        r = plan_forward_impl(P, d_frame, d_coef);
+        if (r != J2K_OK) return r;
+        HIPCHK(ctx, hipMemcpyAsync(data, d_coef, n * csz, hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        HIPCHK(ctx, hipMemcpyAsync(d_coef, data, n * csz, hipMemcpyHostToDevice, ctx->stream));
+        r = plan_inverse_impl(P, d_coef, d_frame);
+        if (r != J2K_OK) return r;
+        HIPCHK(ctx, hipMemcpyAsync(data, d_frame, n * fsz, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return J2K_OK;
+}
+
+extern "C" int j2k_forward53(j2k_ctx *c, int32_t *d, int n) { return host_dwt(c, d, n, 1, 1, W53, false, Q_NONE, false); }
+extern "C" int j2k_inverse53(j2k_ctx *c, int32_t *d, int n) { return host_dwt(c, d, n, 1, 1, W53, true, Q_NONE, false); }
+extern "C" int j2k_forward97(j2k_ctx *c, double *d, int n) { return host_dwt(c, d, n, 1, 1, W97, false, Q_NONE, true); }
+extern "C" int j2k_inverse97(j2k_ctx *c, double *d, int n) { return host_dwt(c, d, n, 1, 1, W97, true, Q_NONE, true); }
+extern "C" int j2k_forward2d53(j2k_ctx *c, int32_t *d, int w, int h) { return host_dwt(c, d, w, h, 1, W53, false, Q_NONE, false); }
+extern "C" int j2k_inverse2d53(j2k_ctx *c, int32_t *d, int w, int h) { return host_dwt(c, d, w, h, 1, W53, true, Q_NONE, false); }
+extern "C" int j2k_forward2d97(j2k_ctx *c, double *d, int w, int h) { return host_dwt(c, d, w, h, 1, W97, false, Q_NONE, true); }
+extern "C" int j2k_inverse2d97(j2k_ctx *c, double *d, int w, int h) { return host_dwt(c, d, w, h, 1, W97, true, Q_NONE, true); }
+extern "C" int j2k_decompose_multilevel53(j2k_ctx *c, int32_t *d, int w, int h, int l) { return host_dwt(c, d, w, h, l, W53, false, Q_NONE, false); }
+extern "C" int j2k_reconstruct_multilevel53(j2k_ctx *c, int32_t *d, int w, int h, int l) { return host_dwt(c, d, w, h, l, W53, true, Q_NONE, false); }
+extern "C" int j2k_decompose_multilevel97(j2k_ctx *c, double *d, int w, int h, int l) { return host_dwt(c, d, w, h, l, W97, false, Q_NONE, true); }
+extern "C" int j2k_reconstruct_multilevel97(j2k_ctx *c, double *d, int w, int h, int l) { return host_dwt(c, d, w, h, l, W97, true, Q_NONE, true); }
+
+extern "C" int j2k_tcd_apply_forward_dwt(j2k_ctx *c, int32_t *d, int w, int h, int levels, int reversible) {
+    if (reversible) return host_dwt(c, d, w, h, levels, W53, false, Q_NONE, false);
+    return host_dwt(c, d, w, h, levels, W97, false, Q_TCD, false);
+}
+extern "C" int j2k_tcd_apply_inverse_dwt(j2k_ctx *c, int32_t *d, int w, int h, int levels, int reversible) {
+    if (reversible) return host_dwt(c, d, w, h, levels, W53, true, Q_NONE, false);
+    return host_dwt(c, d, w, h, levels, W97, true, Q_TCD, false);
+}
+
+// ---- mct ------------------------------------------------------------------------
+static int host_elementwise3(j2k_ctx *ctx, void *a, void *b, void *c, size_t n, size_t esz, int op, int arg) {
+    if (!ctx) return J2K_ERR_INVALID_ARG;
+    if (n == 0) return J2K_OK;
+    if (!a || (op != 0 && (!b || !c))) return fail(ctx, J2K_ERR_INVALID_ARG, "NULL plane");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int np = op == 0 ? 1 : 3;
+    void *h[3] = {a, b, c};
+    for (int i = 0; i < np; i++) {
+        int r = stage_reserve(ctx, i, n * esz);
+        if (r != J2K_OK) return r;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->stage[i], h[i], n * esz, hipMemcpyHostToDevice, ctx->stream));
+    }
+    switch (op) {
+        case 0: HIPCHK(ctx, launch_add_const(ctx->stream, (int32_t *)ctx->stage[0], n, arg)); break;
+        case 1: HIPCHK(ctx, launch_rct(ctx->stream, (int32_t *)ctx->stage[0], (int32_t *)ctx->stage[1], (int32_t *)ctx->stage[2], n, arg)); break;
+        case 2: HIPCHK(ctx, launch_ict(ctx->stream, (double *)ctx->stage[0], (double *)ctx->stage[1], (double *)ctx->stage[2], n, arg)); break;
+    }
+    for (int i = 0; i < np; i++) HIPCHK(ctx, hipMemcpyAsync(h[i], ctx->stage[i], n * esz, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return J2K_OK;
+}
+
+extern "C" int j2k_dc_level_shift_forward(j2k_ctx *ctx, int32_t *d, size_t n, int precision) {
+    if (precision < 1 || precision > 32) return fail(ctx, J2K_ERR_INVALID_ARG, "precision");
+    return host_elementwise3(ctx, d, nullptr, nullptr, n, 4, 0, (int)(0u - ((uint32_t)1 << (precision - 1))));
+}
+extern "C" int j2k_dc_level_shift_inverse(j2k_ctx *ctx, int32_t *d, size_t n, int precision) {
+    if (precision < 1 || precision > 32) return fail(ctx, J2K_ERR_INVALID_ARG, "precision");
+    return host_elementwise3(ctx, d, nullptr, nullptr, n, 4, 0, (int)((uint32_t)1 << (precision - 1)));
+}
+extern "C" int j2k_forward_rct(j2k_ctx *ctx, int32_t *r, int32_t *g, int32_t *b, size_t n) { return host_elementwise3(ctx, r, g, b, n, 4, 1, 0); }
+extern "C" int j2k_inverse_rct(j2k_ctx *ctx, int32_t *y, int32_t *u, int32_t *v, size_t n) { return host_elementwise3(ctx, y, u, v, n, 4, 1, 1); }
+extern "C" int j2k_forward_ict(j2k_ctx *ctx, double *r, double *g, double *b, size_t n) { return host_elementwise3(ctx, r, g, b, n, 8, 2, 0); }
+extern "C" int j2k_inverse_ict(j2k_ctx *ctx, double *y, double *cb, double *cr, size_t n) { return host_elementwise3(ctx, y, cb, cr, n, 8, 2, 1); }
+
+// ---- batched block coding from host planes ----------------------------------------
+extern "C" int j2k_encode_blocks(j2k_ctx *ctx, int coder, const int32_t *const *planes, const int32_t *plane_w,
+                                 const int32_t *plane_h, int nplanes, const j2k_block *blocks, size_t nblocks,
+                                 uint8_t *out, size_t cap, uint64_t *offs, uint32_t *lens, uint8_t *numbps, size_t *total) {
+    if (!ctx) return J2K_ERR_INVALID_ARG;
+    if (total) *total = 0;
+    if (nblocks == 0) return J2K_OK;
+    if (!planes || !plane_w || !plane_h || !blocks || nplanes <= 0) return fail(ctx, J2K_ERR_INVALID_ARG, "NULL argument");
+    if (coder != J2K_CODER_MQ && coder != J2K_CODER_HT) return fail(ctx, J2K_ERR_INVALID_ARG, "coder");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::vector<int64_t> poff(nplanes);
+    int64_t tot = 0;
+    for (int i = 0; i < nplanes; i++) {
+        if (plane_w[i] <= 0 || plane_h[i] <= 0 || !planes[i]) return fail(ctx, J2K_ERR_INVALID_ARG, "bad plane");
+        poff[i] = tot; tot += align4((int64_t)plane_w[i] * plane_h[i]);
+    }
+    std::vector<BlockJob> bj(nblocks);
+    int64_t slot = 0;
+    size_t wpj = 0;
+    for (size_t j = 0; j < nblocks; j++) {
+        const j2k_block &b = blocks[j];
+        if (b.plane < 0 || b.plane >= nplanes || b.w <= 0 || b.h <= 0 || b.x0 < 0 || b.y0 < 0 ||
+            b.x0 + b.w > plane_w[b.plane] || b.y0 + b.h > plane_h[b.plane] || b.band < 0 || b.band > 3)
+            return fail(ctx, J2K_ERR_INVALID_ARG, "block window outside its plane");
+        bj[j].src_off = poff[b.plane] + (int64_t)b.y0 * plane_w[b.plane] + b.x0;
+        bj[j].out_off = slot;
+        bj[j].stride = plane_w[b.plane]; bj[j].w = b.w; bj[j].h = b.h; bj[j].band = b.band;
+        slot += (int64_t)((j2k_block_bound(coder, b.w, b.h) + 15) & ~size_t(15));
+        wpj = std::max(wpj, t1_work_bytes(b.w, b.h));
+    }
+    wpj = (wpj + 255) & ~size_t(255);
+    void *d_coef = nullptr, *d_jobs = nullptr, *d_slots = nullptr, *d_lens = nullptr, *d_nb = nullptr, *d_work = nullptr, *d_fault = nullptr;
+    int status = J2K_OK;
+    auto cleanup = [&]() { for (void *p : {d_coef, d_jobs, d_slots, d_lens, d_nb, d_work, d_fault}) if (p) (void)hipFree(p); };
+#define TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { status = fail_hip(ctx, e_, #call); cleanup(); return status; } } while (0)
+    TRY(hipMalloc(&d_coef, (size_t)tot * 4 + 16));
+    TRY(hipMalloc(&d_jobs, nblocks * sizeof(BlockJob)));
+    TRY(hipMalloc(&d_slots, (size_t)slot + 16));
+    TRY(hipMalloc(&d_lens, nblocks * 4));
+    TRY(hipMalloc(&d_nb, nblocks));
+    TRY(hipMalloc(&d_fault, 16));
+    TRY(hipMemsetAsync(d_fault, 0, 16, ctx->stream));
+    for (int i = 0; i < nplanes; i++)
+        TRY(hipMemcpyAsync((int32_t *)d_coef + poff[i], planes[i], (size_t)plane_w[i] * plane_h[i] * 4, hipMemcpyHostToDevice, ctx->stream));
+    TRY(hipMemcpyAsync(d_jobs, bj.data(), nblocks * sizeof(BlockJob), hipMemcpyHostToDevice, ctx->stream));
+    if (coder == J2K_CODER_HT) {
+        TRY(launch_ht_encode(ctx->stream, (BlockJob *)d_jobs, (int)nblocks, (int32_t *)d_coef, (uint8_t *)d_slots, (uint32_t *)d_lens, (uint8_t *)d_nb, (int *)d_fault));
+    } else {
+        TRY(hipMalloc(&d_work, wpj * nblocks + 256));
+        TRY(launch_t1_encode(ctx->stream, (BlockJob *)d_jobs, (int)nblocks, (int32_t *)d_coef, (uint8_t *)d_slots, (uint32_t *)d_lens, (uint8_t *)d_nb,
+                             (uint8_t *)d_work, wpj, (int *)d_fault));
+    }
+    std::vector<uint32_t> hl(nblocks);
+    std::vector<uint8_t> hn(nblocks);
+    int hf = 0;
+    TRY(hipMemcpyAsync(hl.data(), d_lens, nblocks * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TRY(hipMemcpyAsync(hn.data(), d_nb, nblocks, hipMemcpyDeviceToHost, ctx->stream));
+    TRY(hipMemcpyAsync(&hf, d_fault, 4, hipMemcpyDeviceToHost, ctx->stream));
+    TRY(hipStreamSynchronize(ctx->stream));
+    if (hf) { cleanup(); return fail(ctx, hf == 1 ? J2K_ERR_GO_PANIC : J2K_ERR_CAPACITY, "block coder fault"); }
+    size_t pos = 0;
+    for (size_t j = 0; j < nblocks; j++) {
+        if (offs) offs[j] = pos;
+        if (lens) lens[j] = hl[j];
+        if (numbps) numbps[j] = hn[j];
+        pos += hl[j];
+    }
+    if (total) *total = pos;
+    if (pos > cap || (pos && !out)) { cleanup(); return fail(ctx, J2K_ERR_CAPACITY, "out too small"); }
+    pos = 0;
+    for (size_t j = 0; j < nblocks; j++) {
+        if (hl[j]) TRY(hipMemcpyAsync(out + pos, (uint8_t *)d_slots + bj[j].out_off, hl[j], hipMemcpyDeviceToHost, ctx->stream));
+        pos += hl[j];
+    }
+    TRY(hipStreamSynchronize(ctx->stream));
+    cleanup();
+    return J2K_OK;
+}
+
+extern "C" int j2k_decode_blocks(j2k_ctx *ctx, int coder, const uint8_t *bytes, const uint64_t *offs, const uint32_t *lens,
+                                 const uint8_t *numbps, const j2k_block *blocks, size_t nblocks, int32_t *coeffs,
+                                 const uint64_t *coeff_offs) {
+    if (!ctx) return J2K_ERR_INVALID_ARG;
+    if (nblocks == 0) return J2K_OK;
+    if (!offs || !lens || !blocks || !coeffs || !coeff_offs) return fail(ctx, J2K_ERR_INVALID_ARG, "NULL argument");
+    if (coder != J2K_CODER_MQ && coder != J2K_CODER_HT) return fail(ctx, J2K_ERR_INVALID_ARG, "coder");
+    if (coder == J2K_CODER_MQ && !numbps) return fail(ctx, J2K_ERR_INVALID_ARG, "numbps required for T1.Decode");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    size_t nbytes = 0;
+    std::vector<BlockJob> bj(nblocks);
+    int64_t dec = 0;
+    size_t wpj = 0;
+    for (size_t j = 0; j < nblocks; j++) {
+        const j2k_block &b = blocks[j];
+        if (b.w <= 0 || b.h <= 0 || b.band < 0 || b.band > 3) return fail(ctx, J2K_ERR_INVALID_ARG, "bad block");
+        nbytes = std::max<size_t>(nbytes, (size_t)offs[j] + lens[j]);
+        bj[j].src_off = 0; bj[j].out_off = dec; bj[j].stride = b.w; bj[j].w = b.w; bj[j].h = b.h; bj[j].band = b.band;
+        dec += align4((int64_t)b.w * b.h);
+        wpj = std::max(wpj, t1_work_bytes(b.w, b.h));
+    }
+    if (nbytes && !bytes) return fail(ctx, J2K_ERR_INVALID_ARG, "bytes == NULL");
+    wpj = (wpj + 255) & ~size_t(255);
+    void *d_bytes = nullptr, *d_jobs = nullptr, *d_offs = nullptr, *d_lens = nullptr, *d_nb = nullptr, *d_dec = nullptr, *d_work = nullptr;
+    int status = J2K_OK;
+    auto cleanup = [&]() { for (void *p : {d_bytes, d_jobs, d_offs, d_lens, d_nb, d_dec, d_work}) if (p) (void)hipFree(p); };
+    TRY(hipMalloc(&d_bytes, nbytes + 16));
+    TRY(hipMalloc(&d_jobs, nblocks * sizeof(BlockJob)));
+    TRY(hipMalloc(&d_offs, nblocks * 8));
+    TRY(hipMalloc(&d_lens, nblocks * 4));
+    TRY(hipMalloc(&d_nb, nblocks));
+    TRY(hipMalloc(&d_dec, (size_t)dec * 4 + 16));
+    if (nbytes) TRY(hipMemcpyAsync(d_bytes, bytes, nbytes, hipMemcpyHostToDevice, ctx->stream));
+    TRY(hipMemcpyAsync(d_jobs, bj.data(), nblocks * sizeof(BlockJob), hipMemcpyHostToDevice, ctx->stream));
+    TRY(hipMemcpyAsync(d_offs, offs, nblocks * 8, hipMemcpyHostToDevice, ctx->stream));
+    TRY(hipMemcpyAsync(d_lens, lens, nblocks * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (numbps) TRY(hipMemcpyAsync(d_nb, numbps, nblocks, hipMemcpyHostToDevice, ctx->stream));
+    else TRY(hipMemsetAsync(d_nb, 0, nblocks, ctx->stream));
+    if (coder == J2K_CODER_HT) {
+        TRY(launch_ht_decode(ctx->stream, (BlockJob *)d_jobs, (int)nblocks, (uint8_t *)d_bytes, (uint64_t *)d_offs, (uint32_t *)d_lens, (int32_t *)d_dec));
+    } else {
+        TRY(hipMalloc(&d_work, wpj * nblocks + 256));
+        TRY(launch_t1_decode(ctx->stream, (BlockJob *)d_jobs, (int)nblocks, (uint8_t *)d_bytes, (uint64_t *)d_offs, (uint32_t *)d_lens, (uint8_t *)d_nb,
+                             (int32_t *)d_dec, (uint8_t *)d_work, wpj));
+    }
+    for (size_t j = 0; j < nblocks; j++)
+        TRY(hipMemcpyAsync(coeffs + coeff_offs[j], (int32_t *)d_dec + bj[j].out_off, (size_t)blocks[j].w * blocks[j].h * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TRY(hipStreamSynchronize(ctx->stream));
+    cleanup();
+    return J2K_OK;
+}
+#undef TRY
+
+// ---- whole shard from host planes (encoder.preprocess + encodeTile) ------------------
+extern "C" int j2k_encode_frame(j2k_plan *P, int32_t *const *planes, int32_t *coeff, uint8_t *out, size_t cap,
+                                size_t *out_len, uint64_t *tile_offs, uint32_t *lens, uint8_t *numbps) {
+    if (!P || !planes) return J2K_ERR_INVALID_ARG;
+    j2k_ctx *ctx = P->ctx;
+    const PlanSpec &S = P->spec;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t npx = (size_t)S.W * S.H;
+    const size_t nb = P->blocks.size();
+    int r;
+    if ((r = ensure(ctx, &P->d_frame, npx * S.C * 4)) != J2K_OK) return r;
+    if ((r = ensure(ctx, &P->d_coeff, (size_t)P->coeff_elems * 4)) != J2K_OK) return r;
+    if ((r = ensure(ctx, &P->d_slots, (size_t)P->bytes_cap)) != J2K_OK) return r;
+    if ((r = ensure(ctx, &P->d_stream, (size_t)P->bytes_cap)) != J2K_OK) return r;
+    if ((r = ensure(ctx, &P->d_lens, nb * 4)) != J2K_OK) return r;
+    if ((r = ensure(ctx, &P->d_numbps, nb)) != J2K_OK) return r;
+    if ((r = ensure(ctx, &P->d_offs, (nb + 1) * 8)) != J2K_OK) return r;
+    for (int c = 0; c < S.C; c++) {
+        if (!planes[c]) return fail(ctx, J2K_ERR_INVALID_ARG, "NULL plane");
+        HIPCHK(ctx, hipMemcpyAsync((int32_t *)P->d_frame + (size_t)c * npx, planes[c], npx * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if ((r = plan_forward_impl(P, P->d_frame, P->d_coeff)) != J2K_OK) return r;
+    if ((r = j2k_plan_encode_blocks(P, (int32_t *)P->d_coeff, (uint8_t *)P->d_slots, (uint32_t *)P->d_lens, (uint8_t *)P->d_numbps)) != J2K_OK) return r;
+    if ((r = j2k_plan_compact(P, (uint8_t *)P->d_slots, (uint32_t *)P->d_lens, (uint64_t *)P->d_offs, (uint8_t *)P->d_stream)) != J2K_OK) return r;
+    if ((r = check_fault(ctx)) != J2K_OK) return r;
+    std::vector<uint64_t> offs(nb + 1, 0);
+    if (nb) HIPCHK(ctx, hipMemcpyAsync(offs.data(), P->d_offs, (nb + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (lens && nb) HIPCHK(ctx, hipMemcpyAsync(lens, P->d_lens, nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (numbps && nb) HIPCHK(ctx, hipMemcpyAsync(numbps, P->d_numbps, nb, hipMemcpyDeviceToHost, ctx->stream));
+    // coefficients back: single tile -> in place into planes[] like e.componentData; else into coeff
+    const bool single = (P->tiles_x * P->tiles_y == 1);
+    for (const Group &g : P->groups)
+        for (int k = 0; k < g.nc; k++) {
+            int32_t *dst = single ? planes[g.comp0 + k] : (coeff ? coeff + g.coef_off[k] : nullptr);
+            if (dst) HIPCHK(ctx, hipMemcpyAsync(dst, (int32_t *)P->d_coeff + g.coef_off[k], (size_t)g.w * g.h * 4, hipMemcpyDeviceToHost, ctx->stream));
+        }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t total = (size_t)offs[nb];
+    if (out_len) *out_len = total;
+    if (tile_offs) {
+        size_t j = 0;
+        for (int t = 0; t < P->tile_count; t++) {
+            while (j < nb && P->block_tile[j] < t) j++;
+            tile_offs[t] = j < nb ? offs[j] : total;
+        }
+        tile_offs[P->tile_count] = total;
+    }
+    if (total > cap || (total && !out)) return fail(ctx, J2K_ERR_CAPACITY, "out too small");
+    if (total) HIPCHK(ctx, hipMemcpy(out, P->d_stream, total, hipMemcpyDeviceToHost));
+    return J2K_OK;
+}

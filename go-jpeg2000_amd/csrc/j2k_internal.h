@@ -1,0 +1,53 @@
+// j2k_internal.h -- shared between the HIP kernels and the C-ABI host code.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace j2k {
+
+// One tile-component (or RCT/ICT group of three) at one decomposition level.
+// All offsets are in ELEMENTS relative to the base pointer the launch passes.
+struct DwtPlane {
+    int64_t src_off[3];   // level input: comp k at src + src_off[k], row stride src_stride
+    int64_t out_off[3];   // final coefficient plane of comp k (dense, stride = w of level 0... see n_next)
+    int64_t nxt_off[3];   // scratch that receives the prefix [0, n_next) = input of the next level
+    int32_t src_stride;
+    int32_t w, h;         // dims of this level: dense w x h matrix
+    int32_t n_next;       // w_{l+1}*h_{l+1}; linear idx < n_next -> nxt, else -> out (0 on the last level)
+    int32_t out_stride;   // inverse level 0 only: row stride of the destination frame
+    int32_t pad_;
+};
+
+// One wavefront's work: a column strip x a band of pair-rows of one plane.
+struct DwtJob {
+    int32_t plane;
+    int32_t col0;         // first OWNED input column (multiple of CPL); 0 for the first strip
+    int32_t prow0;        // first pair-row of the band
+    int32_t nprow;        // pair-rows in the band
+};
+
+// One code-block job (device form).
+struct BlockJob {
+    int64_t src_off;      // element offset of the window origin inside the coefficient buffer
+    int64_t out_off;      // byte offset of this job's slot / element offset of its decoded block
+    int32_t stride;       // plane width
+    int32_t w, h;
+    int32_t band;
+};
+
+// launch wrappers (dwt53.hip, dwt97.hip, mct.hip, ht.hip, t1.hip)
+struct LevelLaunch {
+    const DwtJob *jobs;   // device
+    int njobs;
+    const DwtPlane *planes;  // device
+    int cpl;              // columns per lane: 2, 4 or 8
+    int vec;              // 1: every plane satisfies the vector-access alignment rules
+    int ncomp;            // 1 or 3 (3 = fused colour transform on level 0)
+};
+
+hipError_t launch_dwt53_fwd(hipStream_t s, const LevelLaunch &L, const int32_t *src, int32_t *out,
+                            int32_t *nxt, int dc_shift);
+hipError_t launch_dwt53_inv(hipStream_t s, const LevelLaunch &L, const int32_t *coef, const int32_t *prev,
+                            int32_t *dst, int dc_shift, int final_level);
+
+}  // namespace j2k

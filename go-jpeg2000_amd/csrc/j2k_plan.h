@@ -1,0 +1,89 @@
+// j2k_plan.h -- host-side context / plan objects behind the C ABI (include/j2kgfx.h).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/j2kgfx.h"
+#include "j2k_internal.h"
+
+struct j2k_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    int band_prows = 16;       // pair-rows per wavefront band (tunable: J2K_BAND_PROWS)
+    int force_novec = 0;       // J2K_FORCE_NOVEC=1: always take the scalar-access kernels (testing)
+    // cached single-plane plans for the host (unit) calls
+    std::vector<j2k_plan *> cache;
+    // host-call staging buffers (device)
+    void *stage[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t stage_bytes[4] = {0, 0, 0, 0};
+};
+
+namespace j2k {
+
+enum Wavelet { W53 = 0, W97 = 1 };
+enum QuantMode {               // how the 9-7 path turns f64 coefficients into int32
+    Q_NONE = 0,                // keep f64 (dwt.Forward97... unit calls)
+    Q_ENCODER = 1,             // int32(v/step +- 0.5), step = 1/quality (encoder.go:265-276)
+    Q_TCD = 2                  // int32(v +- 0.5) (tcd.go:520-532)
+};
+
+// Internal, richer form of j2k_params.
+struct PlanSpec {
+    int W = 0, H = 0, C = 1;
+    int tile_w = 0, tile_h = 0;
+    int levels = 1;            // DWT levels actually run
+    int wavelet = W53;
+    int dc_shift = 0;          // value subtracted on the way in / added on the way out
+    int mct = 0;               // fused RCT (W53) / ICT (W97) on comps 0-2 when C>=3
+    int quant = Q_NONE;
+    int quality = 100;
+    int num_res_jobs = 6;      // resolutions for the encodeTile job enumeration
+    int cb_w = 64, cb_h = 64;
+    int coder = J2K_CODER_MQ;
+    int tile_first = 0, tile_count = 0;
+    bool frame_is_f64 = false; // unit 9-7 calls: source/destination "frame" is f64
+    bool operator==(const PlanSpec &o) const;
+};
+
+struct Group {                 // one launch unit: a single component or an MCT triple of one tile
+    int tile;                  // shard-local tile index
+    int comp0, nc;
+    int x0, y0, w, h;
+    int64_t coef_off[3];       // element offsets into the coefficient buffer
+    int64_t scrA_off[3], scrB_off[3];
+};
+
+struct LevelTab {
+    DwtPlane *d_planes = nullptr;
+    DwtJob *d_jobs = nullptr;
+    int njobs = 0, nplanes = 0;
+    int cpl = 2, vec = 0, ncomp = 1;
+    int64_t alg_bytes = 0;
+};
+
+}  // namespace j2k
+
+struct j2k_plan {
+    j2k_ctx *ctx = nullptr;
+    j2k::PlanSpec spec;
+    int tiles_x = 1, tiles_y = 1, tile_first = 0, tile_count = 1;
+    std::vector<j2k::Group> groups;
+    std::vector<int64_t> plane_desc;        // 7 x int64 per tile-component
+    int64_t coeff_elems = 0, scrA_elems = 0, scrB_elems = 0;
+    // [cls][level]: cls 0 = single-component groups, cls 1 = MCT triples
+    std::vector<j2k::LevelTab> fwd[2], inv[2];
+    void *d_scrA = nullptr, *d_scrB = nullptr;   // int32 (5-3) or f64 (9-7) prefixes
+    // code-block jobs
+    std::vector<j2k_block> blocks;          // plane = shard-local tile-component index
+    std::vector<int32_t> block_tile;        // tile of each job
+    std::vector<uint64_t> slot_off;         // byte offset of each job's worst-case slot
+    std::vector<uint64_t> dec_off;          // element offset of each job's decoded block
+    j2k::BlockJob *d_bjobs = nullptr;       // out_off = slot byte offset (encode)
+    j2k::BlockJob *d_djobs = nullptr;       // out_off = decoded element offset (decode)
+    int64_t bytes_cap = 0, decoded_elems = 0, block_samples = 0;
+    int64_t dwt_bytes = 0, dwt_level0_bytes = 0;
+    // device workspaces owned by the plan for j2k_encode_frame
+    void *d_frame = nullptr, *d_coeff = nullptr, *d_slots = nullptr, *d_stream = nullptr;
+    void *d_lens = nullptr, *d_numbps = nullptr, *d_offs = nullptr;
+};

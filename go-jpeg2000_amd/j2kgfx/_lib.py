@@ -1,0 +1,90 @@
+"""ctypes loader for libj2kgfx.so -- the HIP implementation behind include/j2kgfx.h.
+
+No fallback of any kind: a missing library or a missing GPU raises.
+"""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_PKG), "libj2kgfx.so")
+
+OK = 0
+ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_GO_PANIC, ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6
+BAND_LL, BAND_HL, BAND_LH, BAND_HH = 0, 1, 2, 3
+CODER_MQ, CODER_HT = 0, 1
+
+
+class J2KError(RuntimeError):
+    def __init__(self, status, msg=""):
+        self.status = status
+        super().__init__("j2kgfx status %d: %s" % (status, msg))
+
+
+class Block(C.Structure):
+    _fields_ = [("plane", C.c_int32), ("band", C.c_int32), ("x0", C.c_int32), ("y0", C.c_int32),
+                ("w", C.c_int32), ("h", C.c_int32)]
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "width", "height", "ncomp", "precision", "is_signed", "lossless", "quality", "num_resolutions",
+        "cb_w", "cb_h", "tile_w", "tile_h", "coder", "tile_first", "tile_count")]
+
+
+class PlanInfo(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in (
+        "tiles", "planes", "blocks", "coeff_elems", "bytes_cap", "dwt_bytes", "dwt_level0_bytes",
+        "block_samples", "decoded_elems")]
+
+
+# every symbol include/j2kgfx.h declares (tests/test_abi_symbols.py checks the header against this list)
+SYMBOLS = [
+    "j2k_ctx_create", "j2k_ctx_destroy", "j2k_ctx_sync", "j2k_ctx_stream", "j2k_ctx_last_error",
+    "j2k_status_string", "j2k_version",
+    "j2k_dc_level_shift_forward", "j2k_dc_level_shift_inverse", "j2k_forward_rct", "j2k_inverse_rct",
+    "j2k_forward_ict", "j2k_inverse_ict",
+    "j2k_forward53", "j2k_inverse53", "j2k_forward97", "j2k_inverse97",
+    "j2k_forward2d53", "j2k_inverse2d53", "j2k_forward2d97", "j2k_inverse2d97",
+    "j2k_decompose_multilevel53", "j2k_reconstruct_multilevel53",
+    "j2k_decompose_multilevel97", "j2k_reconstruct_multilevel97",
+    "j2k_tcd_apply_forward_dwt", "j2k_tcd_apply_inverse_dwt",
+    "j2k_encode_blocks", "j2k_decode_blocks", "j2k_block_bound",
+    "j2k_plan_create", "j2k_plan_destroy", "j2k_plan_get_info", "j2k_plan_get_blocks", "j2k_plan_get_planes",
+    "j2k_plan_forward", "j2k_plan_inverse", "j2k_plan_encode_blocks", "j2k_plan_compact",
+    "j2k_plan_decode_blocks", "j2k_plan_get_decoded_offsets", "j2k_encode_frame",
+]
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (does not touch the GPU)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise J2KError(ERR_NO_DEVICE, "libj2kgfx.so not built (%s); run `make -C go-jpeg2000_amd` or "
+                                          "__graft_entry__.build()" % LIB_PATH)
+        # One HIP runtime per process: torch bundles its own libamdhip64 (same soname as
+        # /opt/rocm's).  Importing torch FIRST makes libj2kgfx bind to that copy; loading ours
+        # first would bring in a second runtime and torch would then see "No HIP GPUs".
+        try:
+            import torch  # noqa: F401
+        except ImportError:  # plain C-ABI use without torch is fine (single runtime from /opt/rocm)
+            pass
+        L = C.CDLL(LIB_PATH)
+        L.j2k_status_string.restype = C.c_char_p
+        L.j2k_version.restype = C.c_char_p
+        L.j2k_ctx_last_error.restype = C.c_char_p
+        L.j2k_ctx_last_error.argtypes = [C.c_void_p]
+        L.j2k_ctx_stream.restype = C.c_void_p
+        L.j2k_ctx_stream.argtypes = [C.c_void_p]
+        L.j2k_block_bound.restype = C.c_size_t
+        L.j2k_block_bound.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.j2k_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.j2k_ctx_destroy.argtypes = [C.c_void_p]
+        L.j2k_ctx_destroy.restype = None
+        L.j2k_ctx_sync.argtypes = [C.c_void_p]
+        L.j2k_plan_destroy.argtypes = [C.c_void_p]
+        L.j2k_plan_destroy.restype = None
+        _lib = L
+    return _lib

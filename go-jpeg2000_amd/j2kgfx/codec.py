@@ -1,0 +1,151 @@
+"""Batched frame pipeline over the plan calls of the C ABI: the device-side mirror of
+encoder.preprocess (encoder.go:216-281), encoder.encodeTile's job loop (encoder.go:597-688),
+tcd.TileDecoder.DecodeCodeBlock / ApplyInverseDWT (tcd.go:393-437) and the tail of
+decoder.decodeTiles (decoder.go:321-348).
+
+torch is used only to own device memory (tensors on `cuda:<ctx.device>`); all kernels are
+launched by libj2kgfx on the context's own HIP stream.  Callers that produce inputs with
+torch ops must torch.cuda.synchronize() first (bench.py and the tests do).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .context import default_context
+
+BLOCK_DTYPE = np.dtype([("plane", "<i4"), ("band", "<i4"), ("x0", "<i4"), ("y0", "<i4"), ("w", "<i4"), ("h", "<i4")])
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class FramePlan:
+    def __init__(self, width, height, ncomp, precision=8, lossless=True, quality=0, num_resolutions=6,
+                 cb=(64, 64), tile=(0, 0), coder=_lib.CODER_MQ, is_signed=False, tile_first=0, tile_count=0,
+                 ctx=None):
+        self.ctx = ctx or default_context()
+        L = self.ctx.L
+        self.params = _lib.Params(width=width, height=height, ncomp=ncomp, precision=precision,
+                                  is_signed=int(bool(is_signed)), lossless=int(bool(lossless)), quality=quality,
+                                  num_resolutions=num_resolutions, cb_w=cb[0], cb_h=cb[1], tile_w=tile[0],
+                                  tile_h=tile[1], coder=coder, tile_first=tile_first, tile_count=tile_count)
+        h = C.c_void_p()
+        self.ctx.check(L.j2k_plan_create(self.ctx.h, C.byref(self.params), C.byref(h)))
+        self.h = h
+        info = _lib.PlanInfo()
+        self.ctx.check(L.j2k_plan_get_info(self.h, C.byref(info)))
+        self.info = info
+        self.width, self.height, self.ncomp = width, height, ncomp
+        self.device = "cuda:%d" % self.ctx.device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.L.j2k_plan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- geometry ---------------------------------------------------------------
+    def blocks(self):
+        n = int(self.info.blocks)
+        out = np.zeros(n, dtype=BLOCK_DTYPE)
+        if n:
+            self.ctx.check(self.ctx.L.j2k_plan_get_blocks(self.h, out.ctypes.data_as(C.c_void_p), C.c_size_t(n)))
+        return out
+
+    def planes(self):
+        """(n,7) int64: tile, comp, x0, y0, w, h, coefficient offset."""
+        n = int(self.info.planes)
+        out = np.zeros((n, 7), dtype=np.int64)
+        self.ctx.check(self.ctx.L.j2k_plan_get_planes(self.h, out.ctypes.data_as(C.c_void_p), C.c_size_t(n)))
+        return out
+
+    def decoded_offsets(self):
+        n = int(self.info.blocks)
+        out = np.zeros(max(n, 1), dtype=np.uint64)
+        self.ctx.check(self.ctx.L.j2k_plan_get_decoded_offsets(self.h, out.ctypes.data_as(C.c_void_p), C.c_size_t(n)))
+        return out[:n]
+
+    # ---- device buffers -----------------------------------------------------------
+    def empty(self, n, dtype):
+        t = _torch()
+        return t.empty(max(int(n), 4), dtype=dtype, device=self.device)
+
+    def alloc_coeff(self):
+        return self.empty(self.info.coeff_elems, _torch().int32)
+
+    def alloc_frame(self):
+        t = _torch()
+        return t.empty((self.ncomp, self.height, self.width), dtype=t.int32, device=self.device)
+
+    @staticmethod
+    def _p(t):
+        return C.c_void_p(t.data_ptr())
+
+    # ---- stages (asynchronous on the ctx stream) ------------------------------------
+    def forward(self, frame, coeff=None):
+        """encoder.preprocess for every tile-component: frame int32 [C,H,W] -> coefficient buffer."""
+        coeff = coeff if coeff is not None else self.alloc_coeff()
+        assert frame.is_contiguous() and frame.numel() == self.ncomp * self.height * self.width
+        self.ctx.check(self.ctx.L.j2k_plan_forward(self.h, self._p(frame), self._p(coeff)))
+        return coeff
+
+    def inverse(self, coeff, frame=None):
+        frame = frame if frame is not None else self.alloc_frame()
+        self.ctx.check(self.ctx.L.j2k_plan_inverse(self.h, self._p(coeff), self._p(frame)))
+        return frame
+
+    def encode_blocks(self, coeff, slots=None, lens=None, numbps=None):
+        t = _torch()
+        n = int(self.info.blocks)
+        slots = slots if slots is not None else self.empty(self.info.bytes_cap, t.uint8)
+        lens = lens if lens is not None else self.empty(n, t.int32)
+        numbps = numbps if numbps is not None else self.empty(n, t.uint8)
+        self.ctx.check(self.ctx.L.j2k_plan_encode_blocks(self.h, self._p(coeff), self._p(slots), self._p(lens),
+                                                         self._p(numbps)))
+        return slots, lens, numbps
+
+    def compact(self, slots, lens, offs=None, stream=None):
+        t = _torch()
+        n = int(self.info.blocks)
+        offs = offs if offs is not None else self.empty(n + 1, t.int64)
+        stream = stream if stream is not None else self.empty(self.info.bytes_cap, t.uint8)
+        self.ctx.check(self.ctx.L.j2k_plan_compact(self.h, self._p(slots), self._p(lens), self._p(offs),
+                                                   self._p(stream)))
+        return offs, stream
+
+    def decode_blocks(self, stream, offs, lens, numbps, decoded=None):
+        t = _torch()
+        decoded = decoded if decoded is not None else self.empty(self.info.decoded_elems, t.int32)
+        self.ctx.check(self.ctx.L.j2k_plan_decode_blocks(self.h, self._p(stream), self._p(offs), self._p(lens),
+                                                         self._p(numbps), self._p(decoded)))
+        return decoded
+
+    # ---- host planes in, bytes out (encoder.preprocess + encodeTile) --------------------
+    def encode_frame(self, planes):
+        """planes: list of C int32 ndarrays (H*W).  Single tile: planes are overwritten with the
+        coefficients like e.componentData.  Returns dict(bytes, lens, numbps, tile_offs, coeff)."""
+        n = int(self.info.blocks)
+        arr = (C.POINTER(C.c_int32) * len(planes))()
+        for i, p in enumerate(planes):
+            assert p.dtype == np.int32 and p.flags.c_contiguous and p.size == self.width * self.height
+            arr[i] = p.ctypes.data_as(C.POINTER(C.c_int32))
+        out = np.zeros(max(int(self.info.bytes_cap), 16), dtype=np.uint8)
+        coeff = np.zeros(max(int(self.info.coeff_elems), 4), dtype=np.int32)
+        lens = np.zeros(max(n, 1), dtype=np.uint32)
+        nbps = np.zeros(max(n, 1), dtype=np.uint8)
+        toffs = np.zeros(int(self.info.tiles) + 1, dtype=np.uint64)
+        olen = C.c_size_t(0)
+        self.ctx.check(self.ctx.L.j2k_encode_frame(
+            self.h, arr, coeff.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.c_size_t(out.size),
+            C.byref(olen), toffs.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p),
+            nbps.ctypes.data_as(C.c_void_p)))
+        return dict(bytes=out[:olen.value].copy(), lens=lens[:n].copy(), numbps=nbps[:n].copy(), tile_offs=toffs,
+                    coeff=coeff)

@@ -1,0 +1,49 @@
+"""j2k_ctx wrapper."""
+import ctypes as C
+
+from . import _lib
+
+
+class Context:
+    def __init__(self, device=0):
+        L = _lib.lib()
+        h = C.c_void_p()
+        st = L.j2k_ctx_create(int(device), C.byref(h))
+        if st != _lib.OK:
+            raise _lib.J2KError(st, L.j2k_status_string(st).decode())
+        self.h = h
+        self.device = int(device)
+        self.L = L
+
+    def check(self, st):
+        if st != _lib.OK:
+            raise _lib.J2KError(st, "%s: %s" % (self.L.j2k_status_string(st).decode(),
+                                                 self.L.j2k_ctx_last_error(self.h).decode()))
+
+    def sync(self):
+        self.check(self.L.j2k_ctx_sync(self.h))
+
+    @property
+    def stream(self):
+        return self.L.j2k_ctx_stream(self.h)
+
+    def close(self):
+        if self.h:
+            self.L.j2k_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default = None
+
+
+def default_context():
+    global _default
+    if _default is None:
+        _default = Context(0)
+    return _default

@@ -1,0 +1,199 @@
+/*
+ * j2kgfx.h -- C ABI of libj2kgfx.so: the MI355X (gfx950) implementation of the
+ * go-jpeg2000 tile-component hot path (DC shift -> MCT -> multi-level DWT ->
+ * code-block entropy coding, and the inverse).
+ *
+ * This is the drop-in boundary.  Every entry point names the
+ * reference function (file:line in mrjoshuak/go-jpeg2000) whose body a cgo shim
+ * would replace with it; INTEGRATION.md shows the Go side.  Plain pointers and
+ * sizes only.  All functions return J2K_OK (0) or a negative status; none abort.
+ *
+ * Two families:
+ *   1. "host" calls -- caller-owned HOST buffers, mutated in place exactly like
+ *      the Go slices they stand for; synchronous (H2D, kernels, D2H inside).
+ *      One call per reference function, for unit parity and for the cgo shim.
+ *   2. "plan" calls -- a frame geometry compiled once into device job tables;
+ *      DEVICE pointers, asynchronous on the context's HIP stream.  This is the
+ *      batched, tile-component-granular path the encoder/decoder drivers use
+ *      (per-call cgo + PCIe cost forbids per-block calls).
+ *
+ * There is no CPU fallback: without a usable HIP device every compute call
+ * returns J2K_ERR_NO_DEVICE.
+ */
+#ifndef J2KGFX_H
+#define J2KGFX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define J2K_OK 0
+#define J2K_ERR_INVALID_ARG (-1)
+#define J2K_ERR_NO_DEVICE (-2)
+#define J2K_ERR_HIP (-3)
+#define J2K_ERR_CAPACITY (-4)     /* caller's output buffer too small */
+#define J2K_ERR_GO_PANIC (-5)     /* input on which the reference itself panics / never returns */
+#define J2K_ERR_UNSUPPORTED (-6)
+
+/* entropy.BandLL..BandHH (internal/entropy/t1.go:125-130) */
+#define J2K_BAND_LL 0
+#define J2K_BAND_HL 1
+#define J2K_BAND_LH 2
+#define J2K_BAND_HH 3
+
+#define J2K_CODER_MQ 0            /* entropy.T1 (EncodeFast5 / Decode)          */
+#define J2K_CODER_HT 1            /* entropy.HTEncoder / HTDecoder (bug for bug) */
+
+typedef struct j2k_ctx j2k_ctx;   /* one HIP device + one stream + workspaces; single-threaded */
+typedef struct j2k_plan j2k_plan; /* frame geometry compiled to device job tables */
+
+/* ---- context --------------------------------------------------------------- */
+int j2k_ctx_create(int device, j2k_ctx **out);
+void j2k_ctx_destroy(j2k_ctx *ctx);
+int j2k_ctx_sync(j2k_ctx *ctx);                 /* hipStreamSynchronize on the ctx stream */
+void *j2k_ctx_stream(j2k_ctx *ctx);             /* the hipStream_t, for event timing / interop */
+const char *j2k_ctx_last_error(j2k_ctx *ctx);   /* text of the last non-OK status */
+const char *j2k_status_string(int status);
+const char *j2k_version(void);
+
+/* ==== 1. host calls: one per reference function ============================= */
+
+/* mct.DCLevelShiftForward / Inverse   (internal/mct/mct.go:96-101, 113-118) */
+int j2k_dc_level_shift_forward(j2k_ctx *ctx, int32_t *data, size_t n, int precision);
+int j2k_dc_level_shift_inverse(j2k_ctx *ctx, int32_t *data, size_t n, int precision);
+/* mct.ForwardRCT / InverseRCT         (mct.go:28-38, 56-66) */
+int j2k_forward_rct(j2k_ctx *ctx, int32_t *r, int32_t *g, int32_t *b, size_t n);
+int j2k_inverse_rct(j2k_ctx *ctx, int32_t *y, int32_t *u, int32_t *v, size_t n);
+/* mct.ForwardICT / InverseICT         (mct.go:14-24, 43-53) */
+int j2k_forward_ict(j2k_ctx *ctx, double *r, double *g, double *b, size_t n);
+int j2k_inverse_ict(j2k_ctx *ctx, double *y, double *cb, double *cr, size_t n);
+
+/* dwt.Forward53 / Inverse53 (1-D)     (internal/dwt/dwt.go:73-118, 122-147) */
+int j2k_forward53(j2k_ctx *ctx, int32_t *data, int length);
+int j2k_inverse53(j2k_ctx *ctx, int32_t *data, int length);
+/* dwt.Forward97 / Inverse97 (1-D)     (dwt.go:161-210, 213-262) */
+int j2k_forward97(j2k_ctx *ctx, double *data, int length);
+int j2k_inverse97(j2k_ctx *ctx, double *data, int length);
+/* dwt.Forward2D53 / Inverse2D53 / Forward2D97 / Inverse2D97 (dwt.go:356-473) */
+int j2k_forward2d53(j2k_ctx *ctx, int32_t *data, int width, int height);
+int j2k_inverse2d53(j2k_ctx *ctx, int32_t *data, int width, int height);
+int j2k_forward2d97(j2k_ctx *ctx, double *data, int width, int height);
+int j2k_inverse2d97(j2k_ctx *ctx, double *data, int width, int height);
+/* dwt.DecomposeMultiLevel53/97, ReconstructMultiLevel53/97 (dwt.go:524-573);
+ * the reference's contiguous-prefix level layout is reproduced exactly. */
+int j2k_decompose_multilevel53(j2k_ctx *ctx, int32_t *data, int width, int height, int levels);
+int j2k_reconstruct_multilevel53(j2k_ctx *ctx, int32_t *data, int width, int height, int levels);
+int j2k_decompose_multilevel97(j2k_ctx *ctx, double *data, int width, int height, int levels);
+int j2k_reconstruct_multilevel97(j2k_ctx *ctx, double *data, int width, int height, int levels);
+
+/* tcd.TileEncoder.ApplyForwardDWT / TileDecoder.ApplyInverseDWT on one
+ * tile-component (internal/tcd/tcd.go:508-534, 416-437): reversible -> 5-3 int32;
+ * else int32->f64, 9-7, int32(v +- 0.5) forward / int32(v + 0.5) inverse. */
+int j2k_tcd_apply_forward_dwt(j2k_ctx *ctx, int32_t *data, int width, int height, int levels, int reversible);
+int j2k_tcd_apply_inverse_dwt(j2k_ctx *ctx, int32_t *data, int width, int height, int levels, int reversible);
+
+/* One code-block job of a batch.  For encode: the window (x0,y0,w,h) of plane
+ * `plane` (stride = that plane's width) is the block, exactly what
+ * encoder.extractCodeBlockData hands to T1.SetData (encoder.go:763-795).
+ * For decode: bytes [in_off, in_off+in_len) of the input stream, numbps, band. */
+typedef struct {
+    int32_t plane;      /* index into the planes[] array of the call */
+    int32_t band;       /* J2K_BAND_* */
+    int32_t x0, y0;     /* window origin in the plane */
+    int32_t w, h;       /* block size (actualWidth, actualHeight) */
+} j2k_block;
+
+/* entropy.(*T1).SetData + Encode(band) (t1.go:292-304, t1_fast5.go:10-899) or
+ * entropy.(*HTEncoder).SetData + Encode(band) (ht.go:935-1045) for n blocks.
+ * planes[i] is a HOST int32 plane of plane_w[i] x plane_h[i].  Output: block j's
+ * bytes at out[offs[j] .. offs[j]+lens[j]) in job order (lens[j]==0 <=> Go nil),
+ * numbps[j] = bit length of max |x| (the value T1.Decode must be told). */
+int j2k_encode_blocks(j2k_ctx *ctx, int coder, const int32_t *const *planes, const int32_t *plane_w,
+                      const int32_t *plane_h, int nplanes, const j2k_block *blocks, size_t nblocks,
+                      uint8_t *out, size_t cap, uint64_t *offs, uint32_t *lens, uint8_t *numbps,
+                      size_t *total);
+/* entropy.NewT1(w,h).Decode(bytes,numBPS,band) (t1.go:1261-1292) or a fresh
+ * entropy.NewHTDecoder(w,h).Decode(bytes,numBitplanes,band) (ht.go:93-150) for n
+ * blocks.  Block j's coefficients (w*h int32, dense) land at coeffs + coeff_offs[j]. */
+int j2k_decode_blocks(j2k_ctx *ctx, int coder, const uint8_t *bytes, const uint64_t *offs,
+                      const uint32_t *lens, const uint8_t *numbps, const j2k_block *blocks,
+                      size_t nblocks, int32_t *coeffs, const uint64_t *coeff_offs);
+/* worst-case bytes one w x h block can produce (sizing of `out`) */
+size_t j2k_block_bound(int coder, int w, int h);
+
+/* ==== 2. plan calls: batched frame pipeline on device buffers ================ */
+
+typedef struct {
+    int32_t width, height;      /* frame size in samples                                     */
+    int32_t ncomp;              /* components; planar int32 [C][H][W] (encoder.componentData) */
+    int32_t precision;          /* bits per sample -> DC shift 1<<(p-1)  (encoder.go:218-220) */
+    int32_t is_signed;          /* decode: skip DC shift for signed comps (decoder.go:344-348) */
+    int32_t lossless;           /* 1: RCT + 5-3 ; 0: ICT + 9-7 + quantise (encoder.go:223-277) */
+    int32_t quality;            /* Options.Quality, <=0 -> 100 (encoder.go:265-269)           */
+    int32_t num_resolutions;    /* Options.NumResolutions; levels = n-1, <=0 -> 5; jobs: <=0 -> 6 */
+    int32_t cb_w, cb_h;         /* REAL code-block size, 1<<(CodeBlockSize+2) (encoder.go:606-613) */
+    int32_t tile_w, tile_h;     /* 0 = one tile (the reference); else tile t == the reference
+                                   pipeline run on the cropped sub-image          */
+    int32_t coder;              /* J2K_CODER_MQ | J2K_CODER_HT                                */
+    int32_t tile_first, tile_count; /* shard: tiles [first, first+count); count<=0 -> all     */
+} j2k_params;
+
+typedef struct {
+    int64_t tiles;              /* tiles in this shard                                        */
+    int64_t planes;             /* tile-components                                            */
+    int64_t blocks;             /* code-block jobs                                            */
+    int64_t coeff_elems;        /* int32 elements of the coefficient buffer                   */
+    int64_t bytes_cap;          /* bytes of the worst-case slotted block output               */
+    int64_t dwt_bytes;          /* algorithmic bytes of the multi-level DWT       */
+    int64_t dwt_level0_bytes;   /* algorithmic bytes of the level-0 kernel launch             */
+    int64_t block_samples;      /* samples the block coder reads                              */
+    int64_t decoded_elems;      /* int32 elements of the dense decoded-block buffer           */
+} j2k_plan_info;
+
+int j2k_plan_create(j2k_ctx *ctx, const j2k_params *params, j2k_plan **out);
+void j2k_plan_destroy(j2k_plan *plan);
+int j2k_plan_get_info(const j2k_plan *plan, j2k_plan_info *info);
+/* copy out the job list (reference order: tile -> comp -> res -> band -> cby -> cbx) */
+int j2k_plan_get_blocks(const j2k_plan *plan, j2k_block *blocks, size_t cap);
+/* per-plane geometry: tile index, component, x0, y0, w, h, coefficient offset (7 x int64 each) */
+int j2k_plan_get_planes(const j2k_plan *plan, int64_t *desc7, size_t cap_planes);
+
+/* encoder.preprocess (encoder.go:216-281) for every tile-component of the shard:
+ * d_frame = device int32 [C][H][W] pixels (read only), d_coeff = device coefficient
+ * buffer (coeff_elems int32; each tile-component dense w_t x h_t at its offset). */
+int j2k_plan_forward(j2k_plan *plan, const int32_t *d_frame, int32_t *d_coeff);
+/* inverse path: ApplyInverseDWT per tile-component + inverse MCT + DC shift
+ * (tcd.go:416-437, decoder.go:321-348): d_coeff -> d_frame (pixels). */
+int j2k_plan_inverse(j2k_plan *plan, const int32_t *d_coeff, int32_t *d_frame);
+/* encoder.encodeTile job loop (encoder.go:616-688), sequential semantics: every job's
+ * bytes into worst-case slots of d_slots (bytes_cap), lengths into d_lens (u32 per job),
+ * bit-plane counts into d_numbps (u8 per job). */
+int j2k_plan_encode_blocks(j2k_plan *plan, const int32_t *d_coeff, uint8_t *d_slots,
+                           uint32_t *d_lens, uint8_t *d_numbps);
+/* exclusive scan of d_lens -> d_offs (u64 per job, +1 total at the end) and gather of the
+ * slots into the dense stream d_stream (concatenation in job order, encoder.go:684). */
+int j2k_plan_compact(j2k_plan *plan, const uint8_t *d_slots, const uint32_t *d_lens,
+                     uint64_t *d_offs, uint8_t *d_stream);
+/* tcd.TileDecoder.DecodeCodeBlock (tcd.go:393-413) for every job: dense stream + offsets
+ * + lens + numbps -> d_decoded (decoded_elems int32, block j dense at its job offset). */
+int j2k_plan_decode_blocks(j2k_plan *plan, const uint8_t *d_stream, const uint64_t *d_offs,
+                           const uint32_t *d_lens, const uint8_t *d_numbps, int32_t *d_decoded);
+/* job j's offset (in int32 elements) into d_decoded */
+int j2k_plan_get_decoded_offsets(const j2k_plan *plan, uint64_t *offs, size_t cap);
+
+/* Whole shard from HOST planes, mirroring encoder.preprocess + encodeTile
+ * (encoder.go:216-281, 597-688): planes[c] = host int32 W*H, mutated in place to
+ * the coefficients like e.componentData when the frame is a single tile (with tiles
+ * the coefficients are returned tile-plane by tile-plane in `coeff` if non-NULL).
+ * out receives the concatenated block bytes of all tiles in job order;
+ * tile_offs[t] (tiles+1 entries) delimits each tile's data for SOT assembly. */
+int j2k_encode_frame(j2k_plan *plan, int32_t *const *planes, int32_t *coeff, uint8_t *out, size_t cap,
+                     size_t *out_len, uint64_t *tile_offs, uint32_t *lens, uint8_t *numbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
