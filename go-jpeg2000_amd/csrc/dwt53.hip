@@ -397,6 +397,24 @@ __device__ __forceinline__ void inv_finish_row(int32_t *__restrict__ dst, const 
     }
 }
 
+// xe[q] = s[q] - ((d[q-1] + d[q] + 2) >> 2) with the mirror rules of dwt.go:132-138
+template <int CPL, int NC, bool VEC>
+__device__ __forceinline__ void inv_compute_xe(int q, int nhigh, const FwdRow<CPL, NC, VEC> &S, const FwdRow<CPL, NC, VEC> &Dp,
+                                               const FwdRow<CPL, NC, VEC> &Dc, int (&xl)[NC][CPL / 2], int (&xh)[NC][CPL / 2]) {
+    constexpr int H = CPL / 2;
+    const bool has_d = q < nhigh;
+#pragma unroll
+    for (int k = 0; k < NC; k++)
+#pragma unroll
+        for (int j = 0; j < H; j++) {
+            int dpl = Dp.lo[k][j], dph = Dp.hi[k][j];
+            int dcl = has_d ? Dc.lo[k][j] : dpl, dch = has_d ? Dc.hi[k][j] : dph;
+            if (q == 0) { dpl = dcl; dph = dch; }
+            xl[k][j] = wsub(S.lo[k][j], avg2(dpl, dcl));
+            xh[k][j] = wsub(S.hi[k][j], avg2(dph, dch));
+        }
+}
+
 template <int CPL, int NC, bool VEC>
 __global__ __launch_bounds__(256) void dwt53_inv_kernel(const DwtJob *__restrict__ jobs, int njobs,
                                                         const DwtPlane *__restrict__ planes,
@@ -435,23 +453,10 @@ __global__ __launch_bounds__(256) void dwt53_inv_kernel(const DwtJob *__restrict
     //   xo[q] = d[q] + ((xe[q] + xe[q+1]) >> 1)      (no xe[q+1] := xe[q])
     Row s, dcur, dprev;
     int xe_lo[NC][H], xe_hi[NC][H];
-    auto compute_xe = [&](int q, const Row &S, const Row &Dp, const Row &Dc, int (&xl)[NC][H], int (&xh)[NC][H]) {
-        const bool has_d = q < nhigh;
-#pragma unroll
-        for (int k = 0; k < NC; k++)
-#pragma unroll
-            for (int j = 0; j < H; j++) {
-                int dpl = Dp.lo[k][j], dph = Dp.hi[k][j];
-                int dcl = has_d ? Dc.lo[k][j] : dpl, dch = has_d ? Dc.hi[k][j] : dph;
-                if (q == 0) { dpl = dcl; dph = dch; }
-                xl[k][j] = wsub(S.lo[k][j], avg2(dpl, dcl));
-                xh[k][j] = wsub(S.hi[k][j], avg2(dph, dch));
-            }
-    };
     inv_load_row<CPL, NC, VEC>(coef, prev, P, pr_begin, p0, c, s);
     if (pr_begin < nhigh) inv_load_row<CPL, NC, VEC>(coef, prev, P, halfH + pr_begin, p0, c, dcur);
     if (pr_begin > 0) inv_load_row<CPL, NC, VEC>(coef, prev, P, halfH + pr_begin - 1, p0, c, dprev);
-    compute_xe(pr_begin, s, dprev, dcur, xe_lo, xe_hi);
+    inv_compute_xe<CPL, NC, VEC>(pr_begin, nhigh, s, dprev, dcur, xe_lo, xe_hi);
     for (int q = pr_begin; q < pr_end; q++) {
         const bool has_d = q < nhigh;         // row 2q+1 exists
         const bool has_next = (q + 1) < halfH;  // row 2q+2 exists
@@ -460,7 +465,7 @@ __global__ __launch_bounds__(256) void dwt53_inv_kernel(const DwtJob *__restrict
         if (has_next) {
             inv_load_row<CPL, NC, VEC>(coef, prev, P, q + 1, p0, c, sn);
             if (q + 1 < nhigh) inv_load_row<CPL, NC, VEC>(coef, prev, P, halfH + q + 1, p0, c, dn);
-            compute_xe(q + 1, sn, dcur, dn, xn_lo, xn_hi);
+            inv_compute_xe<CPL, NC, VEC>(q + 1, nhigh, sn, dcur, dn, xn_lo, xn_hi);
         }
         inv_finish_row<CPL, NC, VEC>(dst, P, 2 * q, c, owned, xe_lo, xe_hi, dc_shift, fin);
         if (has_d) {

@@ -10,7 +10,7 @@ struct j2k_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
     std::string last_error;
-    int band_prows = 16;       // pair-rows per wavefront band (tunable: J2K_BAND_PROWS)
+    int band_prows = 4;        // pair-rows per wavefront band (tunable: J2K_BAND_PROWS)
     int force_novec = 0;       // J2K_FORCE_NOVEC=1: always take the scalar-access kernels (testing)
     // cached single-plane plans for the host (unit) calls
     std::vector<j2k_plan *> cache;

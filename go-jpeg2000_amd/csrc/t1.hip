@@ -1,0 +1,500 @@
+// t1.hip -- the reference's MQ-based Tier-1 block coder (what public jpeg2000.Encode runs).
+//
+//   T1.SetData + T1.Encode == EncodeFast5   internal/entropy/t1.go:292-304, t1_fast5.go:10-899
+//   mqByteOutLocal                          internal/entropy/t1_fast.go:11-34
+//   T1.Decode + decode*Pass, MQDecoder      internal/entropy/t1.go:1261-1410, mqc.go:352-497
+//   MQ state table / contexts / LUT rules   mqc.go:21-166, t1_luts.go:32-231
+//
+// Reference behaviour reproduced (it is NOT ISO 15444-1 EBCOT): every bit-plane, including the
+// first, runs SigProp (raster order) -> MagRef (raster order) -> Cleanup (4-row stripes, column
+// by column, run-length mode); all contexts start at state 0 except UNI = 92; the sign-context
+// LUT maps (hc==1, vc not in {0,1}) to SC1 and hc==2 to SC3; output = MQ bytes without the
+// leading sentinel, trailing 0xFF dropped, nil for an all-zero block.
+//
+// Kernel shape (round 1): one code-block per wavefront.  The wave loads the block, strips the
+// signs, finds the bit-plane count and builds the LUTs cooperatively; the context-adaptive
+// state machine itself is sequential by construction (every decision's context depends on the
+// significance state left by the previous decision, and the MQ interval on every previous
+// symbol) and runs on lane 0 with flags + magnitudes + tables in LDS (or in a global
+// workspace for blocks too large for LDS).
+#include "j2k_internal.h"
+
+namespace j2k {
+
+enum { T1Sig = 1, T1Visit = 2, T1Refine = 4, T1SignNeg = 8, T1SigN = 16, T1SigS = 32, T1SigE = 64, T1SigW = 128 };  // t1.go:74-91
+enum { CtxSC0 = 9, CtxMag0 = 14, CtxMag1 = 15, CtxMag2 = 16, CtxRL = 17, CtxUni = 18, NumContexts = 19 };         // mqc.go:135-166
+
+// ISO/IEC 15444-1 Table C.2 (Qe, NMPS, NLPS, SWITCH); expanded to the reference's 94-entry
+// MPS-interleaved form (mqc.go:21-116) by rule: state 2i+m, nmps = 2*NMPS+m, nlps = 2*NLPS + (SWITCH ? 1-m : m).
+__device__ __constant__ uint16_t c_iso_qe[47] = {
+    0x5601, 0x3401, 0x1801, 0x0AC1, 0x0521, 0x0221, 0x5601, 0x5401, 0x4801, 0x3801, 0x3001, 0x2401, 0x1C01, 0x1601, 0x5601, 0x5401,
+    0x5101, 0x4801, 0x3801, 0x3401, 0x3001, 0x2801, 0x2401, 0x2201, 0x1C01, 0x1801, 0x1601, 0x1401, 0x1201, 0x1101, 0x0AC1, 0x09C1,
+    0x08A1, 0x0521, 0x0441, 0x02A1, 0x0221, 0x0141, 0x0111, 0x0085, 0x0049, 0x0025, 0x0015, 0x0009, 0x0005, 0x0001, 0x5601};
+__device__ __constant__ uint8_t c_iso_nmps[47] = {1, 2, 3, 4, 5, 38, 7, 8, 9, 10, 11, 12, 13, 29, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24,
+                                                  25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 45, 46};
+__device__ __constant__ uint8_t c_iso_nlps[47] = {1, 6, 9, 12, 29, 33, 6, 14, 14, 14, 17, 18, 20, 21, 14, 14, 15, 16, 17, 18, 19, 19, 20, 21,
+                                                  22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 46};
+__device__ __constant__ uint8_t c_iso_switch[47] = {1, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                                    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+// LDS-resident tables shared by encoder and decoder
+struct T1Tables {
+    uint32_t mq[96];      // qe | nmps << 16 | nlps << 24
+    uint8_t zc[256];      // lutZCCtx for this block's band (t1_luts.go:34-110)
+    uint8_t sc[256];      // lutSignCtx | lutSignPred << 3 (t1_luts.go:153-230)
+    uint8_t ctx[32];      // MQ context states
+};
+
+__device__ void build_tables(T1Tables &T, int band, int lane) {
+    for (int s = lane; s < 94; s += 64) {
+        const int i = s >> 1, m = s & 1;
+        const uint32_t nm = 2 * c_iso_nmps[i] + m;
+        const uint32_t nl = 2 * c_iso_nlps[i] + (c_iso_switch[i] ? 1 - m : m);
+        T.mq[s] = (uint32_t)c_iso_qe[i] | nm << 16 | nl << 24;
+    }
+    for (int p = lane; p < 256; p += 64) {
+        const int w = p & 1, e = (p >> 1) & 1, n = (p >> 2) & 1, s = (p >> 3) & 1;
+        const int d = ((p >> 4) & 1) + ((p >> 5) & 1) + ((p >> 6) & 1) + ((p >> 7) & 1);
+        int hh = w + e, v = n + s, ctx;
+        if (band == 1) { const int t = hh; hh = v; v = t; }   // HL: swap h and v
+        if (band == 3) {
+            const int hv = hh + v;
+            if (hv >= 3) ctx = 8;
+            else if (hv == 2) ctx = d >= 2 ? 7 : (d >= 1 ? 6 : 5);
+            else if (hv == 1) ctx = d >= 2 ? 4 : 3;
+            else ctx = d >= 2 ? 2 : (d >= 1 ? 1 : 0);
+        } else {
+            if (hh == 2) ctx = 8;
+            else if (hh == 1) ctx = v >= 1 ? 7 : (d >= 1 ? 6 : 5);
+            else if (v == 2) ctx = 4;
+            else if (v == 1) ctx = d >= 1 ? 3 : 2;
+            else ctx = d >= 2 ? 1 : 0;
+        }
+        T.zc[p] = (uint8_t)ctx;
+        // sign LUT: index bits 0=W_sig 1=W_chi 2=E_sig 3=E_chi 4=N_sig 5=N_chi 6=S_sig 7=S_chi
+        int hc = 0, vc = 0, pred = 0, sctx = 0;
+        if (p & 1) hc += (p & 2) ? -1 : 1;
+        if (p & 4) hc += (p & 8) ? -1 : 1;
+        if (p & 16) vc += (p & 32) ? -1 : 1;
+        if (p & 64) vc += (p & 128) ? -1 : 1;
+        if (hc < 0) { pred = 1; hc = -hc; }
+        if (hc == 0 && vc < 0) { pred = 1; vc = -vc; }
+        if (hc == 1) sctx = vc == 1 ? 4 : (vc == 0 ? 2 : 1);
+        else if (hc == 0) sctx = vc == 1 ? 1 : 0;
+        else if (hc == 2) sctx = 3;
+        T.sc[p] = (uint8_t)(sctx | pred << 3);
+    }
+    if (lane < NumContexts) T.ctx[lane] = (lane == CtxUni) ? 92 : 0;
+}
+
+// ---- MQ encoder with the "current byte" (buf[bp]) held in a register ---------------------
+struct MqEnc {
+    uint32_t A, C, CT;
+    uint32_t cur;      // value of buf[bp]
+    long bp;           // index of the byte in `cur`; byte k>=1 goes to out[k-1]
+    uint8_t *out;
+    long cap;
+    int overflow;
+};
+
+__device__ __forceinline__ void mq_advance(MqEnc &e, uint32_t nv) {
+    if (e.bp >= 1) {
+        if (e.bp - 1 < e.cap) e.out[e.bp - 1] = (uint8_t)e.cur; else e.overflow = 1;
+    }
+    e.bp++;
+    e.cur = nv & 0xFF;
+}
+
+__device__ __forceinline__ void mq_byte_out(MqEnc &e) {   // t1_fast.go:11-34
+    if (e.cur == 0xFF) { mq_advance(e, e.C >> 20); e.C &= 0xFFFFF; e.CT = 7; return; }
+    if ((e.C & 0x8000000) == 0) { mq_advance(e, e.C >> 19); e.C &= 0x7FFFF; e.CT = 8; return; }
+    e.cur = (e.cur + 1) & 0xFF;
+    if (e.cur == 0xFF) { e.C &= 0x7FFFFFF; mq_advance(e, e.C >> 20); e.C &= 0xFFFFF; e.CT = 7; return; }
+    mq_advance(e, e.C >> 19); e.C &= 0x7FFFF; e.CT = 8;
+}
+
+__device__ __forceinline__ void mq_encode(MqEnc &e, T1Tables &T, int ctx, int d) {   // mqc.go:224-255
+    const uint32_t st = T.ctx[ctx];
+    const uint32_t ent = T.mq[st];
+    const uint32_t qe = ent & 0xFFFF;
+    e.A -= qe;
+    if ((uint32_t)d == (st & 1)) {
+        if (e.A & 0x8000) { e.C += qe; return; }
+        if (e.A < qe) e.A = qe; else e.C += qe;
+        T.ctx[ctx] = (uint8_t)((ent >> 16) & 0xFF);
+    } else {
+        if (e.A < qe) e.C += qe; else e.A = qe;
+        T.ctx[ctx] = (uint8_t)(ent >> 24);
+    }
+    do {   // renorm (mqc.go:258-267)
+        e.A <<= 1; e.C <<= 1; e.CT--;
+        if (e.CT == 0) mq_byte_out(e);
+    } while ((e.A & 0x8000) == 0);
+}
+
+__device__ __forceinline__ int zc_packed(const uint8_t *f, int stride) {   // t1_fast5.go:118-125
+    return (f[-1] & T1Sig) | ((f[1] & T1Sig) << 1) | ((f[-stride] & T1Sig) << 2) | ((f[stride] & T1Sig) << 3) |
+           ((f[-stride - 1] & T1Sig) << 4) | ((f[-stride + 1] & T1Sig) << 5) | ((f[stride - 1] & T1Sig) << 6) |
+           ((f[stride + 1] & T1Sig) << 7);
+}
+__device__ __forceinline__ int sc_index(uint32_t fW, uint32_t fE, uint32_t fN, uint32_t fS) {   // t1_fast5.go:171-181
+    return (fW & T1Sig) | (((fW & T1SignNeg) >> 3) << 1) | ((fE & T1Sig) << 2) | (((fE & T1SignNeg) >> 3) << 3) |
+           ((fN & T1Sig) << 4) | (((fN & T1SignNeg) >> 3) << 5) | ((fS & T1Sig) << 6) | (((fS & T1SignNeg) >> 3) << 7);
+}
+__device__ __forceinline__ void set_significant(uint8_t *f, int x, int y, int w, int h, int stride) {   // t1_fast5.go:233-245
+    *f |= T1Sig;
+    if (y > 0) f[-stride] |= T1SigS;
+    if (y < h - 1) f[stride] |= T1SigN;
+    if (x > 0) f[-1] |= T1SigE;
+    if (x < w - 1) f[1] |= T1SigW;
+}
+__device__ __forceinline__ bool any_sig8(const uint8_t *f, int stride) {
+    return ((f[-1] | f[1] | f[-stride] | f[stride] | f[-stride - 1] | f[-stride + 1] | f[stride - 1] | f[stride + 1]) & T1Sig) != 0;
+}
+
+size_t t1_work_bytes(int w, int h) {
+    const size_t flags = ((size_t)(w + 2) * (h + 2) + 15) & ~size_t(15);
+    return flags + (size_t)w * h * 4;
+}
+
+#define T1_LDS_LIMIT (60 * 1024)
+
+__global__ __launch_bounds__(64) void t1_encode_kernel(const BlockJob *__restrict__ jobs, int njobs, const int32_t *__restrict__ coef,
+                                                       uint8_t *__restrict__ slots, uint32_t *__restrict__ lens,
+                                                       uint8_t *__restrict__ numbps, uint8_t *__restrict__ work, size_t work_per_job,
+                                                       int lds_work_bytes, int *__restrict__ fault) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int jid = blockIdx.x;
+    if (jid >= njobs) return;
+    const int lane = threadIdx.x;
+    const BlockJob J = jobs[jid];
+    const int w = J.w, h = J.h, stride = w + 2;
+    const size_t n = (size_t)w * h;
+    T1Tables &T = *reinterpret_cast<T1Tables *>(smem);
+    const size_t flag_bytes = ((size_t)(w + 2) * (h + 2) + 15) & ~size_t(15);
+    const bool in_lds = (flag_bytes + n * 4) <= (size_t)lds_work_bytes;
+    uint8_t *wk = in_lds ? smem + ((sizeof(T1Tables) + 15) & ~size_t(15)) : work + (size_t)jid * work_per_job;
+    uint8_t *flags = wk;
+    int32_t *data = reinterpret_cast<int32_t *>(wk + flag_bytes);
+
+    build_tables(T, J.band, lane);
+    for (size_t i = lane; i < (size_t)(w + 2) * (h + 2); i += 64) flags[i] = 0;
+    __syncthreads();
+    // SetData (t1.go:292-304) + max magnitude (t1_fast5.go:13-28)
+    const int32_t *src = coef + J.src_off;
+    int maxVal = 0;
+    for (int y = 0; y < h; y++)
+        for (int x = lane; x < w; x += 64) {
+            int v = src[(size_t)y * J.stride + x];
+            if (v < 0) {
+                v = (int)(0u - (uint32_t)v);
+                flags[(size_t)(y + 1) * stride + x + 1] = T1SignNeg;
+            }
+            data[(size_t)y * w + x] = v;
+            maxVal = max(maxVal, v);
+        }
+    for (int o = 32; o > 0; o >>= 1) maxVal = max(maxVal, __shfl_xor(maxVal, o));
+    __syncthreads();
+    if (maxVal == 0) {
+        if (lane == 0) { lens[jid] = 0; numbps[jid] = 0; }
+        return;
+    }
+    if (lane != 0) return;
+    const int numBPS = 32 - __clz((uint32_t)maxVal);
+    uint8_t *out = slots + J.out_off;
+    MqEnc e{0x8000, 0, 12, 0, 0, out, (long)(n * 2 + 1024), 0};
+
+    for (int bp = numBPS - 1; bp >= 0; bp--) {
+        const int32_t bit = (int32_t)(1u << bp);
+        // ---- significance propagation (t1_fast5.go:72-249) ----
+        for (int y = 0; y < h; y++) {
+            uint8_t *frow = flags + (size_t)(y + 1) * stride + 1;
+            const int32_t *drow = data + (size_t)y * w;
+            for (int x = 0; x < w; x++) {
+                uint8_t *f = frow + x;
+                const uint32_t fv = *f;
+                if (fv & T1Sig) continue;
+                uint32_t fW = 0, fE = 0, fN = 0, fS = 0, fNW, fNE, fSW, fSE;
+                if ((fv & (T1SigN | T1SigS | T1SigE | T1SigW)) == 0) {
+                    fNW = f[-stride - 1]; fNE = f[-stride + 1]; fSW = f[stride - 1]; fSE = f[stride + 1];
+                    if (((fNW | fNE | fSW | fSE) & T1Sig) == 0) continue;
+                } else {
+                    fW = f[-1]; fE = f[1]; fN = f[-stride]; fS = f[stride];
+                    fNW = f[-stride - 1]; fNE = f[-stride + 1]; fSW = f[stride - 1]; fSE = f[stride + 1];
+                }
+                const int sig = (drow[x] >> bp) & 1;
+                const int packed = (fW & T1Sig) | ((fE & T1Sig) << 1) | ((fN & T1Sig) << 2) | ((fS & T1Sig) << 3) |
+                                   ((fNW & T1Sig) << 4) | ((fNE & T1Sig) << 5) | ((fSW & T1Sig) << 6) | ((fSE & T1Sig) << 7);
+                mq_encode(e, T, T.zc[packed], sig);
+                if (sig) {
+                    const uint32_t sc = T.sc[sc_index(fW, fE, fN, fS)];
+                    mq_encode(e, T, CtxSC0 + (sc & 7), ((fv & T1SignNeg) ? 1 : 0) ^ (sc >> 3));
+                    set_significant(f, x, y, w, h, stride);
+                }
+                *f |= T1Visit;
+            }
+        }
+        // ---- magnitude refinement (t1_fast5.go:252-335) ----
+        for (int y = 0; y < h; y++) {
+            uint8_t *frow = flags + (size_t)(y + 1) * stride + 1;
+            const int32_t *drow = data + (size_t)y * w;
+            for (int x = 0; x < w; x++) {
+                uint8_t *f = frow + x;
+                const uint32_t fv = *f;
+                if ((fv & T1Sig) == 0 || (fv & T1Visit) != 0) continue;
+                int ctx;
+                if ((fv & T1Refine) == 0) ctx = any_sig8(f, stride) ? CtxMag1 : CtxMag0;
+                else ctx = CtxMag2;
+                mq_encode(e, T, ctx, (drow[x] & bit) ? 1 : 0);
+                *f = (uint8_t)(fv | T1Refine);
+            }
+        }
+        // ---- cleanup (t1_fast5.go:338-876) ----
+        for (int y = 0; y < h; y += 4) {
+            for (int x = 0; x < w; x++) {
+                bool canRL = (y + 4 <= h);
+                if (canRL) {
+                    for (int yy = 0; yy < 4; yy++) {
+                        const uint8_t *f = flags + (size_t)(y + yy + 1) * stride + x + 1;
+                        if ((*f & (T1Sig | T1Visit)) || any_sig8(f, stride)) { canRL = false; break; }
+                    }
+                }
+                if (canRL) {
+                    int firstSig = -1;
+                    for (int i = 0; i < 4; i++)
+                        if (data[(size_t)(y + i) * w + x] & bit) { firstSig = i; break; }
+                    mq_encode(e, T, CtxRL, firstSig >= 0 ? 1 : 0);
+                    if (firstSig < 0) continue;
+                    mq_encode(e, T, CtxUni, (firstSig >> 1) & 1);
+                    mq_encode(e, T, CtxUni, firstSig & 1);
+                    {
+                        const int yy = y + firstSig;
+                        uint8_t *f = flags + (size_t)(yy + 1) * stride + x + 1;
+                        const uint32_t sc = T.sc[sc_index(f[-1], f[1], f[-stride], f[stride])];
+                        mq_encode(e, T, CtxSC0 + (sc & 7), ((*f & T1SignNeg) ? 1 : 0) ^ (sc >> 3));
+                        set_significant(f, x, yy, w, h, stride);
+                    }
+                    for (int i = firstSig + 1; i < 4; i++) {
+                        const int yy = y + i;
+                        uint8_t *f = flags + (size_t)(yy + 1) * stride + x + 1;
+                        const int sig = (data[(size_t)yy * w + x] & bit) ? 1 : 0;
+                        const uint32_t fW = f[-1], fE = f[1], fN = f[-stride], fS = f[stride];
+                        mq_encode(e, T, T.zc[zc_packed(f, stride)], sig);
+                        if (sig) {
+                            const uint32_t sc = T.sc[sc_index(fW, fE, fN, fS)];
+                            mq_encode(e, T, CtxSC0 + (sc & 7), ((*f & T1SignNeg) ? 1 : 0) ^ (sc >> 3));
+                            set_significant(f, x, yy, w, h, stride);
+                        }
+                    }
+                    continue;
+                }
+                const int yEnd = min(y + 4, h);
+                for (int yy = y; yy < yEnd; yy++) {
+                    uint8_t *f = flags + (size_t)(yy + 1) * stride + x + 1;
+                    const uint32_t fv = *f;
+                    if (fv & T1Visit) { *f = (uint8_t)(fv & ~T1Visit); continue; }
+                    if (fv & T1Sig) continue;
+                    const int sig = (data[(size_t)yy * w + x] & bit) ? 1 : 0;
+                    const uint32_t fW = f[-1], fE = f[1], fN = f[-stride], fS = f[stride];
+                    mq_encode(e, T, T.zc[zc_packed(f, stride)], sig);
+                    if (sig) {
+                        const uint32_t sc = T.sc[sc_index(fW, fE, fN, fS)];
+                        mq_encode(e, T, CtxSC0 + (sc & 7), ((fv & T1SignNeg) ? 1 : 0) ^ (sc >> 3));
+                        set_significant(f, x, yy, w, h, stride);
+                    }
+                }
+            }
+        }
+    }
+    // ---- flush (t1_fast5.go:878-898) ----
+    const uint32_t tempC = e.C + e.A;
+    e.C |= 0xFFFF;
+    if (e.C >= tempC) e.C -= 0x8000;
+    e.C <<= e.CT; mq_byte_out(e);
+    e.C <<= e.CT; mq_byte_out(e);
+    // bytes buf[1..bp]; the last one is still in `cur`
+    long end = e.bp + 1;                       // endPos
+    if (e.cur == 0xFF) end--;                  // drop a trailing 0xFF
+    else if (e.bp >= 1) { if (e.bp - 1 < e.cap) out[e.bp - 1] = (uint8_t)e.cur; else e.overflow = 1; }
+    if (e.overflow) atomicMax(fault, 2);
+    lens[jid] = end > 1 ? (uint32_t)(end - 1) : 0;
+    numbps[jid] = (uint8_t)numBPS;
+}
+
+// ---- MQ decoder (mqc.go:352-497) --------------------------------------------------------------
+struct MqDec { uint32_t C, A, CT; long bp, len; const uint8_t *data; };
+
+__device__ __forceinline__ void mq_byte_in(MqDec &d) {   // mqc.go:402-439
+    if (d.bp < 0) d.bp = 0;
+    if (d.bp >= d.len) { d.C += 0xFF00; d.CT = 8; return; }
+    const uint32_t next = (d.bp + 1 < d.len) ? d.data[d.bp + 1] : 0xFF;
+    if (d.data[d.bp] == 0xFF) {
+        if (next > 0x8F) { d.C += 0xFF00; d.CT = 8; }
+        else { d.bp++; d.C += next << 9; d.CT = 7; }
+    } else { d.bp++; d.C += next << 8; d.CT = 8; }
+}
+__device__ __forceinline__ void mq_renorm_dec(MqDec &d) {   // mqc.go:488-497
+    do {
+        if (d.CT == 0) mq_byte_in(d);
+        d.A <<= 1; d.C <<= 1; d.CT--;
+    } while ((d.A & 0x8000) == 0);
+}
+__device__ __forceinline__ int mq_decode(MqDec &d, T1Tables &T, int ctx) {   // mqc.go:443-485
+    const uint32_t st = T.ctx[ctx];
+    const uint32_t ent = T.mq[st];
+    const uint32_t qe = ent & 0xFFFF;
+    const int mps = st & 1;
+    int dec;
+    d.A -= qe;
+    if ((d.C >> 16) < qe) {
+        if (d.A < qe) { dec = mps; T.ctx[ctx] = (uint8_t)((ent >> 16) & 0xFF); }
+        else { dec = 1 - mps; T.ctx[ctx] = (uint8_t)(ent >> 24); }
+        d.A = qe;
+        mq_renorm_dec(d);
+        return dec;
+    }
+    d.C -= qe << 16;
+    if ((d.A & 0x8000) == 0) {
+        if (d.A < qe) { dec = 1 - mps; T.ctx[ctx] = (uint8_t)(ent >> 24); }
+        else { dec = mps; T.ctx[ctx] = (uint8_t)((ent >> 16) & 0xFF); }
+        mq_renorm_dec(d);
+        return dec;
+    }
+    return mps;
+}
+
+__device__ __forceinline__ void dec_sign(MqDec &d, T1Tables &T, uint8_t *f, int stride) {   // t1.go:1322-1328
+    const uint32_t sc = T.sc[sc_index(f[-1], f[1], f[-stride], f[stride])];
+    if (mq_decode(d, T, CtxSC0 + (sc & 7)) ^ (int)(sc >> 3)) *f |= T1SignNeg;
+}
+
+__global__ __launch_bounds__(64) void t1_decode_kernel(const BlockJob *__restrict__ jobs, int njobs, const uint8_t *__restrict__ stream,
+                                                       const uint64_t *__restrict__ offs, const uint32_t *__restrict__ lens,
+                                                       const uint8_t *__restrict__ numbps, int32_t *__restrict__ decoded,
+                                                       uint8_t *__restrict__ work, size_t work_per_job, int lds_work_bytes) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int jid = blockIdx.x;
+    if (jid >= njobs) return;
+    const int lane = threadIdx.x;
+    const BlockJob J = jobs[jid];
+    const int w = J.w, h = J.h, stride = w + 2;
+    const size_t n = (size_t)w * h;
+    T1Tables &T = *reinterpret_cast<T1Tables *>(smem);
+    const size_t flag_bytes = ((size_t)(w + 2) * (h + 2) + 15) & ~size_t(15);
+    const bool in_lds = (flag_bytes + n * 4) <= (size_t)lds_work_bytes;
+    uint8_t *wk = in_lds ? smem + ((sizeof(T1Tables) + 15) & ~size_t(15)) : work + (size_t)jid * work_per_job;
+    uint8_t *flags = wk;
+    int32_t *data = reinterpret_cast<int32_t *>(wk + flag_bytes);
+    int32_t *out = decoded + J.out_off;
+
+    build_tables(T, J.band, lane);
+    for (size_t i = lane; i < (size_t)(w + 2) * (h + 2); i += 64) flags[i] = 0;
+    for (size_t i = lane; i < n; i += 64) data[i] = 0;
+    __syncthreads();
+    if (lane == 0) {
+        const int numBPS = numbps[jid];
+        MqDec d{0, 0x8000, 0, -1, (long)lens[jid], stream + offs[jid]};   // NewMQDecoder mqc.go:370-399
+        if (d.len == 0) d.C = 0xFFu << 16; else { d.bp = 0; d.C = (uint32_t)d.data[0] << 16; }
+        mq_byte_in(d);
+        d.C <<= 7; d.CT -= 7; d.A = 0x8000;
+        for (int bp = numBPS - 1; bp >= 0; bp--) {
+            const int32_t bit = bp < 32 ? (int32_t)(1u << bp) : 0;
+            for (int y = 0; y < h; y++)                                   // t1.go:1295-1319
+                for (int x = 0; x < w; x++) {
+                    uint8_t *f = flags + (size_t)(y + 1) * stride + x + 1;
+                    if (*f & T1Sig) continue;
+                    if (!any_sig8(f, stride)) continue;
+                    if (mq_decode(d, T, T.zc[zc_packed(f, stride)])) {
+                        data[(size_t)y * w + x] = bit;
+                        dec_sign(d, T, f, stride);
+                        set_significant(f, x, y, w, h, stride);
+                    }
+                    *f |= T1Visit;
+                }
+            for (int y = 0; y < h; y++)                                   // t1.go:1331-1347
+                for (int x = 0; x < w; x++) {
+                    uint8_t *f = flags + (size_t)(y + 1) * stride + x + 1;
+                    const uint32_t fv = *f;
+                    if ((fv & T1Sig) == 0 || (fv & T1Visit) != 0) continue;
+                    const int ctx = (fv & T1Refine) ? CtxMag2 : (any_sig8(f, stride) ? CtxMag1 : CtxMag0);
+                    if (mq_decode(d, T, ctx)) data[(size_t)y * w + x] |= bit;
+                    *f = (uint8_t)(fv | T1Refine);
+                }
+            for (int y = 0; y < h; y += 4)                                // t1.go:1350-1410
+                for (int x = 0; x < w; x++) {
+                    bool canRL = (y + 4 <= h);
+                    if (canRL)
+                        for (int yy = y; yy < y + 4; yy++) {
+                            const uint8_t *f = flags + (size_t)(yy + 1) * stride + x + 1;
+                            if ((*f & (T1Sig | T1Visit)) || any_sig8(f, stride)) { canRL = false; break; }
+                        }
+                    if (canRL) {
+                        if (mq_decode(d, T, CtxRL) == 0) continue;
+                        int pos = mq_decode(d, T, CtxUni) << 1;
+                        pos |= mq_decode(d, T, CtxUni);
+                        {
+                            uint8_t *f = flags + (size_t)(y + pos + 1) * stride + x + 1;
+                            data[(size_t)(y + pos) * w + x] = bit;
+                            dec_sign(d, T, f, stride);
+                            set_significant(f, x, y + pos, w, h, stride);
+                        }
+                        for (int i = pos + 1; i < 4 && y + i < h; i++) {
+                            uint8_t *f = flags + (size_t)(y + i + 1) * stride + x + 1;
+                            if (mq_decode(d, T, T.zc[zc_packed(f, stride)])) {
+                                data[(size_t)(y + i) * w + x] = bit;
+                                dec_sign(d, T, f, stride);
+                                set_significant(f, x, y + i, w, h, stride);
+                            }
+                        }
+                        continue;
+                    }
+                    for (int yy = y; yy < y + 4 && yy < h; yy++) {
+                        uint8_t *f = flags + (size_t)(yy + 1) * stride + x + 1;
+                        const uint32_t fv = *f;
+                        if (fv & T1Visit) { *f = (uint8_t)(fv & ~T1Visit); continue; }
+                        if (fv & T1Sig) continue;
+                        if (mq_decode(d, T, T.zc[zc_packed(f, stride)])) {
+                            data[(size_t)yy * w + x] = bit;
+                            dec_sign(d, T, f, stride);
+                            set_significant(f, x, yy, w, h, stride);
+                        }
+                    }
+                }
+        }
+    }
+    __syncthreads();
+    for (size_t i = lane; i < n; i += 64) {                               // t1.go:1281-1289
+        const int v = data[i];
+        const bool neg = flags[(i / w + 1) * stride + (i % w) + 1] & T1SignNeg;
+        out[i] = neg ? (int32_t)(0u - (uint32_t)v) : v;
+    }
+}
+
+static int lds_for(size_t work_per_job) {
+    const size_t tab = (sizeof(T1Tables) + 15) & ~size_t(15);
+    size_t wb = work_per_job;
+    if (tab + wb > T1_LDS_LIMIT) wb = 0;       // largest block does not fit: LDS holds the tables only
+    return (int)wb;
+}
+
+hipError_t launch_t1_encode(hipStream_t s, const BlockJob *jobs, int njobs, const int32_t *coef, uint8_t *slots,
+                            uint32_t *lens, uint8_t *numbps, uint8_t *work, size_t work_per_job, int *fault) {
+    if (njobs <= 0) return hipSuccess;
+    const int wb = lds_for(work_per_job);
+    const size_t lds = ((sizeof(T1Tables) + 15) & ~size_t(15)) + (size_t)wb;
+    hipLaunchKernelGGL(t1_encode_kernel, dim3(njobs), dim3(64), lds, s, jobs, njobs, coef, slots, lens, numbps, work,
+                       work_per_job, wb, fault);
+    return hipGetLastError();
+}
+
+hipError_t launch_t1_decode(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs,
+                            const uint32_t *lens, const uint8_t *numbps, int32_t *decoded, uint8_t *work, size_t work_per_job) {
+    if (njobs <= 0) return hipSuccess;
+    const int wb = lds_for(work_per_job);
+    const size_t lds = ((sizeof(T1Tables) + 15) & ~size_t(15)) + (size_t)wb;
+    hipLaunchKernelGGL(t1_decode_kernel, dim3(njobs), dim3(64), lds, s, jobs, njobs, stream, offs, lens, numbps, decoded,
+                       work, work_per_job, wb);
+    return hipGetLastError();
+}
+
+}  // namespace j2k

@@ -1,0 +1,129 @@
+"""GPU parity: T1 (MQ) and HT block coders through the C ABI vs the C oracle: encoded BYTES are
+compared (the reference only asserts round trips: internal/entropy/t1_test.go:7-96,
+coverage_test.go:72-98,414-446,464-535,814-842,883-902; ht_test.go:7-77,126-147)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ent():
+    from j2kgfx import entropy
+    return entropy
+
+
+def ref_test_block(w, h):
+    """input generator of the reference's own tests: (i*17)%512 with every 7th negated (t1_test.go)"""
+    i = np.arange(w * h, dtype=np.int64)
+    v = (i * 17) % 512
+    v[i % 7 == 0] *= -1
+    return v.astype(np.int32).reshape(h, w)
+
+
+SHAPES = [(4, 4), (8, 8), (16, 16), (32, 32), (1, 1), (8, 1), (1, 8), (8, 5), (64, 64), (13, 9), (5, 3), (64, 7), (33, 64)]
+
+
+@pytest.mark.parametrize("w,h", SHAPES)
+@pytest.mark.parametrize("band", [0, 1, 2, 3])
+def test_t1_encode_bytes_and_roundtrip(ent, oracle, w, h, band):
+    rng = np.random.default_rng(w * 131 + h * 7 + band)
+    for x in (ref_test_block(w, h), rng.integers(-300, 301, (h, w)).astype(np.int32),
+              -np.abs(rng.integers(1, 40000, (h, w))).astype(np.int32), np.zeros((h, w), np.int32)):
+        t1 = ent.NewT1(w, h)
+        t1.SetData(x)
+        got = t1.Encode(band)
+        want, nb = oracle.t1_encode(x, w, h, band)
+        if want.size == 0:
+            assert got is None and t1.numBPS == 0
+            continue
+        assert got == bytes(want) and t1.numBPS == nb
+        back = ent.NewT1(w, h).Decode(got, nb, band)
+        assert np.array_equal(back.reshape(h, w), x)                     # Decode(Encode(x)) == x
+
+
+def test_t1_decode_arbitrary_bytes(ent, oracle):
+    """decoder parity on streams that are not encoder output (FuzzT1Decode's domain)"""
+    rng = np.random.default_rng(3)
+    for (w, h) in [(8, 8), (16, 5), (64, 64)]:
+        for nb in (1, 5, 12):
+            g = rng.integers(0, 256, rng.integers(0, 200)).astype(np.uint8)
+            got = ent.NewT1(w, h).Decode(bytes(g), nb, 2)
+            assert np.array_equal(got.reshape(h, w), oracle.t1_decode(g, nb, 2, w, h))
+
+
+def test_t1_large_block_global_workspace(ent, oracle):
+    """256x256 = the reference's default real block size (1 << (6+2), encoder.go:606-607)"""
+    rng = np.random.default_rng(11)
+    x = rng.integers(-2000, 2001, (256, 256)).astype(np.int32)
+    t1 = ent.NewT1(256, 256); t1.SetData(x)
+    got = t1.Encode(3)
+    want, nb = oracle.t1_encode(x, 256, 256, 3)
+    assert got == bytes(want) and t1.numBPS == nb
+    assert np.array_equal(ent.NewT1(256, 256).Decode(got, nb, 3).reshape(256, 256), x)
+
+
+HT_SHAPES = [(4, 4), (8, 8), (16, 16), (64, 64), (32, 32), (8, 5), (13, 9), (7, 4), (5, 8), (12, 16), (64, 7), (3, 16), (128, 128)]
+
+
+@pytest.mark.parametrize("w,h", HT_SHAPES)
+def test_ht_encode_decode_bytes(ent, oracle, w, h):
+    rng = np.random.default_rng(w * 17 + h)
+    for amp in (1, 3, 300, 40000):
+        x = rng.integers(-amp, amp + 1, (h, w)).astype(np.int32)
+        if amp == 3:
+            x[rng.random((h, w)) < 0.7] = 0
+        try:
+            want = oracle.ht_encode(x, w, h)
+        except ValueError:                       # the Go code would panic on this input
+            from j2kgfx import J2KError
+            enc = ent.NewHTEncoder(w, h); enc.SetData(x)
+            with pytest.raises(J2KError):
+                enc.Encode(0)
+            continue
+        enc = ent.NewHTEncoder(w, h); enc.SetData(x)
+        got = enc.Encode(0)
+        if want.size == 0:
+            assert got is None
+            continue
+        assert got == bytes(want)
+        dec = ent.NewHTDecoder(w, h).Decode(got, 0, 0)
+        assert np.array_equal(dec.reshape(h, w), oracle.ht_decode(want, w, h))
+
+
+def test_ht_decoder_edge_inputs(ent, oracle):
+    """ht_test.go:126-147: nil, 1-byte and 2-byte inputs; plus bad SCUP and random payloads"""
+    rng = np.random.default_rng(4)
+    w = h = 16
+    for data in (b"", b"\x00", b"\x00\x00", b"\xff\xff", bytes(rng.integers(0, 256, 64).astype(np.uint8))):
+        got = ent.NewHTDecoder(w, h).Decode(data, 8, 0)
+        assert np.array_equal(got.reshape(h, w), oracle.ht_decode(np.frombuffer(data, np.uint8), w, h))
+    x = rng.integers(-50, 51, (h, w)).astype(np.int32)
+    good = oracle.ht_encode(x, w, h)
+    for _ in range(20):
+        g = rng.integers(0, 256, good.size).astype(np.uint8)
+        g[-2:] = good[-2:]
+        got = ent.NewHTDecoder(w, h).Decode(bytes(g), 8, 0)
+        assert np.array_equal(got.reshape(h, w), oracle.ht_decode(g, w, h))
+
+
+@pytest.mark.parametrize("coder", [0, 1])
+@pytest.mark.parametrize("W,H,Cn,nres,cb", [(64, 64, 3, 3, 16), (128, 96, 1, 4, 32), (100, 75, 3, 6, 64), (512, 512, 3, 3, 256)])
+def test_encode_frame_matches_encoder(oracle, coder, W, H, Cn, nres, cb):
+    """encoder.preprocess + encodeTile (sequential path) on a single tile: coefficients in place and
+    the concatenated block bytes, lens and numbps in job order."""
+    from j2kgfx.codec import FramePlan
+    rng = np.random.default_rng(W + H + coder)
+    yy, xx = np.mgrid[0:H, 0:W]
+    base = [xx * 255 // W, yy * 255 // H, (xx + yy) * 127 // max(W, H)]          # jpeg2000_test.go:340-352
+    planes = [np.clip(base[c % 3] + rng.integers(-16, 17, (H, W)), 0, 255).astype(np.int32) for c in range(Cn)]
+    want_coeff = oracle.preprocess(planes, W, H, 8, True, nres)
+    want_bytes, want_lens, want_nb = oracle.encode_tile_blocks(want_coeff, W, H, nres, cb, cb, coder)
+    plan = FramePlan(W, H, Cn, precision=8, lossless=True, num_resolutions=nres, cb=(cb, cb), coder=coder)
+    host = [p.copy().reshape(-1) for p in planes]
+    res = plan.encode_frame(host)
+    for c in range(Cn):
+        assert np.array_equal(host[c].reshape(H, W), want_coeff[c])               # like e.componentData
+    assert np.array_equal(res["lens"], want_lens)
+    assert np.array_equal(res["numbps"], want_nb)
+    assert bytes(res["bytes"]) == bytes(want_bytes)
