@@ -99,6 +99,7 @@ extern "C" void j2k_ctx_destroy(j2k_ctx *ctx) {
     for (j2k_plan *p : ctx->cache) j2k_plan_destroy(p);
     for (int i = 0; i < 4; i++)
         if (ctx->stage[i]) (void)hipFree(ctx->stage[i]);
+    for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -109,6 +110,40 @@ extern "C" int j2k_ctx_sync(j2k_ctx *ctx) {
     return J2K_OK;
 }
 extern "C" void *j2k_ctx_stream(j2k_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+extern "C" int j2k_ctx_profile_enable(j2k_ctx *ctx, int on) {
+    if (!ctx) return J2K_ERR_INVALID_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->profile = on ? 1 : 0;
+    ctx->ev_used = 0;
+    return J2K_OK;
+}
+extern "C" int j2k_ctx_profile_read(j2k_ctx *ctx, int64_t *launches, double *total_ms) {
+    if (!ctx || !launches || !total_ms) return J2K_ERR_INVALID_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    double tot = 0;
+    for (size_t i = 0; i + 1 < ctx->ev_used; i += 2) {
+        float ms = 0;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));
+        tot += ms;
+    }
+    *launches = (int64_t)(ctx->ev_used / 2);
+    *total_ms = tot;
+    ctx->ev_used = 0;
+    return J2K_OK;
+}
+// next free event of the pool (grows on demand, capped), or nullptr
+static hipEvent_t profile_event(j2k_ctx *ctx) {
+    if (!ctx->profile || ctx->ev_used >= 8192) return nullptr;
+    if (ctx->ev_used >= ctx->ev.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        ctx->ev.push_back(e);
+    }
+    return ctx->ev[ctx->ev_used++];
+}
 
 static int stage_reserve(j2k_ctx *ctx, int slot, size_t bytes) {
     if (ctx->stage_bytes[slot] >= bytes) return J2K_OK;
@@ -431,6 +466,8 @@ static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff) {
     for (int l = 0; l < S.levels; l++) {
         void *in = (l == 0) ? const_cast<void *>(d_frame) : ((l & 1) ? P->d_scrA : P->d_scrB);
         void *nx = (l & 1) ? P->d_scrB : P->d_scrA;
+        hipEvent_t ev0 = (l == 0) ? profile_event(ctx) : nullptr, ev1 = ev0 ? profile_event(ctx) : nullptr;
+        if (ev1) HIPCHK(ctx, hipEventRecord(ev0, ctx->stream));
         for (int cls = 0; cls < 2; cls++) {
             const LevelTab &T = P->fwd[cls][l];
             if (!T.njobs) continue;
@@ -442,6 +479,7 @@ static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff) {
                                              l == 0 ? S.dc_shift : 0, S.quant, step, (cls == 1) ? 1 : 0));
             }
         }
+        if (ev1) HIPCHK(ctx, hipEventRecord(ev1, ctx->stream));
     }
     return J2K_OK;
 }

@@ -17,6 +17,10 @@ struct j2k_ctx {
     // host-call staging buffers (device)
     void *stage[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t stage_bytes[4] = {0, 0, 0, 0};
+    // level-0 kernel timing (j2k_ctx_profile_*)
+    int profile = 0;
+    std::vector<hipEvent_t> ev;     // pool of event pairs
+    size_t ev_used = 0;             // events recorded since the last read
 };
 
 namespace j2k {

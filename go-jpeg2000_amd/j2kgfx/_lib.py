@@ -40,7 +40,7 @@ class PlanInfo(C.Structure):
 # every symbol include/j2kgfx.h declares (tests/test_abi_symbols.py checks the header against this list)
 SYMBOLS = [
     "j2k_ctx_create", "j2k_ctx_destroy", "j2k_ctx_sync", "j2k_ctx_stream", "j2k_ctx_last_error",
-    "j2k_status_string", "j2k_version",
+    "j2k_status_string", "j2k_version", "j2k_ctx_profile_enable", "j2k_ctx_profile_read",
     "j2k_dc_level_shift_forward", "j2k_dc_level_shift_inverse", "j2k_forward_rct", "j2k_inverse_rct",
     "j2k_forward_ict", "j2k_inverse_ict",
     "j2k_forward53", "j2k_inverse53", "j2k_forward97", "j2k_inverse97",

@@ -23,6 +23,15 @@ class Context:
     def sync(self):
         self.check(self.L.j2k_ctx_sync(self.h))
 
+    def profile_enable(self, on=True):
+        self.check(self.L.j2k_ctx_profile_enable(self.h, int(bool(on))))
+
+    def profile_read(self):
+        """(launches, total_ms) of the level-0 DWT launches recorded since the last read."""
+        n = C.c_int64(0); ms = C.c_double(0)
+        self.check(self.L.j2k_ctx_profile_read(self.h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
     @property
     def stream(self):
         return self.L.j2k_ctx_stream(self.h)

@@ -58,6 +58,12 @@ void *j2k_ctx_stream(j2k_ctx *ctx);             /* the hipStream_t, for event ti
 const char *j2k_ctx_last_error(j2k_ctx *ctx);   /* text of the last non-OK status */
 const char *j2k_status_string(int status);
 const char *j2k_version(void);
+/* Kernel timing for bench.py's roofline line: while enabled, every j2k_plan_forward records a
+ * HIP event pair around its level-0 DWT launch(es) on the ctx stream.  j2k_ctx_profile_read
+ * synchronises, returns the number of recorded launches and their summed duration in ms, and
+ * resets the counters. */
+int j2k_ctx_profile_enable(j2k_ctx *ctx, int on);
+int j2k_ctx_profile_read(j2k_ctx *ctx, int64_t *launches, double *total_ms);
 
 /* ==== 1. host calls: one per reference function ============================= */
 
