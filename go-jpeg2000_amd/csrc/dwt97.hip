@@ -1,0 +1,495 @@
+// dwt97.hip -- 9-7 irreversible lifting DWT (float64, like the reference) for gfx950, fused with
+// DC shift + ICT + the encoder's quantisation on the way in and the decoder's rounding + inverse
+// ICT + DC shift on the way out.
+//
+// Replaces (reference, mrjoshuak/go-jpeg2000):
+//   dwt.Forward97/Inverse97                 internal/dwt/dwt.go:161-262 (constants :150-157)
+//   dwt.Forward2D97/Inverse2D97             dwt.go:432-473
+//   one level of Decompose/ReconstructMultiLevel97   dwt.go:551-573
+//   encoder.preprocess lossy branch         encoder.go:227-244 (ICT + round half away), 259-276 (v/step +- 0.5)
+//   tcd ApplyForwardDWT / ApplyInverseDWT   internal/tcd/tcd.go:520-532, 428-435
+//   decoder.decodeTiles lossy tail          decoder.go:326-339 (InverseICT, int32(v+0.5)), 344-348
+//
+// Same streaming structure as dwt53.hip: a wavefront owns a column strip x a band of row pairs;
+// horizontal neighbours by DPP wave shifts (4 per row: one per lifting step); the four vertical
+// lifting steps are a software pipeline over row pairs held in registers (look-ahead of two pairs,
+// so a band reads 7 halo rows).  Every sample is read once and written once per level.
+//
+// Bit-exactness vs Go/amd64: compiled with -ffp-contract=off (no FMA), the reference's literal
+// constants, the same operand association; the symmetric-extension edge terms are computed as
+// c*(x+x), which is bitwise equal to the reference's (2*c)*x (scaling by two is exact).
+#include "j2k_internal.h"
+
+namespace j2k {
+
+#define A97 (-1.586134342059924)
+#define B97 (-0.052980118572961)
+#define G97 (0.882911075530934)
+#define D97 (0.443506852043971)
+#define K97 (1.230174104914001)
+#define K97I (0.812893066115961)
+
+__device__ __forceinline__ double dshift(double v, int ctrl_shr) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    if (ctrl_shr) {
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+        hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    } else {
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
+        hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    }
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dleft(double v) { return dshift(v, 1); }    // lane i <- lane i-1
+__device__ __forceinline__ double dright(double v) { return dshift(v, 0); }   // lane i <- lane i+1
+
+// Go int32(float64): truncation toward zero; on amd64 out-of-range values go through a 64-bit convert
+__device__ __forceinline__ int go_int32(double v) {
+    if (v > -2147483648.0 && v < 2147483648.0) return (int)v;
+    return (int)(long long)v;
+}
+__device__ __forceinline__ int round_half_away(double v) { return v >= 0 ? go_int32(v + 0.5) : go_int32(v - 0.5); }
+
+enum { SRC_I32 = 0, SRC_F64 = 1 };
+enum { Q_NONE_ = 0, Q_ENCODER_ = 1, Q_TCD_ = 2 };
+enum { DST_F64_SCRATCH = 0, DST_F64_FRAME = 1, DST_I32_FRAME = 2 };
+
+template <int CPL, int NC> struct Row97 { double lo[NC][CPL / 2]; double hi[NC][CPL / 2]; };
+
+// ---- horizontal forward: x[CPL] (columns c..) -> lo/hi (scaled) ----------------------------------
+template <int CPL>
+__device__ __forceinline__ void hfwd97(const double (&x)[CPL], int c, int w, double (&lo)[CPL / 2], double (&hi)[CPL / 2]) {
+    constexpr int H = CPL / 2;
+    if (w < 2) {
+#pragma unroll
+        for (int j = 0; j < H; j++) { lo[j] = x[2 * j]; hi[j] = 0.0; }
+        return;
+    }
+    double d1[H], s1[H], d2[H];
+    const double e_r = dright(x[0]);
+#pragma unroll
+    for (int j = 0; j < H; j++) {
+        const int ce = c + 2 * j;
+        const double en = (ce + 2 < w) ? ((j + 1 < H) ? x[2 * j + 2] : e_r) : x[2 * j];
+        d1[j] = x[2 * j + 1] + A97 * (x[2 * j] + en);
+    }
+    const double d1_l = dleft(d1[H - 1]);
+#pragma unroll
+    for (int j = 0; j < H; j++) {
+        const int ce = c + 2 * j;
+        double dp = (j > 0) ? d1[j - 1] : d1_l;
+        if (ce + 1 >= w) d1[j] = dp;           // no odd partner: mirrors d[n-2]
+        if (ce == 0) dp = d1[j];
+        s1[j] = x[2 * j] + B97 * (dp + d1[j]);
+    }
+    const double s1_r = dright(s1[0]);
+#pragma unroll
+    for (int j = 0; j < H; j++) {
+        const int ce = c + 2 * j;
+        const double sn = (ce + 2 < w) ? ((j + 1 < H) ? s1[j + 1] : s1_r) : s1[j];
+        d2[j] = d1[j] + G97 * (s1[j] + sn);
+    }
+    const double d2_l = dleft(d2[H - 1]);
+#pragma unroll
+    for (int j = 0; j < H; j++) {
+        const int ce = c + 2 * j;
+        double dp = (j > 0) ? d2[j - 1] : d2_l;
+        if (ce + 1 >= w) d2[j] = dp;
+        if (ce == 0) dp = d2[j];
+        lo[j] = (s1[j] + D97 * (dp + d2[j])) * K97I;
+        hi[j] = d2[j] * K97;
+    }
+}
+
+// ---- horizontal inverse: lo/hi -> x[CPL] -----------------------------------------------------------
+template <int CPL>
+__device__ __forceinline__ void hinv97(const double (&lo)[CPL / 2], const double (&hi)[CPL / 2], int c, int w, double (&x)[CPL]) {
+    constexpr int H = CPL / 2;
+    if (w < 2) {
+#pragma unroll
+        for (int j = 0; j < H; j++) { x[2 * j] = lo[j]; x[2 * j + 1] = 0.0; }
+        return;
+    }
+    double d2[H], s1[H], d1[H], e[H];
+#pragma unroll
+    for (int j = 0; j < H; j++) d2[j] = hi[j] * K97I;
+    const double d2_l = dleft(d2[H - 1]);
+#pragma unroll
+    for (int j = 0; j < H; j++) {
+        const int ce = c + 2 * j;
+        double dp = (j > 0) ? d2[j - 1] : d2_l;
+        if (ce + 1 >= w) d2[j] = dp;
+        if (ce == 0) dp = d2[j];
+        s1[j] = lo[j] * K97 - D97 * (dp + d2[j]);
+    }
+    const double s1_r = dright(s1[0]);
+#pragma unroll
+    for (int j = 0; j < H; j++) {
+        const int ce = c + 2 * j;
+        const double sn = (ce + 2 < w) ? ((j + 1 < H) ? s1[j + 1] : s1_r) : s1[j];
+        d1[j] = d2[j] - G97 * (s1[j] + sn);
+    }
+    const double d1_l = dleft(d1[H - 1]);
+#pragma unroll
+    for (int j = 0; j < H; j++) {
+        const int ce = c + 2 * j;
+        double dp = (j > 0) ? d1[j - 1] : d1_l;
+        if (ce + 1 >= w) d1[j] = dp;
+        if (ce == 0) dp = d1[j];
+        e[j] = s1[j] - B97 * (dp + d1[j]);
+    }
+    const double e_r = dright(e[0]);
+#pragma unroll
+    for (int j = 0; j < H; j++) {
+        const int ce = c + 2 * j;
+        const double en = (ce + 2 < w) ? ((j + 1 < H) ? e[j + 1] : e_r) : e[j];
+        x[2 * j] = e[j];
+        x[2 * j + 1] = d1[j] - A97 * (e[j] + en);
+    }
+}
+
+// ================================================================================
+// forward
+// ================================================================================
+template <int CPL, int NC>
+__device__ __forceinline__ void fwd97_load_row(const void *__restrict__ src, int src_f64, const DwtPlane &P, int r, int c,
+                                               int dc_shift, int mct, Row97<CPL, NC> &R) {
+    double x[NC][CPL];
+#pragma unroll
+    for (int k = 0; k < NC; k++) {
+        const int64_t base = P.src_off[k] + (int64_t)r * P.src_stride;
+        if (src_f64) {
+            const double *p = reinterpret_cast<const double *>(src) + base;
+#pragma unroll
+            for (int i = 0; i < CPL; i++) x[k][i] = (c + i < P.w) ? p[c + i] : 0.0;
+        } else {
+            const int32_t *p = reinterpret_cast<const int32_t *>(src) + base;
+#pragma unroll
+            for (int i = 0; i < CPL; i++) {
+                const int v = (c + i < P.w) ? p[c + i] : 0;
+                x[k][i] = (double)(int)((unsigned)v - (unsigned)dc_shift);   // mct.go:96-101, encoder.go:228-233/260-262
+            }
+        }
+    }
+    if constexpr (NC == 3) {
+        if (mct) {   // mct.go:14-24 then round half away to int32 and back to f64 (encoder.go:235-244, 259-262)
+#pragma unroll
+            for (int i = 0; i < CPL; i++) {
+                const double r_ = x[0][i], g_ = x[1][i], b_ = x[2][i];
+                const double y = 0.299 * r_ + 0.587 * g_ + 0.114 * b_;
+                const double cb = -0.16875 * r_ - 0.33126 * g_ + 0.5 * b_;
+                const double cr = 0.5 * r_ - 0.41869 * g_ - 0.08131 * b_;
+                x[0][i] = (double)round_half_away(y);
+                x[1][i] = (double)round_half_away(cb);
+                x[2][i] = (double)round_half_away(cr);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NC; k++) hfwd97<CPL>(x[k], c, P.w, R.lo[k], R.hi[k]);
+}
+
+template <int CPL, int NC>
+__device__ __forceinline__ void fwd97_store_row(int32_t *__restrict__ out_i32, double *__restrict__ out_f64, double *__restrict__ nxt,
+                                                const DwtPlane &P, int ro, int p0, bool owned, int quant, double step,
+                                                const double (&lo)[NC][CPL / 2], const double (&hi)[NC][CPL / 2]) {
+    constexpr int H = CPL / 2;
+    if (!owned) return;
+    const int halfW = (P.w + 1) >> 1;
+    const int nL = halfW - p0, nH = (P.w - halfW) - p0;
+    const int idxL = ro * P.w + p0, idxH = idxL + halfW;
+#pragma unroll
+    for (int k = 0; k < NC; k++)
+#pragma unroll
+        for (int j = 0; j < 2 * H; j++) {
+            const bool is_lo = j < H;
+            const int jj = is_lo ? j : j - H;
+            if (jj >= (is_lo ? nL : nH)) continue;
+            const int idx = (is_lo ? idxL : idxH) + jj;
+            const double v = is_lo ? lo[k][jj] : hi[k][jj];
+            if (idx < P.n_next) nxt[P.nxt_off[k] + idx] = v;
+            else if (quant == Q_NONE_) out_f64[P.out_off[k] + idx] = v;
+            else if (quant == Q_ENCODER_) out_i32[P.out_off[k] + idx] = v >= 0 ? go_int32(v / step + 0.5) : go_int32(v / step - 0.5);   // encoder.go:270-275
+            else out_i32[P.out_off[k] + idx] = round_half_away(v);                                                                        // tcd.go:526-531
+        }
+}
+
+template <int CPL, int NC>
+__global__ __launch_bounds__(256) void dwt97_fwd_kernel(const DwtJob *__restrict__ jobs, int njobs, const DwtPlane *__restrict__ planes,
+                                                        const void *__restrict__ src, int src_f64, int32_t *__restrict__ out_i32,
+                                                        double *__restrict__ out_f64, double *__restrict__ nxt, int dc_shift,
+                                                        int quant, double step, int mct) {
+    constexpr int H = CPL / 2;
+    constexpr int HL = (H >= 2) ? 1 : 2;   // halo lanes per side
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (wave >= njobs) return;
+    const int lane = threadIdx.x & 63;
+    const DwtJob job = jobs[wave];
+    const DwtPlane P = planes[job.plane];
+    const int w = P.w, h = P.h;
+    const int lane_first = (job.col0 == 0) ? 0 : HL;
+    const int c_base = job.col0 - lane_first * CPL;
+    const int c = c_base + lane * CPL;
+    const bool reach_end = (c_base + 64 * CPL >= w);
+    const bool owned = (lane >= lane_first) && (c < w) && (reach_end || lane < 64 - HL);
+    const int p0 = c >> 1;
+    const int halfH = (h + 1) >> 1;
+    const int q0 = job.prow0, q1 = min(job.prow0 + job.nprow, halfH);
+    typedef Row97<CPL, NC> Row;
+
+    if (h < 2) {   // columns untouched (no scaling either, dwt.go:162-164)
+        if (q0 == 0) {
+            Row r0;
+            fwd97_load_row<CPL, NC>(src, src_f64, P, 0, c, dc_shift, mct, r0);
+            fwd97_store_row<CPL, NC>(out_i32, out_f64, nxt, P, 0, p0, owned, quant, step, r0.lo, r0.hi);
+        }
+        return;
+    }
+    const int t_start = max(q0 - 2, 0);
+    const int t_last = min(q1, halfH);
+    Row e, o, en;                       // rows 2t, 2t+1, 2t+2 after the horizontal pass
+    double d1p[2][NC][H], s1p[2][NC][H], d2p[2][NC][H];   // [0]=lo half, [1]=hi half; values of pair t-1 (d2p: pair t-2)
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+#pragma unroll
+            for (int j = 0; j < H; j++) { d1p[a][k][j] = 0.0; s1p[a][k][j] = 0.0; d2p[a][k][j] = 0.0; }
+    fwd97_load_row<CPL, NC>(src, src_f64, P, 2 * t_start, c, dc_shift, mct, e);
+    for (int t = t_start; t <= t_last; t++) {
+        const bool real = t < halfH;
+        const bool o_ex = real && (2 * t + 1 < h), en_ex = real && (2 * t + 2 < h);
+        if (o_ex) fwd97_load_row<CPL, NC>(src, src_f64, P, 2 * t + 1, c, dc_shift, mct, o);
+        if (en_ex) fwd97_load_row<CPL, NC>(src, src_f64, P, 2 * t + 2, c, dc_shift, mct, en);
+        const bool prev_o_ex = (t >= 1) && (2 * (t - 1) + 1 < h);
+        double outl[NC][H], outh[NC][H], outl2[NC][H], outh2[NC][H];
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int k = 0; k < NC; k++)
+#pragma unroll
+                for (int j = 0; j < H; j++) {
+                    const double ev = a ? e.hi[k][j] : e.lo[k][j];
+                    const double ov = a ? o.hi[k][j] : o.lo[k][j];
+                    const double env = a ? en.hi[k][j] : en.lo[k][j];
+                    double d1t, s1t;
+                    if (real) {
+                        d1t = o_ex ? ov + A97 * (ev + (en_ex ? env : ev)) : d1p[a][k][j];
+                        s1t = ev + B97 * ((t == 0 ? d1t : d1p[a][k][j]) + d1t);
+                    } else {
+                        d1t = d1p[a][k][j];
+                        s1t = s1p[a][k][j];     // mirror: s1[q+1] := s1[q]
+                    }
+                    if (t >= 1) {               // finalize pair t-1
+                        const double d2 = prev_o_ex ? d1p[a][k][j] + G97 * (s1p[a][k][j] + s1t) : d2p[a][k][j];
+                        const double s2 = s1p[a][k][j] + D97 * ((t - 1 == 0 ? d2 : d2p[a][k][j]) + d2);
+                        if (a == 0) { outl[k][j] = s2 * K97I; outl2[k][j] = d2 * K97; }
+                        else { outh[k][j] = s2 * K97I; outh2[k][j] = d2 * K97; }
+                        d2p[a][k][j] = d2;
+                    }
+                    d1p[a][k][j] = d1t;
+                    s1p[a][k][j] = s1t;
+                }
+        if (t >= 1 && t - 1 >= q0) {
+            fwd97_store_row<CPL, NC>(out_i32, out_f64, nxt, P, t - 1, p0, owned, quant, step, outl, outh);
+            if (prev_o_ex) fwd97_store_row<CPL, NC>(out_i32, out_f64, nxt, P, halfH + t - 1, p0, owned, quant, step, outl2, outh2);
+        }
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+#pragma unroll
+            for (int j = 0; j < H; j++) { e.lo[k][j] = en.lo[k][j]; e.hi[k][j] = en.hi[k][j]; }
+    }
+}
+
+// ================================================================================
+// inverse
+// ================================================================================
+template <int CPL, int NC>
+__device__ __forceinline__ void inv97_load_row(const void *__restrict__ coef, int coef_f64, const double *__restrict__ prev,
+                                               const DwtPlane &P, int ri, int p0, Row97<CPL, NC> &R) {
+    constexpr int H = CPL / 2;
+    const int halfW = (P.w + 1) >> 1;
+    const int nL = halfW - p0, nH = (P.w - halfW) - p0;
+    const int idxL = ri * P.w + p0, idxH = idxL + halfW;
+#pragma unroll
+    for (int k = 0; k < NC; k++)
+#pragma unroll
+        for (int j = 0; j < 2 * H; j++) {
+            const bool is_lo = j < H;
+            const int jj = is_lo ? j : j - H;
+            double v = 0.0;
+            if (jj < (is_lo ? nL : nH)) {
+                const int idx = (is_lo ? idxL : idxH) + jj;
+                if (idx < P.n_next) v = prev[P.nxt_off[k] + idx];
+                else if (coef_f64) v = reinterpret_cast<const double *>(coef)[P.src_off[k] + idx];
+                else v = (double)reinterpret_cast<const int32_t *>(coef)[P.src_off[k] + idx];   // tcd.go:429-431
+            }
+            if (is_lo) R.lo[k][jj] = v; else R.hi[k][jj] = v;
+        }
+}
+
+template <int CPL, int NC>
+__device__ __forceinline__ void inv97_finish_row(void *__restrict__ dst, const DwtPlane &P, int ro, int c, bool owned, int dc_shift,
+                                                 int dst_mode, int mct, const double (&lo)[NC][CPL / 2], const double (&hi)[NC][CPL / 2]) {
+    double x[NC][CPL];
+#pragma unroll
+    for (int k = 0; k < NC; k++) hinv97<CPL>(lo[k], hi[k], c, P.w, x[k]);
+    if (!owned) return;
+    if (dst_mode == DST_I32_FRAME) {
+        int v[NC][CPL];
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+#pragma unroll
+            for (int i = 0; i < CPL; i++) v[k][i] = go_int32(x[k][i] + 0.5);        // tcd.go:433-435 (negatives round toward +)
+        if constexpr (NC == 3) {
+            if (mct) {   // decoder.go:326-339 + mct.go:43-53
+#pragma unroll
+                for (int i = 0; i < CPL; i++) {
+                    const double y = (double)v[0][i], cb = (double)v[1][i], cr = (double)v[2][i];
+                    const double r_ = y + 1.402 * cr;
+                    const double g_ = y - 0.34413 * cb - 0.71414 * cr;
+                    const double b_ = y + 1.772 * cb;
+                    v[0][i] = go_int32(r_ + 0.5); v[1][i] = go_int32(g_ + 0.5); v[2][i] = go_int32(b_ + 0.5);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NC; k++) {
+            int32_t *p = reinterpret_cast<int32_t *>(dst) + P.out_off[k] + (int64_t)ro * P.out_stride + c;
+#pragma unroll
+            for (int i = 0; i < CPL; i++)
+                if (c + i < P.w) p[i] = (int)((unsigned)v[k][i] + (unsigned)dc_shift);   // mct.go:113-118
+        }
+    } else {
+        const int stride = (dst_mode == DST_F64_FRAME) ? P.out_stride : P.w;
+#pragma unroll
+        for (int k = 0; k < NC; k++) {
+            double *p = reinterpret_cast<double *>(dst) + P.out_off[k] + (int64_t)ro * stride + c;
+#pragma unroll
+            for (int i = 0; i < CPL; i++)
+                if (c + i < P.w) p[i] = x[k][i];
+        }
+    }
+}
+
+template <int CPL, int NC>
+__global__ __launch_bounds__(256) void dwt97_inv_kernel(const DwtJob *__restrict__ jobs, int njobs, const DwtPlane *__restrict__ planes,
+                                                        const void *__restrict__ coef, int coef_f64, const double *__restrict__ prev,
+                                                        void *__restrict__ dst, int dc_shift, int dst_mode, int mct) {
+    constexpr int H = CPL / 2;
+    constexpr int HL = (H >= 2) ? 1 : 2;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (wave >= njobs) return;
+    const int lane = threadIdx.x & 63;
+    const DwtJob job = jobs[wave];
+    const DwtPlane P = planes[job.plane];
+    const int w = P.w, h = P.h;
+    const int lane_first = (job.col0 == 0) ? 0 : HL;
+    const int c_base = job.col0 - lane_first * CPL;
+    const int c = c_base + lane * CPL;
+    const bool reach_end = (c_base + 64 * CPL >= w);
+    const bool owned = (lane >= lane_first) && (c < w) && (reach_end || lane < 64 - HL);
+    const int p0 = c >> 1;
+    const int halfH = (h + 1) >> 1;
+    const int q0 = job.prow0, q1 = min(job.prow0 + job.nprow, halfH);
+    typedef Row97<CPL, NC> Row;
+
+    if (h < 2) {
+        if (q0 == 0) {
+            Row r0;
+            inv97_load_row<CPL, NC>(coef, coef_f64, prev, P, 0, p0, r0);
+            inv97_finish_row<CPL, NC>(dst, P, 0, c, owned, dc_shift, dst_mode, mct, r0.lo, r0.hi);
+        }
+        return;
+    }
+    // software pipeline over input pairs t: s1[t] <- (s2[t], d2[t-1], d2[t]); d1[t-1] <- (d2[t-1], s1[t-1], s1[t]);
+    // e[t-1] <- (s1[t-1], d1[t-2], d1[t-1]); o[t-2] <- (d1[t-2], e[t-2], e[t-1]); pair t-2 is complete at step t.
+    const int t_start = max(q0 - 2, 0);
+    const int t_last = min(q1 + 1, halfH + 1);
+    double d2p[2][NC][H], s1p[2][NC][H], d1p[2][NC][H], ep[2][NC][H], e2[2][NC][H];
+    // d2p = d2[t-1], s1p = s1[t-1], d1p = d1[t-2], ep = e[t-1] (after update), e2 = e[t-2]
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+#pragma unroll
+            for (int j = 0; j < H; j++) { d2p[a][k][j] = 0.0; s1p[a][k][j] = 0.0; d1p[a][k][j] = 0.0; ep[a][k][j] = 0.0; e2[a][k][j] = 0.0; }
+    for (int t = t_start; t <= t_last; t++) {
+        const bool real = t < halfH;
+        const bool hi_ex = real && (2 * t + 1 < h);
+        Row L, Hh;
+        if (real) inv97_load_row<CPL, NC>(coef, coef_f64, prev, P, t, p0, L);
+        if (hi_ex) inv97_load_row<CPL, NC>(coef, coef_f64, prev, P, halfH + t, p0, Hh);
+        const bool p1_real = (t >= 1) && (t - 1 < halfH);            // pair t-1 exists
+        const bool p1_hi = p1_real && (2 * (t - 1) + 1 < h);
+        const bool p2_real = (t >= 2) && (t - 2 < halfH);            // pair t-2 exists
+        const bool p2_hi = p2_real && (2 * (t - 2) + 1 < h);
+        double re_lo[NC][H], re_hi[NC][H], ro_lo[NC][H], ro_hi[NC][H];
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int k = 0; k < NC; k++)
+#pragma unroll
+                for (int j = 0; j < H; j++) {
+                    double d2t = d2p[a][k][j], s1t = s1p[a][k][j];
+                    if (real) {
+                        const double s2t = (a ? L.hi[k][j] : L.lo[k][j]) * K97;
+                        if (hi_ex) d2t = (a ? Hh.hi[k][j] : Hh.lo[k][j]) * K97I;     // else mirrors d2[t-1]
+                        s1t = s2t - D97 * ((t == 0 ? d2t : d2p[a][k][j]) + d2t);
+                    }
+                    double d1n = d1p[a][k][j], en_ = ep[a][k][j];
+                    if (p1_real) {
+                        if (p1_hi) d1n = d2p[a][k][j] - G97 * (s1p[a][k][j] + (real ? s1t : s1p[a][k][j]));   // d1[t-1]; else mirrors d1[t-2]
+                        en_ = s1p[a][k][j] - B97 * ((t - 1 == 0 ? d1n : d1p[a][k][j]) + d1n);               // e[t-1]
+                    }
+                    if (p2_real) {
+                        const double e_t2 = e2[a][k][j];
+                        const double on = d1p[a][k][j] - A97 * (e_t2 + (p1_real ? en_ : e_t2));             // o[t-2]
+                        if (a == 0) { re_lo[k][j] = e_t2; ro_lo[k][j] = on; } else { re_hi[k][j] = e_t2; ro_hi[k][j] = on; }
+                    }
+                    e2[a][k][j] = ep[a][k][j];
+                    if (p1_real) { ep[a][k][j] = en_; e2[a][k][j] = en_; }
+                    d1p[a][k][j] = d1n;
+                    d2p[a][k][j] = d2t;
+                    s1p[a][k][j] = s1t;
+                }
+        if (p2_real && t - 2 >= q0 && t - 2 < q1) {
+            inv97_finish_row<CPL, NC>(dst, P, 2 * (t - 2), c, owned, dc_shift, dst_mode, mct, re_lo, re_hi);
+            if (p2_hi) inv97_finish_row<CPL, NC>(dst, P, 2 * (t - 2) + 1, c, owned, dc_shift, dst_mode, mct, ro_lo, ro_hi);
+        }
+    }
+}
+
+// ================================================================================
+// launchers
+// ================================================================================
+hipError_t launch_dwt97_fwd(hipStream_t s, const LevelLaunch &L, const void *src, int src_is_f64, int32_t *out_i32, double *out_f64,
+                            double *nxt, int dc_shift, int quant, double step, int mct) {
+    if (L.njobs <= 0) return hipSuccess;
+    const int blocks = (L.njobs + 3) / 4;
+    if (L.ncomp == 3) {
+        hipLaunchKernelGGL((dwt97_fwd_kernel<2, 3>), dim3(blocks), dim3(256), 0, s, L.jobs, L.njobs, L.planes, src, src_is_f64, out_i32, out_f64, nxt, dc_shift, quant, step, mct);
+    } else if (L.cpl == 4) {
+        hipLaunchKernelGGL((dwt97_fwd_kernel<4, 1>), dim3(blocks), dim3(256), 0, s, L.jobs, L.njobs, L.planes, src, src_is_f64, out_i32, out_f64, nxt, dc_shift, quant, step, mct);
+    } else {
+        hipLaunchKernelGGL((dwt97_fwd_kernel<2, 1>), dim3(blocks), dim3(256), 0, s, L.jobs, L.njobs, L.planes, src, src_is_f64, out_i32, out_f64, nxt, dc_shift, quant, step, mct);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_dwt97_inv(hipStream_t s, const LevelLaunch &L, const void *coef, int coef_is_f64, const double *prev, void *dst,
+                            int dc_shift, int final_level, int dst_mode, int mct) {
+    (void)final_level;
+    if (L.njobs <= 0) return hipSuccess;
+    const int blocks = (L.njobs + 3) / 4;
+    if (L.ncomp == 3) {
+        hipLaunchKernelGGL((dwt97_inv_kernel<2, 3>), dim3(blocks), dim3(256), 0, s, L.jobs, L.njobs, L.planes, coef, coef_is_f64, prev, dst, dc_shift, dst_mode, mct);
+    } else if (L.cpl == 4) {
+        hipLaunchKernelGGL((dwt97_inv_kernel<4, 1>), dim3(blocks), dim3(256), 0, s, L.jobs, L.njobs, L.planes, coef, coef_is_f64, prev, dst, dc_shift, dst_mode, mct);
+    } else {
+        hipLaunchKernelGGL((dwt97_inv_kernel<2, 1>), dim3(blocks), dim3(256), 0, s, L.jobs, L.njobs, L.planes, coef, coef_is_f64, prev, dst, dc_shift, dst_mode, mct);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace j2k

@@ -190,14 +190,15 @@ static int upload(j2k_ctx *ctx, T **dptr, const std::vector<T> &v) {
     return J2K_OK;
 }
 
-static void make_jobs(std::vector<DwtJob> &jobs, int plane, int w, int h, int cpl, int band) {
+// halo = lanes per side that only feed their neighbours (1 for 5-3; 9-7: 1 if a lane holds >= 2 pairs, else 2)
+static void make_jobs(std::vector<DwtJob> &jobs, int plane, int w, int h, int cpl, int band, int halo) {
     const int halfH = (h + 1) / 2;
     int col0 = 0;
     for (;;) {
-        const int c_base = col0 - (col0 ? cpl : 0);
+        const int c_base = col0 - (col0 ? halo * cpl : 0);
         for (int pr = 0; pr < std::max(halfH, 1); pr += band) jobs.push_back(DwtJob{plane, col0, pr, band});
         if (c_base + 64 * cpl >= w) break;
-        col0 = c_base + 63 * cpl;
+        col0 = c_base + (64 - halo) * cpl;
     }
 }
 
@@ -291,7 +292,7 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                 T.nplanes = (int)planes.size();
                 if (planes.empty()) continue;
                 int cpl = pick_cpl(maxw);
-                if (S.wavelet == W97 && cpl == 8) cpl = 4;   // 4 f64 = 32 B per lane already
+                if (S.wavelet == W97) cpl = (cls == 1) ? 2 : (maxw >= 192 ? 4 : 2);   // f64: 2 or 4 columns per lane
                 for (size_t i = 0; i < planes.size() && vec_ok; i++) {
                     const DwtPlane &D = planes[i];
                     if (D.w % cpl) vec_ok = false;
@@ -299,11 +300,14 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                     for (int k = 0; k < T.ncomp; k++)
                         if ((D.src_off[k] % 4) || (D.out_off[k] % 4) || (D.nxt_off[k] % 4)) vec_ok = false;
                 }
-                if (!vec_ok) cpl = (S.wavelet == W97) ? 4 : 2;
+                if (S.wavelet == W97) vec_ok = false;        // the 9-7 kernels use scalar accesses
+                else if (!vec_ok) cpl = 2;
                 T.cpl = cpl; T.vec = vec_ok ? 1 : 0;
+                const int halo = (S.wavelet == W97 && cpl < 4) ? 2 : 1;
+                const int band = (S.wavelet == W97) ? std::max(ctx->band_prows, 8) : ctx->band_prows;
                 std::vector<DwtJob> jobs;
                 for (size_t i = 0; i < planes.size(); i++) {
-                    make_jobs(jobs, (int)i, pw[i], ph[i], cpl, ctx->band_prows);
+                    make_jobs(jobs, (int)i, pw[i], ph[i], cpl, band, halo);
                     T.alg_bytes += (int64_t)2 * esz * pw[i] * ph[i] * T.ncomp;
                 }
                 T.njobs = (int)jobs.size();
