@@ -1,0 +1,60 @@
+"""CPU: libj2kgfx.so loads without a GPU and exports every function include/j2kgfx.h declares;
+without a device the product fails loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "go-jpeg2000_amd")])
+    from j2kgfx import _lib
+    return _lib
+
+
+def declared_functions():
+    txt = open(os.path.join(ROOT, "include", "j2kgfx.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(j2k_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    L = lib.lib()
+    names = declared_functions()
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(L, n), "libj2kgfx.so does not export %s" % n
+    assert sorted(lib.SYMBOLS) == names            # the python binding knows exactly the header's surface
+
+
+def test_no_oracle_linkage(lib):
+    """the product library must not depend on the oracle in any form"""
+    out = subprocess.run(["readelf", "-d", lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+    syms = subprocess.run(["nm", "-D", "--defined-only", lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "orc_" not in syms
+
+
+def test_host_only_functions(lib, oracle):
+    L = lib.lib()
+    assert L.j2k_version().startswith(b"j2kgfx")
+    assert L.j2k_status_string(-2).startswith(b"no usable HIP device")
+    for (w, h) in [(64, 64), (4, 4), (1, 1), (128, 128), (8, 5)]:
+        assert L.j2k_block_bound(1, w, h) == oracle.ht_bound(w, h)
+        assert L.j2k_block_bound(0, w, h) == w * h * 2 + 1024
+
+
+def test_fails_loudly_without_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    assert lib.lib().j2k_ctx_create(0, C.byref(h)) == lib.ERR_NO_DEVICE
+    from j2kgfx import Context, J2KError
+    with pytest.raises(J2KError):
+        Context(0)
