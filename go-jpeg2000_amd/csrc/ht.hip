@@ -99,10 +99,183 @@ __device__ __forceinline__ void uvlc_one(BitWriter &v, uint32_t u) {  // ht.go:1
     else { vlc_write(v, 0, 3); vlc_write(v, u - 3, 5); }
 }
 
+// ---- wave-parallel encoder (fast path) --------------------------------------------------------
+// Every quad pair of every coded row is an ITEM; its VLC bits (two table code words + UVLC) and its
+// MagSgn bits depend only on its own 8 samples (the first quad's context is always 0, the second's is
+// rho>>2), so all items are formed in parallel, one per lane.  An exclusive prefix sum of the bit
+// lengths gives every item its position; the bits are OR-ed into LDS bit strings (OR, because the
+// reference ORs the UNMASKED table index into its buffer and the stray high bits overlap the next
+// code word -- ht.go:1266-1268).  Byte stuffing is then applied while the bytes are emitted:
+//   VLC   : a byte keeps its position, only bit 7 may be cleared depending on the previous FINAL byte;
+//   MagSgn: after a 0xFF byte the next byte takes 7 bits, which shifts everything behind it, so
+//           emission runs in 64-byte chunks that stop at the first 0xFF of the chunk.
+#define HT_FAST_MAX_SAMPLES 2048                       /* coded samples (rows y%4==0) per block      */
+#define HT_MS_WORDS (HT_FAST_MAX_SAMPLES * 31 / 32 + 4) /* worst case 31 bits per coded sample       */
+#define HT_VLC_WORDS (HT_FAST_MAX_SAMPLES / 8 + 8)      /* <= 30 bits per item of 8 samples          */
+
+__device__ __forceinline__ void or_bits(uint32_t *buf, uint32_t bitpos, uint64_t val) {
+    const uint32_t wd = bitpos >> 5, sh = bitpos & 31;
+    const uint32_t lo = (uint32_t)(val << sh);
+    const uint64_t hi = sh ? (val >> (32 - sh)) : (val >> 32);
+    if (lo) atomicOr(&buf[wd], lo);
+    if ((uint32_t)hi) atomicOr(&buf[wd + 1], (uint32_t)hi);
+    if ((uint32_t)(hi >> 32)) atomicOr(&buf[wd + 2], (uint32_t)(hi >> 32));
+}
+__device__ __forceinline__ uint32_t get_bits8(const uint32_t *buf, uint32_t bitpos) {
+    const uint32_t wd = bitpos >> 5, sh = bitpos & 31;
+    const uint64_t two = (uint64_t)buf[wd] | ((uint64_t)buf[wd + 1] << 32);
+    return (uint32_t)(two >> sh) & 0xFF;
+}
+
+__device__ bool ht_encode_fast(const BlockJob &J, const int32_t *__restrict__ src, uint8_t *__restrict__ out, int lane,
+                               uint32_t *vbuf, uint32_t *mbuf, long &magLenOut, long &vlcLenOut) {
+    const int w = J.w, h = J.h, stride = J.stride;
+    const int quadCols = (w + 3) / 4, P = (quadCols + 1) / 2, R = (h + 3) / 4, N = R * P;
+    const size_t nsamp = (size_t)w * h;
+    const size_t maxSize = nsamp * 2 < 64 ? 64 : nsamp * 2;
+    const long msCap = (long)(maxSize / 2), vlcCap = (long)(maxSize / 2);
+    const size_t melLen = maxSize / 4;
+    for (int i = lane; i < HT_VLC_WORDS; i += 64) vbuf[i] = 0;
+    for (int i = lane; i < HT_MS_WORDS; i += 64) mbuf[i] = 0;
+    __syncthreads();
+    uint32_t vbase = 0, mbase = 0;   // running bit totals
+    int bad = 0;
+    for (int i0 = 0; i0 < N; i0 += 64) {
+        const int it = i0 + lane;
+        uint64_t vv = 0; uint32_t vl = 0, ml = 0;
+        uint32_t mval[8], mlen[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { mval[i] = 0; mlen[i] = 0; }
+        if (it < N) {
+            const int r = it / P, pi = it - r * P;
+            const int initial = (r == 0);
+            const int32_t *row = src + (size_t)(4 * r) * stride;
+            const int xb = pi * 8;
+            int v[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = (xb + i < w) ? row[xb + i] : 0;
+            uint32_t rho = 0, rho2 = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (v[i] != 0) rho |= 1u << i;
+                if (v[4 + i] != 0) rho2 |= 1u << i;
+            }
+            const uint32_t e1 = g_vlc_enc[(initial << 6) | rho];
+            const uint32_t e2 = g_vlc_enc[(initial << 6) | ((rho >> 2) << 4) | rho2];
+            vv = (uint64_t)(e1 >> 4);
+            vl = e1 & 0xF;
+            vv |= (uint64_t)(e2 >> 4) << vl;
+            vl += e2 & 0xF;
+            if (rho | rho2) {
+                uint32_t u1 = 1, u2 = 1;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    if (xb + i < w && uabs(v[i]) >= shl32(1, u1)) u1++;
+                    if (xb + 4 + i < w && uabs(v[4 + i]) >= shl32(1, u2)) u2++;
+                }
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    if (!(q ? rho2 : rho)) continue;
+                    const uint32_t u = q ? u2 : u1;
+                    if (u <= 1) { vv |= (uint64_t)1 << vl; vl += 1; }
+                    else if (u <= 2) { vv |= (uint64_t)2 << vl; vl += 2; }
+                    else { vv |= (uint64_t)(u - 3) << (vl + 3); vl += 8; }   // (0,3) then (u-3,5)
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint32_t rr = (i < 4) ? rho : rho2;
+                if (!((rr >> (i & 3)) & 1)) continue;
+                const uint32_t mag = uabs(v[i]);
+                if (mag >= 0x80000000u) { bad = 1; continue; }
+                const uint32_t emb = 32 - __clz(mag);
+                mval[i] = (mag & (shl32(1, emb - 1) - 1)) | ((v[i] < 0 ? 1u : 0u) << (emb - 1));
+                mlen[i] = emb;
+                ml += emb;
+            }
+        }
+        // exclusive prefix sums over the 64 items of this round
+        uint32_t vs = vl, ms = ml;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t a = __shfl_up(vs, o), b = __shfl_up(ms, o);
+            if (lane >= o) { vs += a; ms += b; }
+        }
+        const uint32_t vtot = __shfl(vs, 63), mtot = __shfl(ms, 63);
+        uint32_t vpos = vbase + vs - vl, mpos = mbase + ms - ml;
+        if (it < N) {
+            or_bits(vbuf, vpos, vv);
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (mlen[i]) { or_bits(mbuf, mpos, (uint64_t)mval[i]); mpos += mlen[i]; }
+        }
+        vbase += vtot; mbase += mtot;
+    }
+    bad = __any(bad);
+    __syncthreads();
+    if (bad) return false;
+    // ---- MagSgn emission with 0xFF stuffing (ht.go:1303-1341) ----
+    const uint32_t TM = mbase;
+    uint32_t pos = 0, last = 0;
+    long outpos = 0;
+    while (TM - pos >= 8) {
+        if (last == 0xFF) {                         // wave-uniform: one 7-bit byte
+            const uint32_t b = get_bits8(mbuf, pos) & 0x7F;
+            if (outpos >= msCap) return false;
+            if (lane == 0) out[outpos] = (uint8_t)b;
+            outpos++; pos += 7; last = b;
+            continue;
+        }
+        const uint32_t p = pos + 8 * lane;
+        const bool valid = (p + 8 <= TM);
+        const uint32_t b = valid ? get_bits8(mbuf, p) : 0;
+        const unsigned long long vmask = __ballot(valid), fmask = __ballot(valid && b == 0xFF);
+        const int nvalid = __popcll(vmask);
+        const int first = fmask ? __ffsll((long long)fmask) - 1 : 64;
+        const int count = min(nvalid, first + 1);
+        if (outpos + count > msCap) return false;
+        if (lane < count) out[outpos + lane] = (uint8_t)b;
+        outpos += count; pos += 8 * count;
+        last = (first < nvalid) ? 0xFF : __shfl(b, count - 1);
+    }
+    if (TM > pos) {                                 // magSgnFlush: the remaining < 8 bits, no stuffing rule
+        if (outpos >= msCap) return false;
+        if (lane == 0) out[outpos] = (uint8_t)get_bits8(mbuf, pos);
+        outpos++;
+    }
+    const long magLen = outpos;
+    // ---- VLC bytes: position-preserving stuffing (ht.go:1271-1300) ----
+    const uint32_t TV = vbase;
+    const long nfull = TV >> 3, vlcLen = (TV + 7) >> 3;
+    if (vlcLen > vlcCap) return false;
+    uint8_t *vout = out + magLen + melLen;
+    for (long i = lane; i < vlcLen; i += 64) {
+        uint32_t b = get_bits8(vbuf, (uint32_t)(8 * i));
+        if (i < nfull && (b & 0x7F) == 0x7F && i > 0) {
+            // final value of the previous byte: walk back over the run of bytes whose low 7 bits are all ones
+            long j = i - 1;
+            while (j > 0 && (get_bits8(vbuf, (uint32_t)(8 * j)) & 0x7F) == 0x7F) j--;
+            uint32_t prev = (j == 0 && (get_bits8(vbuf, 0) & 0x7F) == 0x7F) ? get_bits8(vbuf, 0)      // byte 0: lastByte starts at 0, never masked
+                                                                             : get_bits8(vbuf, (uint32_t)(8 * j));
+            for (long k = j + 1; k < i; k++) {
+                uint32_t rb = get_bits8(vbuf, (uint32_t)(8 * k));
+                if (prev > 0x8F && (rb & 0x7F) == 0x7F) rb &= 0x7F;
+                prev = rb;
+            }
+            if (prev > 0x8F) b &= 0x7F;
+        }
+        vout[i] = (uint8_t)b;
+    }
+    magLenOut = magLen; vlcLenOut = vlcLen;
+    return true;
+}
+
 __global__ __launch_bounds__(64) void ht_encode_kernel(const BlockJob *__restrict__ jobs, int njobs,
                                                        const int32_t *__restrict__ coef, uint8_t *__restrict__ slots,
                                                        uint32_t *__restrict__ lens, uint8_t *__restrict__ numbps,
                                                        int *__restrict__ fault) {
+    __shared__ uint32_t s_vbuf[HT_VLC_WORDS];
+    __shared__ uint32_t s_mbuf[HT_MS_WORDS];
     const int jid = blockIdx.x;
     if (jid >= njobs) return;
     const int lane = threadIdx.x;
@@ -113,17 +286,49 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(const BlockJob *__restric
 
     // ---- max |x| over the WHOLE block: nil decision (ht.go:947-960) and numbps ----
     int maxMag = 0;  // Go compares int32: -MinInt32 stays negative and never wins
-    for (int y = 0; y < h; y++)
-        for (int x = lane; x < w; x += 64) {
-            int v = src[(size_t)y * stride + x];
-            if (v < 0) v = (int)(0u - (uint32_t)v);
-            maxMag = max(maxMag, v);
+    if ((w & 3) == 0 && (stride & 3) == 0 && (J.src_off & 3) == 0) {
+        const int wq = w >> 2, nq = wq * h;
+        for (int e = lane; e < nq; e += 64) {
+            const int y = e / wq, xq = e - y * wq;
+            const int4 q = *reinterpret_cast<const int4 *>(src + (size_t)y * stride + 4 * xq);
+            const int a0 = q.x < 0 ? (int)(0u - (uint32_t)q.x) : q.x, a1 = q.y < 0 ? (int)(0u - (uint32_t)q.y) : q.y;
+            const int a2 = q.z < 0 ? (int)(0u - (uint32_t)q.z) : q.z, a3 = q.w < 0 ? (int)(0u - (uint32_t)q.w) : q.w;
+            maxMag = max(max(maxMag, max(a0, a1)), max(a2, a3));
         }
+    } else {
+        for (int y = 0; y < h; y++)
+            for (int x = lane; x < w; x += 64) {
+                int v = src[(size_t)y * stride + x];
+                if (v < 0) v = (int)(0u - (uint32_t)v);
+                maxMag = max(maxMag, v);
+            }
+    }
     for (int o = 32; o > 0; o >>= 1) maxMag = max(maxMag, __shfl_xor(maxMag, o));
     if (maxMag == 0) {
         if (lane == 0) { lens[jid] = 0; numbps[jid] = 0; }
         return;
     }
+    if ((size_t)((h + 3) / 4) * (size_t)w <= HT_FAST_MAX_SAMPLES) {
+        long mLen = 0, vLen = 0;
+        const size_t nsamp_ = (size_t)w * h;
+        const size_t maxSize_ = nsamp_ * 2 < 64 ? 64 : nsamp_ * 2;
+        const size_t melLen_ = maxSize_ / 4;
+        if (!ht_encode_fast(J, src, out, lane, s_vbuf, s_mbuf, mLen, vLen)) {
+            if (lane == 0) { atomicMax(fault, 1); lens[jid] = 0; numbps[jid] = 0; }
+            return;
+        }
+        for (size_t i = lane; i < melLen_; i += 64) out[mLen + i] = 0;
+        if (lane == 0) {
+            const size_t scup = melLen_ + (size_t)vLen + 2;
+            const size_t total = (size_t)mLen + scup;
+            out[total - 2] = (uint8_t)(scup >> 8);
+            out[total - 1] = (uint8_t)(scup & 0xFF);
+            lens[jid] = (uint32_t)total;
+            numbps[jid] = (uint8_t)(32 - __clz((uint32_t)maxMag));
+        }
+        return;
+    }
+    // ---- generic path for large blocks: bit-serial packing on lane 0 ----
     const size_t nsamp = (size_t)w * h;
     const size_t maxSize = nsamp * 2 < 64 ? 64 : nsamp * 2;   // ht.go:969-972
     const size_t msCap = maxSize / 2, melLen = maxSize / 4, vlcCap = maxSize / 2;
