@@ -552,9 +552,163 @@ __device__ bool init_mel_ok(const uint8_t *data, long len, long lcup, long scup)
     return true;
 }
 
+// ---- wave-parallel decoder (fast path) ---------------------------------------------------------
+// 1. both byte streams are UNSTUFFED in parallel into LDS bit strings (a byte's width -- 7 or 8 bits --
+//    depends only on its predecessor; prefix sum of widths; OR-deposit, because the reference ORs a full
+//    byte at a 7-bit advance: ht.go:344-377, 467-500);
+// 2. lane 0 walks the VLC bit string (the only truly sequential part: each code word's length comes out
+//    of the table lookup of the previous one) and records (rho, rho2, u0, u1) per quad pair;
+// 3. all lanes extract magnitudes and signs: a pair's MagSgn position is the prefix sum of
+//    popcount(rho)*(u+1) over the pairs before it.
+// Falls back to the bit-serial decoder for blocks with more than HT_FAST_MAX_SAMPLES coded samples or when
+// a decoded u exceeds 32 (the reference's uint32 bit counter then wraps, ht.go:515-519).
+#define HT_DEC_VWORDS (46 * (HT_FAST_MAX_SAMPLES / 8) / 32 + 8)
+#define HT_DEC_MWORDS (33 * HT_FAST_MAX_SAMPLES / 32 + 8)
+
+__device__ __forceinline__ uint32_t get_bits32(const uint32_t *buf, uint32_t bitpos) {
+    const uint32_t wd = bitpos >> 5, sh = bitpos & 31;
+    const uint64_t two = (uint64_t)buf[wd] | ((uint64_t)buf[wd + 1] << 32);
+    return (uint32_t)(two >> sh);
+}
+
+struct HtDecShared {
+    uint32_t vbuf[HT_DEC_VWORDS];
+    uint32_t mbuf[HT_DEC_MWORDS];
+    uint32_t pair[HT_FAST_MAX_SAMPLES / 8];
+    uint16_t tbl0[512], tbl1[512];
+};
+
+// returns false if the block must be decoded by the serial path instead
+__device__ bool ht_decode_fast(HtDecShared &S, const uint8_t *__restrict__ data, long len, long scup, int w, int h,
+                               int32_t *__restrict__ out, int lane) {
+    const int quadCols = (w + 3) / 4, P = (quadCols + 1) / 2, R = (h + 3) / 4, N = R * P;
+    const long lcup = len;
+    for (int i = lane; i < HT_DEC_VWORDS; i += 64) S.vbuf[i] = 0;
+    for (int i = lane; i < HT_DEC_MWORDS; i += 64) S.mbuf[i] = 0;
+    for (int i = lane; i < 512; i += 64) { S.tbl0[i] = c_vlc_tbl0[i]; S.tbl1[i] = c_vlc_tbl1[i]; }
+    __syncthreads();
+    // ---- VLC (reverse) bit string: initVLC + revRead (ht.go:276-378) ----
+    {
+        const uint32_t b0 = data[lcup - 2];
+        const uint32_t t0 = b0 >> 4;
+        uint32_t off = 4 - ((t0 & 7) >> 2);
+        if (lane == 0) atomicOr(&S.vbuf[0], t0);
+        const long size = scup - 2;
+        const long maxbytes = (long)(46 * N + 7) / 8 + 8;
+        const long nb = size < maxbytes ? size : maxbytes;
+        for (long k0 = 1; k0 <= nb; k0 += 64) {
+            const long k = k0 + lane;
+            uint32_t b = 0, width = 0;
+            if (k <= nb) {
+                b = data[lcup - 2 - k];
+                const uint32_t prev = (k == 1) ? (b0 | 0x0F) : data[lcup - 1 - k];
+                width = (prev > 0x8F && (b & 0x7F) == 0x7F) ? 7 : 8;
+            }
+            uint32_t ws = width;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t a = __shfl_up(ws, o); if (lane >= o) ws += a; }
+            if (k <= nb && b) or_bits(S.vbuf, off + ws - width, (uint64_t)b);
+            off += __shfl(ws, 63);
+        }
+    }
+    // ---- MagSgn (forward) bit string: initMagSgn + frwdRead (ht.go:399-501); exhausted -> all ones ----
+    {
+        const long segLen = lcup - scup;
+        const long maxbytes = (long)HT_DEC_MWORDS * 4 - 16;
+        const long nb = segLen < maxbytes ? segLen : maxbytes;
+        uint32_t off = 0;
+        for (long k0 = 0; k0 < nb; k0 += 64) {
+            const long k = k0 + lane;
+            uint32_t b = 0, width = 0;
+            if (k < nb) {
+                b = data[k];
+                width = (k > 0 && data[k - 1] == 0xFF) ? 7 : 8;
+            }
+            uint32_t ws = width;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t a = __shfl_up(ws, o); if (lane >= o) ws += a; }
+            if (k < nb && b) or_bits(S.mbuf, off + ws - width, (uint64_t)b);
+            off += __shfl(ws, 63);
+        }
+        __syncthreads();
+        if (nb == segLen) {   // everything past the segment reads as ones
+            const uint32_t wd0 = off >> 5;
+            for (uint32_t i = wd0 + lane; i < HT_DEC_MWORDS; i += 64)
+                S.mbuf[i] = (i == wd0) ? (S.mbuf[i] | (0xFFFFFFFFu << (off & 31))) : 0xFFFFFFFFu;
+        }
+    }
+    __syncthreads();
+    // ---- sequential VLC walk on lane 0 (ht.go:589-658) ----
+    int too_big = 0;
+    if (lane == 0) {
+        uint32_t cv = 0;
+        for (int r = 0; r < R; r++) {
+            const int initial = (r == 0);
+            const uint16_t *tbl = initial ? S.tbl0 : S.tbl1;
+            for (int pi = 0; pi < P; pi++) {
+                uint32_t vlcVal = get_bits32(S.vbuf, cv);
+                const uint32_t qinf = tbl[vlcVal & 0x7F];
+                const uint32_t rho = (qinf >> 4) & 0xF, uOff1 = (qinf >> 3) & 1;
+                cv += qinf & 0xF;
+                vlcVal = get_bits32(S.vbuf, cv);
+                const uint32_t qinf2 = tbl[((rho >> 2) << 7) | (vlcVal & 0x7F)];
+                const uint32_t rho2 = (qinf2 >> 4) & 0xF, uOff2 = (qinf2 >> 3) & 1;
+                cv += qinf2 & 0xF;
+                uint32_t u[2] = {1, 1};
+                const uint32_t mode = (uOff1 << 1) | uOff2;
+                if (mode > 0) cv += decode_uvlc(get_bits32(S.vbuf, cv), mode, u, initial);
+                if (u[0] > 32 || u[1] > 32) too_big = 1;
+                S.pair[r * P + pi] = rho | rho2 << 4 | (u[0] & 0x3F) << 8 | (u[1] & 0x3F) << 16;
+            }
+        }
+    }
+    too_big = __shfl(too_big, 0);
+    __syncthreads();
+    if (too_big) return false;
+    // ---- parallel MagSgn extraction (ht.go:661-710) ----
+    uint32_t mbase = 0;
+    for (int i0 = 0; i0 < N; i0 += 64) {
+        const int it = i0 + lane;
+        uint32_t info = 0, nbits = 0, rho = 0, rho2 = 0, u0 = 1, u1 = 1;
+        int r = 0, pi = 0;
+        if (it < N) {
+            info = S.pair[it];
+            r = it / P; pi = it - r * P;
+            rho = info & 0xF; rho2 = (info >> 4) & 0xF; u0 = (info >> 8) & 0x3F; u1 = (info >> 16) & 0x3F;
+            const int xb = pi * 8;
+            // samples beyond the block width are skipped even when their rho bit is set (ht.go:661, 689)
+            const uint32_t m1 = (xb + 4 <= w) ? 0xFu : ((xb < w) ? ((1u << (w - xb)) - 1) : 0u);
+            const uint32_t m2 = (xb + 8 <= w) ? 0xFu : ((xb + 4 < w) ? ((1u << (w - xb - 4)) - 1) : 0u);
+            rho &= m1; rho2 &= m2;
+            nbits = __popc(rho) * (u0 + 1) + __popc(rho2) * (u1 + 1);
+        }
+        uint32_t ns = nbits;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t a = __shfl_up(ns, o); if (lane >= o) ns += a; }
+        uint32_t mpos = mbase + ns - nbits;
+        mbase += __shfl(ns, 63);
+        if (it < N) {
+            int32_t *orow = out + (size_t)(4 * r) * w + pi * 8;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint32_t rr = (i < 4) ? rho : rho2, emb = (i < 4) ? u0 : u1;
+                if (!((rr >> (i & 3)) & 1)) continue;
+                const uint32_t magVal = get_bits32(S.mbuf, mpos);
+                const uint32_t mag = (magVal & (shl32(1, emb) - 1)) + shl32(1, emb - 1);
+                mpos += emb;
+                const uint32_t sign = get_bits32(S.mbuf, mpos) & 1;
+                mpos += 1;
+                orow[i] = sign ? (int32_t)(0u - mag) : (int32_t)mag;
+            }
+        }
+    }
+    return true;
+}
+
 __global__ __launch_bounds__(64) void ht_decode_kernel(const BlockJob *__restrict__ jobs, int njobs,
                                                        const uint8_t *__restrict__ stream, const uint64_t *__restrict__ offs,
                                                        const uint32_t *__restrict__ lens, int32_t *__restrict__ decoded) {
+    __shared__ HtDecShared S;
     const int jid = blockIdx.x;
     if (jid >= njobs) return;
     const int lane = threadIdx.x;
@@ -564,6 +718,16 @@ __global__ __launch_bounds__(64) void ht_decode_kernel(const BlockJob *__restric
     const size_t n = (size_t)w * h;
     for (size_t i = lane; i < n; i += 64) out[i] = 0;           // fresh NewHTDecoder: zeroed data
     __syncthreads();
+    if ((size_t)((h + 3) / 4) * (size_t)w <= HT_FAST_MAX_SAMPLES) {
+        const uint8_t *fdata = stream + offs[jid];
+        const long flen = (long)lens[jid];
+        if (flen < 2) return;                                   // ht.go:94-100
+        const long fscup = (long)fdata[flen - 1] + ((long)(fdata[flen - 2] & 0x0F) << 8);
+        if (fscup < 2 || fscup > flen) return;                  // ht.go:104-111
+        if (!init_mel_ok(fdata, flen, flen, fscup)) return;     // ht.go:117-122
+        if (ht_decode_fast(S, fdata, flen, fscup, w, h, out, lane)) return;
+        __syncthreads();
+    }
     if (lane != 0) return;
     const uint8_t *data = stream + offs[jid];
     const long len = (long)lens[jid];
