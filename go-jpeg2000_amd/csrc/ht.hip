@@ -16,6 +16,8 @@
 // code word's position depends on all previous lengths and on byte stuffing -- runs on lane 0
 // straight into the block's output slot; the MEL zero fill and the final VLC move are done by
 // all 64 lanes.  Go semantics kept: uint32 wraparound, shifts >= 32 give 0.
+#include <cstdlib>
+
 #include "ht_tables.h"
 #include "j2k_internal.h"
 
@@ -109,9 +111,9 @@ __device__ __forceinline__ void uvlc_one(BitWriter &v, uint32_t u) {  // ht.go:1
 //   VLC   : a byte keeps its position, only bit 7 may be cleared depending on the previous FINAL byte;
 //   MagSgn: after a 0xFF byte the next byte takes 7 bits, which shifts everything behind it, so
 //           emission runs in 64-byte chunks that stop at the first 0xFF of the chunk.
-#define HT_FAST_MAX_SAMPLES 2048                       /* coded samples (rows y%4==0) per block      */
+#define HT_FAST_MAX_SAMPLES 1024                       /* coded samples (rows y%4==0) per block      */
 #define HT_MS_WORDS (HT_FAST_MAX_SAMPLES * 31 / 32 + 4) /* worst case 31 bits per coded sample       */
-#define HT_VLC_WORDS (HT_FAST_MAX_SAMPLES / 8 + 8)      /* <= 30 bits per item of 8 samples          */
+#define HT_VLC_WORDS (46 * (HT_FAST_MAX_SAMPLES / 8) / 32 + 8) /* <= 15+15+16 bits per item (the "length" nibble reaches 15) */
 
 __device__ __forceinline__ void or_bits(uint32_t *buf, uint32_t bitpos, uint64_t val) {
     const uint32_t wd = bitpos >> 5, sh = bitpos & 31;
@@ -140,6 +142,7 @@ __device__ bool ht_encode_fast(const BlockJob &J, const int32_t *__restrict__ sr
     __syncthreads();
     uint32_t vbase = 0, mbase = 0;   // running bit totals
     int bad = 0;
+    const bool vec_ok = ((stride & 3) == 0) && ((J.src_off & 3) == 0);
     for (int i0 = 0; i0 < N; i0 += 64) {
         const int it = i0 + lane;
         uint64_t vv = 0; uint32_t vl = 0, ml = 0;
@@ -152,8 +155,16 @@ __device__ bool ht_encode_fast(const BlockJob &J, const int32_t *__restrict__ sr
             const int32_t *row = src + (size_t)(4 * r) * stride;
             const int xb = pi * 8;
             int v[8];
+            if (vec_ok && xb + 8 <= w) {
+                const int4 a = *reinterpret_cast<const int4 *>(row + xb), b = *reinterpret_cast<const int4 *>(row + xb + 4);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            } else {
 #pragma unroll
-            for (int i = 0; i < 8; i++) v[i] = (xb + i < w) ? row[xb + i] : 0;
+                for (int i = 0; i < 8; i++) {
+                    const int t = row[xb + i < w ? xb + i : w - 1];        // clamped index: unconditional load
+                    v[i] = (xb + i < w) ? t : 0;
+                }
+            }
             uint32_t rho = 0, rho2 = 0;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -501,10 +512,8 @@ __device__ __forceinline__ uint32_t fwd_fetch(FwdStream &f) {  // ht.go:504-512
 __device__ __forceinline__ void fwd_advance(FwdStream &f, uint32_t n) { f.tmp = shr64(f.tmp, n); f.bits -= n; }
 
 __device__ __forceinline__ uint32_t uvlc_entry(uint32_t idx) {  // ht.go:718-727: prefix len | suffix len<<2 | base<<5
-    // {3|5<<2|5<<5, 1|1<<5, 2|2<<5, 1|1<<5, 3|1<<2|3<<5, 1|1<<5, 2|2<<5, 1|1<<5}
-    const uint32_t packed[8] = {3 | (5 << 2) | (5 << 5), 1 | (1 << 5), 2 | (2 << 5), 1 | (1 << 5),
-                                3 | (1 << 2) | (3 << 5), 1 | (1 << 5), 2 | (2 << 5), 1 | (1 << 5)};
-    return packed[idx & 7] & 0xFF;   // the Go table is [8]uint8
+    // {3|5<<2|5<<5, 1|1<<5, 2|2<<5, 1|1<<5, 3|1<<2|3<<5, 1|1<<5, 2|2<<5, 1|1<<5} = {183,33,66,33,103,33,66,33}, one byte each
+    return (uint32_t)(0x21422167214221B7ull >> (8 * (idx & 7))) & 0xFF;
 }
 
 __device__ uint32_t decode_uvlc(uint32_t vlc, uint32_t mode, uint32_t (&u)[2], int initial) {  // ht.go:716-864
@@ -552,18 +561,39 @@ __device__ bool init_mel_ok(const uint8_t *data, long len, long lcup, long scup)
     return true;
 }
 
-// ---- wave-parallel decoder (fast path) ---------------------------------------------------------
-// 1. both byte streams are UNSTUFFED in parallel into LDS bit strings (a byte's width -- 7 or 8 bits --
-//    depends only on its predecessor; prefix sum of widths; OR-deposit, because the reference ORs a full
-//    byte at a 7-bit advance: ht.go:344-377, 467-500);
-// 2. lane 0 walks the VLC bit string (the only truly sequential part: each code word's length comes out
-//    of the table lookup of the previous one) and records (rho, rho2, u0, u1) per quad pair;
-// 3. all lanes extract magnitudes and signs: a pair's MagSgn position is the prefix sum of
-//    popcount(rho)*(u+1) over the pairs before it.
-// Falls back to the bit-serial decoder for blocks with more than HT_FAST_MAX_SAMPLES coded samples or when
-// a decoded u exceeds 32 (the reference's uint32 bit counter then wraps, ht.go:515-519).
-#define HT_DEC_VWORDS (46 * (HT_FAST_MAX_SAMPLES / 8) / 32 + 8)
+// ---- parallel decoder (fast path), two kernels -------------------------------------------------
+// The VLC stream is inherently sequential (each code word's length comes out of the table lookup of the
+// previous one), ~150 dependent instructions per quad pair.  Run as "one block per wavefront" that walk
+// saturates the CU's single scalar unit (measured: 36 us for one block, 290 us for 7005).  So:
+//   ht_walk_kernel   : one block per LANE.  The tail of every block's stream (where the VLC bytes live) is
+//                      staged into LDS with coalesced loads, then 64 lanes walk 64 blocks at once with the
+//                      reference's own reverse reader (initVLC/revRead, ht.go:276-396) and write one record
+//                      (rho, rho2, u0, u1) per quad pair to a global scratch.
+//   ht_decode_kernel : one block per WAVEFRONT.  Zero fill, parallel unstuffing of the MagSgn bytes into an
+//                      LDS bit string (a byte is 7 bits wide iff its predecessor is 0xFF; prefix sum of
+//                      widths; OR-deposit because the reference ORs a full byte at a 7-bit advance,
+//                      ht.go:467-500; past the segment everything reads as ones), then every lane extracts
+//                      the samples of its pairs: a pair's bit position is the prefix sum of
+//                      popcount(rho)*(u+1) over the pairs before it (ht.go:661-710).
+// Blocks with more than HT_FAST_MAX_SAMPLES coded samples / HT_WALK_MAX_PAIRS pairs, or where a decoded u
+// exceeds 32 (the reference's uint32 bit counter then wraps, ht.go:515-519), take the bit-serial path.
+#define HT_WALK_MAX_PAIRS 128
+#define HT_WALK_TAIL 756                       /* staged stream tail: >= 46*128/8 + 2 + read-ahead slack          */
+#define HT_WALK_ROW 764                        /* LDS row: tail + 3 alignment bytes, 191 words (odd stride)          */
 #define HT_DEC_MWORDS (33 * HT_FAST_MAX_SAMPLES / 32 + 8)
+#define HT_WALK_REC 132                        /* words per block: 128 pair records + flags (+pad) */
+#define HT_FLAG_BIGU 1u                         /* some decoded u exceeds 32: the extraction must emulate the bit-counter wrap */
+#define HT_PAIR_SERIAL 0xFFFFFFFFu              /* record[0]: decode this block with the serial path */
+#define HT_PAIR_ZERO 0xFFFFFFFEu                /* record[0]: invalid stream -> output stays zero     */
+
+// Single-wavefront workgroups: DS instructions of one wave execute in order, so LDS written by one lane is
+// visible to the others without an s_barrier; only the compiler must not reorder.  Unlike __syncthreads()
+// this does NOT wait for outstanding global stores (vmcnt), which lets the zero fill drain in the background.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 __device__ __forceinline__ uint32_t get_bits32(const uint32_t *buf, uint32_t bitpos) {
     const uint32_t wd = bitpos >> 5, sh = bitpos & 31;
@@ -571,110 +601,291 @@ __device__ __forceinline__ uint32_t get_bits32(const uint32_t *buf, uint32_t bit
     return (uint32_t)(two >> sh);
 }
 
-struct HtDecShared {
-    uint32_t vbuf[HT_DEC_VWORDS];
-    uint32_t mbuf[HT_DEC_MWORDS];
-    uint32_t pair[HT_FAST_MAX_SAMPLES / 8];
+// reads for blocks with u > 32: positions clamped into the staged string (its tail is all ones) and cut to zero at L
+__device__ __forceinline__ uint32_t get_bits32_cut(const uint32_t *buf, uint32_t bitpos, uint32_t L) {
+    if (bitpos >= L) return 0;
+    const uint32_t p = bitpos < (HT_DEC_MWORDS - 2) * 32u ? bitpos : (HT_DEC_MWORDS - 2) * 32u + (bitpos & 31);
+    uint32_t v = get_bits32(buf, p);
+    if (L - bitpos < 32) v &= (1u << (L - bitpos)) - 1;
+    return v;
+}
+
+struct HtWalkShared {
+    uint32_t raw[64][HT_WALK_ROW / 4];
     uint16_t tbl0[512], tbl1[512];
 };
 
-// returns false if the block must be decoded by the serial path instead
-__device__ bool ht_decode_fast(HtDecShared &S, const uint8_t *__restrict__ data, long len, long scup, int w, int h,
-                               int32_t *__restrict__ out, int lane) {
+__global__ __launch_bounds__(64) void ht_walk_kernel(const BlockJob *__restrict__ jobs, int njobs,
+                                                     const uint8_t *__restrict__ stream, const uint64_t *__restrict__ offs,
+                                                     const uint32_t *__restrict__ lens, uint32_t *__restrict__ pairs) {
+    __shared__ HtWalkShared S;
+    const int lane = threadIdx.x;
+    const int jid = blockIdx.x * 64 + lane;
+    const bool have = jid < njobs;
+    reinterpret_cast<uint4 *>(S.tbl0)[lane] = reinterpret_cast<const uint4 *>(c_vlc_tbl0)[lane];   // contexts 0..3 = 1 KiB
+    reinterpret_cast<uint4 *>(S.tbl1)[lane] = reinterpret_cast<const uint4 *>(c_vlc_tbl1)[lane];
+    int w = 1, h = 1;
+    long len = 0;
+    const uint8_t *data = stream;
+    if (have) { w = jobs[jid].w; h = jobs[jid].h; len = (long)lens[jid]; data = stream + offs[jid]; }
     const int quadCols = (w + 3) / 4, P = (quadCols + 1) / 2, R = (h + 3) / 4, N = R * P;
-    const long lcup = len;
-    for (int i = lane; i < HT_DEC_VWORDS; i += 64) S.vbuf[i] = 0;
-    for (int i = lane; i < HT_DEC_MWORDS; i += 64) S.mbuf[i] = 0;
-    for (int i = lane; i < 512; i += 64) { S.tbl0[i] = c_vlc_tbl0[i]; S.tbl1[i] = c_vlc_tbl1[i]; }
-    __syncthreads();
-    // ---- VLC (reverse) bit string: initVLC + revRead (ht.go:276-378) ----
-    {
-        const uint32_t b0 = data[lcup - 2];
-        const uint32_t t0 = b0 >> 4;
-        uint32_t off = 4 - ((t0 & 7) >> 2);
-        if (lane == 0) atomicOr(&S.vbuf[0], t0);
-        const long size = scup - 2;
-        const long maxbytes = (long)(46 * N + 7) / 8 + 8;
-        const long nb = size < maxbytes ? size : maxbytes;
-        for (long k0 = 1; k0 <= nb; k0 += 64) {
-            const long k = k0 + lane;
-            uint32_t b = 0, width = 0;
-            if (k <= nb) {
-                b = data[lcup - 2 - k];
-                const uint32_t prev = (k == 1) ? (b0 | 0x0F) : data[lcup - 1 - k];
-                width = (prev > 0x8F && (b & 0x7F) == 0x7F) ? 7 : 8;
-            }
-            uint32_t ws = width;
+    const bool fast = have && (size_t)R * (size_t)w <= HT_FAST_MAX_SAMPLES && N <= HT_WALK_MAX_PAIRS;
+    const long T = len < HT_WALK_TAIL ? len : HT_WALK_TAIL;       // staged bytes: stream[len-T, len)
+    // ---- stage every block's tail: aligned dword loads, all lanes serve one block at a time, eight blocks'
+    //      loads in flight before the first LDS store (one memory latency per group, not per block) ----
+    const uintptr_t tail_addr = (uintptr_t)(data + (len - T));
+    const uint32_t delta = (uint32_t)(tail_addr & 3);                // bytes of junk in front of the tail in the LDS row
+    for (int g = 0; g < 64; g += 8) {
+        uint32_t v[8][3];
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const uint32_t a = __shfl_up(ws, o); if (lane >= o) ws += a; }
-            if (k <= nb && b) or_bits(S.vbuf, off + ws - width, (uint64_t)b);
-            off += __shfl(ws, 63);
+        for (int j = 0; j < 8; j++) {
+            const int bsel = g + j;
+            const long bT = __shfl(fast ? T : 0, bsel);
+            const uint64_t ba = __shfl((uint64_t)(tail_addr & ~(uintptr_t)3), bsel);
+            const uint32_t bd = __shfl(delta, bsel);
+            const int nd = bT ? (int)((bd + bT + 3) >> 2) : 0;       // dwords to copy (<= 190)
+            const uint32_t *src = reinterpret_cast<const uint32_t *>((uintptr_t)ba);
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const int i = lane + 64 * c;
+                const uint32_t t = src[(nd > 0) ? (i < nd ? i : nd - 1) : 0];   // clamped index: unconditional loads
+                v[j][c] = t;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int bsel = g + j;
+            const long bT = __shfl(fast ? T : 0, bsel);
+            const uint32_t bd = __shfl(delta, bsel);
+            const int nd = bT ? (int)((bd + bT + 3) >> 2) : 0;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const int i = lane + 64 * c;
+                if (i < nd) S.raw[bsel][i] = v[j][c];
+            }
         }
     }
-    // ---- MagSgn (forward) bit string: initMagSgn + frwdRead (ht.go:399-501); exhausted -> all ones ----
+    __syncthreads();
+    if (!have) return;
+    uint32_t *rec = pairs + (size_t)jid * HT_WALK_REC;
+    if (!fast) { rec[0] = HT_PAIR_SERIAL; return; }
+    if (len < 2) { rec[0] = HT_PAIR_ZERO; return; }                 // ht.go:94-100
+    const uint8_t *vd = reinterpret_cast<const uint8_t *>(&S.raw[lane][0]) + delta - (len - T);   // vd[i] = stream byte i, i in [len-T, len)
+    const long scup = (long)vd[len - 1] + ((long)(vd[len - 2] & 0x0F) << 8);
+    if (scup < 2 || scup > len) { rec[0] = HT_PAIR_ZERO; return; }  // ht.go:104-111
+    if (!init_mel_ok(data, len, len, scup)) { rec[0] = HT_PAIR_ZERO; return; }   // ht.go:117-122 (first MEL bytes: global)
+    const long lcup = len;
+    RevStream vlc{vd, len, lcup - 2, scup - 2, 0, 0, 0};            // initVLC ht.go:276-314
+    {
+        const uint32_t b = vd[vlc.pos];
+        vlc.pos--;
+        vlc.tmp = (uint64_t)(b >> 4);
+        vlc.bits = 4 - (uint32_t)((vlc.tmp & 7) >> 2);
+        vlc.unstuff = (b | 0x0F) > 0x8F;
+        long num = 1 + (vlc.pos & 3);
+        if (num > vlc.size) num = vlc.size;
+        for (long i = 0; i < num; i++) {
+            uint32_t bb = 0;
+            if (vlc.pos >= 0 && vlc.pos < len) { bb = vd[vlc.pos]; vlc.pos--; }
+            const uint32_t dBits = (vlc.unstuff && (bb & 0x7F) == 0x7F) ? 7 : 8;
+            vlc.tmp |= shl64((uint64_t)bb, vlc.bits);
+            vlc.bits += dBits;
+            vlc.unstuff = bb > 0x8F;
+        }
+        vlc.size -= num;
+        rev_read(vlc);
+    }
+    uint32_t first = 0;
+    bool too_big = false;
+    for (int r = 0; r < R; r++) {                                   // ht.go:589-658
+        const int initial = (r == 0);
+        const uint16_t *tbl = initial ? S.tbl0 : S.tbl1;
+        for (int pi = 0; pi < P; pi++) {
+            uint32_t vlcVal = rev_fetch(vlc);
+            const uint32_t qinf = tbl[vlcVal & 0x7F];               // first quad: context is always 0
+            const uint32_t rho = (qinf >> 4) & 0xF, uOff1 = (qinf >> 3) & 1;
+            rev_advance(vlc, qinf & 0xF);
+            vlcVal = rev_fetch(vlc);
+            const uint32_t qinf2 = tbl[((rho >> 2) << 7) | (vlcVal & 0x7F)];
+            const uint32_t rho2 = (qinf2 >> 4) & 0xF, uOff2 = (qinf2 >> 3) & 1;
+            rev_advance(vlc, qinf2 & 0xF);
+            uint32_t u[2] = {1, 1};
+            const uint32_t mode = (uOff1 << 1) | uOff2;
+            if (mode > 0) {
+                vlcVal = rev_fetch(vlc);
+                rev_advance(vlc, decode_uvlc(vlcVal, mode, u, initial));
+            }
+            if (u[0] > 32 || u[1] > 32) too_big = true;
+            const uint32_t v = rho | rho2 << 4 | (u[0] & 0x3F) << 8 | (u[1] & 0x3F) << 14;
+            const int it = r * P + pi;
+            if (it == 0) first = v; else rec[it] = v;
+        }
+    }
+    // rec[0] also carries SCUP (12 bits) so that the extraction kernel needs no dependent byte loads from the
+    // stream (a 2-byte load at an odd address costs ~150 us per launch there).  u <= 37, so no record equals a tag.
+    rec[0] = first | (uint32_t)scup << 20;
+    rec[HT_WALK_MAX_PAIRS] = too_big ? HT_FLAG_BIGU : 0u;
+}
+
+#define HT_MAX_FF 64
+struct HtDecShared {
+    uint32_t mbuf[HT_DEC_MWORDS];
+    uint32_t pair[HT_WALK_MAX_PAIRS];
+    uint32_t ffpos[HT_MAX_FF];      // indices of 0xFF bytes in the MagSgn segment (only needed when a u exceeds 32)
+    uint32_t nff;
+};
+
+// MagSgn unstuffing + extraction for one block (one wavefront); records come from ht_walk_kernel
+// bit offset the reference's forward reader has LOADED after j 4-byte reads (ht.go:399-501): byte k of the
+// segment starts at 8k - #{0xFF bytes among b[0..k-2]}; past the segment the reader feeds 0xFF bytes, 7 bits each
+// (8 for the first one unless the last real byte is 0xFF).
+__device__ uint32_t ht_loaded_bits(const HtDecShared &S, uint32_t nff, long segLen, uint32_t j) {
+    const long k = 4 * (long)j;
+    const long kk = k < segLen ? k : segLen;
+    uint32_t f = 0, last_ff = 0;
+    for (uint32_t i = 0; i < nff; i++) {
+        if ((long)S.ffpos[i] + 2 <= kk) f++;
+        if ((long)S.ffpos[i] == segLen - 1) last_ff = 1;
+    }
+    uint32_t b = (uint32_t)(8 * kk) - f;
+    if (k > segLen) b += (last_ff ? 7u : 8u) + 7u * (uint32_t)(k - segLen - 1);
+    return b;
+}
+
+// returns false when the block needs the bit-serial decoder (never on encoder output)
+__device__ bool ht_extract_fast(HtDecShared &S, const uint8_t *__restrict__ data, long len, long scup, int w, int h,
+                                int32_t *__restrict__ out, int lane, int phases, bool bigu) {
+    const int quadCols = (w + 3) / 4, P = (quadCols + 1) / 2, R = (h + 3) / 4, N = R * P;
+    const long lcup = len;
+    if (phases == 21) return true;
+    for (int i = lane; i < HT_DEC_MWORDS; i += 64) S.mbuf[i] = 0;
+    if (lane == 0) S.nff = 0;
+    wave_sync();
+    if (phases == 22) return true;
+    constexpr int PF = 4;   // prefetch 4 x 256 bytes (one aligned dword per lane each) before processing
     {
         const long segLen = lcup - scup;
         const long maxbytes = (long)HT_DEC_MWORDS * 4 - 16;
         const long nb = segLen < maxbytes ? segLen : maxbytes;
-        uint32_t off = 0;
-        for (long k0 = 0; k0 < nb; k0 += 64) {
-            const long k = k0 + lane;
-            uint32_t b = 0, width = 0;
-            if (k < nb) {
-                b = data[k];
-                width = (k > 0 && data[k - 1] == 0xFF) ? 7 : 8;
-            }
-            uint32_t ws = width;
+        const uintptr_t a0 = (uintptr_t)data & ~(uintptr_t)3;
+        const long d = (long)((uintptr_t)data - a0);               // segment byte k lives at aligned byte d + k
+        const uint32_t *wsrc = reinterpret_cast<const uint32_t *>(a0);
+        const long ndw = (d + nb + 3) >> 2;                          // aligned dwords covering the segment
+        uint32_t off = 0, carry = 0;
+        for (long j0 = 0; j0 < ndw; j0 += 64 * PF) {
+            uint32_t raw[PF];
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const uint32_t a = __shfl_up(ws, o); if (lane >= o) ws += a; }
-            if (k < nb && b) or_bits(S.mbuf, off + ws - width, (uint64_t)b);
-            off += __shfl(ws, 63);
+            for (int c = 0; c < PF; c++) {
+                const long j = j0 + 64 * c + lane;
+                raw[c] = wsrc[j < ndw ? j : ndw - 1];               // clamped: unconditional, issued back to back
+            }
+#pragma unroll
+            for (int c = 0; c < PF; c++) {
+                if (j0 + 64 * c >= ndw) break;
+                const long j = j0 + 64 * c + lane;
+                const uint32_t dw = raw[c];
+                uint32_t prev3 = __shfl_up(dw >> 24, 1);            // last byte of the previous dword
+                if (lane == 0) prev3 = carry;
+                carry = __shfl(dw >> 24, 63);
+                const long k0 = 4 * j - d;                           // segment index of this dword's byte 0
+                uint32_t wd[4], tot = 0;
+                bool plain = (j < ndw) && k0 >= 1 && k0 + 4 <= nb && prev3 != 0xFF;
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const long k = k0 + t;
+                    const uint32_t pb = t ? ((dw >> (8 * (t - 1))) & 0xFF) : prev3;
+                    const bool valid = (j < ndw) && k >= 0 && k < nb;
+                    wd[t] = valid ? ((k > 0 && pb == 0xFF) ? 7u : 8u) : 0u;
+                    if (t && pb == 0xFF) plain = false;
+                    tot += wd[t];
+                    if (bigu && valid && ((dw >> (8 * t)) & 0xFF) == 0xFF) {      // rare path: remember where the 0xFF bytes are
+                        const uint32_t idx = atomicAdd(&S.nff, 1u);
+                        if (idx < HT_MAX_FF) S.ffpos[idx] = (uint32_t)k;
+                    }
+                }
+                uint32_t ws = tot;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const uint32_t a = __shfl_up(ws, o); if (lane >= o) ws += a; }
+                uint32_t pos = off + ws - tot;
+                if (plain) {
+                    if (dw) or_bits(S.mbuf, pos, (uint64_t)dw);      // four 8-bit bytes: one deposit
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const uint32_t bt = (dw >> (8 * t)) & 0xFF;
+                        if (wd[t] && bt) or_bits(S.mbuf, pos, (uint64_t)bt);
+                        pos += wd[t];
+                    }
+                }
+                off += __shfl(ws, 63);
+            }
         }
-        __syncthreads();
-        if (nb == segLen) {   // everything past the segment reads as ones
+        wave_sync();
+        if (phases == 23) return true;
+        if (bigu && (nb != segLen || S.nff > HT_MAX_FF)) return false;
+        if (nb == segLen) {   // everything past the segment reads as ones (ht.go:407, 447-449, 462-464)
             const uint32_t wd0 = off >> 5;
             for (uint32_t i = wd0 + lane; i < HT_DEC_MWORDS; i += 64)
                 S.mbuf[i] = (i == wd0) ? (S.mbuf[i] | (0xFFFFFFFFu << (off & 31))) : 0xFFFFFFFFu;
         }
     }
-    __syncthreads();
-    // ---- sequential VLC walk on lane 0 (ht.go:589-658) ----
-    int too_big = 0;
-    if (lane == 0) {
-        uint32_t cv = 0;
-        for (int r = 0; r < R; r++) {
-            const int initial = (r == 0);
-            const uint16_t *tbl = initial ? S.tbl0 : S.tbl1;
-            for (int pi = 0; pi < P; pi++) {
-                uint32_t vlcVal = get_bits32(S.vbuf, cv);
-                const uint32_t qinf = tbl[vlcVal & 0x7F];
-                const uint32_t rho = (qinf >> 4) & 0xF, uOff1 = (qinf >> 3) & 1;
-                cv += qinf & 0xF;
-                vlcVal = get_bits32(S.vbuf, cv);
-                const uint32_t qinf2 = tbl[((rho >> 2) << 7) | (vlcVal & 0x7F)];
-                const uint32_t rho2 = (qinf2 >> 4) & 0xF, uOff2 = (qinf2 >> 3) & 1;
-                cv += qinf2 & 0xF;
-                uint32_t u[2] = {1, 1};
-                const uint32_t mode = (uOff1 << 1) | uOff2;
-                if (mode > 0) cv += decode_uvlc(get_bits32(S.vbuf, cv), mode, u, initial);
-                if (u[0] > 32 || u[1] > 32) too_big = 1;
-                S.pair[r * P + pi] = rho | rho2 << 4 | (u[0] & 0x3F) << 8 | (u[1] & 0x3F) << 16;
+    wave_sync();
+    if (phases < 3 || phases > 20) return true;
+    // ---- u > 32: the reference's uint32 bit counter wraps when it advances by more bits than it has loaded
+    //      (ht.go:515-519); from then on the reader never refills and everything reads as zero.  Equivalent:
+    //      the bit string is cut to zeros at L = "bits loaded when the first such advance happens".  Find L. ----
+    uint32_t Lcut = 0xFFFFFFFFu;
+    if (bigu) {
+        const long segLen = lcup - scup;
+        const uint32_t nff = S.nff;
+        uint32_t best_key = 0xFFFFFFFFu, best_L = 0xFFFFFFFFu, mb = 0;
+        for (int i0 = 0; i0 < N; i0 += 64) {
+            const int it = i0 + lane;
+            uint32_t nbits = 0, rho = 0, rho2 = 0, u0 = 1, u1 = 1;
+            if (it < N) {
+                const uint32_t info = S.pair[it];
+                const int pi = it % P, xb = pi * 8;
+                rho = info & 0xF; rho2 = (info >> 4) & 0xF; u0 = (info >> 8) & 0x3F; u1 = (info >> 14) & 0x3F;
+                const uint32_t m1 = (xb + 4 <= w) ? 0xFu : ((xb < w) ? ((1u << (w - xb)) - 1) : 0u);
+                const uint32_t m2 = (xb + 8 <= w) ? 0xFu : ((xb + 4 < w) ? ((1u << (w - xb - 4)) - 1) : 0u);
+                rho &= m1; rho2 &= m2;
+                nbits = __popc(rho) * (u0 + 1) + __popc(rho2) * (u1 + 1);
+            }
+            uint32_t ns = nbits;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t a = __shfl_up(ns, o); if (lane >= o) ns += a; }
+            uint32_t mpos = mb + ns - nbits;
+            mb += __shfl(ns, 63);
+            if (it < N) {
+                for (int i = 0; i < 8; i++) {
+                    const uint32_t rr = (i < 4) ? rho : rho2, emb = (i < 4) ? u0 : u1;
+                    if (!((rr >> (i & 3)) & 1)) continue;
+                    if (emb > 32 && best_key == 0xFFFFFFFFu) {
+                        uint32_t j = (mpos + 32) / 32;
+                        if (j < 2) j = 2;                              // two reads happen during initMagSgn
+                        uint32_t G = ht_loaded_bits(S, nff, segLen, j);
+                        while (G < mpos + 32) G = ht_loaded_bits(S, nff, segLen, ++j);
+                        if (G - mpos < emb) { best_key = (uint32_t)(it * 8 + i); best_L = G; }
+                    }
+                    mpos += emb + 1;
+                }
             }
         }
+        uint32_t k = best_key;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) k = min(k, (uint32_t)__shfl_xor(k, o));
+        const unsigned long long who = __ballot(best_key == k && k != 0xFFFFFFFFu);
+        if (who) Lcut = __shfl(best_L, __ffsll((long long)who) - 1);
     }
-    too_big = __shfl(too_big, 0);
-    __syncthreads();
-    if (too_big) return false;
-    // ---- parallel MagSgn extraction (ht.go:661-710) ----
     uint32_t mbase = 0;
     for (int i0 = 0; i0 < N; i0 += 64) {
         const int it = i0 + lane;
-        uint32_t info = 0, nbits = 0, rho = 0, rho2 = 0, u0 = 1, u1 = 1;
+        uint32_t nbits = 0, rho = 0, rho2 = 0, u0 = 1, u1 = 1;
         int r = 0, pi = 0;
         if (it < N) {
-            info = S.pair[it];
+            const uint32_t info = S.pair[it];
             r = it / P; pi = it - r * P;
-            rho = info & 0xF; rho2 = (info >> 4) & 0xF; u0 = (info >> 8) & 0x3F; u1 = (info >> 16) & 0x3F;
+            rho = info & 0xF; rho2 = (info >> 4) & 0xF; u0 = (info >> 8) & 0x3F; u1 = (info >> 14) & 0x3F;
             const int xb = pi * 8;
             // samples beyond the block width are skipped even when their rho bit is set (ht.go:661, 689)
             const uint32_t m1 = (xb + 4 <= w) ? 0xFu : ((xb < w) ? ((1u << (w - xb)) - 1) : 0u);
@@ -688,46 +899,99 @@ __device__ bool ht_decode_fast(HtDecShared &S, const uint8_t *__restrict__ data,
         uint32_t mpos = mbase + ns - nbits;
         mbase += __shfl(ns, 63);
         if (it < N) {
-            int32_t *orow = out + (size_t)(4 * r) * w + pi * 8;
+            int vals[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const uint32_t rr = (i < 4) ? rho : rho2, emb = (i < 4) ? u0 : u1;
+                vals[i] = 0;
                 if (!((rr >> (i & 3)) & 1)) continue;
-                const uint32_t magVal = get_bits32(S.mbuf, mpos);
+                const uint32_t magVal = bigu ? get_bits32_cut(S.mbuf, mpos, Lcut) : get_bits32(S.mbuf, mpos);
                 const uint32_t mag = (magVal & (shl32(1, emb) - 1)) + shl32(1, emb - 1);
                 mpos += emb;
-                const uint32_t sign = get_bits32(S.mbuf, mpos) & 1;
+                const uint32_t sign = (bigu ? get_bits32_cut(S.mbuf, mpos, Lcut) : get_bits32(S.mbuf, mpos)) & 1;
                 mpos += 1;
-                orow[i] = sign ? (int32_t)(0u - mag) : (int32_t)mag;
+                vals[i] = sign ? (int32_t)(0u - mag) : (int32_t)mag;
+            }
+            // the pair's 8 columns of the coded row are written exactly once (zeros included): the zero fill
+            // of the kernel skips coded rows, so no store ever has to be ordered behind another
+            const int xb = pi * 8;
+            int32_t *orow = out + (size_t)(4 * r) * w + xb;
+            if (xb + 8 <= w && (((uintptr_t)orow) & 15) == 0) {
+                reinterpret_cast<int4 *>(orow)[0] = make_int4(vals[0], vals[1], vals[2], vals[3]);
+                reinterpret_cast<int4 *>(orow)[1] = make_int4(vals[4], vals[5], vals[6], vals[7]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                    if (xb + i < w) orow[i] = vals[i];
             }
         }
     }
     return true;
 }
 
-__global__ __launch_bounds__(64) void ht_decode_kernel(const BlockJob *__restrict__ jobs, int njobs,
-                                                       const uint8_t *__restrict__ stream, const uint64_t *__restrict__ offs,
-                                                       const uint32_t *__restrict__ lens, int32_t *__restrict__ decoded) {
-    __shared__ HtDecShared S;
-    const int jid = blockIdx.x;
+// four independent wavefronts per workgroup, one block each (no workgroup barrier anywhere on the fast path)
+__global__ __launch_bounds__(256) void ht_decode_kernel(const BlockJob *__restrict__ jobs, int njobs,
+                                                        const uint8_t *__restrict__ stream, const uint64_t *__restrict__ offs,
+                                                        const uint32_t *__restrict__ lens, int32_t *__restrict__ decoded,
+                                                        const uint32_t *__restrict__ pairs, int phases) {
+    __shared__ HtDecShared S4[4];
+    HtDecShared &S = S4[threadIdx.x >> 6];
+    const int jid = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (jid >= njobs) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const BlockJob J = jobs[jid];
     const int w = J.w, h = J.h;
     int32_t *out = decoded + J.out_off;
     const size_t n = (size_t)w * h;
-    for (size_t i = lane; i < n; i += 64) out[i] = 0;           // fresh NewHTDecoder: zeroed data
-    __syncthreads();
-    if ((size_t)((h + 3) / 4) * (size_t)w <= HT_FAST_MAX_SAMPLES) {
+    // records first (their latency hides behind the zero fill)
+    const uint32_t *rec = pairs + (size_t)jid * HT_WALK_REC;
+    const uint32_t r0 = rec[lane], r1 = rec[64 + lane];
+    const uint32_t tag = __shfl(r0, 0);
+    const bool fast = (tag != HT_PAIR_ZERO) && (tag != HT_PAIR_SERIAL) && (phases & 0xFF) >= 2;
+    // fresh NewHTDecoder: zeroed data.  On the fast path the coded rows (y % 4 == 0) are written in full by the
+    // extraction and the other rows are zeroed LAST (vmcnt retires in order: a load issued behind these
+    // stores would wait for all of them).  Other paths zero everything up front.
+    // (row index kept incrementally: a 64-bit i / wq per iteration costs ~150 VALU instructions and made this
+    //  loop the most expensive part of the kernel)
+    auto zero_fill = [&](bool skip_coded) {
+        if ((w & 3) == 0 && (J.out_off & 3) == 0) {
+            const uint32_t wq = (uint32_t)w >> 2, nq = (uint32_t)(n >> 2);
+            const uint32_t dy = 64u / wq, dx = 64u % wq;
+            uint32_t y = (uint32_t)lane / wq, x = (uint32_t)lane % wq;
+            for (uint32_t i = lane; i < nq; i += 64) {
+                if (!skip_coded || (y & 3)) reinterpret_cast<int4 *>(out)[i] = make_int4(0, 0, 0, 0);
+                y += dy; x += dx;
+                if (x >= wq) { x -= wq; y++; }
+            }
+        } else {
+            const uint32_t uw = (uint32_t)w;
+            const uint32_t dy = 64u / uw, dx = 64u % uw;
+            uint32_t y = (uint32_t)lane / uw, x = (uint32_t)lane % uw;
+            for (uint32_t i = lane; i < (uint32_t)n; i += 64) {
+                if (!skip_coded || (y & 3)) out[i] = 0;
+                y += dy; x += dx;
+                if (x >= uw) { x -= uw; y++; }
+            }
+        }
+    };
+    if (!fast) zero_fill(false);
+    S.pair[lane] = r0; S.pair[64 + lane] = r1;
+    wave_sync();
+    if (tag == HT_PAIR_ZERO || (phases & 0xFF) < 2 || (phases & 0xFF) == 20) return;
+    if (tag != HT_PAIR_SERIAL) {
         const uint8_t *fdata = stream + offs[jid];
         const long flen = (long)lens[jid];
-        if (flen < 2) return;                                   // ht.go:94-100
-        const long fscup = (long)fdata[flen - 1] + ((long)(fdata[flen - 2] & 0x0F) << 8);
-        if (fscup < 2 || fscup > flen) return;                  // ht.go:104-111
-        if (!init_mel_ok(fdata, flen, flen, fscup)) return;     // ht.go:117-122
-        if (ht_decode_fast(S, fdata, flen, fscup, w, h, out, lane)) return;
-        __syncthreads();
+        const long fscup = (long)(tag >> 20);                    // validated by ht_walk_kernel
+        const bool bigu = (__shfl(rec[HT_WALK_MAX_PAIRS], 0) & HT_FLAG_BIGU) != 0;
+        if (ht_extract_fast(S, fdata, flen, fscup, w, h, out, lane, phases & 0xFF, bigu)) {
+            zero_fill(true);
+            return;
+        }
+        zero_fill(false);       // exotic input (more than HT_MAX_FF 0xFF bytes together with u > 32): serial decoder
     }
+    // serial path: the zero fill must be complete before lane 0 overwrites samples (single wave: wait, no barrier)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
     if (lane != 0) return;
     const uint8_t *data = stream + offs[jid];
     const long len = (long)lens[jid];
@@ -825,10 +1089,32 @@ hipError_t launch_ht_encode(hipStream_t s, const BlockJob *jobs, int njobs, cons
     return hipGetLastError();
 }
 
+// global scratch for the per-pair records written by ht_walk_kernel (grown on demand, per device)
+static uint32_t *g_pairs[16] = {nullptr};
+static size_t g_pairs_cap[16] = {0};
+
 hipError_t launch_ht_decode(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs,
                             const uint32_t *lens, int32_t *decoded) {
     if (njobs <= 0) return hipSuccess;
-    hipLaunchKernelGGL(ht_decode_kernel, dim3(njobs), dim3(64), 0, s, jobs, njobs, stream, offs, lens, decoded);
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+    const size_t need = (size_t)njobs * HT_WALK_REC;
+    if (g_pairs_cap[dev] < need) {
+        if (g_pairs[dev]) {
+            if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+            (void)hipFree(g_pairs[dev]);
+            g_pairs[dev] = nullptr; g_pairs_cap[dev] = 0;
+        }
+        if ((e = hipMalloc((void **)&g_pairs[dev], need * sizeof(uint32_t))) != hipSuccess) return e;
+        g_pairs_cap[dev] = need;
+    }
+    hipLaunchKernelGGL(ht_walk_kernel, dim3((njobs + 63) / 64), dim3(64), 0, s, jobs, njobs, stream, offs, lens, g_pairs[dev]);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    static int phases = -1;   // debug knob (timing only): J2K_HT_DEC_PHASES=1 zero fill, 2 + MagSgn unstuffing, 3 everything
+    if (phases < 0) { const char *en = getenv("J2K_HT_DEC_PHASES"); phases = en ? atoi(en) : 3; }
+    hipLaunchKernelGGL(ht_decode_kernel, dim3((njobs + 3) / 4), dim3(256), 0, s, jobs, njobs, stream, offs, lens, decoded, g_pairs[dev], phases);
     return hipGetLastError();
 }
 

@@ -127,3 +127,37 @@ def test_encode_frame_matches_encoder(oracle, coder, W, H, Cn, nres, cb):
     assert np.array_equal(res["lens"], want_lens)
     assert np.array_equal(res["numbps"], want_nb)
     assert bytes(res["bytes"]) == bytes(want_bytes)
+
+
+@pytest.mark.parametrize("coder", [0, 1])
+def test_plan_decode_blocks_matches_decoders(oracle, coder):
+    """tcd.TileDecoder.DecodeCodeBlock for every job of a 512x512 RGB tile (bench-like content): the decoded
+    coefficients equal NewT1(...).Decode / a fresh NewHTDecoder(...).Decode on the same bytes.  For HT this
+    content contains blocks whose decoded u exceeds 32 (the reference's bit counter wraps, ht.go:515-519)."""
+    import torch
+    from j2kgfx.codec import FramePlan
+    W = H = 512 if coder == 1 else 128
+    rng = np.random.default_rng(0x4A324B30)
+    yy, xx = np.mgrid[0:H, 0:W]
+    base = np.stack([xx * 255 // W, yy * 255 // H, (xx + yy) * 127 // W])
+    frame = np.clip(base + rng.integers(-16, 17, size=(3, H, W)), 0, 255).astype(np.int32)
+    plan = FramePlan(W, H, 3, precision=8, lossless=True, num_resolutions=6, cb=(64, 64), coder=coder)
+    d = torch.from_numpy(frame).to(plan.device)
+    torch.cuda.synchronize()
+    coeff = plan.forward(d)
+    slots, lens, nb = plan.encode_blocks(coeff)
+    offs, stream = plan.compact(slots, lens)
+    dec = plan.decode_blocks(stream, offs, lens, nb)
+    plan.ctx.sync()
+    n = int(plan.info.blocks)
+    ho, hl, hn = offs.cpu().numpy(), lens.cpu().numpy(), nb.cpu().numpy()
+    hs, hd = stream.cpu().numpy(), dec.cpu().numpy()
+    blocks, doffs = plan.blocks(), plan.decoded_offsets()
+    big = 0
+    for j in range(n):
+        w, h, band = int(blocks[j]["w"]), int(blocks[j]["h"]), int(blocks[j]["band"])
+        chunk = hs[int(ho[j]):int(ho[j]) + int(hl[j])]
+        want = oracle.ht_decode(chunk, w, h) if coder == 1 else oracle.t1_decode(chunk, int(hn[j]), band, w, h)
+        got = hd[int(doffs[j]):int(doffs[j]) + w * h].reshape(h, w)
+        assert np.array_equal(got, want), j
+        big += int(np.abs(want).max() >= (1 << 31) - 1) if want.size else 0
