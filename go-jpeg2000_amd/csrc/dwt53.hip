@@ -47,27 +47,41 @@ __device__ __forceinline__ int wsub(int a, int b) { return (int)((unsigned)a - (
 __device__ __forceinline__ int avg1(int a, int b) { return wadd(a, b) >> 1; }
 __device__ __forceinline__ int avg2(int a, int b) { return wadd(wadd(a, b), 2) >> 2; }
 
-template <int N> struct Vec { int v[N]; };
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+// J2K_NT_MODE (set at build time for A/B): bit 0 = non-temporal loads of level-0 source rows,
+//                                          bit 1 = non-temporal stores of FINAL coefficients
+#ifndef J2K_NT_MODE
+#define J2K_NT_MODE 0
+#endif
+__device__ __forceinline__ int4 ld4(const int32_t *p, bool nt) {
+    if ((J2K_NT_MODE & 1) && nt) { const v4i v = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(p)); return make_int4(v.x, v.y, v.z, v.w); }
+    return *reinterpret_cast<const int4 *>(p);
+}
+__device__ __forceinline__ void st4(int32_t *p, int a, int b, int c, int d, bool nt) {
+    if ((J2K_NT_MODE & 2) && nt) { v4i v = {a, b, c, d}; __builtin_nontemporal_store(v, reinterpret_cast<v4i *>(p)); return; }
+    *reinterpret_cast<int4 *>(p) = make_int4(a, b, c, d);
+}
 
 // ---- global access helpers ------------------------------------------------------
 template <int CPL, bool VEC>
-__device__ __forceinline__ void load_cols(const int32_t *__restrict__ p, int c, int w, int (&x)[CPL]) {
+__device__ __forceinline__ void load_cols(const int32_t *__restrict__ p, int c, int w, int (&x)[CPL], bool nt = false) {
     if constexpr (VEC) {
-        if (c < w) {
-            if constexpr (CPL == 8) {
-                int4 a = *reinterpret_cast<const int4 *>(p + c);
-                int4 b = *reinterpret_cast<const int4 *>(p + c + 4);
-                x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
-            } else if constexpr (CPL == 4) {
-                int4 a = *reinterpret_cast<const int4 *>(p + c);
-                x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w;
-            } else {
-                int2 a = *reinterpret_cast<const int2 *>(p + c);
-                x[0] = a.x; x[1] = a.y;
-            }
+        // branch-free: lanes past the row end load from column 0 (always valid) and are zeroed by a select, so the
+        // loads of consecutive rows can be issued back to back
+        const bool in = c < w;
+        const int cc = in ? c : 0;
+        if constexpr (CPL == 8) {
+            int4 a = ld4(p + cc, nt);
+            int4 b = ld4(p + cc + 4, nt);
+            x[0] = in ? a.x : 0; x[1] = in ? a.y : 0; x[2] = in ? a.z : 0; x[3] = in ? a.w : 0;
+            x[4] = in ? b.x : 0; x[5] = in ? b.y : 0; x[6] = in ? b.z : 0; x[7] = in ? b.w : 0;
+        } else if constexpr (CPL == 4) {
+            int4 a = ld4(p + cc, nt);
+            x[0] = in ? a.x : 0; x[1] = in ? a.y : 0; x[2] = in ? a.z : 0; x[3] = in ? a.w : 0;
         } else {
-#pragma unroll
-            for (int i = 0; i < CPL; i++) x[i] = 0;
+            int2 a = *reinterpret_cast<const int2 *>(p + cc);
+            x[0] = in ? a.x : 0; x[1] = in ? a.y : 0;
         }
     } else {
 #pragma unroll
@@ -77,10 +91,10 @@ __device__ __forceinline__ void load_cols(const int32_t *__restrict__ p, int c, 
 
 // store n = CPL/2 consecutive values at p[0..n) ; valid = number of in-range elements
 template <int H, bool VEC>
-__device__ __forceinline__ void store_half(int32_t *__restrict__ p, const int *v, int valid) {
+__device__ __forceinline__ void store_half(int32_t *__restrict__ p, const int *v, int valid, bool nt = false) {
     if constexpr (VEC) {
         if (valid > 0) {
-            if constexpr (H == 4) *reinterpret_cast<int4 *>(p) = make_int4(v[0], v[1], v[2], v[3]);
+            if constexpr (H == 4) st4(p, v[0], v[1], v[2], v[3], nt);
             else if constexpr (H == 2) *reinterpret_cast<int2 *>(p) = make_int2(v[0], v[1]);
             else p[0] = v[0];
         }
@@ -170,9 +184,33 @@ template <int CPL, int NC, bool VEC>
 __device__ __forceinline__ void fwd_load_row(const int32_t *__restrict__ src, const DwtPlane &P, int r, int c, int dc_shift,
                                              FwdRow<CPL, NC, VEC> &R) {
     int x[NC][CPL];
+    if constexpr (NC == 1) {
+        if (P.role != 0) {
+            // split-component mode: this wavefront produces ONE component of the RCT (mct.go:28-38) and loads only the
+            // source planes that component needs (Y: R,G,B; U: B,G; V: R,G); the sibling wavefronts of the same rows sit
+            // in the same workgroup, so the extra reads are L1/L2 hits, and the register footprint stays at NC=1.
+            int a[CPL], b[CPL], g[CPL];
+            load_cols<CPL, VEC>(src + P.src_off[1] + (int64_t)r * P.src_stride, c, P.w, g);
+            if (P.role == 1) {
+                load_cols<CPL, VEC>(src + P.src_off[0] + (int64_t)r * P.src_stride, c, P.w, a);
+                load_cols<CPL, VEC>(src + P.src_off[2] + (int64_t)r * P.src_stride, c, P.w, b);
+#pragma unroll
+                for (int i = 0; i < CPL; i++) {
+                    const int r_ = wsub(a[i], dc_shift), g_ = wsub(g[i], dc_shift), b_ = wsub(b[i], dc_shift);
+                    x[0][i] = wadd(wadd(r_, wadd(g_, g_)), b_) >> 2;
+                }
+            } else {
+                load_cols<CPL, VEC>(src + P.src_off[P.role == 2 ? 2 : 0] + (int64_t)r * P.src_stride, c, P.w, a);
+#pragma unroll
+                for (int i = 0; i < CPL; i++) x[0][i] = wsub(wsub(a[i], dc_shift), wsub(g[i], dc_shift));   // B-G or R-G
+            }
+            hfwd<CPL>(x[0], c, P.w, R.lo[0], R.hi[0]);
+            return;
+        }
+    }
 #pragma unroll
     for (int k = 0; k < NC; k++) {
-        load_cols<CPL, VEC>(src + P.src_off[k] + (int64_t)r * P.src_stride, c, P.w, x[k]);
+        load_cols<CPL, VEC>(src + P.src_off[k] + (int64_t)r * P.src_stride, c, P.w, x[k], NC == 3);
 #pragma unroll
         for (int i = 0; i < CPL; i++) x[k][i] = wsub(x[k][i], dc_shift);  // mct.go:96-101
     }
@@ -204,8 +242,8 @@ __device__ __forceinline__ void fwd_store_row(int32_t *__restrict__ out, int32_t
         if constexpr (VEC) {
             int32_t *bl = (idxL < P.n_next) ? nxt + P.nxt_off[k] : out + P.out_off[k];
             int32_t *bh = (idxH < P.n_next) ? nxt + P.nxt_off[k] : out + P.out_off[k];
-            store_half<H, true>(bl + idxL, lo[k], nL);
-            store_half<H, true>(bh + idxH, hi[k], nH);
+            store_half<H, true>(bl + idxL, lo[k], nL, idxL >= P.n_next);
+            store_half<H, true>(bh + idxH, hi[k], nH, idxH >= P.n_next);
         } else {
 #pragma unroll
             for (int j = 0; j < H; j++) {
@@ -232,6 +270,7 @@ __global__ __launch_bounds__(256) void dwt53_fwd_kernel(const DwtJob *__restrict
     if (wave >= njobs) return;
     const int lane = threadIdx.x & 63;
     const DwtJob job = jobs[wave];
+    if (job.plane < 0) return;   // padding entry of the XCD-aware job order
     const DwtPlane P = planes[job.plane];
     const int w = P.w, h = P.h;
     const int lane_first = (job.col0 == 0) ? 0 : 1;
@@ -324,20 +363,18 @@ __device__ __forceinline__ void inv_load_row(const int32_t *__restrict__ coef, c
         if constexpr (VEC) {
             const int32_t *bl = (idxL < P.n_next) ? prev + P.nxt_off[k] : coef + P.src_off[k];
             const int32_t *bh = (idxH < P.n_next) ? prev + P.nxt_off[k] : coef + P.src_off[k];
-            if (c < P.w) {
-                if constexpr (H == 4) {
-                    int4 a = *reinterpret_cast<const int4 *>(bl + idxL), b = *reinterpret_cast<const int4 *>(bh + idxH);
-                    R.lo[k][0] = a.x; R.lo[k][1] = a.y; R.lo[k][2] = a.z; R.lo[k][3] = a.w;
-                    R.hi[k][0] = b.x; R.hi[k][1] = b.y; R.hi[k][2] = b.z; R.hi[k][3] = b.w;
-                } else if constexpr (H == 2) {
-                    int2 a = *reinterpret_cast<const int2 *>(bl + idxL), b = *reinterpret_cast<const int2 *>(bh + idxH);
-                    R.lo[k][0] = a.x; R.lo[k][1] = a.y; R.hi[k][0] = b.x; R.hi[k][1] = b.y;
-                } else {
-                    R.lo[k][0] = bl[idxL]; R.hi[k][0] = bh[idxH];
-                }
+            const bool in = c < P.w;
+            const int oL = in ? idxL : 0, oH = in ? idxH : 0;      // clamped: always a valid address, no branch
+            if constexpr (H == 4) {
+                int4 a = *reinterpret_cast<const int4 *>(bl + oL), b = *reinterpret_cast<const int4 *>(bh + oH);
+                R.lo[k][0] = in ? a.x : 0; R.lo[k][1] = in ? a.y : 0; R.lo[k][2] = in ? a.z : 0; R.lo[k][3] = in ? a.w : 0;
+                R.hi[k][0] = in ? b.x : 0; R.hi[k][1] = in ? b.y : 0; R.hi[k][2] = in ? b.z : 0; R.hi[k][3] = in ? b.w : 0;
+            } else if constexpr (H == 2) {
+                int2 a = *reinterpret_cast<const int2 *>(bl + oL), b = *reinterpret_cast<const int2 *>(bh + oH);
+                R.lo[k][0] = in ? a.x : 0; R.lo[k][1] = in ? a.y : 0; R.hi[k][0] = in ? b.x : 0; R.hi[k][1] = in ? b.y : 0;
             } else {
-#pragma unroll
-                for (int j = 0; j < H; j++) { R.lo[k][j] = 0; R.hi[k][j] = 0; }
+                const int a = bl[oL], b = bh[oH];
+                R.lo[k][0] = in ? a : 0; R.hi[k][0] = in ? b : 0;
             }
         } else {
 #pragma unroll
@@ -425,6 +462,7 @@ __global__ __launch_bounds__(256) void dwt53_inv_kernel(const DwtJob *__restrict
     if (wave >= njobs) return;
     const int lane = threadIdx.x & 63;
     const DwtJob job = jobs[wave];
+    if (job.plane < 0) return;   // padding entry of the XCD-aware job order
     const DwtPlane P = planes[job.plane];
     const int w = P.w, h = P.h;
     const int lane_first = (job.col0 == 0) ? 0 : 1;

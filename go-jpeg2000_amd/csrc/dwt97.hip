@@ -225,6 +225,7 @@ __global__ __launch_bounds__(256) void dwt97_fwd_kernel(const DwtJob *__restrict
     if (wave >= njobs) return;
     const int lane = threadIdx.x & 63;
     const DwtJob job = jobs[wave];
+    if (job.plane < 0) return;   // padding entry of the XCD-aware job order
     const DwtPlane P = planes[job.plane];
     const int w = P.w, h = P.h;
     const int lane_first = (job.col0 == 0) ? 0 : HL;
@@ -382,6 +383,7 @@ __global__ __launch_bounds__(256) void dwt97_inv_kernel(const DwtJob *__restrict
     if (wave >= njobs) return;
     const int lane = threadIdx.x & 63;
     const DwtJob job = jobs[wave];
+    if (job.plane < 0) return;   // padding entry of the XCD-aware job order
     const DwtPlane P = planes[job.plane];
     const int w = P.w, h = P.h;
     const int lane_first = (job.col0 == 0) ? 0 : HL;

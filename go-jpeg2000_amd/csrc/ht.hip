@@ -610,110 +610,157 @@ __device__ __forceinline__ uint32_t get_bits32_cut(const uint32_t *buf, uint32_t
     return v;
 }
 
+#define HT_VBITS_WORDS 192                     /* unstuffed VLC bit string per block: 46 bits x 128 pairs + slack */
+#define HT_VROW 193                            /* LDS row stride in the walk kernel (odd: no bank conflicts)        */
+
+// ---- kernel 1: one block per wavefront -- validate the stream, unstuff the VLC bytes into a linear bit string ----
+// initVLC + revRead (ht.go:276-378): the high nibble of byte lcup-2 (3 or 4 bits), then bytes lcup-3, lcup-4, ...
+// each 8 bits wide, or 7 when the previous byte is > 0x8F and this one's low 7 bits are all ones (the byte itself
+// is OR-ed in whole at the shorter advance); after scup-2 bytes, zeros.  Byte widths depend only on the neighbour
+// byte, so all bytes are placed in parallel: prefix sum of widths, OR-deposit into LDS, coalesced copy to global.
+__global__ __launch_bounds__(256) void ht_vlcprep_kernel(const BlockJob *__restrict__ jobs, int njobs,
+                                                         const uint8_t *__restrict__ stream, const uint64_t *__restrict__ offs,
+                                                         const uint32_t *__restrict__ lens, uint32_t *__restrict__ vbits,
+                                                         uint32_t *__restrict__ pairs) {
+    __shared__ uint32_t vb4[4][HT_VBITS_WORDS + 8];
+    uint32_t *vb = vb4[threadIdx.x >> 6];
+    const int jid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (jid >= njobs) return;
+    const int lane = threadIdx.x & 63;
+    const int w = jobs[jid].w, h = jobs[jid].h;
+    const long len = (long)lens[jid];
+    const uint8_t *data = stream + offs[jid];
+    uint32_t *rec = pairs + (size_t)jid * HT_WALK_REC;
+    const int quadCols = (w + 3) / 4, P = (quadCols + 1) / 2, R = (h + 3) / 4, N = R * P;
+    const bool fast = (size_t)R * (size_t)w <= HT_FAST_MAX_SAMPLES && N <= HT_WALK_MAX_PAIRS;
+    uint32_t tag = 0;
+    long scup = 0;
+    if (!fast) tag = HT_PAIR_SERIAL;
+    else if (len < 2) tag = HT_PAIR_ZERO;                            // ht.go:94-100
+    else {
+        scup = (long)data[len - 1] + ((long)(data[len - 2] & 0x0F) << 8);
+        if (scup < 2 || scup > len) tag = HT_PAIR_ZERO;              // ht.go:104-111
+        else if (!init_mel_ok(data, len, len, scup)) tag = HT_PAIR_ZERO;   // ht.go:117-122
+    }
+    if (tag) {                                                       // wave-uniform
+        if (lane == 0) { rec[0] = tag; rec[HT_WALK_MAX_PAIRS] = 0; }
+        return;
+    }
+    for (int i = lane; i < HT_VBITS_WORDS + 8; i += 64) vb[i] = 0;
+    wave_sync();
+    const long lcup = len;
+    const uint32_t b0 = data[lcup - 2];
+    const uint32_t t0 = b0 >> 4;
+    uint32_t off = 4 - ((t0 & 7) >> 2);
+    if (lane == 0) atomicOr(&vb[0], t0);
+    const long size = scup - 2;
+    const long maxbytes = (long)(46 * N + 7) / 8 + 8;
+    const long nb = size < maxbytes ? size : maxbytes;
+    constexpr int PF = 8;
+    uint32_t carry = b0 | 0x0F;                                      // "previous byte" of k = 1
+    for (long k0 = 1; k0 <= nb; k0 += 64 * PF) {
+        uint32_t raw[PF];
+#pragma unroll
+        for (int c = 0; c < PF; c++) {
+            const long k = k0 + 64 * c + lane;
+            const uint32_t t = data[lcup - 2 - (k <= nb ? k : nb)];  // clamped: unconditional loads
+            raw[c] = (k <= nb) ? t : 0;
+        }
+#pragma unroll
+        for (int c = 0; c < PF; c++) {
+            const long k = k0 + 64 * c + lane;
+            if (k0 + 64 * c > nb) break;
+            const uint32_t b = raw[c];
+            uint32_t prev = __shfl_up(b, 1);
+            if (lane == 0) prev = carry;
+            carry = __shfl(b, 63);
+            const uint32_t width = (k <= nb) ? ((prev > 0x8F && (b & 0x7F) == 0x7F) ? 7u : 8u) : 0u;
+            uint32_t ws = width;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t a = __shfl_up(ws, o); if (lane >= o) ws += a; }
+            if (k <= nb && b) or_bits(vb, off + ws - width, (uint64_t)b);
+            off += __shfl(ws, 63);
+        }
+    }
+    wave_sync();
+    uint32_t *dst = vbits + (size_t)jid * HT_VBITS_WORDS;
+    for (int i = lane; i < HT_VBITS_WORDS; i += 64) dst[i] = vb[i];
+    if (lane == 0) rec[0] = (uint32_t)scup << 20;                    // provisional: the walk kernel adds pair 0
+}
+
 struct HtWalkShared {
-    uint32_t raw[64][HT_WALK_ROW / 4];
+    uint32_t vb[64][HT_VROW];
     uint16_t tbl0[512], tbl1[512];
 };
 
+// ---- kernel 2: one block per LANE -- the sequential VLC walk (ht.go:589-658) on the linear bit strings ----
 __global__ __launch_bounds__(64) void ht_walk_kernel(const BlockJob *__restrict__ jobs, int njobs,
-                                                     const uint8_t *__restrict__ stream, const uint64_t *__restrict__ offs,
-                                                     const uint32_t *__restrict__ lens, uint32_t *__restrict__ pairs) {
+                                                     const uint32_t *__restrict__ vbits, uint32_t *__restrict__ pairs) {
     __shared__ HtWalkShared S;
     const int lane = threadIdx.x;
-    const int jid = blockIdx.x * 64 + lane;
+    const int jid0 = blockIdx.x * 64;
+    const int jid = jid0 + lane;
     const bool have = jid < njobs;
     reinterpret_cast<uint4 *>(S.tbl0)[lane] = reinterpret_cast<const uint4 *>(c_vlc_tbl0)[lane];   // contexts 0..3 = 1 KiB
     reinterpret_cast<uint4 *>(S.tbl1)[lane] = reinterpret_cast<const uint4 *>(c_vlc_tbl1)[lane];
-    int w = 1, h = 1;
-    long len = 0;
-    const uint8_t *data = stream;
-    if (have) { w = jobs[jid].w; h = jobs[jid].h; len = (long)lens[jid]; data = stream + offs[jid]; }
-    const int quadCols = (w + 3) / 4, P = (quadCols + 1) / 2, R = (h + 3) / 4, N = R * P;
-    const bool fast = have && (size_t)R * (size_t)w <= HT_FAST_MAX_SAMPLES && N <= HT_WALK_MAX_PAIRS;
-    const long T = len < HT_WALK_TAIL ? len : HT_WALK_TAIL;       // staged bytes: stream[len-T, len)
-    // ---- stage every block's tail: aligned dword loads, all lanes serve one block at a time, eight blocks'
-    //      loads in flight before the first LDS store (one memory latency per group, not per block) ----
-    const uintptr_t tail_addr = (uintptr_t)(data + (len - T));
-    const uint32_t delta = (uint32_t)(tail_addr & 3);                // bytes of junk in front of the tail in the LDS row
-    for (int g = 0; g < 64; g += 8) {
+    // coalesced staging: 64 blocks x 192 words, eight blocks' loads in flight at a time
+    const int nblk = min(64, njobs - jid0);
+    for (int g = 0; g < nblk; g += 8) {
         uint32_t v[8][3];
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const int bsel = g + j;
-            const long bT = __shfl(fast ? T : 0, bsel);
-            const uint64_t ba = __shfl((uint64_t)(tail_addr & ~(uintptr_t)3), bsel);
-            const uint32_t bd = __shfl(delta, bsel);
-            const int nd = bT ? (int)((bd + bT + 3) >> 2) : 0;       // dwords to copy (<= 190)
-            const uint32_t *src = reinterpret_cast<const uint32_t *>((uintptr_t)ba);
+            const int bsel = min(g + j, nblk - 1);
+            const uint32_t *src = vbits + (size_t)(jid0 + bsel) * HT_VBITS_WORDS;
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const int i = lane + 64 * c;
-                const uint32_t t = src[(nd > 0) ? (i < nd ? i : nd - 1) : 0];   // clamped index: unconditional loads
-                v[j][c] = t;
-            }
+            for (int c = 0; c < 3; c++) v[j][c] = src[lane + 64 * c];
         }
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const int bsel = g + j;
-            const long bT = __shfl(fast ? T : 0, bsel);
-            const uint32_t bd = __shfl(delta, bsel);
-            const int nd = bT ? (int)((bd + bT + 3) >> 2) : 0;
+            if (g + j >= nblk) break;
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const int i = lane + 64 * c;
-                if (i < nd) S.raw[bsel][i] = v[j][c];
-            }
+            for (int c = 0; c < 3; c++) S.vb[g + j][lane + 64 * c] = v[j][c];
         }
     }
     __syncthreads();
     if (!have) return;
     uint32_t *rec = pairs + (size_t)jid * HT_WALK_REC;
-    if (!fast) { rec[0] = HT_PAIR_SERIAL; return; }
-    if (len < 2) { rec[0] = HT_PAIR_ZERO; return; }                 // ht.go:94-100
-    const uint8_t *vd = reinterpret_cast<const uint8_t *>(&S.raw[lane][0]) + delta - (len - T);   // vd[i] = stream byte i, i in [len-T, len)
-    const long scup = (long)vd[len - 1] + ((long)(vd[len - 2] & 0x0F) << 8);
-    if (scup < 2 || scup > len) { rec[0] = HT_PAIR_ZERO; return; }  // ht.go:104-111
-    if (!init_mel_ok(data, len, len, scup)) { rec[0] = HT_PAIR_ZERO; return; }   // ht.go:117-122 (first MEL bytes: global)
-    const long lcup = len;
-    RevStream vlc{vd, len, lcup - 2, scup - 2, 0, 0, 0};            // initVLC ht.go:276-314
-    {
-        const uint32_t b = vd[vlc.pos];
-        vlc.pos--;
-        vlc.tmp = (uint64_t)(b >> 4);
-        vlc.bits = 4 - (uint32_t)((vlc.tmp & 7) >> 2);
-        vlc.unstuff = (b | 0x0F) > 0x8F;
-        long num = 1 + (vlc.pos & 3);
-        if (num > vlc.size) num = vlc.size;
-        for (long i = 0; i < num; i++) {
-            uint32_t bb = 0;
-            if (vlc.pos >= 0 && vlc.pos < len) { bb = vd[vlc.pos]; vlc.pos--; }
-            const uint32_t dBits = (vlc.unstuff && (bb & 0x7F) == 0x7F) ? 7 : 8;
-            vlc.tmp |= shl64((uint64_t)bb, vlc.bits);
-            vlc.bits += dBits;
-            vlc.unstuff = bb > 0x8F;
-        }
-        vlc.size -= num;
-        rev_read(vlc);
-    }
+    const uint32_t tag = rec[0];
+    if (tag == HT_PAIR_SERIAL || tag == HT_PAIR_ZERO) return;
+    const int w = jobs[jid].w, h = jobs[jid].h;
+    const int quadCols = (w + 3) / 4, P = (quadCols + 1) / 2, R = (h + 3) / 4;
+    const uint32_t *row = &S.vb[lane][0];
+    // 64-bit window over the bit string; the next word is requested one refill ahead of its use
+    uint64_t tmp = (uint64_t)row[0] | ((uint64_t)row[1] << 32);
+    uint32_t bits = 64, wi = 2, nxt = row[2];
+#define HT_ENSURE32()                                                             \
+    do {                                                                           \
+        if (bits <= 32) {                                                          \
+            tmp |= (uint64_t)nxt << bits;                                          \
+            bits += 32;                                                            \
+            wi++;                                                                  \
+            nxt = row[wi < HT_VBITS_WORDS ? wi : HT_VBITS_WORDS - 1];              \
+        }                                                                          \
+    } while (0)
     uint32_t first = 0;
     bool too_big = false;
-    for (int r = 0; r < R; r++) {                                   // ht.go:589-658
+    for (int r = 0; r < R; r++) {
         const int initial = (r == 0);
         const uint16_t *tbl = initial ? S.tbl0 : S.tbl1;
         for (int pi = 0; pi < P; pi++) {
-            uint32_t vlcVal = rev_fetch(vlc);
-            const uint32_t qinf = tbl[vlcVal & 0x7F];               // first quad: context is always 0
+            HT_ENSURE32();
+            const uint32_t qinf = tbl[(uint32_t)tmp & 0x7F];        // first quad: context is always 0
             const uint32_t rho = (qinf >> 4) & 0xF, uOff1 = (qinf >> 3) & 1;
-            rev_advance(vlc, qinf & 0xF);
-            vlcVal = rev_fetch(vlc);
-            const uint32_t qinf2 = tbl[((rho >> 2) << 7) | (vlcVal & 0x7F)];
+            tmp >>= (qinf & 0xF); bits -= (qinf & 0xF);
+            HT_ENSURE32();
+            const uint32_t qinf2 = tbl[((rho >> 2) << 7) | ((uint32_t)tmp & 0x7F)];
             const uint32_t rho2 = (qinf2 >> 4) & 0xF, uOff2 = (qinf2 >> 3) & 1;
-            rev_advance(vlc, qinf2 & 0xF);
+            tmp >>= (qinf2 & 0xF); bits -= (qinf2 & 0xF);
             uint32_t u[2] = {1, 1};
             const uint32_t mode = (uOff1 << 1) | uOff2;
             if (mode > 0) {
-                vlcVal = rev_fetch(vlc);
-                rev_advance(vlc, decode_uvlc(vlcVal, mode, u, initial));
+                HT_ENSURE32();
+                const uint32_t used = decode_uvlc((uint32_t)tmp, mode, u, initial);
+                tmp >>= used; bits -= used;
             }
             if (u[0] > 32 || u[1] > 32) too_big = true;
             const uint32_t v = rho | rho2 << 4 | (u[0] & 0x3F) << 8 | (u[1] & 0x3F) << 14;
@@ -721,9 +768,9 @@ __global__ __launch_bounds__(64) void ht_walk_kernel(const BlockJob *__restrict_
             if (it == 0) first = v; else rec[it] = v;
         }
     }
-    // rec[0] also carries SCUP (12 bits) so that the extraction kernel needs no dependent byte loads from the
-    // stream (a 2-byte load at an odd address costs ~150 us per launch there).  u <= 37, so no record equals a tag.
-    rec[0] = first | (uint32_t)scup << 20;
+#undef HT_ENSURE32
+    // rec[0] also carries SCUP (12 bits); u <= 37, so no record equals a tag
+    rec[0] = tag | first;
     rec[HT_WALK_MAX_PAIRS] = too_big ? HT_FLAG_BIGU : 0u;
 }
 
@@ -1089,7 +1136,7 @@ hipError_t launch_ht_encode(hipStream_t s, const BlockJob *jobs, int njobs, cons
     return hipGetLastError();
 }
 
-// global scratch for the per-pair records written by ht_walk_kernel (grown on demand, per device)
+// global scratch: per-pair records (ht_walk_kernel) and unstuffed VLC bit strings (ht_vlcprep_kernel); per device
 static uint32_t *g_pairs[16] = {nullptr};
 static size_t g_pairs_cap[16] = {0};
 
@@ -1100,7 +1147,7 @@ hipError_t launch_ht_decode(hipStream_t s, const BlockJob *jobs, int njobs, cons
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 16) return hipErrorInvalidDevice;
-    const size_t need = (size_t)njobs * HT_WALK_REC;
+    const size_t need = (size_t)njobs * (HT_WALK_REC + HT_VBITS_WORDS);
     if (g_pairs_cap[dev] < need) {
         if (g_pairs[dev]) {
             if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
@@ -1110,11 +1157,14 @@ hipError_t launch_ht_decode(hipStream_t s, const BlockJob *jobs, int njobs, cons
         if ((e = hipMalloc((void **)&g_pairs[dev], need * sizeof(uint32_t))) != hipSuccess) return e;
         g_pairs_cap[dev] = need;
     }
-    hipLaunchKernelGGL(ht_walk_kernel, dim3((njobs + 63) / 64), dim3(64), 0, s, jobs, njobs, stream, offs, lens, g_pairs[dev]);
+    uint32_t *pairs = g_pairs[dev], *vbits = g_pairs[dev] + (size_t)njobs * HT_WALK_REC;
+    hipLaunchKernelGGL(ht_vlcprep_kernel, dim3((njobs + 3) / 4), dim3(256), 0, s, jobs, njobs, stream, offs, lens, vbits, pairs);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(ht_walk_kernel, dim3((njobs + 63) / 64), dim3(64), 0, s, jobs, njobs, vbits, pairs);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     static int phases = -1;   // debug knob (timing only): J2K_HT_DEC_PHASES=1 zero fill, 2 + MagSgn unstuffing, 3 everything
     if (phases < 0) { const char *en = getenv("J2K_HT_DEC_PHASES"); phases = en ? atoi(en) : 3; }
-    hipLaunchKernelGGL(ht_decode_kernel, dim3((njobs + 3) / 4), dim3(256), 0, s, jobs, njobs, stream, offs, lens, decoded, g_pairs[dev], phases);
+    hipLaunchKernelGGL(ht_decode_kernel, dim3((njobs + 3) / 4), dim3(256), 0, s, jobs, njobs, stream, offs, lens, decoded, pairs, phases);
     return hipGetLastError();
 }
 

@@ -88,6 +88,9 @@ extern "C" int j2k_ctx_create(int device, j2k_ctx **out) {
         if (v >= 1 && v <= 4096) ctx->band_prows = v;
     }
     if (const char *e = getenv("J2K_FORCE_NOVEC")) ctx->force_novec = atoi(e) != 0;
+    if (const char *e = getenv("J2K_FWD_SPLIT")) ctx->fwd_split = atoi(e) != 0;
+    if (const char *e = getenv("J2K_XCD_MAP")) ctx->xcd_map = atoi(e) != 0;
+    if (const char *e = getenv("J2K_CPL0")) { int v = atoi(e); if (v == 2 || v == 4 || v == 8) ctx->cpl0 = v; }
     *out = ctx;
     return J2K_OK;
 }
@@ -253,18 +256,21 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                 std::vector<int> pw, ph;
                 bool vec_ok = !ctx->force_novec;
                 int maxw = 0;
+                const bool split = (dir == 0 && l == 0 && cls == 1 && S.wavelet == W53 && ctx->fwd_split);
+                std::vector<int> triple_first;   // index of the first of three role planes (split mode)
                 for (const Group &g : P->groups) {
                     const bool as_triple = (g.nc == 3 && l == 0);
                     if ((cls == 1) != as_triple) continue;
                     int w = g.w, h = g.h;
                     for (int i = 0; i < l; i++) { w = (w + 1) / 2; h = (h + 1) / 2; }
                     const int wn = (w + 1) / 2, hn = (h + 1) / 2;
-                    const int nplanes_here = as_triple ? 1 : g.nc;
+                    const int nplanes_here = (as_triple && !split) ? 1 : g.nc;
+                    if (split) triple_first.push_back((int)planes.size());
                     for (int k0 = 0; k0 < nplanes_here; k0++) {
                         DwtPlane D{};
-                        const int kn = as_triple ? 3 : 1;
+                        const int kn = (as_triple && !split) ? 3 : 1;
                         for (int k = 0; k < kn; k++) {
-                            const int kk = as_triple ? k : k0;
+                            const int kk = (as_triple && !split) ? k : k0;
                             const int64_t frame_off = (int64_t)(g.comp0 + kk) * S.H * S.W + (int64_t)g.y0 * S.W + g.x0;
                             const int64_t *scr_in = (l & 1) ? g.scrA_off : g.scrB_off;    // where level l's input prefix lives
                             const int64_t *scr_out = (l & 1) ? g.scrB_off : g.scrA_off;   // where level l's output prefix goes
@@ -278,6 +284,11 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                                 D.out_off[k] = (l == 0) ? frame_off : scr_in[kk];
                             }
                         }
+                        if (split) {   // role plane k0: sources = the three frame planes, destination = component k0
+                            for (int k = 0; k < 3; k++)
+                                D.src_off[k] = (int64_t)(g.comp0 + k) * S.H * S.W + (int64_t)g.y0 * S.W + g.x0;
+                            D.role = k0 + 1;
+                        }
                         D.src_stride = (dir == 0 && l == 0) ? S.W : w;
                         D.out_stride = S.W;
                         D.w = w; D.h = h;
@@ -288,16 +299,17 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                     }
                 }
                 LevelTab &T = (dir == 0 ? P->fwd : P->inv)[cls][l];
-                T.ncomp = cls ? 3 : 1;
+                T.ncomp = (cls && !split) ? 3 : 1;
                 T.nplanes = (int)planes.size();
                 if (planes.empty()) continue;
                 int cpl = pick_cpl(maxw);
+                if (l == 0 && ctx->cpl0 > 0 && S.wavelet == W53) cpl = ctx->cpl0;   // tuning knob J2K_CPL0
                 if (S.wavelet == W97) cpl = (cls == 1) ? 2 : (maxw >= 192 ? 4 : 2);   // f64: 2 or 4 columns per lane
                 for (size_t i = 0; i < planes.size() && vec_ok; i++) {
                     const DwtPlane &D = planes[i];
                     if (D.w % cpl) vec_ok = false;
                     if (l == 0 && (S.W % cpl)) vec_ok = false;
-                    for (int k = 0; k < T.ncomp; k++)
+                    for (int k = 0; k < 3; k++)
                         if ((D.src_off[k] % 4) || (D.out_off[k] % 4) || (D.nxt_off[k] % 4)) vec_ok = false;
                 }
                 if (S.wavelet == W97) vec_ok = false;        // the 9-7 kernels use scalar accesses
@@ -306,9 +318,34 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                 const int halo = (S.wavelet == W97 && cpl < 4) ? 2 : 1;
                 const int band = (S.wavelet == W97) ? std::max(ctx->band_prows, 8) : ctx->band_prows;
                 std::vector<DwtJob> jobs;
-                for (size_t i = 0; i < planes.size(); i++) {
-                    make_jobs(jobs, (int)i, pw[i], ph[i], cpl, band, halo);
-                    T.alg_bytes += (int64_t)2 * esz * pw[i] * ph[i] * T.ncomp;
+                if (split) {
+                    // the three role jobs of the same strip x band are adjacent -> same workgroup -> shared L1
+                    for (int f : triple_first) {
+                        std::vector<DwtJob> one;
+                        make_jobs(one, f, pw[f], ph[f], cpl, band, halo);
+                        for (const DwtJob &j : one)
+                            for (int k = 0; k < 3; k++) jobs.push_back(DwtJob{f + k, j.col0, j.prow0, j.nprow});
+                    }
+                    for (size_t i = 0; i < planes.size(); i++) T.alg_bytes += (int64_t)2 * esz * pw[i] * ph[i];
+                } else {
+                    for (size_t i = 0; i < planes.size(); i++) {
+                        make_jobs(jobs, (int)i, pw[i], ph[i], cpl, band, halo);
+                        T.alg_bytes += (int64_t)2 * esz * pw[i] * ph[i] * T.ncomp;
+                    }
+                }
+                if (ctx->xcd_map && jobs.size() >= 64) {
+                    // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one), so the
+                    // wavefronts of one plane -- whose bands share halo rows -- are placed in workgroups = x (mod 8):
+                    // the halo re-reads then hit that XCD's L2 instead of going back to HBM.  Speed only.
+                    std::vector<std::vector<DwtJob>> per(8);
+                    for (const DwtJob &j : jobs) per[(split ? j.plane / 3 : j.plane) % 8].push_back(j);
+                    size_t m = 0;
+                    for (auto &v : per) m = std::max(m, v.size());
+                    m = (m + 3) & ~size_t(3);
+                    std::vector<DwtJob> perm(m * 8, DwtJob{-1, 0, 0, 0});
+                    for (int x = 0; x < 8; x++)
+                        for (size_t i = 0; i < per[x].size(); i++) perm[((i / 4) * 8 + x) * 4 + (i % 4)] = per[x][i];
+                    jobs.swap(perm);
                 }
                 T.njobs = (int)jobs.size();
                 int r = upload(ctx, &T.d_planes, planes);

@@ -15,7 +15,7 @@ struct DwtPlane {
     int32_t w, h;         // dims of this level: dense w x h matrix
     int32_t n_next;       // w_{l+1}*h_{l+1}; linear idx < n_next -> nxt, else -> out (0 on the last level)
     int32_t out_stride;   // inverse level 0 only: row stride of the destination frame
-    int32_t pad_;
+    int32_t role;         // forward level 0, split-component mode: 0 plain, 1/2/3 = compute Y/U/V of the RCT from src_off[0..2]
 };
 
 // One wavefront's work: a column strip x a band of pair-rows of one plane.

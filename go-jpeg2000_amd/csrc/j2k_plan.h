@@ -11,6 +11,9 @@ struct j2k_ctx {
     hipStream_t stream = nullptr;
     std::string last_error;
     int band_prows = 4;        // pair-rows per wavefront band (tunable: J2K_BAND_PROWS)
+    int fwd_split = 0;         // level-0 forward: one wavefront per RCT component (J2K_FWD_SPLIT=0: three per wavefront)
+    int xcd_map = 1;           // J2K_XCD_MAP=0: plain job order (A/B)
+    int cpl0 = 0;              // J2K_CPL0: force columns-per-lane of the level-0 5-3 kernels (tuning)
     int force_novec = 0;       // J2K_FORCE_NOVEC=1: always take the scalar-access kernels (testing)
     // cached single-plane plans for the host (unit) calls
     std::vector<j2k_plan *> cache;
