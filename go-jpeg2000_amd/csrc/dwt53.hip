@@ -530,6 +530,186 @@ __global__ __launch_bounds__(256) void dwt53_inv_kernel(const DwtJob *__restrict
 }
 
 // ================================================================================
+// fused tail: the small decomposition levels of one plane inside LDS
+// ================================================================================
+// Once a level's input (w*h <= 16384 samples, w <= 128) fits in LDS, the remaining levels are latency-bound
+// launches of a few hundred wavefronts each.  One workgroup per plane runs them all: the level input lives in
+// an LDS buffer, each of the 4 wavefronts streams a band of row pairs exactly like the global kernels (one
+// column pair per lane, DPP neighbours, register sliding window), final coefficients go straight to global
+// memory and the prefix that feeds the next level goes to the other LDS buffer.
+#define TAIL_WAVES 16   /* 1024-thread workgroups: 16 wavefronts share one plane's levels */
+__device__ __forceinline__ void tail_fwd_level(const int32_t *cur, int32_t *nxt, int32_t *gout, int w, int h, int n_next,
+                                               int wave, int lane) {
+    const int halfW = (w + 1) >> 1, halfH = (h + 1) >> 1;
+    const int c = 2 * lane;
+    const bool owned = c < w;
+    const int per = (halfH + TAIL_WAVES - 1) / TAIL_WAVES;
+    const int q0 = wave * per, q1 = min(q0 + per, halfH);
+    if (q0 >= q1) return;
+    auto load = [&](int r, int &lo, int &hi) {
+        int x[2];
+        x[0] = (c < w) ? cur[r * w + c] : 0;
+        x[1] = (c + 1 < w) ? cur[r * w + c + 1] : 0;
+        int l1[1], h1[1];
+        hfwd<2>(x, c, w, l1, h1);
+        lo = l1[0]; hi = h1[0];
+    };
+    auto store = [&](int ro, int lo, int hi) {
+        if (!owned) return;
+        const int idxL = ro * w + lane, idxH = idxL + halfW;
+        if (lane < halfW) { if (idxL < n_next) nxt[idxL] = lo; else gout[idxL] = lo; }
+        if (lane < w - halfW) { if (idxH < n_next) nxt[idxH] = hi; else gout[idxH] = hi; }
+    };
+    int ye_lo, ye_hi, dvp_lo = 0, dvp_hi = 0;
+    load(2 * q0, ye_lo, ye_hi);
+    if (h < 2) { if (q0 == 0) store(0, ye_lo, ye_hi); return; }
+    if (q0 > 0) {
+        int a_lo, a_hi, b_lo, b_hi;
+        load(2 * q0 - 2, a_lo, a_hi);
+        load(2 * q0 - 1, b_lo, b_hi);
+        dvp_lo = wsub(b_lo, avg1(a_lo, ye_lo));
+        dvp_hi = wsub(b_hi, avg1(a_hi, ye_hi));
+    }
+    for (int q = q0; q < q1; q++) {
+        const int r1 = 2 * q + 1, r2 = 2 * q + 2;
+        const bool has_odd = r1 < h, has_next = r2 < h;
+        int yo_lo = 0, yo_hi = 0, yn_lo = 0, yn_hi = 0;
+        if (has_odd) load(r1, yo_lo, yo_hi);
+        if (has_next) load(r2, yn_lo, yn_hi);
+        int dl, dh;
+        if (has_odd) {
+            dl = wsub(yo_lo, has_next ? avg1(ye_lo, yn_lo) : ye_lo);
+            dh = wsub(yo_hi, has_next ? avg1(ye_hi, yn_hi) : ye_hi);
+        } else { dl = dvp_lo; dh = dvp_hi; }
+        const int pl = (q == 0) ? dl : dvp_lo, ph = (q == 0) ? dh : dvp_hi;
+        store(q, wadd(ye_lo, avg2(pl, dl)), wadd(ye_hi, avg2(ph, dh)));
+        if (has_odd) store(halfH + q, dl, dh);
+        dvp_lo = dl; dvp_hi = dh; ye_lo = yn_lo; ye_hi = yn_hi;
+    }
+}
+
+__global__ __launch_bounds__(64 * TAIL_WAVES) void dwt53_tail_fwd_kernel(const TailPlane *__restrict__ planes, const int32_t *__restrict__ scr,
+                                                             int32_t *__restrict__ coef) {
+    extern __shared__ __attribute__((aligned(16))) int32_t tail_lds[];
+    const TailPlane P = planes[blockIdx.x];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int w = P.w, h = P.h;
+    const int n0 = w * h;
+    int32_t *bufA = tail_lds, *bufB = tail_lds + ((n0 + 3) & ~3);
+    const int32_t *src = scr + P.scr_off;
+    if ((n0 & 3) == 0 && (P.scr_off & 3) == 0) {
+        for (int i = threadIdx.x; i < n0 / 4; i += 64 * TAIL_WAVES) reinterpret_cast<int4 *>(bufA)[i] = reinterpret_cast<const int4 *>(src)[i];
+    } else {
+        for (int i = threadIdx.x; i < n0; i += 64 * TAIL_WAVES) bufA[i] = src[i];
+    }
+    __syncthreads();
+    int32_t *gout = coef + P.coef_off;
+    int32_t *cur = bufA, *nxt = bufB;
+    for (int l = 0; l < P.nlev; l++) {
+        const int wn = (w + 1) >> 1, hn = (h + 1) >> 1;
+        const int n_next = (l == P.nlev - 1) ? 0 : wn * hn;
+        tail_fwd_level(cur, nxt, gout, w, h, n_next, wave, lane);
+        __syncthreads();
+        int32_t *t = cur; cur = nxt; nxt = t;
+        w = wn; h = hn;
+    }
+}
+
+__device__ __forceinline__ void tail_inv_level(const int32_t *prev, const int32_t *gcoef, int32_t *dst, int w, int h, int n_next,
+                                               int wave, int lane) {
+    const int halfW = (w + 1) >> 1, halfH = (h + 1) >> 1, nhigh = h - halfH;
+    const int c = 2 * lane;
+    const bool owned = c < w;
+    const int per = (halfH + TAIL_WAVES - 1) / TAIL_WAVES;
+    const int q0 = wave * per, q1 = min(q0 + per, halfH);
+    if (q0 >= q1) return;
+    auto load = [&](int ri, int &lo, int &hi) {
+        const int idxL = ri * w + lane, idxH = idxL + halfW;
+        lo = (lane < halfW) ? ((idxL < n_next) ? prev[idxL] : gcoef[idxL]) : 0;
+        hi = (lane < w - halfW) ? ((idxH < n_next) ? prev[idxH] : gcoef[idxH]) : 0;
+    };
+    auto finish = [&](int ro, int lo, int hi) {
+        int l1[1] = {lo}, h1[1] = {hi}, x[2];
+        hinv<2>(l1, h1, c, w, x);
+        if (!owned) return;
+        dst[ro * w + c] = x[0];
+        if (c + 1 < w) dst[ro * w + c + 1] = x[1];
+    };
+    if (h < 2) { if (q0 == 0) { int lo, hi; load(0, lo, hi); finish(0, lo, hi); } return; }
+    auto xe_of = [&](int q, int s_lo, int s_hi, int dp_lo, int dp_hi, int dc_lo, int dc_hi, int &xl, int &xh) {
+        const bool has_d = q < nhigh;
+        int a_lo = dp_lo, a_hi = dp_hi;
+        const int b_lo = has_d ? dc_lo : a_lo, b_hi = has_d ? dc_hi : a_hi;
+        if (q == 0) { a_lo = b_lo; a_hi = b_hi; }
+        xl = wsub(s_lo, avg2(a_lo, b_lo));
+        xh = wsub(s_hi, avg2(a_hi, b_hi));
+    };
+    int s_lo, s_hi, dc_lo = 0, dc_hi = 0, dp_lo = 0, dp_hi = 0, xe_lo, xe_hi;
+    load(q0, s_lo, s_hi);
+    if (q0 < nhigh) load(halfH + q0, dc_lo, dc_hi);
+    if (q0 > 0) load(halfH + q0 - 1, dp_lo, dp_hi);
+    xe_of(q0, s_lo, s_hi, dp_lo, dp_hi, dc_lo, dc_hi, xe_lo, xe_hi);
+    for (int q = q0; q < q1; q++) {
+        const bool has_d = q < nhigh, has_next = (q + 1) < halfH;
+        int sn_lo = 0, sn_hi = 0, dn_lo = 0, dn_hi = 0, xn_lo = 0, xn_hi = 0;
+        if (has_next) {
+            load(q + 1, sn_lo, sn_hi);
+            if (q + 1 < nhigh) load(halfH + q + 1, dn_lo, dn_hi);
+            xe_of(q + 1, sn_lo, sn_hi, dc_lo, dc_hi, dn_lo, dn_hi, xn_lo, xn_hi);
+        }
+        finish(2 * q, xe_lo, xe_hi);
+        if (has_d) {
+            const int xo_lo = wadd(dc_lo, has_next ? avg1(xe_lo, xn_lo) : xe_lo);
+            const int xo_hi = wadd(dc_hi, has_next ? avg1(xe_hi, xn_hi) : xe_hi);
+            finish(2 * q + 1, xo_lo, xo_hi);
+        }
+        xe_lo = xn_lo; xe_hi = xn_hi; dc_lo = dn_lo; dc_hi = dn_hi;
+    }
+}
+
+__global__ __launch_bounds__(64 * TAIL_WAVES) void dwt53_tail_inv_kernel(const TailPlane *__restrict__ planes, const int32_t *__restrict__ coef,
+                                                             int32_t *__restrict__ scr) {
+    extern __shared__ __attribute__((aligned(16))) int32_t tail_lds[];
+    const TailPlane P = planes[blockIdx.x];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int ws[32], hs[32];
+    ws[0] = P.w; hs[0] = P.h;
+    for (int l = 1; l <= P.nlev; l++) { ws[l] = (ws[l - 1] + 1) >> 1; hs[l] = (hs[l - 1] + 1) >> 1; }
+    const int n1 = ws[1] * hs[1];
+    int32_t *bufA = tail_lds, *bufB = tail_lds + ((n1 + 3) & ~3);      // X_{l0+1} (largest LDS-resident), X_{l0+2}, ...
+    const int32_t *gcoef = coef + P.coef_off;
+    // level index l counts from l0: X_l goes to bufA when (l odd), bufB when (l even, l>0), global scratch when l == 0
+    for (int l = P.nlev - 1; l >= 0; l--) {
+        const int n_next = (l == P.nlev - 1) ? 0 : ws[l + 1] * hs[l + 1];
+        const int32_t *prev = ((l + 1) & 1) ? bufA : bufB;
+        int32_t *dst = (l == 0) ? scr + P.scr_off : ((l & 1) ? bufA : bufB);
+        tail_inv_level(prev, gcoef, dst, ws[l], hs[l], n_next, wave, lane);
+        __syncthreads();
+    }
+}
+
+hipError_t launch_dwt53_tail_fwd(hipStream_t s, const TailPlane *planes, int nplanes, size_t lds_bytes, const int32_t *scr,
+                                 int32_t *coef) {
+    if (nplanes <= 0) return hipSuccess;
+    if (lds_bytes > 64 * 1024) {   // above the default dynamic-LDS limit: raise it (gfx950 has 160 KiB per workgroup)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(dwt53_tail_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(dwt53_tail_fwd_kernel, dim3(nplanes), dim3(64 * TAIL_WAVES), lds_bytes, s, planes, scr, coef);
+    return hipGetLastError();
+}
+hipError_t launch_dwt53_tail_inv(hipStream_t s, const TailPlane *planes, int nplanes, size_t lds_bytes, const int32_t *coef,
+                                 int32_t *scr) {
+    if (nplanes <= 0) return hipSuccess;
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(dwt53_tail_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(dwt53_tail_inv_kernel, dim3(nplanes), dim3(64 * TAIL_WAVES), lds_bytes, s, planes, coef, scr);
+    return hipGetLastError();
+}
+
+// ================================================================================
 // launchers
 // ================================================================================
 template <int CPL, int NC, bool VEC>

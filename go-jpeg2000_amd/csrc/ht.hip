@@ -1136,28 +1136,14 @@ hipError_t launch_ht_encode(hipStream_t s, const BlockJob *jobs, int njobs, cons
     return hipGetLastError();
 }
 
-// global scratch: per-pair records (ht_walk_kernel) and unstuffed VLC bit strings (ht_vlcprep_kernel); per device
-static uint32_t *g_pairs[16] = {nullptr};
-static size_t g_pairs_cap[16] = {0};
+// words of device scratch launch_ht_decode needs for njobs blocks: per-pair records + unstuffed VLC bit strings
+size_t ht_decode_scratch_words(int njobs) { return (size_t)njobs * (HT_WALK_REC + HT_VBITS_WORDS); }
 
 hipError_t launch_ht_decode(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs,
-                            const uint32_t *lens, int32_t *decoded) {
+                            const uint32_t *lens, int32_t *decoded, uint32_t *scratch) {
     if (njobs <= 0) return hipSuccess;
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (dev < 0 || dev >= 16) return hipErrorInvalidDevice;
-    const size_t need = (size_t)njobs * (HT_WALK_REC + HT_VBITS_WORDS);
-    if (g_pairs_cap[dev] < need) {
-        if (g_pairs[dev]) {
-            if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
-            (void)hipFree(g_pairs[dev]);
-            g_pairs[dev] = nullptr; g_pairs_cap[dev] = 0;
-        }
-        if ((e = hipMalloc((void **)&g_pairs[dev], need * sizeof(uint32_t))) != hipSuccess) return e;
-        g_pairs_cap[dev] = need;
-    }
-    uint32_t *pairs = g_pairs[dev], *vbits = g_pairs[dev] + (size_t)njobs * HT_WALK_REC;
+    hipError_t e;
+    uint32_t *pairs = scratch, *vbits = scratch + (size_t)njobs * HT_WALK_REC;
     hipLaunchKernelGGL(ht_vlcprep_kernel, dim3((njobs + 3) / 4), dim3(256), 0, s, jobs, njobs, stream, offs, lens, vbits, pairs);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     hipLaunchKernelGGL(ht_walk_kernel, dim3((njobs + 63) / 64), dim3(64), 0, s, jobs, njobs, vbits, pairs);

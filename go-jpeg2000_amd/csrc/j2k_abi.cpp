@@ -22,7 +22,8 @@ hipError_t launch_dwt97_inv(hipStream_t s, const LevelLaunch &L, const void *coe
 hipError_t launch_ht_encode(hipStream_t s, const BlockJob *jobs, int njobs, const int32_t *coef, uint8_t *slots,
                             uint32_t *lens, uint8_t *numbps, int *fault);
 hipError_t launch_ht_decode(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs,
-                            const uint32_t *lens, int32_t *decoded);
+                            const uint32_t *lens, int32_t *decoded, uint32_t *scratch);
+size_t ht_decode_scratch_words(int njobs);
 hipError_t launch_t1_encode(hipStream_t s, const BlockJob *jobs, int njobs, const int32_t *coef, uint8_t *slots,
                             uint32_t *lens, uint8_t *numbps, uint8_t *work, size_t work_per_job, int *fault);
 hipError_t launch_t1_decode(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs,
@@ -89,6 +90,7 @@ extern "C" int j2k_ctx_create(int device, j2k_ctx **out) {
     }
     if (const char *e = getenv("J2K_FORCE_NOVEC")) ctx->force_novec = atoi(e) != 0;
     if (const char *e = getenv("J2K_FWD_SPLIT")) ctx->fwd_split = atoi(e) != 0;
+    if (const char *e = getenv("J2K_TAIL")) ctx->use_tail = atoi(e) != 0;
     if (const char *e = getenv("J2K_XCD_MAP")) ctx->xcd_map = atoi(e) != 0;
     if (const char *e = getenv("J2K_CPL0")) { int v = atoi(e); if (v == 2 || v == 4 || v == 8) ctx->cpl0 = v; }
     *out = ctx;
@@ -246,6 +248,40 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
         }
     }
     P->coeff_elems = coef; P->scrA_elems = sa; P->scrB_elems = sb;
+
+    // ---- fused LDS tail for the small levels (5-3 only) --------------------------------
+    if (S.wavelet == W53 && ctx->use_tail && L >= 3) {
+        for (int l0 = 1; l0 <= L - 2 && P->tail_l0 < 0; l0++) {
+            bool ok = true;
+            for (const Group &g : P->groups) {
+                int w = g.w, h = g.h;
+                for (int i = 0; i < l0; i++) { w = (w + 1) / 2; h = (h + 1) / 2; }
+                if (w > 128 || (int64_t)w * h > 16384) ok = false;
+            }
+            if (ok) P->tail_l0 = l0;
+        }
+        if (P->tail_l0 >= 0) {
+            const int l0 = P->tail_l0;
+            std::vector<TailPlane> tp;
+            for (const Group &g : P->groups) {
+                int w = g.w, h = g.h;
+                for (int i = 0; i < l0; i++) { w = (w + 1) / 2; h = (h + 1) / 2; }
+                const int w1 = (w + 1) / 2, h1 = (h + 1) / 2, w2 = (w1 + 1) / 2, h2 = (h1 + 1) / 2;
+                P->tail_lds_fwd = std::max(P->tail_lds_fwd, (size_t)(((w * h + 3) & ~3) + w1 * h1 + 8) * 4);
+                P->tail_lds_inv = std::max(P->tail_lds_inv, (size_t)(((w1 * h1 + 3) & ~3) + w2 * h2 + 8) * 4);
+                for (int k = 0; k < g.nc; k++) {
+                    TailPlane T{};
+                    T.scr_off = ((l0 & 1) ? g.scrA_off : g.scrB_off)[k];   // where level l0's input prefix lives
+                    T.coef_off = g.coef_off[k];
+                    T.w = w; T.h = h; T.nlev = L - l0;
+                    tp.push_back(T);
+                }
+            }
+            P->ntail = (int)tp.size();
+            int r = upload(ctx, &P->d_tail, tp);
+            if (r != J2K_OK) { j2k_plan_destroy(P); return r; }
+        }
+    }
 
     // ---- per-level launch tables --------------------------------------------------
     for (int cls = 0; cls < 2; cls++) { P->fwd[cls].resize(L); P->inv[cls].resize(L); }
@@ -424,7 +460,7 @@ extern "C" void j2k_plan_destroy(j2k_plan *P) {
         for (auto &T : P->fwd[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); }
         for (auto &T : P->inv[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); }
     }
-    void *ptrs[] = {P->d_scrA, P->d_scrB, P->d_bjobs, P->d_djobs, P->d_frame, P->d_coeff, P->d_slots, P->d_stream, P->d_lens, P->d_numbps, P->d_offs};
+    void *ptrs[] = {P->d_scrA, P->d_scrB, P->d_tail, P->d_bjobs, P->d_djobs, P->d_frame, P->d_coeff, P->d_slots, P->d_stream, P->d_lens, P->d_numbps, P->d_offs};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete P;
 }
@@ -504,7 +540,8 @@ static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff) {
     if (((uintptr_t)d_frame & 15) || ((uintptr_t)d_coeff & 15)) return fail(ctx, J2K_ERR_INVALID_ARG, "device pointers must be 16-byte aligned");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const double step = 1.0 / (double)S.quality;   // encoder.go:269
-    for (int l = 0; l < S.levels; l++) {
+    const int nlevel_launches = (P->tail_l0 >= 0) ? P->tail_l0 : S.levels;
+    for (int l = 0; l < nlevel_launches; l++) {
         void *in = (l == 0) ? const_cast<void *>(d_frame) : ((l & 1) ? P->d_scrA : P->d_scrB);
         void *nx = (l & 1) ? P->d_scrB : P->d_scrA;
         hipEvent_t ev0 = (l == 0) ? profile_event(ctx) : nullptr, ev1 = ev0 ? profile_event(ctx) : nullptr;
@@ -522,6 +559,9 @@ static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff) {
         }
         if (ev1) HIPCHK(ctx, hipEventRecord(ev1, ctx->stream));
     }
+    if (P->tail_l0 >= 0)
+        HIPCHK(ctx, launch_dwt53_tail_fwd(ctx->stream, P->d_tail, P->ntail, P->tail_lds_fwd,
+                                          (const int32_t *)((P->tail_l0 & 1) ? P->d_scrA : P->d_scrB), (int32_t *)d_coeff));
     return J2K_OK;
 }
 
@@ -530,7 +570,10 @@ static int plan_inverse_impl(j2k_plan *P, const void *d_coeff, void *d_frame) {
     const PlanSpec &S = P->spec;
     if (((uintptr_t)d_frame & 15) || ((uintptr_t)d_coeff & 15)) return fail(ctx, J2K_ERR_INVALID_ARG, "device pointers must be 16-byte aligned");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    for (int l = S.levels - 1; l >= 0; l--) {
+    if (P->tail_l0 >= 0)
+        HIPCHK(ctx, launch_dwt53_tail_inv(ctx->stream, P->d_tail, P->ntail, P->tail_lds_inv, (const int32_t *)d_coeff,
+                                          (int32_t *)((P->tail_l0 & 1) ? P->d_scrA : P->d_scrB)));
+    for (int l = ((P->tail_l0 >= 0) ? P->tail_l0 : S.levels) - 1; l >= 0; l--) {
         void *prev = (l & 1) ? P->d_scrB : P->d_scrA;                     // X_{l+1}
         void *dst = (l == 0) ? d_frame : ((l & 1) ? P->d_scrA : P->d_scrB);  // X_l
         for (int cls = 0; cls < 2; cls++) {
@@ -624,7 +667,9 @@ extern "C" int j2k_plan_decode_blocks(j2k_plan *P, const uint8_t *d_stream, cons
     const int n = (int)P->blocks.size();
     if (!n) return J2K_OK;
     if (P->spec.coder == J2K_CODER_HT) {
-        HIPCHK(ctx, launch_ht_decode(ctx->stream, P->d_djobs, n, d_stream, d_offs, d_lens, d_decoded));
+        int r = stage_reserve(ctx, 2, ht_decode_scratch_words(n) * 4 + 256);
+        if (r != J2K_OK) return r;
+        HIPCHK(ctx, launch_ht_decode(ctx->stream, P->d_djobs, n, d_stream, d_offs, d_lens, d_decoded, (uint32_t *)ctx->stage[2]));
     } else {
         const size_t wpj = t1_work_per_job(P);
         int r = stage_reserve(ctx, 2, wpj * (size_t)n + 256);
@@ -861,7 +906,8 @@ extern "C" int j2k_decode_blocks(j2k_ctx *ctx, int coder, const uint8_t *bytes, 
     if (numbps) TRY(hipMemcpyAsync(d_nb, numbps, nblocks, hipMemcpyHostToDevice, ctx->stream));
     else TRY(hipMemsetAsync(d_nb, 0, nblocks, ctx->stream));
     if (coder == J2K_CODER_HT) {
-        TRY(launch_ht_decode(ctx->stream, (BlockJob *)d_jobs, (int)nblocks, (uint8_t *)d_bytes, (uint64_t *)d_offs, (uint32_t *)d_lens, (int32_t *)d_dec));
+        TRY(hipMalloc(&d_work, ht_decode_scratch_words((int)nblocks) * 4 + 256));
+        TRY(launch_ht_decode(ctx->stream, (BlockJob *)d_jobs, (int)nblocks, (uint8_t *)d_bytes, (uint64_t *)d_offs, (uint32_t *)d_lens, (int32_t *)d_dec, (uint32_t *)d_work));
     } else {
         TRY(hipMalloc(&d_work, wpj * nblocks + 256));
         TRY(launch_t1_decode(ctx->stream, (BlockJob *)d_jobs, (int)nblocks, (uint8_t *)d_bytes, (uint64_t *)d_offs, (uint32_t *)d_lens, (uint8_t *)d_nb,

@@ -35,6 +35,15 @@ struct BlockJob {
     int32_t band;
 };
 
+// One tile-component for the fused "tail" kernels: decomposition levels l0..l0+nlev-1 run inside LDS.
+struct TailPlane {
+    int64_t scr_off;      // forward: level-l0 input prefix in scratch; inverse: where X_{l0} is written
+    int64_t coef_off;     // final coefficient plane
+    int32_t w, h;         // dims at level l0
+    int32_t nlev;
+    int32_t pad_;
+};
+
 // launch wrappers (dwt53.hip, dwt97.hip, mct.hip, ht.hip, t1.hip)
 struct LevelLaunch {
     const DwtJob *jobs;   // device
@@ -49,5 +58,9 @@ hipError_t launch_dwt53_fwd(hipStream_t s, const LevelLaunch &L, const int32_t *
                             int32_t *nxt, int dc_shift);
 hipError_t launch_dwt53_inv(hipStream_t s, const LevelLaunch &L, const int32_t *coef, const int32_t *prev,
                             int32_t *dst, int dc_shift, int final_level);
+hipError_t launch_dwt53_tail_fwd(hipStream_t s, const TailPlane *planes, int nplanes, size_t lds_bytes, const int32_t *scr,
+                                 int32_t *coef);
+hipError_t launch_dwt53_tail_inv(hipStream_t s, const TailPlane *planes, int nplanes, size_t lds_bytes, const int32_t *coef,
+                                 int32_t *scr);
 
 }  // namespace j2k

@@ -12,7 +12,8 @@ struct j2k_ctx {
     std::string last_error;
     int band_prows = 4;        // pair-rows per wavefront band (tunable: J2K_BAND_PROWS)
     int fwd_split = 0;         // level-0 forward: one wavefront per RCT component (J2K_FWD_SPLIT=0: three per wavefront)
-    int xcd_map = 1;           // J2K_XCD_MAP=0: plain job order (A/B)
+    int use_tail = 1;          // J2K_TAIL=0: every level as its own launch (A/B)
+    int xcd_map = 0;           // J2K_XCD_MAP=0: plain job order (A/B)
     int cpl0 = 0;              // J2K_CPL0: force columns-per-lane of the level-0 5-3 kernels (tuning)
     int force_novec = 0;       // J2K_FORCE_NOVEC=1: always take the scalar-access kernels (testing)
     // cached single-plane plans for the host (unit) calls
@@ -81,6 +82,11 @@ struct j2k_plan {
     // [cls][level]: cls 0 = single-component groups, cls 1 = MCT triples
     std::vector<j2k::LevelTab> fwd[2], inv[2];
     void *d_scrA = nullptr, *d_scrB = nullptr;   // int32 (5-3) or f64 (9-7) prefixes
+    // fused LDS tail (5-3): levels tail_l0 .. levels-1 in one launch per direction; -1 = not used
+    int tail_l0 = -1;
+    j2k::TailPlane *d_tail = nullptr;
+    int ntail = 0;
+    size_t tail_lds_fwd = 0, tail_lds_inv = 0;
     // code-block jobs
     std::vector<j2k_block> blocks;          // plane = shard-local tile-component index
     std::vector<int32_t> block_tile;        // tile of each job
