@@ -107,10 +107,10 @@ __device__ __forceinline__ void store_half(int32_t *__restrict__ p, const int *v
 
 // ---- horizontal forward lifting of one row held across the wave -------------------
 // in : x[CPL] = columns c..c+CPL-1 of the row.  out: lo[CPL/2], hi[CPL/2] (pair j = column c+2j).
-template <int CPL>
+template <int CPL, bool THIN>
 __device__ __forceinline__ void hfwd(const int (&x)[CPL], int c, int w, int (&lo)[CPL / 2], int (&hi)[CPL / 2]) {
     constexpr int H = CPL / 2;
-    if (w < 2) {  // dwt.go:74-76: length < 2 -> untouched
+    if (THIN && w < 2) {  // dwt.go:74-76: length < 2 -> untouched
 #pragma unroll
         for (int j = 0; j < H; j++) { lo[j] = x[2 * j]; hi[j] = 0; }
         return;
@@ -179,52 +179,81 @@ struct FwdRow {
     int lo[NC][CPL / 2];
     int hi[NC][CPL / 2];
 };
-
-template <int CPL, int NC, bool VEC>
-__device__ __forceinline__ void fwd_load_row(const int32_t *__restrict__ src, const DwtPlane &P, int r, int c, int dc_shift,
-                                             FwdRow<CPL, NC, VEC> &R) {
+template <int CPL, int NC>
+struct RawRow {
     int x[NC][CPL];
-    if constexpr (NC == 1) {
-        if (P.role != 0) {
-            // split-component mode: this wavefront produces ONE component of the RCT (mct.go:28-38) and loads only the
-            // source planes that component needs (Y: R,G,B; U: B,G; V: R,G); the sibling wavefronts of the same rows sit
-            // in the same workgroup, so the extra reads are L1/L2 hits, and the register footprint stays at NC=1.
-            int a[CPL], b[CPL], g[CPL];
-            load_cols<CPL, VEC>(src + P.src_off[1] + (int64_t)r * P.src_stride, c, P.w, g);
-            if (P.role == 1) {
-                load_cols<CPL, VEC>(src + P.src_off[0] + (int64_t)r * P.src_stride, c, P.w, a);
-                load_cols<CPL, VEC>(src + P.src_off[2] + (int64_t)r * P.src_stride, c, P.w, b);
-#pragma unroll
-                for (int i = 0; i < CPL; i++) {
-                    const int r_ = wsub(a[i], dc_shift), g_ = wsub(g[i], dc_shift), b_ = wsub(b[i], dc_shift);
-                    x[0][i] = wadd(wadd(r_, wadd(g_, g_)), b_) >> 2;
-                }
-            } else {
-                load_cols<CPL, VEC>(src + P.src_off[P.role == 2 ? 2 : 0] + (int64_t)r * P.src_stride, c, P.w, a);
-#pragma unroll
-                for (int i = 0; i < CPL; i++) x[0][i] = wsub(wsub(a[i], dc_shift), wsub(g[i], dc_shift));   // B-G or R-G
-            }
-            hfwd<CPL>(x[0], c, P.w, R.lo[0], R.hi[0]);
-            return;
-        }
-    }
+};
+
+// Issue the global loads of one source row (NC component planes) and nothing else, so the caller can put the
+// loads of several rows in flight before the first use.  Out-of-range lanes/columns read a clamped, valid address:
+// their values never reach a stored result (the lifting only looks at in-range neighbours), so they need no mask.
+template <int CPL, int NC, bool VEC>
+__device__ __forceinline__ void fwd_issue_row(const int32_t *__restrict__ src, const DwtPlane &P, int r, int c,
+                                              RawRow<CPL, NC> &R) {
 #pragma unroll
     for (int k = 0; k < NC; k++) {
-        load_cols<CPL, VEC>(src + P.src_off[k] + (int64_t)r * P.src_stride, c, P.w, x[k], NC == 3);
+        const int32_t *p = src + P.src_off[k] + (int64_t)r * P.src_stride;
+        if constexpr (VEC) {
+            const int cc = (c < P.w) ? c : 0;
+            if constexpr (CPL == 8) {
+                const int4 a = ld4(p + cc, NC == 3), b = ld4(p + cc + 4, NC == 3);
+                R.x[k][0] = a.x; R.x[k][1] = a.y; R.x[k][2] = a.z; R.x[k][3] = a.w;
+                R.x[k][4] = b.x; R.x[k][5] = b.y; R.x[k][6] = b.z; R.x[k][7] = b.w;
+            } else if constexpr (CPL == 4) {
+                const int4 a = ld4(p + cc, NC == 3);
+                R.x[k][0] = a.x; R.x[k][1] = a.y; R.x[k][2] = a.z; R.x[k][3] = a.w;
+            } else {
+                const int2 a = *reinterpret_cast<const int2 *>(p + cc);
+                R.x[k][0] = a.x; R.x[k][1] = a.y;
+            }
+        } else {
 #pragma unroll
-        for (int i = 0; i < CPL; i++) x[k][i] = wsub(x[k][i], dc_shift);  // mct.go:96-101
+            for (int i = 0; i < CPL; i++) R.x[k][i] = p[min(c + i, P.w - 1)];
+        }
     }
-    if constexpr (NC == 3) {  // mct.go:28-38
+}
+
+// DC shift (mct.go:96-101) + RCT (mct.go:28-38) + horizontal lifting of one issued row
+template <int CPL, int NC, bool VEC>
+__device__ __forceinline__ void fwd_finish_row(RawRow<CPL, NC> &X, const DwtPlane &P, int c, int dc_shift, FwdRow<CPL, NC, VEC> &R) {
+#pragma unroll
+    for (int k = 0; k < NC; k++)
+#pragma unroll
+        for (int i = 0; i < CPL; i++) X.x[k][i] = wsub(X.x[k][i], dc_shift);
+    if constexpr (NC == 3) {
 #pragma unroll
         for (int i = 0; i < CPL; i++) {
-            const int r_ = x[0][i], g_ = x[1][i], b_ = x[2][i];
-            x[0][i] = wadd(wadd(r_, wadd(g_, g_)), b_) >> 2;
-            x[1][i] = wsub(b_, g_);
-            x[2][i] = wsub(r_, g_);
+            const int r_ = X.x[0][i], g_ = X.x[1][i], b_ = X.x[2][i];
+            X.x[0][i] = wadd(wadd(r_, wadd(g_, g_)), b_) >> 2;
+            X.x[1][i] = wsub(b_, g_);
+            X.x[2][i] = wsub(r_, g_);
         }
     }
 #pragma unroll
-    for (int k = 0; k < NC; k++) hfwd<CPL>(x[k], c, P.w, R.lo[k], R.hi[k]);
+    for (int k = 0; k < NC; k++) hfwd<CPL, false>(X.x[k], c, P.w, R.lo[k], R.hi[k]);
+}
+
+// thin planes (w < 2 or h < 2): masked loads, the length<2 pass-through rules of dwt.go:74-76
+template <int CPL, int NC, bool VEC>
+__device__ __forceinline__ void fwd_load_row_thin(const int32_t *__restrict__ src, const DwtPlane &P, int r, int c, int dc_shift,
+                                                  FwdRow<CPL, NC, VEC> &R) {
+    RawRow<CPL, NC> X;
+    fwd_issue_row<CPL, NC, VEC>(src, P, r, c, X);
+#pragma unroll
+    for (int k = 0; k < NC; k++)
+#pragma unroll
+        for (int i = 0; i < CPL; i++) X.x[k][i] = (c + i < P.w) ? wsub(X.x[k][i], dc_shift) : 0;
+    if constexpr (NC == 3) {
+#pragma unroll
+        for (int i = 0; i < CPL; i++) {
+            const int r_ = X.x[0][i], g_ = X.x[1][i], b_ = X.x[2][i];
+            X.x[0][i] = wadd(wadd(r_, wadd(g_, g_)), b_) >> 2;
+            X.x[1][i] = wsub(b_, g_);
+            X.x[2][i] = wsub(r_, g_);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NC; k++) hfwd<CPL, true>(X.x[k], c, P.w, R.lo[k], R.hi[k]);
 }
 
 template <int CPL, int NC, bool VEC>
@@ -260,42 +289,26 @@ __device__ __forceinline__ void fwd_store_row(int32_t *__restrict__ out, int32_t
     }
 }
 
+// w < 2 or h < 2: one of the two passes is the identity.  Rare (deepest levels of tiny planes); kept simple.
 template <int CPL, int NC, bool VEC>
-__global__ __launch_bounds__(256) void dwt53_fwd_kernel(const DwtJob *__restrict__ jobs, int njobs,
-                                                        const DwtPlane *__restrict__ planes,
-                                                        const int32_t *__restrict__ src, int32_t *__restrict__ out,
-                                                        int32_t *__restrict__ nxt, int dc_shift) {
+__device__ __forceinline__ void fwd_job_thin(const DwtJob &job, const DwtPlane &P, const int32_t *__restrict__ src,
+                                          int32_t *__restrict__ out, int32_t *__restrict__ nxt, int dc_shift, int c, int p0,
+                                          bool owned) {
     constexpr int H = CPL / 2;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-    if (wave >= njobs) return;
-    const int lane = threadIdx.x & 63;
-    const DwtJob job = jobs[wave];
-    if (job.plane < 0) return;   // padding entry of the XCD-aware job order
-    const DwtPlane P = planes[job.plane];
-    const int w = P.w, h = P.h;
-    const int lane_first = (job.col0 == 0) ? 0 : 1;
-    const int c_base = job.col0 - lane_first * CPL;
-    const int c = c_base + lane * CPL;
-    const bool reach_end = (c_base + 64 * CPL >= w);
-    const bool owned = (lane >= lane_first) && (c < w) && (reach_end || lane < 63);
-    const int p0 = c >> 1;
-    const int halfH = (h + 1) >> 1;
-    const int pr_begin = job.prow0;
-    const int pr_end = min(job.prow0 + job.nprow, halfH);
-
     typedef FwdRow<CPL, NC, VEC> Row;
+    const int h = P.h, halfH = (h + 1) >> 1;
+    const int pr_end = min(job.prow0 + job.nprow, halfH);
     Row ye, yo, yn;
-    int dvp_lo[NC][H], dvp_hi[NC][H];  // vertical d of the previous pair-row
-
-    fwd_load_row<CPL, NC, VEC>(src, P, 2 * pr_begin, c, dc_shift, ye);
-    if (h < 2) {  // vertical pass untouched (dwt.go:74-76)
-        if (pr_begin == 0) fwd_store_row<CPL, NC, VEC>(out, nxt, P, 0, p0, owned, ye.lo, ye.hi);
+    int dvp_lo[NC][H], dvp_hi[NC][H];
+    fwd_load_row_thin<CPL, NC, VEC>(src, P, 2 * job.prow0, c, dc_shift, ye);
+    if (h < 2) {
+        if (job.prow0 == 0) fwd_store_row<CPL, NC, VEC>(out, nxt, P, 0, p0, owned, ye.lo, ye.hi);
         return;
     }
-    if (pr_begin > 0) {
+    if (job.prow0 > 0) {
         Row ym2, ym1;
-        fwd_load_row<CPL, NC, VEC>(src, P, 2 * pr_begin - 2, c, dc_shift, ym2);
-        fwd_load_row<CPL, NC, VEC>(src, P, 2 * pr_begin - 1, c, dc_shift, ym1);
+        fwd_load_row_thin<CPL, NC, VEC>(src, P, 2 * job.prow0 - 2, c, dc_shift, ym2);
+        fwd_load_row_thin<CPL, NC, VEC>(src, P, 2 * job.prow0 - 1, c, dc_shift, ym1);
 #pragma unroll
         for (int k = 0; k < NC; k++)
 #pragma unroll
@@ -304,11 +317,11 @@ __global__ __launch_bounds__(256) void dwt53_fwd_kernel(const DwtJob *__restrict
                 dvp_hi[k][j] = wsub(ym1.hi[k][j], avg1(ym2.hi[k][j], ye.hi[k][j]));
             }
     }
-    for (int pr = pr_begin; pr < pr_end; pr++) {
+    for (int pr = job.prow0; pr < pr_end; pr++) {
         const int r1 = 2 * pr + 1, r2 = 2 * pr + 2;
         const bool has_odd = r1 < h, has_next = r2 < h;
-        if (has_odd) fwd_load_row<CPL, NC, VEC>(src, P, r1, c, dc_shift, yo);
-        if (has_next) fwd_load_row<CPL, NC, VEC>(src, P, r2, c, dc_shift, yn);
+        if (has_odd) fwd_load_row_thin<CPL, NC, VEC>(src, P, r1, c, dc_shift, yo);
+        if (has_next) fwd_load_row_thin<CPL, NC, VEC>(src, P, r2, c, dc_shift, yn);
         int dv_lo[NC][H], dv_hi[NC][H], sv_lo[NC][H], sv_hi[NC][H];
 #pragma unroll
         for (int k = 0; k < NC; k++)
@@ -316,18 +329,14 @@ __global__ __launch_bounds__(256) void dwt53_fwd_kernel(const DwtJob *__restrict
             for (int j = 0; j < H; j++) {
                 int dl, dh;
                 if (has_odd) {
-                    const int pl = has_next ? avg1(ye.lo[k][j], yn.lo[k][j]) : ye.lo[k][j];
-                    const int ph = has_next ? avg1(ye.hi[k][j], yn.hi[k][j]) : ye.hi[k][j];
-                    dl = wsub(yo.lo[k][j], pl);
-                    dh = wsub(yo.hi[k][j], ph);
-                } else {  // odd height: last even row mirrors d[n-2]
+                    dl = wsub(yo.lo[k][j], has_next ? avg1(ye.lo[k][j], yn.lo[k][j]) : ye.lo[k][j]);
+                    dh = wsub(yo.hi[k][j], has_next ? avg1(ye.hi[k][j], yn.hi[k][j]) : ye.hi[k][j]);
+                } else {
                     dl = dvp_lo[k][j];
                     dh = dvp_hi[k][j];
                 }
-                const int pl_ = (pr == 0) ? dl : dvp_lo[k][j];
-                const int ph_ = (pr == 0) ? dh : dvp_hi[k][j];
-                sv_lo[k][j] = wadd(ye.lo[k][j], avg2(pl_, dl));
-                sv_hi[k][j] = wadd(ye.hi[k][j], avg2(ph_, dh));
+                sv_lo[k][j] = wadd(ye.lo[k][j], avg2((pr == 0) ? dl : dvp_lo[k][j], dl));
+                sv_hi[k][j] = wadd(ye.hi[k][j], avg2((pr == 0) ? dh : dvp_hi[k][j], dh));
                 dv_lo[k][j] = dl;
                 dv_hi[k][j] = dh;
             }
@@ -337,11 +346,181 @@ __global__ __launch_bounds__(256) void dwt53_fwd_kernel(const DwtJob *__restrict
         for (int k = 0; k < NC; k++)
 #pragma unroll
             for (int j = 0; j < H; j++) {
-                dvp_lo[k][j] = dv_lo[k][j];
-                dvp_hi[k][j] = dv_hi[k][j];
-                ye.lo[k][j] = yn.lo[k][j];
-                ye.hi[k][j] = yn.hi[k][j];
+                dvp_lo[k][j] = dv_lo[k][j]; dvp_hi[k][j] = dv_hi[k][j];
+                ye.lo[k][j] = yn.lo[k][j]; ye.hi[k][j] = yn.hi[k][j];
             }
+    }
+}
+
+#ifdef J2K_FWD_WPE
+#define J2K_FWD_ATTR __attribute__((amdgpu_waves_per_eu(J2K_FWD_WPE)))
+#else
+#define J2K_FWD_ATTR
+#endif
+// Forward level kernel.  One wavefront = column strip x band of pair-rows (DwtJob); the four wavefronts of a
+// workgroup normally hold four vertically adjacent bands of one strip, and then they are LINKED (flags in
+// DwtJob::nprow, set by the host): instead of re-reading the three halo rows of its neighbours from memory
+//   * a band with J2K_LINK_UP skips the two rows above it; it publishes its first lifted even row and its first
+//     vertical d to LDS and leaves the low-pass output row of its first pair-row to the band above,
+//   * a band with J2K_LINK_DOWN takes that even row from LDS instead of loading it (last predict step) and, after
+//     its last pair-row, emits the first low-pass row of the band below (it owns the d above it).
+// One __syncthreads() per wavefront (after its first pair-row) orders publish -> consume; linked bands have >= 2
+// pair-rows so the consumer side always comes after the barrier.  Source rows are then read from HBM once plus
+// three rows per WORKGROUP (not per wavefront).
+// PF: the loads of pair-row q+1 are issued before the vertical lifting and the stores of pair-row q (software
+// pipelining, one pair-row deep; costs CPL*NC*2 more live registers)
+template <int CPL, int NC, bool VEC, bool PF>
+__global__ __launch_bounds__(256) J2K_FWD_ATTR void dwt53_fwd_kernel(const DwtJob *__restrict__ jobs, int njobs,
+                                                                     const DwtPlane *__restrict__ planes,
+                                                                     const int32_t *__restrict__ src, int32_t *__restrict__ out,
+                                                                     int32_t *__restrict__ nxt, int dc_shift) {
+    constexpr int H = CPL / 2;
+    constexpr int PUB = 2 * NC * CPL * 64;   // ints one wavefront publishes: {even row, d row} x NC x (lo|hi) x 64 lanes
+    __shared__ int sh[4 * PUB];
+    const int wv = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wv));
+    const int lane = threadIdx.x & 63;
+    DwtJob job{-1, 0, 0, 0};
+    if (wave < njobs) job = jobs[wave];
+    if (job.plane < 0) {             // past the end / padding entry of the XCD-aware job order
+        __syncthreads();
+        return;
+    }
+    const bool link_up = (job.nprow & J2K_LINK_UP) != 0, link_down = (job.nprow & J2K_LINK_DOWN) != 0;
+    job.nprow &= 0xffff;
+    const DwtPlane P = planes[job.plane];
+    const int w = P.w, h = P.h;
+    const int lane_first = (job.col0 == 0) ? 0 : 1;
+    const int c_base = job.col0 - lane_first * CPL;
+    const int c = c_base + lane * CPL;
+    const bool reach_end = (c_base + 64 * CPL >= w);
+    const bool owned = (lane >= lane_first) && (c < w) && (reach_end || lane < 63);
+    const int p0 = c >> 1;
+    if (w < 2 || h < 2) {            // never linked
+        fwd_job_thin<CPL, NC, VEC>(job, P, src, out, nxt, dc_shift, c, p0, owned);
+        __syncthreads();
+        return;
+    }
+    const int halfH = (h + 1) >> 1;
+    const int pr_begin = job.prow0;
+    const int pr_end = min(job.prow0 + job.nprow, halfH);
+    const int hl = h - 1;
+    int *pub_mine = sh + wv * PUB + lane;
+    const int *pub_below = sh + ((wv + 1) & 3) * PUB + lane;   // only read when link_down (then wv < 3)
+
+    typedef FwdRow<CPL, NC, VEC> Row;
+    typedef RawRow<CPL, NC> Raw;
+    Row ye, yo, yn;
+    int dvp_lo[NC][H], dvp_hi[NC][H];  // vertical d of the previous pair-row
+    Raw ra, rb;                        // rows 2q+1, 2q+2 in flight
+    {
+        // the loads of the prologue are issued before the first use: one (PF) or two memory latencies, not five
+        Raw r0, rm2, rm1;
+        const int re = 2 * pr_begin;
+        fwd_issue_row<CPL, NC, VEC>(src, P, re, c, r0);
+        if (!link_up) {
+            fwd_issue_row<CPL, NC, VEC>(src, P, max(re - 2, 0), c, rm2);
+            fwd_issue_row<CPL, NC, VEC>(src, P, max(re - 1, 0), c, rm1);
+        }
+        if (PF) {
+            fwd_issue_row<CPL, NC, VEC>(src, P, min(re + 1, hl), c, ra);
+            fwd_issue_row<CPL, NC, VEC>(src, P, min(re + 2, hl), c, rb);   // linked bands have >= 2 pair-rows: a real row
+        }
+        fwd_finish_row<CPL, NC, VEC>(r0, P, c, dc_shift, ye);
+        if (!link_up) {
+            Row ym2, ym1;
+            fwd_finish_row<CPL, NC, VEC>(rm2, P, c, dc_shift, ym2);
+            fwd_finish_row<CPL, NC, VEC>(rm1, P, c, dc_shift, ym1);
+#pragma unroll
+            for (int k = 0; k < NC; k++)
+#pragma unroll
+                for (int j = 0; j < H; j++) {   // unused (pr == 0 mirrors) when the band starts at the top
+                    dvp_lo[k][j] = wsub(ym1.lo[k][j], avg1(ym2.lo[k][j], ye.lo[k][j]));
+                    dvp_hi[k][j] = wsub(ym1.hi[k][j], avg1(ym2.hi[k][j], ye.hi[k][j]));
+                }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NC; k++)
+#pragma unroll
+                for (int j = 0; j < H; j++) dvp_lo[k][j] = dvp_hi[k][j] = 0;
+        }
+    }
+    for (int pr = pr_begin; pr < pr_end; pr++) {
+        const bool first = pr == pr_begin, last = pr + 1 == pr_end;
+        const bool has_odd = 2 * pr + 1 < h, has_next = 2 * pr + 2 < h;
+        const bool yn_from_lds = link_down && last;
+        if (!PF) {
+            fwd_issue_row<CPL, NC, VEC>(src, P, min(2 * pr + 1, hl), c, ra);
+            if (!yn_from_lds) fwd_issue_row<CPL, NC, VEC>(src, P, min(2 * pr + 2, hl), c, rb);
+        }
+        fwd_finish_row<CPL, NC, VEC>(ra, P, c, dc_shift, yo);
+        if (yn_from_lds) {
+#pragma unroll
+            for (int k = 0; k < NC; k++)
+#pragma unroll
+                for (int j = 0; j < H; j++) {
+                    yn.lo[k][j] = pub_below[(k * CPL + j) * 64];
+                    yn.hi[k][j] = pub_below[(k * CPL + H + j) * 64];
+                }
+        } else {
+            fwd_finish_row<CPL, NC, VEC>(rb, P, c, dc_shift, yn);
+        }
+        if (PF && !last) {
+            fwd_issue_row<CPL, NC, VEC>(src, P, min(2 * pr + 3, hl), c, ra);
+            if (!(link_down && pr + 2 == pr_end)) fwd_issue_row<CPL, NC, VEC>(src, P, min(2 * pr + 4, hl), c, rb);
+        }
+        int dv_lo[NC][H], dv_hi[NC][H], sv_lo[NC][H], sv_hi[NC][H];
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+#pragma unroll
+            for (int j = 0; j < H; j++) {
+                // predict: d = o - ((e + e_next) >> 1); no next even row: d = o - e; no odd row (odd height, last even
+                // row): the update mirrors d[n-2]
+                const int pl = has_next ? avg1(ye.lo[k][j], yn.lo[k][j]) : ye.lo[k][j];
+                const int ph = has_next ? avg1(ye.hi[k][j], yn.hi[k][j]) : ye.hi[k][j];
+                const int dl = has_odd ? wsub(yo.lo[k][j], pl) : dvp_lo[k][j];
+                const int dh = has_odd ? wsub(yo.hi[k][j], ph) : dvp_hi[k][j];
+                sv_lo[k][j] = wadd(ye.lo[k][j], avg2((pr == 0) ? dl : dvp_lo[k][j], dl));
+                sv_hi[k][j] = wadd(ye.hi[k][j], avg2((pr == 0) ? dh : dvp_hi[k][j], dh));
+                dv_lo[k][j] = dl;
+                dv_hi[k][j] = dh;
+            }
+        if (first && link_up) {   // the band above finishes this pair-row's low-pass output
+#pragma unroll
+            for (int k = 0; k < NC; k++)
+#pragma unroll
+                for (int j = 0; j < H; j++) {
+                    pub_mine[(k * CPL + j) * 64] = ye.lo[k][j];
+                    pub_mine[(k * CPL + H + j) * 64] = ye.hi[k][j];
+                    pub_mine[((NC + k) * CPL + j) * 64] = dv_lo[k][j];
+                    pub_mine[((NC + k) * CPL + H + j) * 64] = dv_hi[k][j];
+                }
+        } else {
+            fwd_store_row<CPL, NC, VEC>(out, nxt, P, pr, p0, owned, sv_lo, sv_hi);
+        }
+        if (has_odd) fwd_store_row<CPL, NC, VEC>(out, nxt, P, halfH + pr, p0, owned, dv_lo, dv_hi);
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+#pragma unroll
+            for (int j = 0; j < H; j++) {
+                dvp_lo[k][j] = dv_lo[k][j]; dvp_hi[k][j] = dv_hi[k][j];
+                ye.lo[k][j] = yn.lo[k][j]; ye.hi[k][j] = yn.hi[k][j];
+            }
+        if (first) __syncthreads();   // every wavefront of the workgroup arrives exactly once
+    }
+    if (link_down) {
+        // low-pass row of the first pair-row of the band below: s = e + ((d_above + d_own + 2) >> 2), e = `ye` (rotated
+        // in from LDS), d_above = this band's last d, d_own = published by the band below
+        int sv_lo[NC][H], sv_hi[NC][H];
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+#pragma unroll
+            for (int j = 0; j < H; j++) {
+                const int dl = pub_below[((NC + k) * CPL + j) * 64], dh = pub_below[((NC + k) * CPL + H + j) * 64];
+                sv_lo[k][j] = wadd(ye.lo[k][j], avg2(dvp_lo[k][j], dl));
+                sv_hi[k][j] = wadd(ye.hi[k][j], avg2(dvp_hi[k][j], dh));
+            }
+        fwd_store_row<CPL, NC, VEC>(out, nxt, P, pr_end, p0, owned, sv_lo, sv_hi);
     }
 }
 
@@ -452,17 +631,29 @@ __device__ __forceinline__ void inv_compute_xe(int q, int nhigh, const FwdRow<CP
         }
 }
 
+// Inverse level kernel.  Same decomposition and the same workgroup links as the forward kernel: a band needs the
+// s and d rows of its own pair-rows plus d[q0-1] above and s[q1], d[q1] below.  The two rows below are the FIRST rows
+// the band below loads, so a band with J2K_LINK_UP publishes them to LDS and a band with J2K_LINK_DOWN takes them from
+// there at its last pair-row; only d[q0-1] is still read twice (one halo row per band instead of three).
 template <int CPL, int NC, bool VEC>
 __global__ __launch_bounds__(256) void dwt53_inv_kernel(const DwtJob *__restrict__ jobs, int njobs,
                                                         const DwtPlane *__restrict__ planes,
                                                         const int32_t *__restrict__ coef, const int32_t *__restrict__ prev,
                                                         int32_t *__restrict__ dst, int dc_shift, int final_level) {
     constexpr int H = CPL / 2;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-    if (wave >= njobs) return;
+    constexpr int PUB = 2 * NC * CPL * 64;   // ints one wavefront publishes: {s row, d row} x NC x (lo|hi) x 64 lanes
+    __shared__ int sh[4 * PUB];
+    const int wv = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wv));
     const int lane = threadIdx.x & 63;
-    const DwtJob job = jobs[wave];
-    if (job.plane < 0) return;   // padding entry of the XCD-aware job order
+    DwtJob job{-1, 0, 0, 0};
+    if (wave < njobs) job = jobs[wave];
+    if (job.plane < 0) {             // past the end / padding entry of the XCD-aware job order
+        __syncthreads();
+        return;
+    }
+    const bool link_up = (job.nprow & J2K_LINK_UP) != 0, link_down = (job.nprow & J2K_LINK_DOWN) != 0;
+    job.nprow &= 0xffff;
     const DwtPlane P = planes[job.plane];
     const int w = P.w, h = P.h;
     const int lane_first = (job.col0 == 0) ? 0 : 1;
@@ -476,35 +667,62 @@ __global__ __launch_bounds__(256) void dwt53_inv_kernel(const DwtJob *__restrict
     const int pr_begin = job.prow0;
     const int pr_end = min(job.prow0 + job.nprow, halfH);
     const bool fin = final_level != 0;
+    int *pub_mine = sh + wv * PUB + lane;
+    const int *pub_below = sh + ((wv + 1) & 3) * PUB + lane;   // only read when link_down (then wv < 3)
 
     typedef FwdRow<CPL, NC, VEC> Row;
-    if (h < 2) {  // columns untouched
+    if (h < 2) {  // columns untouched; never linked
         if (pr_begin == 0) {
             Row s0;
             inv_load_row<CPL, NC, VEC>(coef, prev, P, 0, p0, c, s0);
             inv_finish_row<CPL, NC, VEC>(dst, P, 0, c, owned, s0.lo, s0.hi, dc_shift, fin);
         }
+        __syncthreads();
         return;
     }
     // vertical inverse (columns first, dwt.go:412-421):
     //   xe[q] = s[q] - ((d[q-1] + d[q] + 2) >> 2)   (d[-1] := d[0]; no d[q] (odd h, last) := d[q-1])
     //   xo[q] = d[q] + ((xe[q] + xe[q+1]) >> 1)      (no xe[q+1] := xe[q])
+    // Row indices are clamped into the plane so every load is unconditional (issued back to back); a clamped row is
+    // only ever combined into values the has_d / has_next selects discard.
     Row s, dcur, dprev;
     int xe_lo[NC][H], xe_hi[NC][H];
     inv_load_row<CPL, NC, VEC>(coef, prev, P, pr_begin, p0, c, s);
-    if (pr_begin < nhigh) inv_load_row<CPL, NC, VEC>(coef, prev, P, halfH + pr_begin, p0, c, dcur);
-    if (pr_begin > 0) inv_load_row<CPL, NC, VEC>(coef, prev, P, halfH + pr_begin - 1, p0, c, dprev);
+    inv_load_row<CPL, NC, VEC>(coef, prev, P, halfH + min(pr_begin, nhigh - 1), p0, c, dcur);
+    inv_load_row<CPL, NC, VEC>(coef, prev, P, halfH + max(pr_begin - 1, 0), p0, c, dprev);
+    if (link_up) {
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+#pragma unroll
+            for (int j = 0; j < H; j++) {
+                pub_mine[(k * CPL + j) * 64] = s.lo[k][j];
+                pub_mine[(k * CPL + H + j) * 64] = s.hi[k][j];
+                pub_mine[((NC + k) * CPL + j) * 64] = dcur.lo[k][j];
+                pub_mine[((NC + k) * CPL + H + j) * 64] = dcur.hi[k][j];
+            }
+    }
     inv_compute_xe<CPL, NC, VEC>(pr_begin, nhigh, s, dprev, dcur, xe_lo, xe_hi);
     for (int q = pr_begin; q < pr_end; q++) {
-        const bool has_d = q < nhigh;         // row 2q+1 exists
+        const bool first = q == pr_begin, last = q + 1 == pr_end;
+        const bool has_d = q < nhigh;           // row 2q+1 exists
         const bool has_next = (q + 1) < halfH;  // row 2q+2 exists
         Row sn, dn;
         int xn_lo[NC][H], xn_hi[NC][H];
-        if (has_next) {
-            inv_load_row<CPL, NC, VEC>(coef, prev, P, q + 1, p0, c, sn);
-            if (q + 1 < nhigh) inv_load_row<CPL, NC, VEC>(coef, prev, P, halfH + q + 1, p0, c, dn);
-            inv_compute_xe<CPL, NC, VEC>(q + 1, nhigh, sn, dcur, dn, xn_lo, xn_hi);
+        if (last && link_down) {
+#pragma unroll
+            for (int k = 0; k < NC; k++)
+#pragma unroll
+                for (int j = 0; j < H; j++) {
+                    sn.lo[k][j] = pub_below[(k * CPL + j) * 64];
+                    sn.hi[k][j] = pub_below[(k * CPL + H + j) * 64];
+                    dn.lo[k][j] = pub_below[((NC + k) * CPL + j) * 64];
+                    dn.hi[k][j] = pub_below[((NC + k) * CPL + H + j) * 64];
+                }
+        } else {
+            inv_load_row<CPL, NC, VEC>(coef, prev, P, min(q + 1, halfH - 1), p0, c, sn);
+            inv_load_row<CPL, NC, VEC>(coef, prev, P, halfH + min(q + 1, nhigh - 1), p0, c, dn);
         }
+        inv_compute_xe<CPL, NC, VEC>(q + 1, nhigh, sn, dcur, dn, xn_lo, xn_hi);   // unused when !has_next
         inv_finish_row<CPL, NC, VEC>(dst, P, 2 * q, c, owned, xe_lo, xe_hi, dc_shift, fin);
         if (has_d) {
             int xo_lo[NC][H], xo_hi[NC][H];
@@ -526,6 +744,7 @@ __global__ __launch_bounds__(256) void dwt53_inv_kernel(const DwtJob *__restrict
                 xe_lo[k][j] = xn_lo[k][j]; xe_hi[k][j] = xn_hi[k][j];
                 dcur.lo[k][j] = dn.lo[k][j]; dcur.hi[k][j] = dn.hi[k][j];
             }
+        if (first) __syncthreads();   // every wavefront of the workgroup arrives exactly once
     }
 }
 
@@ -551,7 +770,7 @@ __device__ __forceinline__ void tail_fwd_level(const int32_t *cur, int32_t *nxt,
         x[0] = (c < w) ? cur[r * w + c] : 0;
         x[1] = (c + 1 < w) ? cur[r * w + c + 1] : 0;
         int l1[1], h1[1];
-        hfwd<2>(x, c, w, l1, h1);
+        hfwd<2, true>(x, c, w, l1, h1);
         lo = l1[0]; hi = h1[0];
     };
     auto store = [&](int ro, int lo, int hi) {
@@ -715,7 +934,8 @@ hipError_t launch_dwt53_tail_inv(hipStream_t s, const TailPlane *planes, int npl
 template <int CPL, int NC, bool VEC>
 static hipError_t fwd_go(hipStream_t s, const LevelLaunch &L, const int32_t *src, int32_t *out, int32_t *nxt, int dc) {
     const int blocks = (L.njobs + 3) / 4;
-    hipLaunchKernelGGL((dwt53_fwd_kernel<CPL, NC, VEC>), dim3(blocks), dim3(256), 0, s, L.jobs, L.njobs, L.planes, src, out, nxt, dc);
+    if (L.pf) hipLaunchKernelGGL((dwt53_fwd_kernel<CPL, NC, VEC, true>), dim3(blocks), dim3(256), 0, s, L.jobs, L.njobs, L.planes, src, out, nxt, dc);
+    else hipLaunchKernelGGL((dwt53_fwd_kernel<CPL, NC, VEC, false>), dim3(blocks), dim3(256), 0, s, L.jobs, L.njobs, L.planes, src, out, nxt, dc);
     return hipGetLastError();
 }
 template <int CPL, int NC, bool VEC>

@@ -89,7 +89,10 @@ extern "C" int j2k_ctx_create(int device, j2k_ctx **out) {
         if (v >= 1 && v <= 4096) ctx->band_prows = v;
     }
     if (const char *e = getenv("J2K_FORCE_NOVEC")) ctx->force_novec = atoi(e) != 0;
-    if (const char *e = getenv("J2K_FWD_SPLIT")) ctx->fwd_split = atoi(e) != 0;
+    if (const char *e = getenv("J2K_FWD_LINK")) ctx->fwd_link = atoi(e) != 0;
+    if (const char *e = getenv("J2K_INV_LINK")) ctx->inv_link = atoi(e) != 0;
+    if (const char *e = getenv("J2K_BAND_PROWS_INV")) { int v = atoi(e); if (v >= 1 && v <= 4096) ctx->band_prows_inv = v; }
+    if (const char *e = getenv("J2K_FWD_PF")) ctx->fwd_pf = atoi(e) != 0;
     if (const char *e = getenv("J2K_TAIL")) ctx->use_tail = atoi(e) != 0;
     if (const char *e = getenv("J2K_XCD_MAP")) ctx->xcd_map = atoi(e) != 0;
     if (const char *e = getenv("J2K_CPL0")) { int v = atoi(e); if (v == 2 || v == 4 || v == 8) ctx->cpl0 = v; }
@@ -292,21 +295,18 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                 std::vector<int> pw, ph;
                 bool vec_ok = !ctx->force_novec;
                 int maxw = 0;
-                const bool split = (dir == 0 && l == 0 && cls == 1 && S.wavelet == W53 && ctx->fwd_split);
-                std::vector<int> triple_first;   // index of the first of three role planes (split mode)
                 for (const Group &g : P->groups) {
                     const bool as_triple = (g.nc == 3 && l == 0);
                     if ((cls == 1) != as_triple) continue;
                     int w = g.w, h = g.h;
                     for (int i = 0; i < l; i++) { w = (w + 1) / 2; h = (h + 1) / 2; }
                     const int wn = (w + 1) / 2, hn = (h + 1) / 2;
-                    const int nplanes_here = (as_triple && !split) ? 1 : g.nc;
-                    if (split) triple_first.push_back((int)planes.size());
+                    const int nplanes_here = as_triple ? 1 : g.nc;
                     for (int k0 = 0; k0 < nplanes_here; k0++) {
                         DwtPlane D{};
-                        const int kn = (as_triple && !split) ? 3 : 1;
+                        const int kn = as_triple ? 3 : 1;
                         for (int k = 0; k < kn; k++) {
-                            const int kk = (as_triple && !split) ? k : k0;
+                            const int kk = as_triple ? k : k0;
                             const int64_t frame_off = (int64_t)(g.comp0 + kk) * S.H * S.W + (int64_t)g.y0 * S.W + g.x0;
                             const int64_t *scr_in = (l & 1) ? g.scrA_off : g.scrB_off;    // where level l's input prefix lives
                             const int64_t *scr_out = (l & 1) ? g.scrB_off : g.scrA_off;   // where level l's output prefix goes
@@ -320,11 +320,6 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                                 D.out_off[k] = (l == 0) ? frame_off : scr_in[kk];
                             }
                         }
-                        if (split) {   // role plane k0: sources = the three frame planes, destination = component k0
-                            for (int k = 0; k < 3; k++)
-                                D.src_off[k] = (int64_t)(g.comp0 + k) * S.H * S.W + (int64_t)g.y0 * S.W + g.x0;
-                            D.role = k0 + 1;
-                        }
                         D.src_stride = (dir == 0 && l == 0) ? S.W : w;
                         D.out_stride = S.W;
                         D.w = w; D.h = h;
@@ -335,7 +330,7 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                     }
                 }
                 LevelTab &T = (dir == 0 ? P->fwd : P->inv)[cls][l];
-                T.ncomp = (cls && !split) ? 3 : 1;
+                T.ncomp = cls ? 3 : 1;
                 T.nplanes = (int)planes.size();
                 if (planes.empty()) continue;
                 int cpl = pick_cpl(maxw);
@@ -352,29 +347,19 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                 else if (!vec_ok) cpl = 2;
                 T.cpl = cpl; T.vec = vec_ok ? 1 : 0;
                 const int halo = (S.wavelet == W97 && cpl < 4) ? 2 : 1;
-                const int band = (S.wavelet == W97) ? std::max(ctx->band_prows, 8) : ctx->band_prows;
+                const int band53 = (dir == 1 && ctx->band_prows_inv > 0) ? ctx->band_prows_inv : ctx->band_prows;
+                const int band = (S.wavelet == W97) ? std::max(ctx->band_prows, 8) : band53;
                 std::vector<DwtJob> jobs;
-                if (split) {
-                    // the three role jobs of the same strip x band are adjacent -> same workgroup -> shared L1
-                    for (int f : triple_first) {
-                        std::vector<DwtJob> one;
-                        make_jobs(one, f, pw[f], ph[f], cpl, band, halo);
-                        for (const DwtJob &j : one)
-                            for (int k = 0; k < 3; k++) jobs.push_back(DwtJob{f + k, j.col0, j.prow0, j.nprow});
-                    }
-                    for (size_t i = 0; i < planes.size(); i++) T.alg_bytes += (int64_t)2 * esz * pw[i] * ph[i];
-                } else {
-                    for (size_t i = 0; i < planes.size(); i++) {
-                        make_jobs(jobs, (int)i, pw[i], ph[i], cpl, band, halo);
-                        T.alg_bytes += (int64_t)2 * esz * pw[i] * ph[i] * T.ncomp;
-                    }
+                for (size_t i = 0; i < planes.size(); i++) {
+                    make_jobs(jobs, (int)i, pw[i], ph[i], cpl, band, halo);
+                    T.alg_bytes += (int64_t)2 * esz * pw[i] * ph[i] * T.ncomp;
                 }
                 if (ctx->xcd_map && jobs.size() >= 64) {
                     // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one), so the
                     // wavefronts of one plane -- whose bands share halo rows -- are placed in workgroups = x (mod 8):
                     // the halo re-reads then hit that XCD's L2 instead of going back to HBM.  Speed only.
                     std::vector<std::vector<DwtJob>> per(8);
-                    for (const DwtJob &j : jobs) per[(split ? j.plane / 3 : j.plane) % 8].push_back(j);
+                    for (const DwtJob &j : jobs) per[j.plane % 8].push_back(j);
                     size_t m = 0;
                     for (auto &v : per) m = std::max(m, v.size());
                     m = (m + 3) & ~size_t(3);
@@ -382,6 +367,22 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                     for (int x = 0; x < 8; x++)
                         for (size_t i = 0; i < per[x].size(); i++) perm[((i / 4) * 8 + x) * 4 + (i % 4)] = per[x][i];
                     jobs.swap(perm);
+                }
+                if (S.wavelet == W53 && (dir == 0 ? ctx->fwd_link : ctx->inv_link)) {
+                    // link vertically adjacent bands that share a workgroup (4 consecutive jobs): see dwt53_fwd_kernel
+                    for (size_t i = 1; i < jobs.size(); i++) {
+                        if (i % 4 == 0) continue;
+                        DwtJob &a = jobs[i - 1], &b = jobs[i];
+                        if (a.plane < 0 || a.plane != b.plane || a.col0 != b.col0) continue;
+                        const int w = pw[a.plane], h = ph[a.plane], halfH = (h + 1) / 2;
+                        if (w < 2 || h < 2) continue;
+                        const int an = a.nprow & 0xffff, bn = b.nprow & 0xffff;
+                        if (a.prow0 + an != b.prow0) continue;
+                        if (std::min(an, halfH - a.prow0) < 2 || std::min(bn, halfH - b.prow0) < 2) continue;
+                        if (2 * b.prow0 + 1 >= h) continue;      // the band below must own a real odd row
+                        a.nprow |= J2K_LINK_DOWN;
+                        b.nprow |= J2K_LINK_UP;
+                    }
                 }
                 T.njobs = (int)jobs.size();
                 int r = upload(ctx, &T.d_planes, planes);
@@ -532,7 +533,7 @@ extern "C" int j2k_plan_get_decoded_offsets(const j2k_plan *P, uint64_t *offs, s
 // ------------------------------------------------------------------------------
 // transform stages on device buffers
 // ------------------------------------------------------------------------------
-static LevelLaunch mk(const LevelTab &T) { return LevelLaunch{T.d_jobs, T.njobs, T.d_planes, T.cpl, T.vec, T.ncomp}; }
+static LevelLaunch mk(const LevelTab &T, int pf = 0) { return LevelLaunch{T.d_jobs, T.njobs, T.d_planes, T.cpl, T.vec, T.ncomp, pf}; }
 
 static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff) {
     j2k_ctx *ctx = P->ctx;
@@ -550,7 +551,7 @@ static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff) {
             const LevelTab &T = P->fwd[cls][l];
             if (!T.njobs) continue;
             if (S.wavelet == W53) {
-                HIPCHK(ctx, launch_dwt53_fwd(ctx->stream, mk(T), (const int32_t *)in, (int32_t *)d_coeff, (int32_t *)nx, l == 0 ? S.dc_shift : 0));
+                HIPCHK(ctx, launch_dwt53_fwd(ctx->stream, mk(T, ctx->fwd_pf), (const int32_t *)in, (int32_t *)d_coeff, (int32_t *)nx, l == 0 ? S.dc_shift : 0));
             } else {
                 const int src_f64 = (l > 0) || S.frame_is_f64;
                 HIPCHK(ctx, launch_dwt97_fwd(ctx->stream, mk(T), in, src_f64, (int32_t *)d_coeff, (double *)d_coeff, (double *)nx,

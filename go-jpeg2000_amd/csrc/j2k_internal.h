@@ -15,7 +15,7 @@ struct DwtPlane {
     int32_t w, h;         // dims of this level: dense w x h matrix
     int32_t n_next;       // w_{l+1}*h_{l+1}; linear idx < n_next -> nxt, else -> out (0 on the last level)
     int32_t out_stride;   // inverse level 0 only: row stride of the destination frame
-    int32_t role;         // forward level 0, split-component mode: 0 plain, 1/2/3 = compute Y/U/V of the RCT from src_off[0..2]
+    int32_t pad_;
 };
 
 // One wavefront's work: a column strip x a band of pair-rows of one plane.
@@ -23,8 +23,11 @@ struct DwtJob {
     int32_t plane;
     int32_t col0;         // first OWNED input column (multiple of CPL); 0 for the first strip
     int32_t prow0;        // first pair-row of the band
-    int32_t nprow;        // pair-rows in the band
+    int32_t nprow;        // pair-rows in the band (low 16 bits) | J2K_LINK_* (forward 5-3 only)
 };
+// forward 5-3: this band and its neighbour in the same workgroup exchange their halo rows through LDS (dwt53.hip)
+#define J2K_LINK_UP 0x10000
+#define J2K_LINK_DOWN 0x20000
 
 // One code-block job (device form).
 struct BlockJob {
@@ -52,6 +55,7 @@ struct LevelLaunch {
     int cpl;              // columns per lane: 2, 4 or 8
     int vec;              // 1: every plane satisfies the vector-access alignment rules
     int ncomp;            // 1 or 3 (3 = fused colour transform on level 0)
+    int pf;               // forward 5-3: software-prefetch variant
 };
 
 hipError_t launch_dwt53_fwd(hipStream_t s, const LevelLaunch &L, const int32_t *src, int32_t *out,

@@ -10,8 +10,11 @@ struct j2k_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
     std::string last_error;
-    int band_prows = 4;        // pair-rows per wavefront band (tunable: J2K_BAND_PROWS)
-    int fwd_split = 0;         // level-0 forward: one wavefront per RCT component (J2K_FWD_SPLIT=0: three per wavefront)
+    int fwd_link = 1;          // forward 5-3: bands of one workgroup exchange halo rows through LDS (J2K_FWD_LINK)
+    int inv_link = 1;          // same for the inverse kernels (J2K_INV_LINK)
+    int band_prows_inv = 0;    // 0: same as band_prows (J2K_BAND_PROWS_INV)
+    int fwd_pf = 0;            // forward 5-3 level kernels: software prefetch of the next pair-row (J2K_FWD_PF)
+    int band_prows = 5;        // pair-rows per wavefront band (tunable: J2K_BAND_PROWS)
     int use_tail = 1;          // J2K_TAIL=0: every level as its own launch (A/B)
     int xcd_map = 0;           // J2K_XCD_MAP=0: plain job order (A/B)
     int cpl0 = 0;              // J2K_CPL0: force columns-per-lane of the level-0 5-3 kernels (tuning)

@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_PKG), "libj2kgfx.so")
+LIB_PATH = os.environ.get("J2K_LIB") or os.path.join(os.path.dirname(_PKG), "libj2kgfx.so")   # J2K_LIB: dev override (A/B builds)
 
 OK = 0
 ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_GO_PANIC, ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6
