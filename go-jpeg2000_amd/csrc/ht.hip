@@ -42,6 +42,26 @@ __global__ void ht_build_enc_table() {
     g_vlc_enc[t] = r;
 }
 
+// decoder view for the rows after the first (tbl1): the next 14 stream bits -> BOTH quads of a quad pair, valid whenever
+// the first quad's "length" nibble is <= 7 (then the second quad's 7 index bits lie inside the 14):
+//   rho1 | rho2 << 4 | (len1 + len2) << 8 | uOff2 << 13 | uOff1 << 14 ; bit 15 = first length > 7, take the two-step path
+// (ht.go:600-640: first quad context 0, second quad context rho1 >> 2)
+__device__ uint16_t g_vlc_pair1[16384];
+
+__global__ void ht_build_pair_table() {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 16384) return;
+    const uint32_t e1 = c_vlc_tbl1[idx & 0x7F];
+    const uint32_t len1 = e1 & 0xF, rho1 = (e1 >> 4) & 0xF, uo1 = (e1 >> 3) & 1;
+    uint32_t r = 0x8000;
+    if (len1 <= 7) {
+        const uint32_t e2 = c_vlc_tbl1[((rho1 >> 2) << 7) | ((idx >> len1) & 0x7F)];
+        const uint32_t len2 = e2 & 0xF, rho2 = (e2 >> 4) & 0xF, uo2 = (e2 >> 3) & 1;
+        r = rho1 | rho2 << 4 | (len1 + len2) << 8 | uo2 << 13 | uo1 << 14;
+    }
+    g_vlc_pair1[idx] = (uint16_t)r;
+}
+
 __device__ __forceinline__ uint32_t shl32(uint32_t x, uint32_t n) { return n >= 32 ? 0u : x << n; }
 __device__ __forceinline__ uint64_t shl64(uint64_t x, uint32_t n) { return n >= 64 ? 0ull : x << n; }
 __device__ __forceinline__ uint64_t shr64(uint64_t x, uint32_t n) { return n >= 64 ? 0ull : x >> n; }
@@ -546,6 +566,21 @@ __device__ uint32_t decode_uvlc(uint32_t vlc, uint32_t mode, uint32_t (&u)[2], i
     return consumed;
 }
 
+// the same for the rows after the first, branch-free: a disabled u is the all-zero table entry.  Note the reference's
+// pairing (ht.go:736-751): mode = uOff1 << 1 | uOff2, mode 1 decodes u[0] and mode 2 decodes u[1] -- so u[0] is
+// present iff uOff2 and u[1] iff uOff1.
+__device__ __forceinline__ uint32_t decode_uvlc_later(uint32_t vlc, uint32_t uOff1, uint32_t uOff2, uint32_t &u0, uint32_t &u1) {
+    const uint32_t t1 = uOff2 ? uvlc_entry(vlc) : 0u;
+    const uint32_t pl1 = t1 & 3; vlc >>= pl1;
+    const uint32_t t2 = uOff1 ? uvlc_entry(vlc) : 0u;
+    const uint32_t pl2 = t2 & 3; vlc >>= pl2;
+    const uint32_t sl1 = (t1 >> 2) & 7, sl2 = (t2 >> 2) & 7;
+    u0 = (t1 >> 5) + (vlc & ((1u << sl1) - 1)) + 1;
+    vlc >>= sl1;
+    u1 = (t2 >> 5) + (vlc & ((1u << sl2) - 1)) + 1;
+    return pl1 + pl2 + sl1 + sl2;
+}
+
 __device__ bool init_mel_ok(const uint8_t *data, long len, long lcup, long scup) {  // ht.go:153-195
     long pos = lcup - scup, size = scup - 1;
     int unstuff = 0;
@@ -685,93 +720,124 @@ __global__ __launch_bounds__(256) void ht_vlcprep_kernel(const BlockJob *__restr
     wave_sync();
     uint32_t *dst = vbits + (size_t)jid * HT_VBITS_WORDS;
     for (int i = lane; i < HT_VBITS_WORDS; i += 64) dst[i] = vb[i];
-    if (lane == 0) rec[0] = (uint32_t)scup << 20;                    // provisional: the walk kernel adds pair 0
+    if (lane == 0) { rec[0] = 0; rec[HT_WALK_MAX_PAIRS] = (uint32_t)scup; }   // not a tag; SCUP travels in the flag word
 }
 
 struct HtWalkShared {
     uint32_t vb[64][HT_VROW];
+    uint16_t pair1[16384];
     uint16_t tbl0[512], tbl1[512];
 };
 
+// bits the u-VLC of a quad pair consumes, rows after the first (see decode_uvlc_later)
+__device__ __forceinline__ uint32_t uvlc_used_later(uint32_t vlc, uint32_t uOff1, uint32_t uOff2) {
+    const uint32_t t1 = uOff2 ? uvlc_entry(vlc) : 0u;
+    const uint32_t pl1 = t1 & 3;
+    const uint32_t t2 = uOff1 ? uvlc_entry(vlc >> pl1) : 0u;
+    return pl1 + (t2 & 3) + ((t1 >> 2) & 7) + ((t2 >> 2) & 7);
+}
+
 // ---- kernel 2: one block per LANE -- the sequential VLC walk (ht.go:589-658) on the linear bit strings ----
-__global__ __launch_bounds__(64) void ht_walk_kernel(const BlockJob *__restrict__ jobs, int njobs,
+// The walk is a dependent chain (a code word's length comes out of the lookup of the previous one) and a block is at
+// most 128 quad pairs long, so the kernel time is 128 x the latency of one pair: everything that is not needed to find
+// the NEXT pair's bit position is left to ht_decode_kernel.  Per pair: fetch 64 bits at the current position
+// (three LDS words + two v_alignbit), ONE LDS lookup that resolves both quads (g_vlc_pair1), the u-VLC's LENGTH, one
+// record store:  rho | rho2 << 4 | (uOff1 << 1 | uOff2) << 8 | (the 16 stream bits at the u-VLC) << 16.
+// The first row (other table, other u-VLC rule) and code words with a length nibble above 7 use two lookups.
+// A pair consumes at most 46 bits and HT_VBITS_WORDS covers 128 of them plus the read-ahead, so no clamping.
+__global__ __launch_bounds__(256) void ht_walk_kernel(const BlockJob *__restrict__ jobs, int njobs,
                                                      const uint32_t *__restrict__ vbits, uint32_t *__restrict__ pairs) {
-    __shared__ HtWalkShared S;
-    const int lane = threadIdx.x;
+    extern __shared__ __align__(16) unsigned char walk_smem[];
+    HtWalkShared &S = *reinterpret_cast<HtWalkShared *>(walk_smem);
+    const int tid = threadIdx.x, lane = tid & 63;
     const int jid0 = blockIdx.x * 64;
     const int jid = jid0 + lane;
     const bool have = jid < njobs;
-    reinterpret_cast<uint4 *>(S.tbl0)[lane] = reinterpret_cast<const uint4 *>(c_vlc_tbl0)[lane];   // contexts 0..3 = 1 KiB
-    reinterpret_cast<uint4 *>(S.tbl1)[lane] = reinterpret_cast<const uint4 *>(c_vlc_tbl1)[lane];
-    // coalesced staging: 64 blocks x 192 words, eight blocks' loads in flight at a time
+#ifdef J2K_WALK_STAMP
+    const long long st0 = __builtin_amdgcn_s_memtime();
+#endif
+    // Staging by all four wavefronts, every load issued before the first use (a lone wavefront doing this in
+    // dependent batches spent 40% of the kernel here): 32 KiB pair table = 8 x 16 B per thread, 64 blocks x 192 words
+    // = 12 x 16 B per thread, the two 1 KiB tables.  Afterwards only wavefront 0 walks.
     const int nblk = min(64, njobs - jid0);
-    for (int g = 0; g < nblk; g += 8) {
-        uint32_t v[8][3];
+    // the walking wavefront's own inputs ride along with the staging loads
+    uint32_t *rec = pairs + (size_t)jid * HT_WALK_REC;
+    uint32_t tag = HT_PAIR_ZERO;
+    int w = 0, h = 0;
+    if (tid < 64 && have) { tag = rec[0]; w = jobs[jid].w; h = jobs[jid].h; }
+    {
+        uint4 t[8], v[12];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int bsel = min(g + j, nblk - 1);
-            const uint32_t *src = vbits + (size_t)(jid0 + bsel) * HT_VBITS_WORDS;
+        for (int j = 0; j < 8; j++) t[j] = reinterpret_cast<const uint4 *>(g_vlc_pair1)[j * 256 + tid];
 #pragma unroll
-            for (int c = 0; c < 3; c++) v[j][c] = src[lane + 64 * c];
+        for (int j = 0; j < 12; j++) {
+            const int q = j * 256 + tid;                      // 16-byte piece q: block q / 48, words 4 * (q % 48) ..
+            const int bsel = min(q / 48, nblk - 1);
+            v[j] = reinterpret_cast<const uint4 *>(vbits + (size_t)(jid0 + bsel) * HT_VBITS_WORDS)[q % 48];
         }
+        if (tid < 64) reinterpret_cast<uint4 *>(S.tbl0)[tid] = reinterpret_cast<const uint4 *>(c_vlc_tbl0)[tid];   // contexts 0..3 = 1 KiB
+        else if (tid < 128) reinterpret_cast<uint4 *>(S.tbl1)[tid - 64] = reinterpret_cast<const uint4 *>(c_vlc_tbl1)[tid - 64];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            if (g + j >= nblk) break;
+        for (int j = 0; j < 8; j++) reinterpret_cast<uint4 *>(S.pair1)[j * 256 + tid] = t[j];
 #pragma unroll
-            for (int c = 0; c < 3; c++) S.vb[g + j][lane + 64 * c] = v[j][c];
+        for (int j = 0; j < 12; j++) {
+            const int q = j * 256 + tid;
+            uint32_t *d = &S.vb[q / 48][4 * (q % 48)];        // rows have an odd word stride: four 4-byte stores
+            d[0] = v[j].x; d[1] = v[j].y; d[2] = v[j].z; d[3] = v[j].w;
         }
     }
     __syncthreads();
-    if (!have) return;
-    uint32_t *rec = pairs + (size_t)jid * HT_WALK_REC;
-    const uint32_t tag = rec[0];
+#ifdef J2K_WALK_STAMP
+    const long long st1 = __builtin_amdgcn_s_memtime();
+#endif
+    if (tid >= 64 || !have) return;
     if (tag == HT_PAIR_SERIAL || tag == HT_PAIR_ZERO) return;
-    const int w = jobs[jid].w, h = jobs[jid].h;
     const int quadCols = (w + 3) / 4, P = (quadCols + 1) / 2, R = (h + 3) / 4;
     const uint32_t *row = &S.vb[lane][0];
-    // 64-bit window over the bit string; the next word is requested one refill ahead of its use
-    uint64_t tmp = (uint64_t)row[0] | ((uint64_t)row[1] << 32);
-    uint32_t bits = 64, wi = 2, nxt = row[2];
-#define HT_ENSURE32()                                                             \
-    do {                                                                           \
-        if (bits <= 32) {                                                          \
-            tmp |= (uint64_t)nxt << bits;                                          \
-            bits += 32;                                                            \
-            wi++;                                                                  \
-            nxt = row[wi < HT_VBITS_WORDS ? wi : HT_VBITS_WORDS - 1];              \
-        }                                                                          \
-    } while (0)
-    uint32_t first = 0;
-    bool too_big = false;
-    for (int r = 0; r < R; r++) {
-        const int initial = (r == 0);
-        const uint16_t *tbl = initial ? S.tbl0 : S.tbl1;
-        for (int pi = 0; pi < P; pi++) {
-            HT_ENSURE32();
-            const uint32_t qinf = tbl[(uint32_t)tmp & 0x7F];        // first quad: context is always 0
-            const uint32_t rho = (qinf >> 4) & 0xF, uOff1 = (qinf >> 3) & 1;
-            tmp >>= (qinf & 0xF); bits -= (qinf & 0xF);
-            HT_ENSURE32();
-            const uint32_t qinf2 = tbl[((rho >> 2) << 7) | ((uint32_t)tmp & 0x7F)];
-            const uint32_t rho2 = (qinf2 >> 4) & 0xF, uOff2 = (qinf2 >> 3) & 1;
-            tmp >>= (qinf2 & 0xF); bits -= (qinf2 & 0xF);
-            uint32_t u[2] = {1, 1};
-            const uint32_t mode = (uOff1 << 1) | uOff2;
-            if (mode > 0) {
-                HT_ENSURE32();
-                const uint32_t used = decode_uvlc((uint32_t)tmp, mode, u, initial);
-                tmp >>= used; bits -= used;
-            }
-            if (u[0] > 32 || u[1] > 32) too_big = true;
-            const uint32_t v = rho | rho2 << 4 | (u[0] & 0x3F) << 8 | (u[1] & 0x3F) << 14;
-            const int it = r * P + pi;
-            if (it == 0) first = v; else rec[it] = v;
-        }
+    uint32_t pos = 0;
+#define HT_FETCH(w0, w1)                                                          \
+    uint32_t w0, w1;                                                               \
+    {                                                                              \
+        const uint32_t *p_ = row + (pos >> 5);                                     \
+        const uint32_t d0_ = p_[0], d1_ = p_[1], d2_ = p_[2];                      \
+        w0 = __builtin_amdgcn_alignbit(d1_, d0_, pos & 31);                        \
+        w1 = __builtin_amdgcn_alignbit(d2_, d1_, pos & 31);                        \
     }
-#undef HT_ENSURE32
-    // rec[0] also carries SCUP (12 bits); u <= 37, so no record equals a tag
-    rec[0] = tag | first;
-    rec[HT_WALK_MAX_PAIRS] = too_big ? HT_FLAG_BIGU : 0u;
+    // ---- first row: tbl0, general u-VLC ----
+    for (int pi = 0; pi < P; pi++) {
+        HT_FETCH(w0, w1)
+        const uint32_t qinf = S.tbl0[w0 & 0x7F];                    // first quad: context is always 0
+        const uint32_t rho = (qinf >> 4) & 0xF, uOff1 = (qinf >> 3) & 1, len1 = qinf & 0xF;
+        const uint32_t qinf2 = S.tbl0[((rho >> 2) << 7) | ((w0 >> len1) & 0x7F)];
+        const uint32_t rho2 = (qinf2 >> 4) & 0xF, uOff2 = (qinf2 >> 3) & 1, len = len1 + (qinf2 & 0xF);
+        const uint32_t vw = __builtin_amdgcn_alignbit(w1, w0, len);  // len <= 30
+        const uint32_t mode = (uOff1 << 1) | uOff2;
+        uint32_t u[2];
+        const uint32_t used = decode_uvlc(vw, mode, u, 1);
+        pos += len + used;
+        rec[pi] = rho | rho2 << 4 | mode << 8 | vw << 16;
+    }
+    // ---- later rows ----
+    for (int it = P; it < R * P; it++) {
+        HT_FETCH(w0, w1)
+        uint32_t e = S.pair1[w0 & 0x3FFF];
+        if (e & 0x8000) {                                            // rare: length nibble > 7
+            const uint32_t qinf = S.tbl1[w0 & 0x7F];
+            const uint32_t rho = (qinf >> 4) & 0xF, len1 = qinf & 0xF;
+            const uint32_t qinf2 = S.tbl1[((rho >> 2) << 7) | ((w0 >> len1) & 0x7F)];
+            e = rho | (qinf2 & 0xF0) | (len1 + (qinf2 & 0xF)) << 8 | ((qinf2 >> 3) & 1) << 13 | ((qinf >> 3) & 1) << 14;
+        }
+        const uint32_t len = (e >> 8) & 0x1F;
+        const uint32_t vw = __builtin_amdgcn_alignbit(w1, w0, len);
+        pos += len + uvlc_used_later(vw, (e >> 14) & 1, (e >> 13) & 1);
+        rec[it] = (e & 0xFF) | ((e >> 5) & 0x300) | vw << 16;
+    }
+#undef HT_FETCH
+#ifdef J2K_WALK_STAMP
+    const long long st2 = __builtin_amdgcn_s_memtime();
+    if ((blockIdx.x == 0 || blockIdx.x == 50) && lane == 0)
+        printf("walk wg %d: staging %lld cyc, loop %lld cyc (%d pairs, %d bits)\n", (int)blockIdx.x, st1 - st0, st2 - st1, R * P, (int)pos);
+#endif
 }
 
 #define HT_MAX_FF 64
@@ -1022,14 +1088,30 @@ __global__ __launch_bounds__(256) void ht_decode_kernel(const BlockJob *__restri
         }
     };
     if (!fast) zero_fill(false);
-    S.pair[lane] = r0; S.pair[64 + lane] = r1;
+    // finish the walk's records: u0/u1 from the 16 stream bits kept at the u-VLC (ht.go:716-864) -> rho | rho2 << 4 | u0 << 8 | u1 << 14
+    bool bigu = false;
+    {
+        const int quadCols = (w + 3) / 4, P = (quadCols + 1) / 2, N = ((h + 3) / 4) * P;
+        uint32_t rr[2] = {r0, r1};
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int it = lane + 64 * t;
+            const uint32_t r = rr[t], mode = (r >> 8) & 3, vw = r >> 16;
+            uint32_t u[2], u0, u1;
+            decode_uvlc(vw, mode, u, 1);
+            decode_uvlc_later(vw, mode >> 1, mode & 1, u0, u1);
+            if (it < P) { u0 = u[0]; u1 = u[1]; }
+            if (it < N && (u0 > 32 || u1 > 32)) bigu = true;
+            S.pair[it] = (r & 0xFF) | (u0 & 0x3F) << 8 | (u1 & 0x3F) << 14;
+        }
+        bigu = __any(bigu);
+    }
     wave_sync();
     if (tag == HT_PAIR_ZERO || (phases & 0xFF) < 2 || (phases & 0xFF) == 20) return;
     if (tag != HT_PAIR_SERIAL) {
         const uint8_t *fdata = stream + offs[jid];
         const long flen = (long)lens[jid];
-        const long fscup = (long)(tag >> 20);                    // validated by ht_walk_kernel
-        const bool bigu = (__shfl(rec[HT_WALK_MAX_PAIRS], 0) & HT_FLAG_BIGU) != 0;
+        const long fscup = (long)__shfl(rec[HT_WALK_MAX_PAIRS], 0);   // validated by ht_vlcprep_kernel
         if (ht_extract_fast(S, fdata, flen, fscup, w, h, out, lane, phases & 0xFF, bigu)) {
             zero_fill(true);
             return;
@@ -1119,19 +1201,30 @@ __global__ __launch_bounds__(256) void ht_decode_kernel(const BlockJob *__restri
 }
 
 // ---------------------------------------------------------------------------------
-static bool g_enc_table_ready[16] = {false};
+static bool g_tables_ready[16] = {false};
+
+// derived tables live in device globals of this code object: build them once per device, in stream order
+static hipError_t ht_tables_ready(hipStream_t s) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+    if (g_tables_ready[dev]) return hipSuccess;
+    hipLaunchKernelGGL(ht_build_enc_table, dim3(1), dim3(128), 0, s);
+    hipLaunchKernelGGL(ht_build_pair_table, dim3(64), dim3(256), 0, s);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(ht_walk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)sizeof(HtWalkShared))) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;   // once per device: other streams may use the tables next
+    g_tables_ready[dev] = true;
+    return hipSuccess;
+}
 
 hipError_t launch_ht_encode(hipStream_t s, const BlockJob *jobs, int njobs, const int32_t *coef, uint8_t *slots,
                             uint32_t *lens, uint8_t *numbps, int *fault) {
     if (njobs <= 0) return hipSuccess;
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (dev >= 0 && dev < 16 && !g_enc_table_ready[dev]) {
-        hipLaunchKernelGGL(ht_build_enc_table, dim3(1), dim3(128), 0, s);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-        g_enc_table_ready[dev] = true;
-    }
+    hipError_t e;
+    if ((e = ht_tables_ready(s)) != hipSuccess) return e;
     hipLaunchKernelGGL(ht_encode_kernel, dim3(njobs), dim3(64), 0, s, jobs, njobs, coef, slots, lens, numbps, fault);
     return hipGetLastError();
 }
@@ -1143,10 +1236,11 @@ hipError_t launch_ht_decode(hipStream_t s, const BlockJob *jobs, int njobs, cons
                             const uint32_t *lens, int32_t *decoded, uint32_t *scratch) {
     if (njobs <= 0) return hipSuccess;
     hipError_t e;
+    if ((e = ht_tables_ready(s)) != hipSuccess) return e;
     uint32_t *pairs = scratch, *vbits = scratch + (size_t)njobs * HT_WALK_REC;
     hipLaunchKernelGGL(ht_vlcprep_kernel, dim3((njobs + 3) / 4), dim3(256), 0, s, jobs, njobs, stream, offs, lens, vbits, pairs);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    hipLaunchKernelGGL(ht_walk_kernel, dim3((njobs + 63) / 64), dim3(64), 0, s, jobs, njobs, vbits, pairs);
+    hipLaunchKernelGGL(ht_walk_kernel, dim3((njobs + 63) / 64), dim3(256), sizeof(HtWalkShared), s, jobs, njobs, vbits, pairs);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     static int phases = -1;   // debug knob (timing only): J2K_HT_DEC_PHASES=1 zero fill, 2 + MagSgn unstuffing, 3 everything
     if (phases < 0) { const char *en = getenv("J2K_HT_DEC_PHASES"); phases = en ? atoi(en) : 3; }
