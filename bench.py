@@ -28,8 +28,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 
 SEED = 0x4A324B30              # "J2K0" 
 # HBM traffic of one level-0 launch from the rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KiB -> bytes);
 # cannot be collected from inside this process, so it is the committed measurement (see profiles/)
-TRAFFIC_BYTES_PER_LAUNCH = None
-TRAFFIC_SOURCE = None
+TRAFFIC_BYTES_PER_LAUNCH = 207044198   # (2 x 52495.8 + 97200.0) KiB: 1.04 x the algorithmic 199 065 600 bytes
+TRAFFIC_SOURCE = "profiles/r01_bench_v3_inflight1_pmc_{FETCH,WRITE}_SIZE.csv (rocprofv3 --pmc, separate passes, FETCH_SIZE x2)"
 
 
 def synth_frame(np, index):

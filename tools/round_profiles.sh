@@ -1,0 +1,12 @@
+# Profiles committed under profiles/ (run on the GPU box): kernel stats for the default bench and for one frame in
+# flight, and the HBM traffic (FETCH_SIZE / WRITE_SIZE in separate passes) with one frame in flight.
+cd /tmp; export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/round
+mkdir -p $O
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_default -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $O/stats_default.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_inflight1 -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --inflight 1 > $O/stats_inflight1.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --inflight 1 > $O/pmc_$c.log 2>&1
+done
+tail -1 $O/stats_default.log; tail -1 $O/stats_inflight1.log
