@@ -65,3 +65,75 @@ def test_full_size_lossless_roundtrip(W, H, Cn, tile, prec):
     o2, st2 = plan.compact(s2[0], s2[1])
     plan.ctx.sync()
     assert int(o2[n].item()) == tot and torch.equal(st2[:tot], a)
+
+
+def _sample_tile_parity(W, H, tile, prec, lossless, quality, coder, sample_tiles, frame):
+    """GPU frame pipeline at full size vs the oracle's per-tile pipeline (encoder.preprocess + encodeTile body,
+    encoder.go:198-281, 616-688) on a few sampled tiles: coefficients, block bytes, lengths, numBPS, and the block
+    decoders' output for those blocks."""
+    import torch
+    import oracle as orc
+    from j2kgfx.codec import FramePlan
+    plan = FramePlan(W, H, 3, precision=prec, lossless=lossless, quality=quality, num_resolutions=6, cb=(64, 64),
+                     tile=(tile, tile), coder=coder)
+    d = torch.from_numpy(frame).to(plan.device)
+    torch.cuda.synchronize()
+    coeff = plan.forward(d)
+    slots, lens, nb = plan.encode_blocks(coeff)
+    offs, stream = plan.compact(slots, lens)
+    dec = plan.decode_blocks(stream, offs, lens, nb)
+    plan.ctx.sync()
+    n = int(plan.info.blocks)
+    hco, hl, hn, ho = coeff.cpu().numpy(), lens.cpu().numpy()[:n], nb.cpu().numpy()[:n], offs.cpu().numpy()
+    hs, hd = stream.cpu().numpy(), dec.cpu().numpy()
+    planes, blocks, doffs = plan.planes(), plan.blocks(), plan.decoded_offsets()
+    tiles_x = (W + tile - 1) // tile
+    first_block_of_tile = {}
+    for j in range(n):
+        first_block_of_tile.setdefault(int(blocks[j]["plane"]) // 3, j)
+    for tl in sample_tiles:
+        x0, y0 = (tl % tiles_x) * tile, (tl // tiles_x) * tile
+        w, h = min(tile, W - x0), min(tile, H - y0)
+        crop = [np.ascontiguousarray(frame[c, y0:y0 + h, x0:x0 + w]) for c in range(3)]
+        want_c = orc.preprocess(crop, w, h, prec, lossless, 6, quality)
+        for c in range(3):
+            row = planes[tl * 3 + c]
+            assert (int(row[0]), int(row[1]), int(row[4]), int(row[5])) == (tl, c, w, h)
+            got = hco[int(row[6]):int(row[6]) + w * h].reshape(h, w)
+            assert np.array_equal(got, want_c[c]), ("coefficients", tl, c)
+        data, wl, wn = orc.encode_tile_blocks(want_c, w, h, 6, 64, 64, coder)
+        j0 = first_block_of_tile[tl]
+        nj = len(wl)
+        assert np.array_equal(hl[j0:j0 + nj], wl.astype(hl.dtype)), ("lens", tl)
+        assert np.array_equal(hn[j0:j0 + nj], wn), ("numbps", tl)
+        a, b = int(ho[j0]), int(ho[j0 + nj])
+        assert np.array_equal(hs[a:b], data), ("bytes", tl)
+        pos = 0
+        for k in range(0, nj, 7):                       # every 7th block of the tile through the decoders
+            j = j0 + k
+            bw, bh, band = int(blocks[j]["w"]), int(blocks[j]["h"]), int(blocks[j]["band"])
+            p0 = int(ho[j]) - a
+            chunk = data[p0:p0 + int(wl[k])]
+            want_d = orc.ht_decode(chunk, bw, bh) if coder == 1 else orc.t1_decode(chunk, int(wn[k]), band, bw, bh)
+            got_d = hd[int(doffs[j]):int(doffs[j]) + bw * bh].reshape(bh, bw)
+            assert np.array_equal(got_d, want_d), ("decoded", tl, k)
+
+
+def test_c2_full_size_sampled_tiles_match_oracle():
+    """BASELINE configs[1] exactly as bench.py runs it (3840x2160 RGB8, 512^2 tiles, 5-3 + HT, 64^2 blocks): the first
+    tile, an interior tile, a 256-wide edge tile, a 112-high edge tile and the corner tile against the oracle."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    import bench
+    frame = bench.synth_frame(np, 0)
+    _sample_tile_parity(3840, 2160, 512, 8, True, 0, 1, [0, 11, 7, 33, 39], frame)
+
+
+def test_c3_full_size_sampled_tiles_match_oracle():
+    """BASELINE C3 geometry: 3840x2160 RGB rescaled to 12 bit (encoder.go:198-210, v*4095/255), 9-7 + ICT lossy,
+    Quality 75, 64^2 blocks, MQ coder (T1).  Quantised coefficients bit-identical, block bytes identical."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    import bench
+    frame = (bench.synth_frame(np, 1).astype(np.int64) * 4095 // 255).astype(np.int32)
+    _sample_tile_parity(3840, 2160, 512, 12, False, 75, 0, [0, 39], frame)
