@@ -25,7 +25,7 @@ hipError_t launch_ht_decode(hipStream_t s, const BlockJob *jobs, int njobs, cons
                             const uint32_t *lens, int32_t *decoded, uint32_t *scratch);
 size_t ht_decode_scratch_words(int njobs);
 hipError_t launch_t1_encode(hipStream_t s, const BlockJob *jobs, int njobs, const int32_t *coef, uint8_t *slots,
-                            uint32_t *lens, uint8_t *numbps, uint8_t *work, size_t work_per_job, int *fault);
+                            uint32_t *lens, uint8_t *numbps, uint8_t *work, size_t work_per_job, int *fault, int max_dim);
 hipError_t launch_t1_decode(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs,
                             const uint32_t *lens, const uint8_t *numbps, int32_t *decoded, uint8_t *work,
                             size_t work_per_job);
@@ -631,10 +631,12 @@ extern "C" int j2k_plan_encode_blocks(j2k_plan *P, const int32_t *d_coeff, uint8
     if (P->spec.coder == J2K_CODER_HT) {
         HIPCHK(ctx, launch_ht_encode(ctx->stream, P->d_bjobs, n, d_coeff, d_slots, d_lens, d_numbps, d_fault));
     } else {
-        const size_t wpj = t1_work_per_job(P);
+        int max_dim = 0;
+        for (const j2k_block &b : P->blocks) max_dim = std::max(max_dim, std::max(b.w, b.h));
+        const size_t wpj = max_dim > 64 ? t1_work_per_job(P) : 0;     // only the serial kernel (blocks > 64) needs a workspace
         r = stage_reserve(ctx, 2, wpj * (size_t)n + 256);
         if (r != J2K_OK) return r;
-        HIPCHK(ctx, launch_t1_encode(ctx->stream, P->d_bjobs, n, d_coeff, d_slots, d_lens, d_numbps, (uint8_t *)ctx->stage[2], wpj, d_fault));
+        HIPCHK(ctx, launch_t1_encode(ctx->stream, P->d_bjobs, n, d_coeff, d_slots, d_lens, d_numbps, (uint8_t *)ctx->stage[2], wpj, d_fault, max_dim));
     }
     return J2K_OK;
 }
@@ -838,8 +840,10 @@ extern "C" int j2k_encode_blocks(j2k_ctx *ctx, int coder, const int32_t *const *
         TRY(launch_ht_encode(ctx->stream, (BlockJob *)d_jobs, (int)nblocks, (int32_t *)d_coef, (uint8_t *)d_slots, (uint32_t *)d_lens, (uint8_t *)d_nb, (int *)d_fault));
     } else {
         TRY(hipMalloc(&d_work, wpj * nblocks + 256));
+        int max_dim = 0;
+        for (size_t j = 0; j < nblocks; j++) max_dim = std::max(max_dim, std::max(bj[j].w, bj[j].h));
         TRY(launch_t1_encode(ctx->stream, (BlockJob *)d_jobs, (int)nblocks, (int32_t *)d_coef, (uint8_t *)d_slots, (uint32_t *)d_lens, (uint8_t *)d_nb,
-                             (uint8_t *)d_work, wpj, (int *)d_fault));
+                             (uint8_t *)d_work, wpj, (int *)d_fault, max_dim));
     }
     std::vector<uint32_t> hl(nblocks);
     std::vector<uint8_t> hn(nblocks);

@@ -162,13 +162,14 @@ size_t t1_work_bytes(int w, int h) {
 __global__ __launch_bounds__(64) void t1_encode_kernel(const BlockJob *__restrict__ jobs, int njobs, const int32_t *__restrict__ coef,
                                                        uint8_t *__restrict__ slots, uint32_t *__restrict__ lens,
                                                        uint8_t *__restrict__ numbps, uint8_t *__restrict__ work, size_t work_per_job,
-                                                       int lds_work_bytes, int *__restrict__ fault) {
+                                                       int lds_work_bytes, int *__restrict__ fault, int skip_small) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int jid = blockIdx.x;
     if (jid >= njobs) return;
     const int lane = threadIdx.x;
     const BlockJob J = jobs[jid];
     const int w = J.w, h = J.h, stride = w + 2;
+    if (skip_small && w <= 64 && h <= 64) return;   // t1_encode64_kernel takes these
     const size_t n = (size_t)w * h;
     T1Tables &T = *reinterpret_cast<T1Tables *>(smem);
     const size_t flag_bytes = ((size_t)(w + 2) * (h + 2) + 15) & ~size_t(15);
@@ -313,6 +314,290 @@ __global__ __launch_bounds__(64) void t1_encode_kernel(const BlockJob *__restric
     e.C <<= e.CT; mq_byte_out(e);
     e.C <<= e.CT; mq_byte_out(e);
     // bytes buf[1..bp]; the last one is still in `cur`
+    long end = e.bp + 1;                       // endPos
+    if (e.cur == 0xFF) end--;                  // drop a trailing 0xFF
+    else if (e.bp >= 1) { if (e.bp - 1 < e.cap) out[e.bp - 1] = (uint8_t)e.cur; else e.overflow = 1; }
+    if (e.overflow) atomicMax(fault, 2);
+    lens[jid] = end > 1 ? (uint32_t)(end - 1) : 0;
+    numbps[jid] = (uint8_t)numBPS;
+}
+
+// ================================================================================================
+// Encoder for blocks up to 64 x 64: wave-parallel context formation, MQ coding from a symbol list
+// ================================================================================================
+// The only truly sequential part of EncodeFast5 is the MQ coder (every symbol moves A, C and one context's state).
+// Everything that decides WHICH (context, decision) pairs are coded, and in which order, is a function of
+// significance bit masks:
+//   * one wavefront per block; lane y keeps row y's masks in registers: S (significant), NEG (sign), REF (refined);
+//     the bit planes of the magnitudes are 64-bit row masks in LDS (built with ballots);
+//   * SigProp membership (raster order) is the recurrence  new[x] = G[x] | (Pr[x] & new[x-1])  along a row, with
+//     Pr = ~S & B (not yet significant, bit set) and G = Pr & (significant neighbour among N-row-updated, S-row-old,
+//     E-old, W-old): a carry chain, solved for a whole row with ONE 64-bit add  (cin = (Pr + G) ^ Pr ^ G).  Rows
+//     depend on the row above, so the 64 lanes iterate the row update until nothing changes (<= h steps);
+//   * MagRef members are the samples significant before this plane; Cleanup members are the samples neither
+//     significant nor visited, and every member whose bit is set becomes significant -- so the significance state a
+//     neighbour had "at visit time" is just a choice between two masks, by coding order;
+//   * symbols are then produced with lanes = columns (row masks broadcast with v_readlane), compacted in coding
+//     order with popcounts / a wave scan into an LDS list, and lane 0 runs the MQ coder over the list.
+// Output is byte-identical to the serial kernel above (which stays for larger blocks).
+#define T1F_SYM_CAP 3072    /* symbol list; drained by the MQ coder whenever the next row / stripe might not fit */
+#define T1F_SYM_STEP 640    /* most symbols one emission step adds: a cleanup stripe = 10 per column x 64 columns */
+struct T1Fast {
+    T1Tables T;
+    uint8_t zc2[256];          // ZC context by this kernel's index: NW | N<<1 | NE<<2 | SW<<3 | S<<4 | SE<<5 | W<<6 | E<<7
+    uint8_t sym[T1F_SYM_CAP];  // ctx | decision << 5
+};
+
+__device__ __forceinline__ uint64_t rl64(uint64_t v, int r) {      // row mask of lane r, broadcast (r wave-uniform)
+    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, r), hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), r);
+    return (uint64_t)hi << 32 | lo;
+}
+__device__ __forceinline__ uint32_t bit_at(uint64_t m, int x) { return (uint32_t)(m >> x) & 1u; }
+// bits x-1, x, x+1 of m as bits 0, 1, 2 (columns outside 0..63 read as 0)
+__device__ __forceinline__ uint32_t win3(uint64_t m, int x) { return (uint32_t)((x == 0) ? (m << 1) : (m >> (x - 1))) & 7u; }
+__device__ __forceinline__ uint64_t spread3(uint64_t m) { return m | (m << 1) | (m >> 1); }
+
+__device__ __forceinline__ void mq_run(MqEnc &e, T1Tables &T, const uint8_t *sym, uint32_t n) {
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t sy = sym[i];
+        mq_encode(e, T, sy & 31, sy >> 5);
+    }
+}
+
+__global__ __launch_bounds__(64) void t1_encode64_kernel(const BlockJob *__restrict__ jobs, int njobs, const int32_t *__restrict__ coef,
+                                                         uint8_t *__restrict__ slots, uint32_t *__restrict__ lens,
+                                                         uint8_t *__restrict__ numbps, int *__restrict__ fault) {
+    __shared__ T1Fast F;
+    const int jid = blockIdx.x;
+    if (jid >= njobs) return;
+    const int lane = threadIdx.x;
+    const BlockJob J = jobs[jid];
+    const int w = J.w, h = J.h;
+    if (w > 64 || h > 64) return;                 // the serial kernel takes these
+    const size_t n = (size_t)w * h;
+    build_tables(F.T, J.band, lane);
+    __syncthreads();
+    for (int p = lane; p < 256; p += 64) {
+        const int ref = ((p >> 6) & 1) | ((p >> 7) & 1) << 1 | ((p >> 1) & 1) << 2 | ((p >> 4) & 1) << 3 |
+                        (p & 1) << 4 | ((p >> 2) & 1) << 5 | ((p >> 3) & 1) << 6 | ((p >> 5) & 1) << 7;
+        F.zc2[p] = F.T.zc[ref];
+    }
+    // ---- SetData (t1.go:292-304) + bit-plane count (t1_fast5.go:13-28): lanes = columns ----
+    const int32_t *src = coef + J.src_off;
+    const bool colok = lane < w;
+    uint32_t maxVal = 0;
+    for (int y0 = 0; y0 < h; y0 += 8) {
+        int v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = src[(size_t)min(y0 + k, h - 1) * J.stride + (colok ? lane : 0)];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (y0 + k < h && colok) maxVal = max(maxVal, (uint32_t)(v[k] < 0 ? 0u - (uint32_t)v[k] : (uint32_t)v[k]));
+    }
+    // the reference compares int32 magnitudes: |MinInt32| stays negative and never wins the max (t1_fast5.go:16-22)
+    {
+        int m = (int)maxVal < 0 ? 0 : (int)maxVal;
+        for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+        maxVal = (uint32_t)m;
+    }
+    if (maxVal == 0) {
+        if (lane == 0) { lens[jid] = 0; numbps[jid] = 0; }
+        return;
+    }
+    const int numBPS = 32 - __clz(maxVal);
+    // row masks of one bit of the samples (bit 31 = sign): loads with lanes = columns, a ballot per row, kept by lane = row.
+    // Re-read from L2 for every plane (16 KB per block) rather than parked in LDS: LDS is what limits how many of the
+    // serial MQ chains a SIMD can interleave.
+    auto row_masks = [&](int bit) -> uint64_t {
+        uint64_t mine = 0;
+        for (int y0 = 0; y0 < h; y0 += 8) {
+            int v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = src[(size_t)min(y0 + k, h - 1) * J.stride + (colok ? lane : 0)];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t t = bit == 31 ? (uint32_t)v[k] : (v[k] < 0 ? 0u - (uint32_t)v[k] : (uint32_t)v[k]);
+                const uint64_t b = __ballot(colok && ((t >> bit) & 1));
+                if (lane == y0 + k) mine = b;
+            }
+        }
+        return lane < h ? mine : 0ull;
+    };
+    const uint64_t NEG = row_masks(31);             // lanes = rows from here on for the register masks
+
+    const uint64_t wmask = (w == 64) ? ~0ull : ((1ull << w) - 1);
+    const uint64_t rowok = (lane < h) ? wmask : 0ull;
+    const uint64_t lt = (1ull << lane) - 1;         // columns before this lane's column
+    uint64_t S = 0, REF = 0;
+    uint8_t *out = slots + J.out_off;
+    MqEnc e{0x8000, 0, 12, 0, 0, out, (long)(n * 2 + 1024), 0};
+    const int x = lane;
+    uint32_t nsym = 0;
+#define T1F_DRAIN()                                           \
+    do {                                                      \
+        __syncthreads();                                      \
+        if (lane == 0) mq_run(e, F.T, F.sym, nsym);           \
+        nsym = 0;                                             \
+        __syncthreads();                                      \
+    } while (0)
+#define T1F_ROOM() do { if (nsym + T1F_SYM_STEP > T1F_SYM_CAP) T1F_DRAIN(); } while (0)
+
+    for (int bp = numBPS - 1; bp >= 0; bp--) {
+        const uint64_t B = row_masks(bp);
+        // =========== significance propagation (t1_fast5.go:72-249) ===========
+        uint64_t newsig = 0, vis = 0;
+        if (__any(S != 0)) {
+            uint64_t Dn = __shfl_down(S, 1);
+            if (lane == 63) Dn = 0;
+            const uint64_t stat = spread3(Dn) | (S << 1) | (S >> 1);      // S-row old, E/W old
+            const uint64_t P = ~S & rowok, Pr = P & B;
+            uint64_t base = stat;
+            for (int it = 0; it <= h; it++) {
+                uint64_t Up = __shfl_up(S | newsig, 1);
+                if (lane == 0) Up = 0;
+                base = stat | spread3(Up);
+                const uint64_t G = Pr & base;
+                const uint64_t cin = (Pr + G) ^ Pr ^ G;
+                const uint64_t ns = G | (Pr & cin);
+                const bool changed = ns != newsig;
+                newsig = ns;
+                if (!__any(changed)) break;
+            }
+            vis = P & (base | (newsig << 1));
+        }
+        const uint64_t Snew = S | newsig;
+        {
+            uint64_t rows = __ballot(vis != 0);
+            while (rows) {
+                const int r = __ffsll((long long)rows) - 1;
+                rows &= rows - 1;
+                T1F_ROOM();
+                const uint64_t Vis = rl64(vis, r), New = rl64(newsig, r), Bm = rl64(B, r);
+                const uint64_t Uf = r > 0 ? rl64(Snew, r - 1) : 0ull, On = rl64(Snew, r), Oo = rl64(S, r);
+                const uint64_t Dd = r < 63 ? rl64(S, r + 1) : 0ull;
+                const uint64_t Nu = r > 0 ? rl64(NEG, r - 1) : 0ull, No = rl64(NEG, r), Nd = r < 63 ? rl64(NEG, r + 1) : 0ull;
+                if (bit_at(Vis, x)) {
+                    const uint32_t n3 = win3(Uf, x), s3 = win3(Dd, x);
+                    const uint32_t Wb = win3(On, x) & 1, Eb = (win3(Oo, x) >> 2) & 1;
+                    const uint32_t d = bit_at(Bm, x);
+                    const uint32_t pos = nsym + __popcll(Vis & lt) + __popcll(New & lt);
+                    F.sym[pos] = (uint8_t)(F.zc2[n3 | s3 << 3 | Wb << 6 | Eb << 7] | d << 5);
+                    if (d) {
+                        const uint32_t g3 = win3(No, x);
+                        const uint32_t sci = Wb | (g3 & 1) << 1 | Eb << 2 | ((g3 >> 2) & 1) << 3 | ((n3 >> 1) & 1) << 4 |
+                                             bit_at(Nu, x) << 5 | ((s3 >> 1) & 1) << 6 | bit_at(Nd, x) << 7;
+                        const uint32_t sc = F.T.sc[sci];
+                        F.sym[pos + 1] = (uint8_t)((CtxSC0 + (sc & 7)) | ((((g3 >> 1) & 1) ^ (sc >> 3)) & 1) << 5);
+                    }
+                }
+                nsym += __popcll(Vis) + __popcll(New);
+            }
+        }
+        // =========== magnitude refinement (t1_fast5.go:252-335): members = significant before this plane ===========
+        {
+            uint64_t rows = __ballot(S != 0);
+            while (rows) {
+                const int r = __ffsll((long long)rows) - 1;
+                rows &= rows - 1;
+                T1F_ROOM();
+                const uint64_t M = rl64(S, r), Rf = rl64(REF, r), Bm = rl64(B, r);
+                const uint64_t Su = r > 0 ? rl64(Snew, r - 1) : 0ull, So = rl64(Snew, r), Sd = r < 63 ? rl64(Snew, r + 1) : 0ull;
+                const uint64_t any8 = spread3(Su) | spread3(Sd) | (So << 1) | (So >> 1);
+                if (bit_at(M, x)) {
+                    const uint32_t ctx = bit_at(Rf, x) ? CtxMag2 : (bit_at(any8, x) ? CtxMag1 : CtxMag0);
+                    F.sym[nsym + __popcll(M & lt)] = (uint8_t)(ctx | bit_at(Bm, x) << 5);
+                }
+                nsym += __popcll(M);
+            }
+        }
+        REF |= S;
+        // =========== cleanup (t1_fast5.go:338-876) ===========
+        const uint64_t mem = ~Snew & ~vis & rowok;          // coded here; every member whose bit is set becomes significant
+        const uint64_t Sc = Snew | (mem & B);
+        for (int r0 = 0; r0 < h; r0 += 4) {
+            uint64_t Mm[4], Bm[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) { Mm[i] = r0 + i < 64 ? rl64(mem, r0 + i) : 0ull; Bm[i] = r0 + i < 64 ? rl64(B, r0 + i) : 0ull; }
+            if ((Mm[0] | Mm[1] | Mm[2] | Mm[3]) == 0) continue;
+            T1F_ROOM();
+            // rows r0-1 .. r0+4 as j = 0..5
+            uint32_t L[6], R[6], Cc[6], Ca[6], Ng[6], NgL[6], NgR[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                const int r = r0 - 1 + j;
+                const bool in = r >= 0 && r < 64;
+                const uint64_t a = in ? rl64(Snew, r) : 0ull, c = in ? rl64(Sc, r) : 0ull, g = in ? rl64(NEG, r) : 0ull;
+                // column x-1 was coded before this column (rows of this stripe and above: updated; next stripe: not yet);
+                // column x+1 after it (only the previous stripe's row is updated)
+                L[j] = win3(j == 5 ? a : c, x) & 1;
+                R[j] = (win3(j == 0 ? c : a, x) >> 2) & 1;
+                Cc[j] = bit_at(c, x);
+                Ca[j] = bit_at(a, x);
+                const uint32_t g3 = win3(g, x);
+                Ng[j] = (g3 >> 1) & 1; NgL[j] = g3 & 1; NgR[j] = (g3 >> 2) & 1;
+            }
+            uint32_t m[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) { m[i] = bit_at(Mm[i], x); b[i] = bit_at(Bm[i], x); }
+            uint8_t sy[10];
+            uint32_t cnt = 0;
+            const bool full = r0 + 4 <= h;
+            uint32_t anyn = Cc[0] | Ca[5];
+#pragma unroll
+            for (int j = 0; j < 6; j++) anyn |= L[j] | R[j];
+            const bool canRL = full && (m[0] & m[1] & m[2] & m[3]) && !anyn;
+            int first = 0;                                   // first row of this column coded sample by sample
+            if (canRL) {
+                const int fs = b[0] ? 0 : (b[1] ? 1 : (b[2] ? 2 : (b[3] ? 3 : -1)));
+                sy[cnt++] = (uint8_t)(CtxRL | (fs >= 0 ? 1u : 0u) << 5);
+                if (fs >= 0) {
+                    sy[cnt++] = (uint8_t)(CtxUni | ((fs >> 1) & 1) << 5);
+                    sy[cnt++] = (uint8_t)(CtxUni | (fs & 1) << 5);
+                }
+                first = fs >= 0 ? fs : 4;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (i < first || !m[i]) continue;
+                const int j = i + 1;                          // index of this row in the 6-row window
+                const bool runhead = canRL && i == first;     // its significance was coded by the run-length symbols
+                if (!runhead) {
+                    const uint32_t idx = L[j - 1] | Cc[j - 1] << 1 | R[j - 1] << 2 | L[j + 1] << 3 | Ca[j + 1] << 4 | R[j + 1] << 5 |
+                                         L[j] << 6 | R[j] << 7;
+                    sy[cnt++] = (uint8_t)(F.zc2[idx] | b[i] << 5);
+                }
+                if (b[i]) {
+                    const uint32_t sci = L[j] | NgL[j] << 1 | R[j] << 2 | NgR[j] << 3 | Cc[j - 1] << 4 | Ng[j - 1] << 5 |
+                                         Ca[j + 1] << 6 | Ng[j + 1] << 7;
+                    const uint32_t sc = F.T.sc[sci];
+                    sy[cnt++] = (uint8_t)((CtxSC0 + (sc & 7)) | ((Ng[j] ^ (sc >> 3)) & 1) << 5);
+                }
+            }
+            // coding order inside a stripe = column order: exclusive scan of the per-column symbol counts
+            uint32_t incl = cnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
+            }
+            const uint32_t base = nsym + incl - cnt;
+#pragma unroll
+            for (int k = 0; k < 10; k++)
+                if ((uint32_t)k < cnt) F.sym[base + k] = sy[k];
+            nsym += __shfl(incl, 63);
+        }
+        S = Sc;
+    }
+    T1F_DRAIN();
+#undef T1F_DRAIN
+#undef T1F_ROOM
+    if (lane != 0) return;
+    // ---- flush (t1_fast5.go:878-898) ----
+    const uint32_t tempC = e.C + e.A;
+    e.C |= 0xFFFF;
+    if (e.C >= tempC) e.C -= 0x8000;
+    e.C <<= e.CT; mq_byte_out(e);
+    e.C <<= e.CT; mq_byte_out(e);
     long end = e.bp + 1;                       // endPos
     if (e.cur == 0xFF) end--;                  // drop a trailing 0xFF
     else if (e.bp >= 1) { if (e.bp - 1 < e.cap) out[e.bp - 1] = (uint8_t)e.cur; else e.overflow = 1; }
@@ -477,13 +762,21 @@ static int lds_for(size_t work_per_job) {
     return (int)wb;
 }
 
+// max_dim: largest block width or height among the jobs (<= 64: every block takes the wave-parallel kernel)
 hipError_t launch_t1_encode(hipStream_t s, const BlockJob *jobs, int njobs, const int32_t *coef, uint8_t *slots,
-                            uint32_t *lens, uint8_t *numbps, uint8_t *work, size_t work_per_job, int *fault) {
+                            uint32_t *lens, uint8_t *numbps, uint8_t *work, size_t work_per_job, int *fault, int max_dim) {
     if (njobs <= 0) return hipSuccess;
+    static int serial_only = -1;   // J2K_T1_SERIAL=1: A/B against the serial kernel
+    if (serial_only < 0) { const char *en = getenv("J2K_T1_SERIAL"); serial_only = en ? atoi(en) : 0; }
+    if (!serial_only) {
+        hipLaunchKernelGGL(t1_encode64_kernel, dim3(njobs), dim3(64), 0, s, jobs, njobs, coef, slots, lens, numbps, fault);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess || max_dim <= 64) return e;
+    }
     const int wb = lds_for(work_per_job);
     const size_t lds = ((sizeof(T1Tables) + 15) & ~size_t(15)) + (size_t)wb;
     hipLaunchKernelGGL(t1_encode_kernel, dim3(njobs), dim3(64), lds, s, jobs, njobs, coef, slots, lens, numbps, work,
-                       work_per_job, wb, fault);
+                       work_per_job, wb, fault, serial_only ? 0 : 1);
     return hipGetLastError();
 }
 
