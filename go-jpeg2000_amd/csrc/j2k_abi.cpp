@@ -30,6 +30,7 @@ hipError_t launch_t1_decode(hipStream_t s, const BlockJob *jobs, int njobs, cons
                             const uint32_t *lens, const uint8_t *numbps, int32_t *decoded, uint8_t *work,
                             size_t work_per_job);
 size_t t1_work_bytes(int w, int h);
+size_t t1_flag_bytes(int w, int h);
 hipError_t launch_compact(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *slots, const uint32_t *lens,
                           uint64_t *offs, uint8_t *stream, void *scan_tmp);
 }  // namespace j2k
@@ -674,7 +675,9 @@ extern "C" int j2k_plan_decode_blocks(j2k_plan *P, const uint8_t *d_stream, cons
         if (r != J2K_OK) return r;
         HIPCHK(ctx, launch_ht_decode(ctx->stream, P->d_djobs, n, d_stream, d_offs, d_lens, d_decoded, (uint32_t *)ctx->stage[2]));
     } else {
-        const size_t wpj = t1_work_per_job(P);
+        size_t wpj = 0;                                  // the decoder's workspace holds the flags only
+        for (const j2k_block &b : P->blocks) wpj = std::max(wpj, t1_flag_bytes(b.w, b.h));
+        wpj = (wpj + 255) & ~size_t(255);
         int r = stage_reserve(ctx, 2, wpj * (size_t)n + 256);
         if (r != J2K_OK) return r;
         HIPCHK(ctx, launch_t1_decode(ctx->stream, P->d_djobs, n, d_stream, d_offs, d_lens, d_numbps, d_decoded,
@@ -891,7 +894,7 @@ extern "C" int j2k_decode_blocks(j2k_ctx *ctx, int coder, const uint8_t *bytes, 
         nbytes = std::max<size_t>(nbytes, (size_t)offs[j] + lens[j]);
         bj[j].src_off = 0; bj[j].out_off = dec; bj[j].stride = b.w; bj[j].w = b.w; bj[j].h = b.h; bj[j].band = b.band;
         dec += align4((int64_t)b.w * b.h);
-        wpj = std::max(wpj, t1_work_bytes(b.w, b.h));
+        wpj = std::max(wpj, t1_flag_bytes(b.w, b.h));
     }
     if (nbytes && !bytes) return fail(ctx, J2K_ERR_INVALID_ARG, "bytes == NULL");
     wpj = (wpj + 255) & ~size_t(255);

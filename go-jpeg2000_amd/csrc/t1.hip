@@ -152,6 +152,7 @@ __device__ __forceinline__ bool any_sig8(const uint8_t *f, int stride) {
     return ((f[-1] | f[1] | f[-stride] | f[stride] | f[-stride - 1] | f[-stride + 1] | f[stride - 1] | f[stride + 1]) & T1Sig) != 0;
 }
 
+size_t t1_flag_bytes(int w, int h) { return ((size_t)(w + 2) * (h + 2) + 15) & ~size_t(15); }
 size_t t1_work_bytes(int w, int h) {
     const size_t flags = ((size_t)(w + 2) * (h + 2) + 15) & ~size_t(15);
     return flags + (size_t)w * h * 4;
@@ -665,16 +666,18 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(const BlockJob *__restric
     const int w = J.w, h = J.h, stride = w + 2;
     const size_t n = (size_t)w * h;
     T1Tables &T = *reinterpret_cast<T1Tables *>(smem);
+    // Only the flags live in the workspace (LDS when they fit): the magnitudes are built in the output buffer itself
+    // (first significance = plain store, refinement = fire-and-forget atomic OR), so LDS does not limit how many of
+    // these serial chains a SIMD interleaves.
     const size_t flag_bytes = ((size_t)(w + 2) * (h + 2) + 15) & ~size_t(15);
-    const bool in_lds = (flag_bytes + n * 4) <= (size_t)lds_work_bytes;
-    uint8_t *wk = in_lds ? smem + ((sizeof(T1Tables) + 15) & ~size_t(15)) : work + (size_t)jid * work_per_job;
-    uint8_t *flags = wk;
-    int32_t *data = reinterpret_cast<int32_t *>(wk + flag_bytes);
+    const bool in_lds = flag_bytes <= (size_t)lds_work_bytes;
+    uint8_t *flags = in_lds ? smem + ((sizeof(T1Tables) + 15) & ~size_t(15)) : work + (size_t)jid * work_per_job;
     int32_t *out = decoded + J.out_off;
+    int32_t *data = out;
 
     build_tables(T, J.band, lane);
     for (size_t i = lane; i < (size_t)(w + 2) * (h + 2); i += 64) flags[i] = 0;
-    for (size_t i = lane; i < n; i += 64) data[i] = 0;
+    for (size_t i = lane; i < n; i += 64) out[i] = 0;
     __syncthreads();
     if (lane == 0) {
         const int numBPS = numbps[jid];
@@ -702,7 +705,7 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(const BlockJob *__restric
                     const uint32_t fv = *f;
                     if ((fv & T1Sig) == 0 || (fv & T1Visit) != 0) continue;
                     const int ctx = (fv & T1Refine) ? CtxMag2 : (any_sig8(f, stride) ? CtxMag1 : CtxMag0);
-                    if (mq_decode(d, T, ctx)) data[(size_t)y * w + x] |= bit;
+                    if (mq_decode(d, T, ctx)) atomicOr(&data[(size_t)y * w + x], bit);
                     *f = (uint8_t)(fv | T1Refine);
                 }
             for (int y = 0; y < h; y += 4)                                // t1.go:1350-1410
@@ -747,11 +750,11 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(const BlockJob *__restric
                 }
         }
     }
-    __syncthreads();
+    __syncthreads();                                                      // includes the wait for lane 0's stores and atomics
     for (size_t i = lane; i < n; i += 64) {                               // t1.go:1281-1289
-        const int v = data[i];
-        const bool neg = flags[(i / w + 1) * stride + (i % w) + 1] & T1SignNeg;
-        out[i] = neg ? (int32_t)(0u - (uint32_t)v) : v;
+        if (!(flags[(i / w + 1) * stride + (i % w) + 1] & T1SignNeg)) continue;
+        const int v = __hip_atomic_load(&out[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // L2, not this CU's L1
+        out[i] = (int32_t)(0u - (uint32_t)v);
     }
 }
 
@@ -783,7 +786,7 @@ hipError_t launch_t1_encode(hipStream_t s, const BlockJob *jobs, int njobs, cons
 hipError_t launch_t1_decode(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs,
                             const uint32_t *lens, const uint8_t *numbps, int32_t *decoded, uint8_t *work, size_t work_per_job) {
     if (njobs <= 0) return hipSuccess;
-    const int wb = lds_for(work_per_job);
+    const int wb = lds_for(work_per_job);     // work_per_job = flag bytes of the largest block
     const size_t lds = ((sizeof(T1Tables) + 15) & ~size_t(15)) + (size_t)wb;
     hipLaunchKernelGGL(t1_decode_kernel, dim3(njobs), dim3(64), lds, s, jobs, njobs, stream, offs, lens, numbps, decoded,
                        work, work_per_job, wb);
