@@ -117,26 +117,49 @@ def main():
             self.back = p.alloc_frame()
             self.gather_buf = None
 
-        def code(self, gather=True):
+        def encode_side(self):
             p = self.plan
             p.forward(self.frame, self.coeff)
             p.encode_blocks(self.coeff, self.slots, self.lens, self.numbps)
             p.compact(self.slots, self.lens, self.offs, self.stream)
-            if world > 1 and gather:
-                self.ctx.sync()                         # bytes must be complete before RCCL reads them
-                total = int(self.offs[self.n].item())
-                self.gather_buf, _ = jdist.gather_streams(self.stream, total, out=self.gather_buf)
+
+        def decode_side(self):
+            p = self.plan
             p.decode_blocks(self.stream, self.offs, self.lens, self.numbps, self.decoded)
             p.inverse(self.coeff, self.back)
+
+        def code(self):
+            self.encode_side()
+            self.decode_side()
 
     lanes = [Lane() for _ in range(F)]
     ctx, plan = lanes[0].ctx, lanes[0].plan
     info, n = plan.info, lanes[0].n
     ext = torch.cuda.ExternalStream(ctx.stream)
 
+    exts = [torch.cuda.ExternalStream(ln.ctx.stream) for ln in lanes]
+
     def step():
+        if world == 1:
+            for ln in lanes:
+                ln.code()
+            return
+        # N > 1: encode every frame in flight, hand all their streams to RCCL in ONE size exchange + ONE batch of
+        # peer->root transfers, decode while the bytes travel, then make the library streams wait for the transfers
+        # before the next step rewrites the send buffers.
         for ln in lanes:
-            ln.code()
+            ln.encode_side()
+        for ln in lanes:
+            ln.ctx.sync()                               # bytes must be complete before RCCL reads them
+        items = [(ln.stream, int(ln.offs[ln.n].item())) for ln in lanes]
+        g = jdist.gather_streams_start(items, outs=[ln.gather_buf for ln in lanes])
+        for ln in lanes:
+            ln.decode_side()
+        for ln, (buf, _) in zip(lanes, g.wait()):
+            ln.gather_buf = buf
+        cur = torch.cuda.current_stream()
+        for e in exts:
+            e.wait_stream(cur)
 
     def barrier():
         for ln in lanes:
@@ -165,11 +188,11 @@ def main():
     iso_launches, iso_ms = 0, 0.0
     if rank == 0:
         for _ in range(3):
-            lanes[0].code(gather=False)
+            lanes[0].code()
         ctx.sync()
         ctx.profile_enable(True)
         for _ in range(min(args.steps, 30)):
-            lanes[0].code(gather=False)
+            lanes[0].code()
         ctx.sync()
         iso_launches, iso_ms = ctx.profile_read()
         ctx.profile_enable(False)

@@ -65,3 +65,60 @@ def gather_streams(stream, nbytes, group=None, out=None):
         for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, stream[:int(nbytes)], 0, group)]):
             w.wait()
     return None, offsets
+
+
+class StreamGather:
+    """Handle of gather_streams_start: the transfers are in flight until wait()."""
+
+    def __init__(self, works, results):
+        self._works, self._results = works, results
+
+    def wait(self):
+        """Completes the transfers (nccl: the current stream waits for them; gloo: blocks) and returns, per item,
+        (buffer, offsets) on rank 0 and (None, offsets) elsewhere -- as gather_streams does."""
+        for w in self._works:
+            w.wait()
+        self._works = []
+        return self._results
+
+
+def gather_streams_start(items, group=None, outs=None):
+    """Gather SEVERAL streams to rank 0 with one size exchange and one batch of point-to-point transfers, without
+    waiting for the bytes: `items` = [(uint8 tensor, nbytes), ...] (e.g. one per frame in flight), `outs` = optional
+    list of reusable receive buffers on rank 0.  The caller overlaps other work and then calls .wait().
+    The source tensors (and `outs`) must not be rewritten before .wait() has returned and, on nccl, before the
+    streams that rewrite them have been made to wait for the current stream."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    F = len(items)
+    dev = items[0][0].device
+    mine = torch.tensor([int(n) for _, n in items], dtype=torch.int64, device=dev)
+    totals = torch.empty(world * F, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(totals, mine, group=group)
+    totals_h = totals.cpu().numpy().reshape(world, F)
+    results, ops = [], []
+    outs = list(outs) if outs is not None else [None] * F
+    for f, (stream, nbytes) in enumerate(items):
+        offsets = np.concatenate(([0], np.cumsum(totals_h[:, f]))).astype(np.int64)
+        if world == 1:
+            results.append((stream[:int(nbytes)], offsets))
+            continue
+        if rank == 0:
+            total = int(offsets[-1])
+            out = outs[f]
+            if out is None or out.numel() < total:
+                out = torch.empty(max(total, 1), dtype=torch.uint8, device=dev)
+            out[:int(nbytes)].copy_(stream[:int(nbytes)])
+            for r in range(1, world):
+                n = int(totals_h[r, f])
+                if n:
+                    ops.append(dist.P2POp(dist.irecv, out[int(offsets[r]):int(offsets[r]) + n], r, group))
+            results.append((out, offsets))
+        else:
+            if int(nbytes):
+                ops.append(dist.P2POp(dist.isend, stream[:int(nbytes)], 0, group))
+            results.append((None, offsets))
+    works = dist.batch_isend_irecv(ops) if ops else []
+    return StreamGather(works, results)

@@ -63,6 +63,54 @@ def test_gather_streams_two_ranks():
         assert np.array_equal(got, np.concatenate(want))
 
 
+def _worker_batched(rank, world, port, lens, q):
+    sys.path.insert(0, os.path.join(ROOT, "go-jpeg2000_amd"))
+    from j2kgfx import dist as jd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        outs = None
+        for step in range(2):                                             # second step reuses the receive buffers
+            items = []
+            for f, n in enumerate(lens[rank]):
+                rng = np.random.default_rng(1000 * rank + 10 * step + f)
+                items.append((torch.from_numpy(rng.integers(0, 256, n + 5).astype(np.uint8)), n))
+            g = jd.gather_streams_start(items, outs=outs)
+            res = g.wait()
+            if rank == 0:
+                outs = [b for b, _ in res]
+                q.put((step, [(b[:int(o[-1])].numpy().copy(), o.copy()) for b, o in res]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_streams_start_batches_frames_in_flight():
+    """bench.py's N>1 step: the streams of all frames in flight go to rank 0 with one size exchange and one batch of
+    point-to-point transfers (gather_streams_start / wait)."""
+    world = 2
+    lens = [[1000, 0, 70001], [17, 4096, 3]]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_batched, args=(r, world, port, lens, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for step, per_frame in results:
+        for f, (got, offs) in enumerate(per_frame):
+            want = []
+            for r in range(world):
+                rng = np.random.default_rng(1000 * r + 10 * step + f)
+                want.append(rng.integers(0, 256, lens[r][f] + 5).astype(np.uint8)[:lens[r][f]])
+            assert offs.tolist() == [0, lens[0][f], lens[0][f] + lens[1][f]]
+            assert np.array_equal(got, np.concatenate(want))
+
+
 def test_shard_range_partitions_exactly():
     from j2kgfx import dist as jd
     for n in (0, 1, 5, 40, 135, 256):
