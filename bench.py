@@ -196,6 +196,25 @@ def main():
         ctx.sync()
         iso_launches, iso_ms = ctx.profile_read()
         ctx.profile_enable(False)
+    # ---- practical HBM roofline of this box ("measure a device-to-device copy ... and report both"):
+    #      int32 copy at the level-0 footprint cycled over 8 buffer pairs so the Infinity Cache cannot serve it ----
+    copy_gbs = None
+    if rank == 0:
+        nel = int(info.dwt_level0_bytes // 8)            # elements read = elements written = one level-0 launch
+        srcs = [torch.empty(nel, dtype=torch.int32, device=plan.device).fill_(i) for i in range(8)]
+        dsts = [torch.empty_like(srcs[0]) for _ in range(8)]
+        for i in range(8):
+            dsts[i].copy_(srcs[i])
+        torch.cuda.synchronize()
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(3):
+            for i in range(8):
+                dsts[i].copy_(srcs[i])
+        c1.record()
+        c1.synchronize()
+        copy_gbs = 24 * 2 * nel * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        del srcs, dsts
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=plan.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -232,7 +251,9 @@ def main():
                          "measured": "HIP events on the library stream around every level-0 launch, in a pass with one "
                                      "frame in flight run right after the timed region (same process, same buffers)",
                          "avg_launch_us_in_timed_region": round(k_conc_s * 1e6, 2), "launches_in_timed_region": int(launches),
-                         "traffic_source": TRAFFIC_SOURCE},
+                         "traffic_source": TRAFFIC_SOURCE,
+                         "copy_gbs_measured": round(copy_gbs, 1) if copy_gbs else None,
+                         "frac_of_measured_copy": round(achieved / copy_gbs, 4) if copy_gbs else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(np, frame_h)
