@@ -159,14 +159,16 @@ __device__ __forceinline__ void fwd97_load_row(const void *__restrict__ src, int
     for (int k = 0; k < NC; k++) {
         const int64_t base = P.src_off[k] + (int64_t)r * P.src_stride;
         if (src_f64) {
+            // columns past the row end read a clamped (valid) address: their values never reach an in-range result
+            // (every neighbour use in hfwd97 is guarded by the row length), so the loads need no branch
             const double *p = reinterpret_cast<const double *>(src) + base;
 #pragma unroll
-            for (int i = 0; i < CPL; i++) x[k][i] = (c + i < P.w) ? p[c + i] : 0.0;
+            for (int i = 0; i < CPL; i++) x[k][i] = p[min(c + i, P.w - 1)];
         } else {
             const int32_t *p = reinterpret_cast<const int32_t *>(src) + base;
 #pragma unroll
             for (int i = 0; i < CPL; i++) {
-                const int v = (c + i < P.w) ? p[c + i] : 0;
+                const int v = p[min(c + i, P.w - 1)];
                 x[k][i] = (double)(int)((unsigned)v - (unsigned)dc_shift);   // mct.go:96-101, encoder.go:228-233/260-262
             }
         }
@@ -260,8 +262,10 @@ __global__ __launch_bounds__(256) void dwt97_fwd_kernel(const DwtJob *__restrict
     for (int t = t_start; t <= t_last; t++) {
         const bool real = t < halfH;
         const bool o_ex = real && (2 * t + 1 < h), en_ex = real && (2 * t + 2 < h);
-        if (o_ex) fwd97_load_row<CPL, NC>(src, src_f64, P, 2 * t + 1, c, dc_shift, mct, o);
-        if (en_ex) fwd97_load_row<CPL, NC>(src, src_f64, P, 2 * t + 2, c, dc_shift, mct, en);
+        if (real) {   // rows clamped into the plane: both rows' loads are issued back to back; o_ex / en_ex discard what is not there
+            fwd97_load_row<CPL, NC>(src, src_f64, P, min(2 * t + 1, h - 1), c, dc_shift, mct, o);
+            fwd97_load_row<CPL, NC>(src, src_f64, P, min(2 * t + 2, h - 1), c, dc_shift, mct, en);
+        }
         const bool prev_o_ex = (t >= 1) && (2 * (t - 1) + 1 < h);
         double outl[NC][H], outh[NC][H], outl2[NC][H], outh2[NC][H];
 #pragma unroll
@@ -318,13 +322,21 @@ __device__ __forceinline__ void inv97_load_row(const void *__restrict__ coef, in
         for (int j = 0; j < 2 * H; j++) {
             const bool is_lo = j < H;
             const int jj = is_lo ? j : j - H;
-            double v = 0.0;
-            if (jj < (is_lo ? nL : nH)) {
-                const int idx = (is_lo ? idxL : idxH) + jj;
-                if (idx < P.n_next) v = prev[P.nxt_off[k] + idx];
-                else if (coef_f64) v = reinterpret_cast<const double *>(coef)[P.src_off[k] + idx];
-                else v = (double)reinterpret_cast<const int32_t *>(coef)[P.src_off[k] + idx];   // tcd.go:429-431
+            // branch-free: an out-of-range element reads the row's first element (valid) and is zeroed by a select; the
+            // source (scratch of the coarser level / coefficient plane) is a pointer or value select
+            const bool ok = jj < (is_lo ? nL : nH);
+            const int idx = ok ? (is_lo ? idxL : idxH) + jj : ri * P.w;
+            const bool from_prev = idx < P.n_next;
+            double v;
+            if (coef_f64) {
+                const double *b = from_prev ? prev + P.nxt_off[k] : reinterpret_cast<const double *>(coef) + P.src_off[k];
+                v = b[idx];
+            } else {
+                const double vp = prev[P.nxt_off[k] + (from_prev ? idx : 0)];
+                const int vc = reinterpret_cast<const int32_t *>(coef)[P.src_off[k] + idx];                // tcd.go:429-431
+                v = from_prev ? vp : (double)vc;
             }
+            if (!ok) v = 0.0;
             if (is_lo) R.lo[k][jj] = v; else R.hi[k][jj] = v;
         }
 }
@@ -420,8 +432,10 @@ __global__ __launch_bounds__(256) void dwt97_inv_kernel(const DwtJob *__restrict
         const bool real = t < halfH;
         const bool hi_ex = real && (2 * t + 1 < h);
         Row L, Hh;
-        if (real) inv97_load_row<CPL, NC>(coef, coef_f64, prev, P, t, p0, L);
-        if (hi_ex) inv97_load_row<CPL, NC>(coef, coef_f64, prev, P, halfH + t, p0, Hh);
+        if (real) {   // the high row is clamped into the plane (hi_ex discards it when it does not exist)
+            inv97_load_row<CPL, NC>(coef, coef_f64, prev, P, t, p0, L);
+            inv97_load_row<CPL, NC>(coef, coef_f64, prev, P, halfH + min(t, h - halfH - 1), p0, Hh);
+        }
         const bool p1_real = (t >= 1) && (t - 1 < halfH);            // pair t-1 exists
         const bool p1_hi = p1_real && (2 * (t - 1) + 1 < h);
         const bool p2_real = (t >= 2) && (t - 2 < halfH);            // pair t-2 exists

@@ -89,6 +89,7 @@ extern "C" int j2k_ctx_create(int device, j2k_ctx **out) {
         int v = atoi(e);
         if (v >= 1 && v <= 4096) ctx->band_prows = v;
     }
+    if (const char *e = getenv("J2K_BAND_PROWS_97")) { int v = atoi(e); if (v >= 2 && v <= 4096) ctx->band_prows_97 = v; }
     if (const char *e = getenv("J2K_FORCE_NOVEC")) ctx->force_novec = atoi(e) != 0;
     if (const char *e = getenv("J2K_FWD_LINK")) ctx->fwd_link = atoi(e) != 0;
     if (const char *e = getenv("J2K_INV_LINK")) ctx->inv_link = atoi(e) != 0;
@@ -349,7 +350,7 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                 T.cpl = cpl; T.vec = vec_ok ? 1 : 0;
                 const int halo = (S.wavelet == W97 && cpl < 4) ? 2 : 1;
                 const int band53 = (dir == 1 && ctx->band_prows_inv > 0) ? ctx->band_prows_inv : ctx->band_prows;
-                const int band = (S.wavelet == W97) ? std::max(ctx->band_prows, 8) : band53;
+                const int band = (S.wavelet == W97) ? ctx->band_prows_97 : band53;
                 std::vector<DwtJob> jobs;
                 for (size_t i = 0; i < planes.size(); i++) {
                     make_jobs(jobs, (int)i, pw[i], ph[i], cpl, band, halo);

@@ -12,6 +12,7 @@ struct j2k_ctx {
     std::string last_error;
     int fwd_link = 1;          // forward 5-3: bands of one workgroup exchange halo rows through LDS (J2K_FWD_LINK)
     int inv_link = 1;          // same for the inverse kernels (J2K_INV_LINK)
+    int band_prows_97 = 8;     // 9-7 kernels: 7 halo rows per band, so taller bands (J2K_BAND_PROWS_97)
     int band_prows_inv = 0;    // 0: same as band_prows (J2K_BAND_PROWS_INV)
     int fwd_pf = 0;            // forward 5-3 level kernels: software prefetch of the next pair-row (J2K_FWD_PF)
     int band_prows = 5;        // pair-rows per wavefront band (tunable: J2K_BAND_PROWS)
