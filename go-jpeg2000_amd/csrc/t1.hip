@@ -346,6 +346,7 @@ __global__ __launch_bounds__(64) void t1_encode_kernel(const BlockJob *__restric
 struct T1Fast {
     T1Tables T;
     uint8_t zc2[256];          // ZC context by this kernel's index: NW | N<<1 | NE<<2 | SW<<3 | S<<4 | SE<<5 | W<<6 | E<<7
+    uint32_t ctxent[32];       // per context: the MQ table entry of its current state
     uint8_t sym[T1F_SYM_CAP];  // ctx | decision << 5
 };
 
@@ -358,14 +359,45 @@ __device__ __forceinline__ uint32_t bit_at(uint64_t m, int x) { return (uint32_t
 __device__ __forceinline__ uint32_t win3(uint64_t m, int x) { return (uint32_t)((x == 0) ? (m << 1) : (m >> (x - 1))) & 7u; }
 __device__ __forceinline__ uint64_t spread3(uint64_t m) { return m | (m << 1) | (m >> 1); }
 
-__device__ __forceinline__ void mq_run(MqEnc &e, T1Tables &T, const uint8_t *sym, uint32_t n) {
-    for (uint32_t i = 0; i < n; i++) {
-        const uint32_t sy = sym[i];
-        mq_encode(e, T, sy & 31, sy >> 5);
+// MQ coder over a symbol list (mqc.go:224-267), arranged for the serial lane: the per-context state is kept as the
+// state's TABLE ENTRY (qe | nmps << 16 | nlps << 24; the MPS is the parity of nmps), so the common case -- MPS coded,
+// interval still >= 0x8000 -- costs one LDS read and a handful of ALU ops; the table is consulted only when a context
+// changes state; renormalisation shifts by count-leading-zeros instead of bit by bit (byte-out when CT reaches 0).
+__device__ __forceinline__ void mq_run(MqEnc &e, const uint32_t *mqtab, uint32_t *ctxent, const uint8_t *sym, uint32_t n) {
+#ifdef J2K_T1_NOMQ
+    e.C += n; return;     // timing experiment: context formation only
+#endif
+    uint32_t A = e.A, C = e.C, CT = e.CT;
+    for (uint32_t i0 = 0; i0 < n; i0 += 4) {
+        uint32_t four = *reinterpret_cast<const uint32_t *>(sym + i0);
+        const uint32_t m = min(n - i0, 4u);
+        for (uint32_t k = 0; k < m; k++, four >>= 8) {
+            const uint32_t ctx = four & 31, d = (four >> 5) & 1;
+            const uint32_t ent = ctxent[ctx];
+            const uint32_t qe = ent & 0xFFFF;
+            const uint32_t A1 = A - qe;
+            const bool isM = d == ((ent >> 16) & 1);
+            if (isM && (A1 & 0x8000)) { A = A1; C += qe; continue; }      // the common case; everything below is select-only:
+            // a divergent branch costs exec-mask bookkeeping on the CU's one scalar unit (measured: as many SALU as VALU
+            // instructions per symbol when every `if` of mqc.go:224-255 is a branch)
+            const bool lt = A1 < qe;
+            C += (isM != lt) ? qe : 0u;                                   // MPS: C += qe unless A < qe; LPS: only if A < qe
+            A = (isM == lt) ? qe : A1;
+            ctxent[ctx] = mqtab[isM ? ((ent >> 16) & 0xFF) : (ent >> 24)];
+            uint32_t shift = (uint32_t)__clz(A) - 16;                     // A < 0x8000 here: 1..15 doublings
+            A <<= shift;
+            if (shift < CT) { C <<= shift; CT -= shift; continue; }
+            do {                                                          // a byte leaves the register
+                const uint32_t sft = min(shift, CT);
+                C <<= sft; CT -= sft; shift -= sft;
+                if (CT == 0) { e.C = C; mq_byte_out(e); C = e.C; CT = e.CT; }
+            } while (shift);
+        }
     }
+    e.A = A; e.C = C; e.CT = CT;
 }
 
-__global__ __launch_bounds__(64) void t1_encode64_kernel(const BlockJob *__restrict__ jobs, int njobs, const int32_t *__restrict__ coef,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void t1_encode64_kernel(const BlockJob *__restrict__ jobs, int njobs, const int32_t *__restrict__ coef,
                                                          uint8_t *__restrict__ slots, uint32_t *__restrict__ lens,
                                                          uint8_t *__restrict__ numbps, int *__restrict__ fault) {
     __shared__ T1Fast F;
@@ -383,6 +415,7 @@ __global__ __launch_bounds__(64) void t1_encode64_kernel(const BlockJob *__restr
                         (p & 1) << 4 | ((p >> 2) & 1) << 5 | ((p >> 3) & 1) << 6 | ((p >> 5) & 1) << 7;
         F.zc2[p] = F.T.zc[ref];
     }
+    if (lane < NumContexts) F.ctxent[lane] = F.T.mq[lane == CtxUni ? 92 : 0];
     // ---- SetData (t1.go:292-304) + bit-plane count (t1_fast5.go:13-28): lanes = columns ----
     const int32_t *src = coef + J.src_off;
     const bool colok = lane < w;
@@ -437,7 +470,7 @@ __global__ __launch_bounds__(64) void t1_encode64_kernel(const BlockJob *__restr
 #define T1F_DRAIN()                                           \
     do {                                                      \
         __syncthreads();                                      \
-        if (lane == 0) mq_run(e, F.T, F.sym, nsym);           \
+        if (lane == 0) mq_run(e, F.T.mq, F.ctxent, F.sym, nsym); \
         nsym = 0;                                             \
         __syncthreads();                                      \
     } while (0)
