@@ -28,8 +28,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 
 SEED = 0x4A324B30              # "J2K0" 
 # HBM traffic of one level-0 launch from the rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KiB -> bytes);
 # cannot be collected from inside this process, so it is the committed measurement (see profiles/)
-TRAFFIC_BYTES_PER_LAUNCH = 207044198   # (2 x 52495.8 + 97200.0) KiB: 1.04 x the algorithmic 199 065 600 bytes
-TRAFFIC_SOURCE = "profiles/r01_bench_v3_inflight1_pmc_{FETCH,WRITE}_SIZE.csv (rocprofv3 --pmc, separate passes, FETCH_SIZE x2)"
+TRAFFIC = {   # frame_io -> (bytes per level-0 forward launch, source)
+    "planes": (207044198, "profiles/r01_bench_v3_inflight1_pmc_{FETCH,WRITE}_SIZE.csv: (2 x 52495.8 + 97200.0) KiB"),
+    "rgba8": (135595213, "profiles/r01_bench_v4_rgba8_inflight1_pmc_{FETCH,WRITE}_SIZE.csv: (2 x 17608.6 + 97200.0) KiB"),
+}
 
 
 def synth_frame(np, index):
@@ -77,6 +79,10 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--io", choices=["planes", "rgba8"], default=os.environ.get("J2K_BENCH_IO", "rgba8"),
+                    help="frame format at the boundary: packed 8-bit RGBA pixels (image.RGBA.Pix) read / written directly by "
+                         "the level-0 kernels (extractImageData / createImage fused, SURVEY 8f rank 2; the default), or "
+                         "int32 component planes (e.componentData, the boundary of SURVEY 8a-e)")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("J2K_BENCH_INFLIGHT", "3")),
                     help="independent frames coded concurrently per step, each on its own context/stream")
     args = ap.parse_args()
@@ -109,6 +115,10 @@ def main():
             p, i = self.plan, self.plan.info
             self.n = int(i.blocks)
             self.frame = torch.from_numpy(frame_h).to(p.device)
+            if args.io == "rgba8":     # image.RGBA Pix of the same frame (alpha 255)
+                rgba = np.concatenate([frame_h.transpose(1, 2, 0), np.full((H, W, 1), 255, np.int32)], axis=2).astype(np.uint8)
+                self.pix = torch.from_numpy(np.ascontiguousarray(rgba.reshape(H, W * 4))).to(p.device)
+                self.back_pix = torch.empty_like(self.pix)
             self.coeff = p.alloc_coeff()
             self.slots = p.empty(i.bytes_cap, torch.uint8); self.stream = p.empty(i.bytes_cap, torch.uint8)
             self.lens = p.empty(self.n, torch.int32); self.numbps = p.empty(self.n, torch.uint8)
@@ -119,14 +129,20 @@ def main():
 
         def encode_side(self):
             p = self.plan
-            p.forward(self.frame, self.coeff)
+            if args.io == "rgba8":
+                p.forward_rgba8(self.pix, self.coeff)
+            else:
+                p.forward(self.frame, self.coeff)
             p.encode_blocks(self.coeff, self.slots, self.lens, self.numbps)
             p.compact(self.slots, self.lens, self.offs, self.stream)
 
         def decode_side(self):
             p = self.plan
             p.decode_blocks(self.stream, self.offs, self.lens, self.numbps, self.decoded)
-            p.inverse(self.coeff, self.back)
+            if args.io == "rgba8":
+                p.inverse_rgba8(self.coeff, self.back_pix)
+            else:
+                p.inverse(self.coeff, self.back)
 
         def code(self):
             self.encode_side()
@@ -200,7 +216,7 @@ def main():
     #      int32 copy at the level-0 footprint cycled over 8 buffer pairs so the Infinity Cache cannot serve it ----
     copy_gbs = None
     if rank == 0:
-        nel = int(info.dwt_level0_bytes // 8)            # elements read = elements written = one level-0 launch
+        nel = int(info.dwt_level0_bytes // 8)            # elements read = elements written = one planar level-0 launch
         srcs = [torch.empty(nel, dtype=torch.int32, device=plan.device).fill_(i) for i in range(8)]
         dsts = [torch.empty_like(srcs[0]) for _ in range(8)]
         for i in range(8):
@@ -222,7 +238,10 @@ def main():
 
     # ---- correctness of what was timed (outside the timed region) ----
     for ln in lanes:
-        assert torch.equal(ln.back, ln.frame), "lossless round trip failed"
+        if args.io == "rgba8":
+            assert torch.equal(ln.back_pix, ln.pix), "lossless round trip failed"
+        else:
+            assert torch.equal(ln.back, ln.frame), "lossless round trip failed"
     total_bytes = int(lanes[0].offs[n].item())
 
     if rank == 0:
@@ -230,7 +249,9 @@ def main():
         ms_step = dt / args.steps * 1e3
         k_conc_s = (k_ms / max(launches, 1)) * 1e-3            # inside the timed region (F frames in flight)
         k_avg_s = (iso_ms / max(iso_launches, 1)) * 1e-3        # roofline pass (one frame in flight)
-        achieved = info.dwt_level0_bytes / k_avg_s / 1e9 if iso_launches else 0.0
+        # level 0 moves 3 int32 planes in + 3 out (24 B/px) or, with packed pixels, one RGBA8 dword in + 3 int32 out (16 B/px)
+        alg_bytes = int(info.dwt_level0_bytes) if args.io == "planes" else int(info.dwt_level0_bytes) * 16 // 24
+        achieved = alg_bytes / k_avg_s / 1e9 if iso_launches else 0.0
         out = {
             "metric": "Mpixels/s encode+decode (4K sRGB, 5-3 lossless)",
             "value": round(world * F * px / (dt / args.steps) / 1e6, 1),
@@ -241,17 +262,20 @@ def main():
                                    "6 resolutions (BASELINE configs[1]); frames_in_flight independent frames per rank per step, "
                                    "each on its own HIP stream; N>1 gathers the compressed streams to rank 0 over RCCL",
                        "tiles": int(info.tiles), "code_blocks": n, "compressed_bytes_per_frame": total_bytes,
-                       "frames_in_flight": F,
+                       "frames_in_flight": F, "frame_io": args.io,
                        "parallelism": "frames/rank" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "dwt53_fwd_kernel<8,3,true> (level 0: DC shift + RCT + 5-3 lifting, fused)",
+            "roofline": {"bound": "hbm",
+                         "kernel": "dwt53_fwd_kernel<8,3,true,false,%s> (level 0: %sDC shift + RCT + 5-3 lifting, fused)"
+                                   % (("true", "RGBA8 unpack + ") if args.io == "rgba8" else ("false", "")),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": TRAFFIC_BYTES_PER_LAUNCH,
-                         "algorithmic_bytes_per_launch": int(info.dwt_level0_bytes),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": TRAFFIC[args.io][0],
+                         "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_us": round(k_avg_s * 1e6, 2), "launches_timed": int(iso_launches),
-                         "measured": "HIP events on the library stream around every level-0 launch, in a pass with one "
-                                     "frame in flight run right after the timed region (same process, same buffers)",
+                         "measured": "HIP start/stop events stamped by every level-0 dispatch on the library stream "
+                                     "(hipExtLaunchKernelGGL), in a pass with one frame in flight run right after the timed "
+                                     "region (same process, same buffers)",
                          "avg_launch_us_in_timed_region": round(k_conc_s * 1e6, 2), "launches_in_timed_region": int(launches),
-                         "traffic_source": TRAFFIC_SOURCE,
+                         "traffic_source": TRAFFIC[args.io][1],
                          "copy_gbs_measured": round(copy_gbs, 1) if copy_gbs else None,
                          "frac_of_measured_copy": round(achieved / copy_gbs, 4) if copy_gbs else None},
         }

@@ -29,6 +29,7 @@
 // Go int32 semantics: '>>' is arithmetic, overflow wraps; all sums are done in
 // uint32 and shifted as int32.
 #include "j2k_internal.h"
+#include <hip/hip_ext.h>
 
 namespace j2k {
 
@@ -187,9 +188,26 @@ struct RawRow {
 // Issue the global loads of one source row (NC component planes) and nothing else, so the caller can put the
 // loads of several rows in flight before the first use.  Out-of-range lanes/columns read a clamped, valid address:
 // their values never reach a stored result (the lifting only looks at in-range neighbours), so they need no mask.
-template <int CPL, int NC, bool VEC>
+template <int CPL, int NC, bool VEC, bool PIX = false>
 __device__ __forceinline__ void fwd_issue_row(const int32_t *__restrict__ src, const DwtPlane &P, int r, int c,
-                                              RawRow<CPL, NC> &R) {
+                                              RawRow<CPL, NC> &R, int64_t pix_row0 = -1, int pix_stride = 0) {
+    if constexpr (PIX && NC == 3 && CPL == 8 && VEC) {
+        {
+            // packed RGBA8 source (encoder.go:107-123 fused): eight pixels = two 16-byte loads instead of six
+            const int cc = (c < P.w) ? c : 0;
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(src) + pix_row0 + (int64_t)r * pix_stride + cc;
+            const int4 a = ld4(reinterpret_cast<const int32_t *>(p), true), b = ld4(reinterpret_cast<const int32_t *>(p + 4), true);
+            const uint32_t px[8] = {(uint32_t)a.x, (uint32_t)a.y, (uint32_t)a.z, (uint32_t)a.w,
+                                    (uint32_t)b.x, (uint32_t)b.y, (uint32_t)b.z, (uint32_t)b.w};
+#pragma unroll
+            for (int i = 0; i < 8; i++) {     // R, G, B are bytes 0, 1, 2 (image.RGBA)
+                R.x[0][i] = (int)(px[i] & 0xFF);
+                R.x[1][i] = (int)((px[i] >> 8) & 0xFF);
+                R.x[2][i] = (int)((px[i] >> 16) & 0xFF);
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int k = 0; k < NC; k++) {
         const int32_t *p = src + P.src_off[k] + (int64_t)r * P.src_stride;
@@ -236,9 +254,10 @@ __device__ __forceinline__ void fwd_finish_row(RawRow<CPL, NC> &X, const DwtPlan
 // thin planes (w < 2 or h < 2): masked loads, the length<2 pass-through rules of dwt.go:74-76
 template <int CPL, int NC, bool VEC>
 __device__ __forceinline__ void fwd_load_row_thin(const int32_t *__restrict__ src, const DwtPlane &P, int r, int c, int dc_shift,
-                                                  FwdRow<CPL, NC, VEC> &R) {
+                                                  FwdRow<CPL, NC, VEC> &R, int64_t pix0, int pix_stride) {
     RawRow<CPL, NC> X;
-    fwd_issue_row<CPL, NC, VEC>(src, P, r, c, X);
+    if (pix_stride > 0) fwd_issue_row<CPL, NC, VEC, true>(src, P, r, c, X, pix0, pix_stride);
+    else fwd_issue_row<CPL, NC, VEC, false>(src, P, r, c, X);
 #pragma unroll
     for (int k = 0; k < NC; k++)
 #pragma unroll
@@ -293,22 +312,22 @@ __device__ __forceinline__ void fwd_store_row(int32_t *__restrict__ out, int32_t
 template <int CPL, int NC, bool VEC>
 __device__ __forceinline__ void fwd_job_thin(const DwtJob &job, const DwtPlane &P, const int32_t *__restrict__ src,
                                           int32_t *__restrict__ out, int32_t *__restrict__ nxt, int dc_shift, int c, int p0,
-                                          bool owned) {
+                                          bool owned, int64_t pix0, int pix_stride) {
     constexpr int H = CPL / 2;
     typedef FwdRow<CPL, NC, VEC> Row;
     const int h = P.h, halfH = (h + 1) >> 1;
     const int pr_end = min(job.prow0 + job.nprow, halfH);
     Row ye, yo, yn;
     int dvp_lo[NC][H], dvp_hi[NC][H];
-    fwd_load_row_thin<CPL, NC, VEC>(src, P, 2 * job.prow0, c, dc_shift, ye);
+    fwd_load_row_thin<CPL, NC, VEC>(src, P, 2 * job.prow0, c, dc_shift, ye, pix0, pix_stride);
     if (h < 2) {
         if (job.prow0 == 0) fwd_store_row<CPL, NC, VEC>(out, nxt, P, 0, p0, owned, ye.lo, ye.hi);
         return;
     }
     if (job.prow0 > 0) {
         Row ym2, ym1;
-        fwd_load_row_thin<CPL, NC, VEC>(src, P, 2 * job.prow0 - 2, c, dc_shift, ym2);
-        fwd_load_row_thin<CPL, NC, VEC>(src, P, 2 * job.prow0 - 1, c, dc_shift, ym1);
+        fwd_load_row_thin<CPL, NC, VEC>(src, P, 2 * job.prow0 - 2, c, dc_shift, ym2, pix0, pix_stride);
+        fwd_load_row_thin<CPL, NC, VEC>(src, P, 2 * job.prow0 - 1, c, dc_shift, ym1, pix0, pix_stride);
 #pragma unroll
         for (int k = 0; k < NC; k++)
 #pragma unroll
@@ -320,8 +339,8 @@ __device__ __forceinline__ void fwd_job_thin(const DwtJob &job, const DwtPlane &
     for (int pr = job.prow0; pr < pr_end; pr++) {
         const int r1 = 2 * pr + 1, r2 = 2 * pr + 2;
         const bool has_odd = r1 < h, has_next = r2 < h;
-        if (has_odd) fwd_load_row_thin<CPL, NC, VEC>(src, P, r1, c, dc_shift, yo);
-        if (has_next) fwd_load_row_thin<CPL, NC, VEC>(src, P, r2, c, dc_shift, yn);
+        if (has_odd) fwd_load_row_thin<CPL, NC, VEC>(src, P, r1, c, dc_shift, yo, pix0, pix_stride);
+        if (has_next) fwd_load_row_thin<CPL, NC, VEC>(src, P, r2, c, dc_shift, yn, pix0, pix_stride);
         int dv_lo[NC][H], dv_hi[NC][H], sv_lo[NC][H], sv_hi[NC][H];
 #pragma unroll
         for (int k = 0; k < NC; k++)
@@ -369,11 +388,11 @@ __device__ __forceinline__ void fwd_job_thin(const DwtJob &job, const DwtPlane &
 // three rows per WORKGROUP (not per wavefront).
 // PF: the loads of pair-row q+1 are issued before the vertical lifting and the stores of pair-row q (software
 // pipelining, one pair-row deep; costs CPL*NC*2 more live registers)
-template <int CPL, int NC, bool VEC, bool PF>
+template <int CPL, int NC, bool VEC, bool PF, bool PIX>
 __global__ __launch_bounds__(256) J2K_FWD_ATTR void dwt53_fwd_kernel(const DwtJob *__restrict__ jobs, int njobs,
                                                                      const DwtPlane *__restrict__ planes,
                                                                      const int32_t *__restrict__ src, int32_t *__restrict__ out,
-                                                                     int32_t *__restrict__ nxt, int dc_shift) {
+                                                                     int32_t *__restrict__ nxt, int dc_shift, int pix_stride) {
     constexpr int H = CPL / 2;
     constexpr int PUB = 2 * NC * CPL * 64;   // ints one wavefront publishes: {even row, d row} x NC x (lo|hi) x 64 lanes
     __shared__ int sh[4 * PUB];
@@ -396,8 +415,14 @@ __global__ __launch_bounds__(256) J2K_FWD_ATTR void dwt53_fwd_kernel(const DwtJo
     const bool reach_end = (c_base + 64 * CPL >= w);
     const bool owned = (lane >= lane_first) && (c < w) && (reach_end || lane < 63);
     const int p0 = c >> 1;
+    // packed-pixel source: pixel index of this tile's origin (src_off[0] = y0 * W + x0 in the planar frame)
+    int64_t pix0 = -1;
+    if (PIX) {
+        const int64_t y0 = P.src_off[0] / P.src_stride;
+        pix0 = y0 * pix_stride + (P.src_off[0] - y0 * P.src_stride);
+    }
     if (w < 2 || h < 2) {            // never linked
-        fwd_job_thin<CPL, NC, VEC>(job, P, src, out, nxt, dc_shift, c, p0, owned);
+        fwd_job_thin<CPL, NC, VEC>(job, P, src, out, nxt, dc_shift, c, p0, owned, pix0, PIX ? pix_stride : 0);
         __syncthreads();
         return;
     }
@@ -417,14 +442,14 @@ __global__ __launch_bounds__(256) J2K_FWD_ATTR void dwt53_fwd_kernel(const DwtJo
         // the loads of the prologue are issued before the first use: one (PF) or two memory latencies, not five
         Raw r0, rm2, rm1;
         const int re = 2 * pr_begin;
-        fwd_issue_row<CPL, NC, VEC>(src, P, re, c, r0);
+        fwd_issue_row<CPL, NC, VEC, PIX>(src, P, re, c, r0, pix0, pix_stride);
         if (!link_up) {
-            fwd_issue_row<CPL, NC, VEC>(src, P, max(re - 2, 0), c, rm2);
-            fwd_issue_row<CPL, NC, VEC>(src, P, max(re - 1, 0), c, rm1);
+            fwd_issue_row<CPL, NC, VEC, PIX>(src, P, max(re - 2, 0), c, rm2, pix0, pix_stride);
+            fwd_issue_row<CPL, NC, VEC, PIX>(src, P, max(re - 1, 0), c, rm1, pix0, pix_stride);
         }
         if (PF) {
-            fwd_issue_row<CPL, NC, VEC>(src, P, min(re + 1, hl), c, ra);
-            fwd_issue_row<CPL, NC, VEC>(src, P, min(re + 2, hl), c, rb);   // linked bands have >= 2 pair-rows: a real row
+            fwd_issue_row<CPL, NC, VEC, PIX>(src, P, min(re + 1, hl), c, ra, pix0, pix_stride);
+            fwd_issue_row<CPL, NC, VEC, PIX>(src, P, min(re + 2, hl), c, rb, pix0, pix_stride);   // linked bands have >= 2 pair-rows: a real row
         }
         fwd_finish_row<CPL, NC, VEC>(r0, P, c, dc_shift, ye);
         if (!link_up) {
@@ -450,8 +475,8 @@ __global__ __launch_bounds__(256) J2K_FWD_ATTR void dwt53_fwd_kernel(const DwtJo
         const bool has_odd = 2 * pr + 1 < h, has_next = 2 * pr + 2 < h;
         const bool yn_from_lds = link_down && last;
         if (!PF) {
-            fwd_issue_row<CPL, NC, VEC>(src, P, min(2 * pr + 1, hl), c, ra);
-            if (!yn_from_lds) fwd_issue_row<CPL, NC, VEC>(src, P, min(2 * pr + 2, hl), c, rb);
+            fwd_issue_row<CPL, NC, VEC, PIX>(src, P, min(2 * pr + 1, hl), c, ra, pix0, pix_stride);
+            if (!yn_from_lds) fwd_issue_row<CPL, NC, VEC, PIX>(src, P, min(2 * pr + 2, hl), c, rb, pix0, pix_stride);
         }
         fwd_finish_row<CPL, NC, VEC>(ra, P, c, dc_shift, yo);
         if (yn_from_lds) {
@@ -466,8 +491,8 @@ __global__ __launch_bounds__(256) J2K_FWD_ATTR void dwt53_fwd_kernel(const DwtJo
             fwd_finish_row<CPL, NC, VEC>(rb, P, c, dc_shift, yn);
         }
         if (PF && !last) {
-            fwd_issue_row<CPL, NC, VEC>(src, P, min(2 * pr + 3, hl), c, ra);
-            if (!(link_down && pr + 2 == pr_end)) fwd_issue_row<CPL, NC, VEC>(src, P, min(2 * pr + 4, hl), c, rb);
+            fwd_issue_row<CPL, NC, VEC, PIX>(src, P, min(2 * pr + 3, hl), c, ra, pix0, pix_stride);
+            if (!(link_down && pr + 2 == pr_end)) fwd_issue_row<CPL, NC, VEC, PIX>(src, P, min(2 * pr + 4, hl), c, rb, pix0, pix_stride);
         }
         int dv_lo[NC][H], dv_hi[NC][H], sv_lo[NC][H], sv_hi[NC][H];
 #pragma unroll
@@ -574,10 +599,10 @@ __device__ __forceinline__ void inv_load_row(const int32_t *__restrict__ coef, c
 }
 
 // horizontal inverse + optional inverse RCT + DC shift + store of one reconstructed row
-template <int CPL, int NC, bool VEC>
+template <int CPL, int NC, bool VEC, bool PIX = false>
 __device__ __forceinline__ void inv_finish_row(int32_t *__restrict__ dst, const DwtPlane &P, int ro, int c, bool owned,
                                                const int (&lo)[NC][CPL / 2], const int (&hi)[NC][CPL / 2], int dc_shift,
-                                               bool final_level) {
+                                               bool final_level, int64_t pix0 = -1, int pix_stride = 0) {
     int x[NC][CPL];
 #pragma unroll
     for (int k = 0; k < NC; k++) hinv<CPL>(lo[k], hi[k], c, P.w, x[k]);
@@ -592,6 +617,23 @@ __device__ __forceinline__ void inv_finish_row(int32_t *__restrict__ dst, const 
         }
     }
     if (!owned) return;
+    if constexpr (PIX && NC == 3 && CPL == 8 && VEC) {
+        {
+            // DCLevelShiftInverse + decoder.createImage for 3 components at 8 bit (decoder.go:477-505): clamp to 0..255,
+            // alpha 255, eight RGBA pixels = two 16-byte stores instead of six
+            uint32_t px[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int r_ = min(max(wadd(x[0][i], dc_shift), 0), 255), g_ = min(max(wadd(x[1][i], dc_shift), 0), 255),
+                          b_ = min(max(wadd(x[2][i], dc_shift), 0), 255);
+                px[i] = (uint32_t)r_ | (uint32_t)g_ << 8 | (uint32_t)b_ << 16 | 0xFF000000u;
+            }
+            uint32_t *p = reinterpret_cast<uint32_t *>(dst) + pix0 + (int64_t)ro * pix_stride + c;
+            *reinterpret_cast<uint4 *>(p) = make_uint4(px[0], px[1], px[2], px[3]);
+            *reinterpret_cast<uint4 *>(p + 4) = make_uint4(px[4], px[5], px[6], px[7]);
+            return;
+        }
+    }
     const int stride = final_level ? P.out_stride : P.w;
 #pragma unroll
     for (int k = 0; k < NC; k++) {
@@ -635,11 +677,11 @@ __device__ __forceinline__ void inv_compute_xe(int q, int nhigh, const FwdRow<CP
 // s and d rows of its own pair-rows plus d[q0-1] above and s[q1], d[q1] below.  The two rows below are the FIRST rows
 // the band below loads, so a band with J2K_LINK_UP publishes them to LDS and a band with J2K_LINK_DOWN takes them from
 // there at its last pair-row; only d[q0-1] is still read twice (one halo row per band instead of three).
-template <int CPL, int NC, bool VEC>
+template <int CPL, int NC, bool VEC, bool PIX>
 __global__ __launch_bounds__(256) void dwt53_inv_kernel(const DwtJob *__restrict__ jobs, int njobs,
                                                         const DwtPlane *__restrict__ planes,
                                                         const int32_t *__restrict__ coef, const int32_t *__restrict__ prev,
-                                                        int32_t *__restrict__ dst, int dc_shift, int final_level) {
+                                                        int32_t *__restrict__ dst, int dc_shift, int final_level, int pix_stride) {
     constexpr int H = CPL / 2;
     constexpr int PUB = 2 * NC * CPL * 64;   // ints one wavefront publishes: {s row, d row} x NC x (lo|hi) x 64 lanes
     __shared__ int sh[4 * PUB];
@@ -667,6 +709,11 @@ __global__ __launch_bounds__(256) void dwt53_inv_kernel(const DwtJob *__restrict
     const int pr_begin = job.prow0;
     const int pr_end = min(job.prow0 + job.nprow, halfH);
     const bool fin = final_level != 0;
+    int64_t pix0 = -1;                 // packed RGBA8 destination (final level only): pixel index of the tile origin
+    if (PIX) {
+        const int64_t y0 = P.out_off[0] / P.out_stride;
+        pix0 = y0 * pix_stride + (P.out_off[0] - y0 * P.out_stride);
+    }
     int *pub_mine = sh + wv * PUB + lane;
     const int *pub_below = sh + ((wv + 1) & 3) * PUB + lane;   // only read when link_down (then wv < 3)
 
@@ -675,7 +722,7 @@ __global__ __launch_bounds__(256) void dwt53_inv_kernel(const DwtJob *__restrict
         if (pr_begin == 0) {
             Row s0;
             inv_load_row<CPL, NC, VEC>(coef, prev, P, 0, p0, c, s0);
-            inv_finish_row<CPL, NC, VEC>(dst, P, 0, c, owned, s0.lo, s0.hi, dc_shift, fin);
+            inv_finish_row<CPL, NC, VEC, PIX>(dst, P, 0, c, owned, s0.lo, s0.hi, dc_shift, fin, pix0, pix_stride);
         }
         __syncthreads();
         return;
@@ -723,7 +770,7 @@ __global__ __launch_bounds__(256) void dwt53_inv_kernel(const DwtJob *__restrict
             inv_load_row<CPL, NC, VEC>(coef, prev, P, halfH + min(q + 1, nhigh - 1), p0, c, dn);
         }
         inv_compute_xe<CPL, NC, VEC>(q + 1, nhigh, sn, dcur, dn, xn_lo, xn_hi);   // unused when !has_next
-        inv_finish_row<CPL, NC, VEC>(dst, P, 2 * q, c, owned, xe_lo, xe_hi, dc_shift, fin);
+        inv_finish_row<CPL, NC, VEC, PIX>(dst, P, 2 * q, c, owned, xe_lo, xe_hi, dc_shift, fin, pix0, pix_stride);
         if (has_d) {
             int xo_lo[NC][H], xo_hi[NC][H];
 #pragma unroll
@@ -735,7 +782,7 @@ __global__ __launch_bounds__(256) void dwt53_inv_kernel(const DwtJob *__restrict
                     xo_lo[k][j] = wadd(dcur.lo[k][j], pl);
                     xo_hi[k][j] = wadd(dcur.hi[k][j], ph);
                 }
-            inv_finish_row<CPL, NC, VEC>(dst, P, 2 * q + 1, c, owned, xo_lo, xo_hi, dc_shift, fin);
+            inv_finish_row<CPL, NC, VEC, PIX>(dst, P, 2 * q + 1, c, owned, xo_lo, xo_hi, dc_shift, fin, pix0, pix_stride);
         }
 #pragma unroll
         for (int k = 0; k < NC; k++)
@@ -934,14 +981,31 @@ hipError_t launch_dwt53_tail_inv(hipStream_t s, const TailPlane *planes, int npl
 template <int CPL, int NC, bool VEC>
 static hipError_t fwd_go(hipStream_t s, const LevelLaunch &L, const int32_t *src, int32_t *out, int32_t *nxt, int dc) {
     const int blocks = (L.njobs + 3) / 4;
-    if (L.pf) hipLaunchKernelGGL((dwt53_fwd_kernel<CPL, NC, VEC, true>), dim3(blocks), dim3(256), 0, s, L.jobs, L.njobs, L.planes, src, out, nxt, dc);
-    else hipLaunchKernelGGL((dwt53_fwd_kernel<CPL, NC, VEC, false>), dim3(blocks), dim3(256), 0, s, L.jobs, L.njobs, L.planes, src, out, nxt, dc);
+    if constexpr (CPL == 8 && NC == 3 && VEC) {
+        if (L.pix_stride > 0) {   // packed RGBA8 frame: its own instantiation, so the planar kernel is untouched
+            hipExtLaunchKernelGGL((dwt53_fwd_kernel<CPL, NC, VEC, false, true>), dim3(blocks), dim3(256), 0, s, L.ev_start, L.ev_stop, 0,
+                                  L.jobs, L.njobs, L.planes, src, out, nxt, dc, L.pix_stride);
+            return hipGetLastError();
+        }
+    }
+    if (L.pix_stride > 0) return hipErrorInvalidValue;
+    if (L.pf) hipExtLaunchKernelGGL((dwt53_fwd_kernel<CPL, NC, VEC, true, false>), dim3(blocks), dim3(256), 0, s, L.ev_start, L.ev_stop, 0,
+                                    L.jobs, L.njobs, L.planes, src, out, nxt, dc, 0);
+    else hipExtLaunchKernelGGL((dwt53_fwd_kernel<CPL, NC, VEC, false, false>), dim3(blocks), dim3(256), 0, s, L.ev_start, L.ev_stop, 0,
+                               L.jobs, L.njobs, L.planes, src, out, nxt, dc, 0);
     return hipGetLastError();
 }
 template <int CPL, int NC, bool VEC>
 static hipError_t inv_go(hipStream_t s, const LevelLaunch &L, const int32_t *coef, const int32_t *prev, int32_t *dst, int dc, int fin) {
     const int blocks = (L.njobs + 3) / 4;
-    hipLaunchKernelGGL((dwt53_inv_kernel<CPL, NC, VEC>), dim3(blocks), dim3(256), 0, s, L.jobs, L.njobs, L.planes, coef, prev, dst, dc, fin);
+    if constexpr (CPL == 8 && NC == 3 && VEC) {
+        if (L.pix_stride > 0) {
+            hipLaunchKernelGGL((dwt53_inv_kernel<CPL, NC, VEC, true>), dim3(blocks), dim3(256), 0, s, L.jobs, L.njobs, L.planes, coef, prev, dst, dc, fin, L.pix_stride);
+            return hipGetLastError();
+        }
+    }
+    if (L.pix_stride > 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((dwt53_inv_kernel<CPL, NC, VEC, false>), dim3(blocks), dim3(256), 0, s, L.jobs, L.njobs, L.planes, coef, prev, dst, dc, fin, 0);
     return hipGetLastError();
 }
 

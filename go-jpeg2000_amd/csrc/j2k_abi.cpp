@@ -537,7 +537,7 @@ extern "C" int j2k_plan_get_decoded_offsets(const j2k_plan *P, uint64_t *offs, s
 // ------------------------------------------------------------------------------
 static LevelLaunch mk(const LevelTab &T, int pf = 0) { return LevelLaunch{T.d_jobs, T.njobs, T.d_planes, T.cpl, T.vec, T.ncomp, pf}; }
 
-static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff) {
+static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff, int pix_stride = 0) {
     j2k_ctx *ctx = P->ctx;
     const PlanSpec &S = P->spec;
     if (((uintptr_t)d_frame & 15) || ((uintptr_t)d_coeff & 15)) return fail(ctx, J2K_ERR_INVALID_ARG, "device pointers must be 16-byte aligned");
@@ -547,20 +547,23 @@ static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff) {
     for (int l = 0; l < nlevel_launches; l++) {
         void *in = (l == 0) ? const_cast<void *>(d_frame) : ((l & 1) ? P->d_scrA : P->d_scrB);
         void *nx = (l & 1) ? P->d_scrB : P->d_scrA;
-        hipEvent_t ev0 = (l == 0) ? profile_event(ctx) : nullptr, ev1 = ev0 ? profile_event(ctx) : nullptr;
-        if (ev1) HIPCHK(ctx, hipEventRecord(ev0, ctx->stream));
+        // profiling (bench.py's roofline line): the level-0 dispatch of the RGB triples stamps its own begin / end
+        hipEvent_t ev0 = (l == 0 && S.wavelet == W53 && P->fwd[1][0].njobs) ? profile_event(ctx) : nullptr;
+        hipEvent_t ev1 = ev0 ? profile_event(ctx) : nullptr;
         for (int cls = 0; cls < 2; cls++) {
             const LevelTab &T = P->fwd[cls][l];
             if (!T.njobs) continue;
             if (S.wavelet == W53) {
-                HIPCHK(ctx, launch_dwt53_fwd(ctx->stream, mk(T, ctx->fwd_pf), (const int32_t *)in, (int32_t *)d_coeff, (int32_t *)nx, l == 0 ? S.dc_shift : 0));
+                LevelLaunch L = mk(T, ctx->fwd_pf);
+                if (l == 0 && cls == 1) L.pix_stride = pix_stride;        // packed RGBA8 frame (j2k_plan_forward_rgba8)
+                if (l == 0 && cls == 1 && ev1) { L.ev_start = ev0; L.ev_stop = ev1; }
+                HIPCHK(ctx, launch_dwt53_fwd(ctx->stream, L, (const int32_t *)in, (int32_t *)d_coeff, (int32_t *)nx, l == 0 ? S.dc_shift : 0));
             } else {
                 const int src_f64 = (l > 0) || S.frame_is_f64;
                 HIPCHK(ctx, launch_dwt97_fwd(ctx->stream, mk(T), in, src_f64, (int32_t *)d_coeff, (double *)d_coeff, (double *)nx,
                                              l == 0 ? S.dc_shift : 0, S.quant, step, (cls == 1) ? 1 : 0));
             }
         }
-        if (ev1) HIPCHK(ctx, hipEventRecord(ev1, ctx->stream));
     }
     if (P->tail_l0 >= 0)
         HIPCHK(ctx, launch_dwt53_tail_fwd(ctx->stream, P->d_tail, P->ntail, P->tail_lds_fwd,
@@ -568,7 +571,7 @@ static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff) {
     return J2K_OK;
 }
 
-static int plan_inverse_impl(j2k_plan *P, const void *d_coeff, void *d_frame) {
+static int plan_inverse_impl(j2k_plan *P, const void *d_coeff, void *d_frame, int pix_stride = 0) {
     j2k_ctx *ctx = P->ctx;
     const PlanSpec &S = P->spec;
     if (((uintptr_t)d_frame & 15) || ((uintptr_t)d_coeff & 15)) return fail(ctx, J2K_ERR_INVALID_ARG, "device pointers must be 16-byte aligned");
@@ -583,7 +586,9 @@ static int plan_inverse_impl(j2k_plan *P, const void *d_coeff, void *d_frame) {
             const LevelTab &T = P->inv[cls][l];
             if (!T.njobs) continue;
             if (S.wavelet == W53) {
-                HIPCHK(ctx, launch_dwt53_inv(ctx->stream, mk(T), (const int32_t *)d_coeff, (const int32_t *)prev, (int32_t *)dst,
+                LevelLaunch L = mk(T);
+                if (l == 0 && cls == 1) L.pix_stride = pix_stride;        // packed RGBA8 frame (j2k_plan_inverse_rgba8)
+                HIPCHK(ctx, launch_dwt53_inv(ctx->stream, L, (const int32_t *)d_coeff, (const int32_t *)prev, (int32_t *)dst,
                                              l == 0 ? S.dc_shift : 0, l == 0));
             } else {
                 // dst_mode: 0 = f64 scratch (l>0), 1 = f64 frame (unit calls), 2 = int32 frame via int32(v+0.5) (tcd.go:433-435)
@@ -612,6 +617,123 @@ static int ensure(j2k_ctx *ctx, void **p, size_t bytes) {
     if (*p) return J2K_OK;
     HIPCHK(ctx, hipMalloc(p, std::max<size_t>(bytes, 16)));
     return J2K_OK;
+}
+
+// ---- pixels at native width (encoder.go:79-213, decoder.go:417-588) ----------------------------
+static const int kPixComp[6] = {1, 1, 3, 3, 4, 4}, kPixPrec[6] = {8, 16, 8, 16, 8, 16}, kPixBytes[6] = {1, 2, 4, 8, 4, 8};
+extern "C" int j2k_pixels_components(int format) { return (format >= 0 && format < 6) ? kPixComp[format] : 0; }
+extern "C" int j2k_pixels_precision(int format) { return (format >= 0 && format < 6) ? kPixPrec[format] : 0; }
+
+static int pix_args_ok(j2k_ctx *ctx, int format, const void *pix, size_t stride, int w, int h, int target_precision) {
+    if (!ctx || !pix || format < 0 || format >= 6 || w < 0 || h < 0 || target_precision < 0 || target_precision > 16)
+        return J2K_ERR_INVALID_ARG;
+    if (stride < (size_t)w * kPixBytes[format]) return J2K_ERR_INVALID_ARG;
+    return J2K_OK;
+}
+
+extern "C" int j2k_unpack_pixels(j2k_ctx *ctx, int format, const void *d_pix, size_t stride, int w, int h, int target_precision,
+                                 int32_t *d_planes) {
+    int r = pix_args_ok(ctx, format, d_pix, stride, w, h, target_precision);
+    if (r != J2K_OK || !d_planes) return ctx ? fail(ctx, J2K_ERR_INVALID_ARG, "j2k_unpack_pixels: bad argument") : J2K_ERR_INVALID_ARG;
+    if ((format == J2K_PIX_RGBA8 || format == J2K_PIX_NRGBA8) && (((uintptr_t)d_pix | stride) & 3))
+        return fail(ctx, J2K_ERR_INVALID_ARG, "RGBA rows must be 4-byte aligned");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int src_max = (1 << kPixPrec[format]) - 1;
+    const int dst_max = (target_precision > 0 && target_precision != kPixPrec[format]) ? (1 << target_precision) - 1 : src_max;
+    HIPCHK(ctx, launch_unpack_pixels(ctx->stream, (const uint8_t *)d_pix, stride, format, w, h, src_max, dst_max, d_planes));
+    return J2K_OK;
+}
+
+extern "C" int j2k_pack_pixels(j2k_ctx *ctx, const int32_t *d_planes, int ncomp, int precision, int w, int h, void *d_pix, size_t stride) {
+    if (!ctx || !d_planes || !d_pix || w < 0 || h < 0 || precision < 1 || precision > 16) return J2K_ERR_INVALID_ARG;
+    if (ncomp != 1 && ncomp != 3 && ncomp != 4) return fail(ctx, J2K_ERR_UNSUPPORTED, "unsupported number of components");   // decoder.go:583-585
+    const size_t bpp = (ncomp == 1 ? 1 : 4) * (precision > 8 ? 2 : 1);
+    if (stride < (size_t)w * bpp) return fail(ctx, J2K_ERR_INVALID_ARG, "stride smaller than a row");
+    if (ncomp != 1 && precision <= 8 && (((uintptr_t)d_pix | stride) & 3)) return fail(ctx, J2K_ERR_INVALID_ARG, "RGBA rows must be 4-byte aligned");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, launch_pack_pixels(ctx->stream, d_planes, ncomp, precision, w, h, (uint8_t *)d_pix, stride));
+    return J2K_OK;
+}
+
+extern "C" int j2k_extract_image_data(j2k_ctx *ctx, int format, const void *pix, size_t stride, int w, int h, int target_precision,
+                                      int32_t *const *planes) {
+    int r = pix_args_ok(ctx, format, pix, stride, w, h, target_precision);
+    if (r != J2K_OK || !planes) return ctx ? fail(ctx, J2K_ERR_INVALID_ARG, "j2k_extract_image_data: bad argument") : J2K_ERR_INVALID_ARG;
+    const size_t n = (size_t)w * h;
+    if (!n) return J2K_OK;
+    const int nc = kPixComp[format];
+    const size_t pbytes = (((size_t)h * stride) + 15) & ~size_t(15);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    r = stage_reserve(ctx, 0, pbytes + 64);                    // pixels cross PCIe at native width
+    if (r == J2K_OK) r = stage_reserve(ctx, 1, n * 4 * nc + 64);
+    if (r != J2K_OK) return r;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->stage[0], pix, (size_t)(h - 1) * stride + (size_t)w * kPixBytes[format], hipMemcpyHostToDevice, ctx->stream));
+    r = j2k_unpack_pixels(ctx, format, ctx->stage[0], stride, w, h, target_precision, (int32_t *)ctx->stage[1]);
+    if (r != J2K_OK) return r;
+    for (int c = 0; c < nc; c++)
+        HIPCHK(ctx, hipMemcpyAsync(planes[c], (int32_t *)ctx->stage[1] + (size_t)c * n, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return J2K_OK;
+}
+
+extern "C" int j2k_create_image(j2k_ctx *ctx, const int32_t *const *planes, int ncomp, int precision, int w, int h, void *pix, size_t stride) {
+    if (!ctx || !planes || !pix || w < 0 || h < 0 || precision < 1 || precision > 16) return J2K_ERR_INVALID_ARG;
+    if (ncomp != 1 && ncomp != 3 && ncomp != 4) return fail(ctx, J2K_ERR_UNSUPPORTED, "unsupported number of components");
+    const size_t n = (size_t)w * h;
+    if (!n) return J2K_OK;
+    const size_t bpp = (ncomp == 1 ? 1 : 4) * (precision > 8 ? 2 : 1);
+    if (stride < (size_t)w * bpp) return fail(ctx, J2K_ERR_INVALID_ARG, "stride smaller than a row");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int r = stage_reserve(ctx, 0, (size_t)h * stride + 64);
+    if (r == J2K_OK) r = stage_reserve(ctx, 1, n * 4 * ncomp + 64);
+    if (r != J2K_OK) return r;
+    for (int c = 0; c < ncomp; c++)
+        HIPCHK(ctx, hipMemcpyAsync((int32_t *)ctx->stage[1] + (size_t)c * n, planes[c], n * 4, hipMemcpyHostToDevice, ctx->stream));
+    // bytes of a row past w*bpp (stride padding) are not the image's: copy the rows back one by one
+    r = j2k_pack_pixels(ctx, (const int32_t *)ctx->stage[1], ncomp, precision, w, h, ctx->stage[0], stride);
+    if (r != J2K_OK) return r;
+    HIPCHK(ctx, hipMemcpy2DAsync(pix, stride, ctx->stage[0], stride, (size_t)w * bpp, (size_t)h, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return J2K_OK;
+}
+
+// can the level-0 5-3 + RCT kernels read / write packed RGBA8 directly?
+static bool rgba8_fusable(const j2k_plan *P, const void *d_pix, size_t stride, bool inverse) {
+    const PlanSpec &S = P->spec;
+    if (S.wavelet != W53 || !S.mct || S.C != 3 || S.levels < 1 || S.dc_shift != 128) return false;
+    const LevelTab &T = (inverse ? P->inv : P->fwd)[1][0];
+    if (!T.njobs || !T.vec || T.cpl != 8 || (inverse ? P->inv : P->fwd)[0][0].njobs) return false;
+    if (P->tail_l0 == 0) return false;
+    return !(((uintptr_t)d_pix | stride) & 15);
+}
+
+extern "C" int j2k_plan_forward_rgba8(j2k_plan *P, const void *d_pix, size_t stride, int32_t *d_coeff) {
+    if (!P || !d_pix || !d_coeff) return J2K_ERR_INVALID_ARG;
+    j2k_ctx *ctx = P->ctx;
+    const PlanSpec &S = P->spec;
+    if (S.C != 3) return fail(ctx, J2K_ERR_INVALID_ARG, "j2k_plan_forward_rgba8 needs a 3-component plan");
+    if (stride < (size_t)S.W * 4 || (((uintptr_t)d_pix | stride) & 3)) return fail(ctx, J2K_ERR_INVALID_ARG, "bad RGBA8 stride / alignment");
+    if (rgba8_fusable(P, d_pix, stride, false)) return plan_forward_impl(P, d_pix, d_coeff, (int)(stride / 4));
+    int r = stage_reserve(ctx, 0, (size_t)S.W * S.H * 3 * 4 + 64);          // int32 staging frame
+    if (r != J2K_OK) return r;
+    r = j2k_unpack_pixels(ctx, J2K_PIX_RGBA8, d_pix, stride, S.W, S.H, 0, (int32_t *)ctx->stage[0]);
+    if (r != J2K_OK) return r;
+    return plan_forward_impl(P, ctx->stage[0], d_coeff);
+}
+
+extern "C" int j2k_plan_inverse_rgba8(j2k_plan *P, const int32_t *d_coeff, void *d_pix, size_t stride) {
+    if (!P || !d_pix || !d_coeff) return J2K_ERR_INVALID_ARG;
+    j2k_ctx *ctx = P->ctx;
+    const PlanSpec &S = P->spec;
+    if (S.C != 3) return fail(ctx, J2K_ERR_INVALID_ARG, "j2k_plan_inverse_rgba8 needs a 3-component plan");
+    if (S.dc_shift != 128) return fail(ctx, J2K_ERR_UNSUPPORTED, "j2k_plan_inverse_rgba8 needs an unsigned 8-bit plan");
+    if (stride < (size_t)S.W * 4 || (((uintptr_t)d_pix | stride) & 3)) return fail(ctx, J2K_ERR_INVALID_ARG, "bad RGBA8 stride / alignment");
+    if (rgba8_fusable(P, d_pix, stride, true)) return plan_inverse_impl(P, d_coeff, d_pix, (int)(stride / 4));
+    int r = stage_reserve(ctx, 0, (size_t)S.W * S.H * 3 * 4 + 64);
+    if (r != J2K_OK) return r;
+    r = plan_inverse_impl(P, d_coeff, ctx->stage[0]);
+    if (r != J2K_OK) return r;
+    return j2k_pack_pixels(ctx, (const int32_t *)ctx->stage[0], 3, 8, S.W, S.H, d_pix, stride);
 }
 
 static size_t t1_work_per_job(const j2k_plan *P) {

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
+#include "../../include/j2kgfx.h"
 
 namespace j2k {
 
@@ -56,6 +58,9 @@ struct LevelLaunch {
     int vec;              // 1: every plane satisfies the vector-access alignment rules
     int ncomp;            // 1 or 3 (3 = fused colour transform on level 0)
     int pf;               // forward 5-3: software-prefetch variant
+    int pix_stride;       // level 0 of an RGB triple: > 0 = the frame is packed RGBA8 with this row stride in PIXELS
+    hipEvent_t ev_start, ev_stop;   // non-null: the dispatch itself stamps these (hipExtLaunchKernelGGL) -- the kernel's own
+                                    // begin / end, without the launch gap an event pair around the launch would include
 };
 
 hipError_t launch_dwt53_fwd(hipStream_t s, const LevelLaunch &L, const int32_t *src, int32_t *out,
@@ -66,5 +71,9 @@ hipError_t launch_dwt53_tail_fwd(hipStream_t s, const TailPlane *planes, int npl
                                  int32_t *coef);
 hipError_t launch_dwt53_tail_inv(hipStream_t s, const TailPlane *planes, int nplanes, size_t lds_bytes, const int32_t *coef,
                                  int32_t *scr);
+
+hipError_t launch_unpack_pixels(hipStream_t s, const uint8_t *pix, size_t stride, int format, int w, int h, int src_max, int dst_max,
+                                int32_t *planes);
+hipError_t launch_pack_pixels(hipStream_t s, const int32_t *planes, int ncomp, int precision, int w, int h, uint8_t *pix, size_t stride);
 
 }  // namespace j2k

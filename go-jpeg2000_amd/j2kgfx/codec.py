@@ -102,6 +102,21 @@ class FramePlan:
         self.ctx.check(self.ctx.L.j2k_plan_inverse(self.h, self._p(coeff), self._p(frame)))
         return frame
 
+    def forward_rgba8(self, pix, coeff=None):
+        """extractImageData + preprocess fused: pix = device uint8 [H, stride] packed RGBA (image.RGBA.Pix)."""
+        coeff = coeff if coeff is not None else self.alloc_coeff()
+        assert pix.dim() == 2 and pix.shape[0] == self.height and pix.is_contiguous()
+        self.ctx.check(self.ctx.L.j2k_plan_forward_rgba8(self.h, self._p(pix), C.c_size_t(int(pix.shape[1])), self._p(coeff)))
+        return coeff
+
+    def inverse_rgba8(self, coeff, pix=None):
+        """inverse path + createImage (3 components, 8 bit) fused: returns device uint8 [H, W*4] packed RGBA."""
+        t = _torch()
+        if pix is None:
+            pix = t.empty((self.height, self.width * 4), dtype=t.uint8, device=self.device)
+        self.ctx.check(self.ctx.L.j2k_plan_inverse_rgba8(self.h, self._p(coeff), self._p(pix), C.c_size_t(int(pix.shape[1]))))
+        return pix
+
     def encode_blocks(self, coeff, slots=None, lens=None, numbps=None):
         t = _torch()
         n = int(self.info.blocks)

@@ -58,8 +58,9 @@ void *j2k_ctx_stream(j2k_ctx *ctx);             /* the hipStream_t, for event ti
 const char *j2k_ctx_last_error(j2k_ctx *ctx);   /* text of the last non-OK status */
 const char *j2k_status_string(int status);
 const char *j2k_version(void);
-/* Kernel timing for bench.py's roofline line: while enabled, every j2k_plan_forward records a
- * HIP event pair around its level-0 DWT launch(es) on the ctx stream.  j2k_ctx_profile_read
+/* Kernel timing for bench.py's roofline line: while enabled, every j2k_plan_forward has the
+ * level-0 5-3 dispatch of its RGB triples stamp a HIP event pair with the kernel's own begin and
+ * end (hipExtLaunchKernelGGL start/stop events on the ctx stream).  j2k_ctx_profile_read
  * synchronises, returns the number of recorded launches and their summed duration in ms, and
  * resets the counters. */
 int j2k_ctx_profile_enable(j2k_ctx *ctx, int on);
@@ -189,6 +190,42 @@ int j2k_plan_decode_blocks(j2k_plan *plan, const uint8_t *d_stream, const uint64
                            const uint32_t *d_lens, const uint8_t *d_numbps, int32_t *d_decoded);
 /* job j's offset (in int32 elements) into d_decoded */
 int j2k_plan_get_decoded_offsets(const j2k_plan *plan, uint64_t *offs, size_t cap);
+
+/* ---- pixels at native width ------------------------------------------------
+ * encoder.extractImageData (encoder.go:79-213) and decoder.createImage (decoder.go:417-588): the
+ * host loops on either side of the tile-component path.  Pixel buffers are Go image.* Pix layouts
+ * (row-major, `stride` bytes per row, 16-bit samples big-endian). */
+enum {
+    J2K_PIX_GRAY8 = 0,     /* *image.Gray     1 component,  8 bit   (encoder.go:83-93)   */
+    J2K_PIX_GRAY16 = 1,    /* *image.Gray16   1 component, 16 bit   (encoder.go:95-105)  */
+    J2K_PIX_RGBA8 = 2,     /* *image.RGBA     3 components (alpha ignored), 8 bit (encoder.go:107-123) */
+    J2K_PIX_RGBA64 = 3,    /* *image.RGBA64   3 components, 16 bit  (encoder.go:125-141) */
+    J2K_PIX_NRGBA8 = 4,    /* *image.NRGBA    4 components, 8 bit   (encoder.go:143-160) */
+    J2K_PIX_NRGBA64 = 5    /* *image.NRGBA64  4 components, 16 bit  (encoder.go:162-179) */
+};
+/* components / source precision of a pixel format (0 for an unknown format) */
+int j2k_pixels_components(int format);
+int j2k_pixels_precision(int format);
+/* extractImageData on HOST buffers: pix -> planes[c] (ncomp planes of w*h int32, caller-allocated).
+ * target_precision 1..16 applies the Options.Precision rescale (encoder.go:196-210); 0 keeps the
+ * source precision.  The pixels cross PCIe at native width. */
+int j2k_extract_image_data(j2k_ctx *ctx, int format, const void *pix, size_t stride, int w, int h,
+                           int target_precision, int32_t *const *planes);
+/* createImage on HOST buffers: planes[c] -> pix.  ncomp 1 -> Gray (precision <= 8) / Gray16;
+ * 3 or 4 -> RGBA (precision <= 8) / RGBA64; other ncomp -> J2K_ERR_UNSUPPORTED (decoder.go:583-585). */
+int j2k_create_image(j2k_ctx *ctx, const int32_t *const *planes, int ncomp, int precision, int w, int h,
+                     void *pix, size_t stride);
+/* the same on DEVICE buffers (d_planes = ncomp planes of w*h int32, contiguous) */
+int j2k_unpack_pixels(j2k_ctx *ctx, int format, const void *d_pix, size_t stride, int w, int h,
+                      int target_precision, int32_t *d_planes);
+int j2k_pack_pixels(j2k_ctx *ctx, const int32_t *d_planes, int ncomp, int precision, int w, int h,
+                    void *d_pix, size_t stride);
+/* j2k_plan_forward / j2k_plan_inverse with the frame as packed 8-bit RGBA on the device
+ * (extractImageData + preprocess, and the inverse path + createImage, fused): for a 3-component
+ * 8-bit plan.  The 5-3 + RCT level-0 kernels read / write the pixels directly when the geometry
+ * allows 16-byte accesses (otherwise the pixels pass through an int32 staging frame). */
+int j2k_plan_forward_rgba8(j2k_plan *plan, const void *d_pix, size_t stride, int32_t *d_coeff);
+int j2k_plan_inverse_rgba8(j2k_plan *plan, const int32_t *d_coeff, void *d_pix, size_t stride);
 
 /* Whole shard from HOST planes, mirroring encoder.preprocess + encodeTile
  * (encoder.go:216-281, 597-688): planes[c] = host int32 W*H, mutated in place to

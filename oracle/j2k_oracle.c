@@ -347,6 +347,66 @@ void orc_tcd_inverse_dwt(int32_t *d, int w, int h, int levels, int reversible) {
     free(f);
 }
 
+/* ---- pixels: encoder.go:79-213, decoder.go:417-588 ------------------------------------------ */
+static int32_t go_mul32(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }   /* Go int32 multiply wraps */
+static int be16p(const uint8_t *p) { return (p[0] << 8) | p[1]; }
+
+int orc_extract_image_data(int format, const uint8_t *pix, size_t stride, int w, int h, int target_precision, int32_t **planes) {
+    static const int comps[6] = {1, 1, 3, 3, 4, 4}, prec[6] = {8, 16, 8, 16, 8, 16};
+    if (format < 0 || format > 5) return 0;
+    const int nc = comps[format];
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const uint8_t *row = pix + (size_t)y * stride;
+            const size_t idx = (size_t)y * w + x;
+            switch (format) {
+            case 0: planes[0][idx] = row[x]; break;                                           /* GrayAt(x,y).Y */
+            case 1: planes[0][idx] = be16p(row + 2 * x); break;                               /* Gray16At */
+            case 2: case 4:                                                                   /* RGBAAt / NRGBAAt */
+                for (int c = 0; c < nc; c++) planes[c][idx] = row[4 * x + c];
+                break;
+            default:                                                                          /* RGBA64At / NRGBA64At */
+                for (int c = 0; c < nc; c++) planes[c][idx] = be16p(row + 8 * x + 2 * c);
+            }
+        }
+    if (target_precision > 0 && target_precision <= 16 && target_precision != prec[format]) {  /* encoder.go:196-210 */
+        const int32_t srcMax = (int32_t)((1 << prec[format]) - 1), dstMax = (int32_t)((1 << target_precision) - 1);
+        for (int c = 0; c < nc; c++)
+            for (size_t i = 0; i < (size_t)w * h; i++) planes[c][i] = go_mul32(planes[c][i], dstMax) / srcMax;
+    }
+    return nc;
+}
+
+int orc_create_image(int32_t *const *planes, int ncomp, int precision, int w, int h, uint8_t *pix, size_t stride) {
+    if (ncomp != 1 && ncomp != 3 && ncomp != 4) return 0;                                     /* decoder.go:583-585 */
+    const int32_t maxVal = (int32_t)((1 << precision) - 1);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const size_t idx = (size_t)y * w + x;
+            uint8_t *row = pix + (size_t)y * stride;
+            int32_t v[4] = {0, 0, 0, 0};
+            for (int c = 0; c < ncomp; c++) {
+                int32_t t = planes[c][idx];
+                if (t < 0) t = 0;
+                if (t > maxVal) t = maxVal;
+                if (precision <= 8) { if (precision != 8) t = go_mul32(t, 255) / maxVal; }
+                else t = go_mul32(t, 65535) / maxVal;
+                v[c] = t;
+            }
+            if (ncomp == 1) {
+                if (precision <= 8) row[x] = (uint8_t)v[0];                                    /* color.Gray{Y: uint8(v)} */
+                else { const uint16_t u = (uint16_t)v[0]; row[2 * x] = (uint8_t)(u >> 8); row[2 * x + 1] = (uint8_t)u; }
+            } else if (precision <= 8) {
+                row[4 * x] = (uint8_t)v[0]; row[4 * x + 1] = (uint8_t)v[1]; row[4 * x + 2] = (uint8_t)v[2];
+                row[4 * x + 3] = ncomp == 4 ? (uint8_t)v[3] : 255;
+            } else {
+                const uint16_t o[4] = {(uint16_t)v[0], (uint16_t)v[1], (uint16_t)v[2], ncomp == 4 ? (uint16_t)v[3] : (uint16_t)65535};
+                for (int c = 0; c < 4; c++) { row[8 * x + 2 * c] = (uint8_t)(o[c] >> 8); row[8 * x + 2 * c + 1] = (uint8_t)o[c]; }
+            }
+        }
+    return ncomp;
+}
+
 void orc_postprocess(int32_t **planes, int ncomp, size_t n, int precision,
                      int reversible, int mct, int is_signed) {        /* decoder.go:321-348 */
     if (mct && ncomp >= 3) {

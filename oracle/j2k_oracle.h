@@ -61,6 +61,10 @@ void orc_tcd_forward_dwt(int32_t *d, int w, int h, int levels, int reversible);
 /* tcd.TileDecoder.ApplyInverseDWT (tcd.go:416-437): 9-7 path rounds int32(v+0.5) */
 void orc_tcd_inverse_dwt(int32_t *d, int w, int h, int levels, int reversible);
 /* decoder.decodeTiles tail (decoder.go:321-348): inverse MCT (if mct && C>=3) + DC shift (unsigned) */
+/* encoder.extractImageData (encoder.go:79-213) / decoder.createImage (decoder.go:417-588) on Go image Pix layouts;
+ * formats: 0 Gray 1 Gray16 2 RGBA 3 RGBA64 4 NRGBA 5 NRGBA64.  Return the component count (0 = bad argument). */
+int orc_extract_image_data(int format, const uint8_t *pix, size_t stride, int w, int h, int target_precision, int32_t **planes);
+int orc_create_image(int32_t *const *planes, int ncomp, int precision, int w, int h, uint8_t *pix, size_t stride);
 void orc_postprocess(int32_t **planes, int ncomp, size_t n, int precision,
                      int reversible, int mct, int is_signed);
 

@@ -150,6 +150,30 @@ def postprocess(planes, precision, reversible, mct=True, is_signed=False):
 
 
 # ---- MQ ----------------------------------------------------------------------
+def extract_image_data(pix, fmt, w, h, target_precision=0):
+    """encoder.extractImageData (encoder.go:79-213) on a Go Pix buffer (uint8 [h, stride])."""
+    pix = np.ascontiguousarray(pix, dtype=np.uint8).reshape(h, -1)
+    nc = [1, 1, 3, 3, 4, 4][fmt]
+    planes = [np.zeros(h * w, dtype=np.int32) for _ in range(nc)]
+    r = lib().orc_extract_image_data(int(fmt), _u8(pix), C.c_size_t(pix.shape[1]), int(w), int(h), int(target_precision),
+                                     _plane_ptrs(planes))
+    assert r == nc
+    return [p.reshape(h, w) for p in planes]
+
+
+def create_image(planes, precision, stride=None):
+    """decoder.createImage (decoder.go:417-588): returns the uint8 Pix buffer [h, stride]."""
+    nc = len(planes)
+    h, w = np.asarray(planes[0]).shape
+    bpp = (1 if nc == 1 else 4) * (2 if precision > 8 else 1)
+    stride = stride or w * bpp
+    planes = [_own_i32(p).reshape(-1) for p in planes]
+    pix = np.zeros((h, stride), dtype=np.uint8)
+    r = lib().orc_create_image(_plane_ptrs(planes), nc, int(precision), int(w), int(h), _u8(pix), C.c_size_t(stride))
+    assert r == nc
+    return pix
+
+
 def mq_encode(ctx, dec):
     ctx = np.ascontiguousarray(ctx, dtype=np.uint8); dec = np.ascontiguousarray(dec, dtype=np.uint8)
     out = np.zeros(ctx.size * 2 + 64, dtype=np.uint8)

@@ -1,0 +1,82 @@
+"""GPU: pixel unpack / pack at native width through the C ABI, against the oracle's
+extractImageData / createImage; and the fused RGBA8 forward / inverse against unpack + j2k_plan_forward."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+BPP = [1, 2, 4, 8, 4, 8]
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import oracle as orc
+    orc.lib()
+    return orc
+
+
+@pytest.mark.parametrize("fmt", range(6))
+@pytest.mark.parametrize("target", [0, 8, 12, 16, 3])
+@pytest.mark.parametrize("w,h,pad", [(64, 48, 0), (37, 11, 12), (1, 1, 4), (513, 3, 4)])
+def test_extract_image_data(oracle, fmt, target, w, h, pad):
+    from j2kgfx import pixels
+    rng = np.random.default_rng(fmt * 131 + target * 7 + w)
+    stride = w * BPP[fmt] + pad
+    pix = rng.integers(0, 256, (h, stride)).astype(np.uint8)
+    got = pixels.extract_image_data(pix, fmt, w, h, target)
+    want = oracle.extract_image_data(pix, fmt, w, h, target)
+    assert len(got) == pixels.components(fmt) == len(want)
+    for g, wnt in zip(got, want):
+        assert np.array_equal(g, wnt)
+
+
+@pytest.mark.parametrize("nc", [1, 3, 4])
+@pytest.mark.parametrize("prec", [1, 5, 8, 10, 12, 16])
+@pytest.mark.parametrize("w,h,pad", [(64, 48, 0), (29, 9, 8), (1, 2, 4)])
+def test_create_image(oracle, nc, prec, w, h, pad):
+    from j2kgfx import pixels
+    rng = np.random.default_rng(nc * 17 + prec + w)
+    mx = (1 << prec) - 1
+    planes = [rng.integers(-40, mx + 40, (h, w)).astype(np.int32) for _ in range(nc)]
+    planes[0][0, 0] = -2147483648
+    planes[-1][h - 1, w - 1] = 2147483647
+    bpp = (1 if nc == 1 else 4) * (2 if prec > 8 else 1)
+    stride = w * bpp + pad
+    got = pixels.create_image(planes, prec, stride)
+    want = oracle.create_image(planes, prec, stride)
+    assert np.array_equal(got[:, :w * bpp], want[:, :w * bpp])          # stride padding is not part of the image
+
+
+def test_create_image_rejects_two_components():
+    from j2kgfx import J2KError, pixels
+    with pytest.raises(J2KError):
+        pixels.create_image([np.zeros((2, 2), np.int32)] * 2, 8)          # decoder.go:583-585
+
+
+@pytest.mark.parametrize("W,H,tile,pad", [(3840, 2160, 512, 0), (1024, 512, 512, 64), (200, 96, 0, 0), (100, 75, 64, 4)])
+def test_plan_forward_inverse_rgba8(oracle, W, H, tile, pad):
+    """fused level-0 path (16-byte aligned geometries) and the staging fallback (odd sizes): identical coefficients to
+    extractImageData + preprocess, identical pixels to the inverse path + createImage."""
+    import torch
+    from j2kgfx.codec import FramePlan
+    rng = np.random.default_rng(W + pad)
+    stride = W * 4 + pad
+    pix = rng.integers(0, 256, (H, stride)).astype(np.uint8)
+    plan = FramePlan(W, H, 3, precision=8, lossless=True, num_resolutions=6, cb=(64, 64), tile=(tile, tile), coder=1)
+    dpix = torch.from_numpy(pix).to(plan.device)
+    planes = oracle.extract_image_data(pix, 2, W, H)                      # image.RGBA: 3 components
+    frame = torch.from_numpy(np.stack(planes)).to(plan.device)
+    torch.cuda.synchronize()
+    want = plan.forward(frame)
+    got = plan.forward_rgba8(dpix)
+    plan.ctx.sync()
+    assert torch.equal(got, want)
+    back = plan.inverse(got)
+    bpix = plan.inverse_rgba8(got)
+    plan.ctx.sync()
+    want_pix = oracle.create_image([p for p in back.cpu().numpy()], 8)
+    assert np.array_equal(bpix.cpu().numpy(), want_pix)
+    assert np.array_equal(bpix.cpu().numpy().reshape(H, W, 4)[..., :3], pix[:, :W * 4].reshape(H, W, 4)[..., :3])   # lossless
