@@ -983,8 +983,10 @@ static hipError_t fwd_go(hipStream_t s, const LevelLaunch &L, const int32_t *src
     const int blocks = (L.njobs + 3) / 4;
     if constexpr (CPL == 8 && NC == 3 && VEC) {
         if (L.pix_stride > 0) {   // packed RGBA8 frame: its own instantiation, so the planar kernel is untouched
-            hipExtLaunchKernelGGL((dwt53_fwd_kernel<CPL, NC, VEC, false, true>), dim3(blocks), dim3(256), 0, s, L.ev_start, L.ev_stop, 0,
-                                  L.jobs, L.njobs, L.planes, src, out, nxt, dc, L.pix_stride);
+            if (L.pf) hipExtLaunchKernelGGL((dwt53_fwd_kernel<CPL, NC, VEC, true, true>), dim3(blocks), dim3(256), 0, s, L.ev_start, L.ev_stop, 0,
+                                            L.jobs, L.njobs, L.planes, src, out, nxt, dc, L.pix_stride);
+            else hipExtLaunchKernelGGL((dwt53_fwd_kernel<CPL, NC, VEC, false, true>), dim3(blocks), dim3(256), 0, s, L.ev_start, L.ev_stop, 0,
+                                       L.jobs, L.njobs, L.planes, src, out, nxt, dc, L.pix_stride);
             return hipGetLastError();
         }
     }
