@@ -99,10 +99,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    if os.environ.get("J2K_BENCH_BACKEND", "nccl") != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        # J2K_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks (ranks share
+        # devices; the streams are staged through host memory for the gather) -- not a measurement mode
+        backend = os.environ.get("J2K_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     F = max(1, args.inflight)
     frame_h = synth_frame(np, rank)
@@ -168,6 +176,8 @@ def main():
         for ln in lanes:
             ln.ctx.sync()                               # bytes must be complete before RCCL reads them
         items = [(ln.stream, int(ln.offs[ln.n].item())) for ln in lanes]
+        if os.environ.get("J2K_BENCH_BACKEND", "nccl") != "nccl":
+            items = [(t[:n_].cpu(), n_) for t, n_ in items]
         g = jdist.gather_streams_start(items, outs=[ln.gather_buf for ln in lanes])
         for ln in lanes:
             ln.decode_side()
@@ -232,7 +242,7 @@ def main():
         copy_gbs = 24 * 2 * nel * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
         del srcs, dsts
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=plan.device)
+        t = torch.tensor([dt], dtype=torch.float64, device=plan.device if os.environ.get("J2K_BENCH_BACKEND", "nccl") == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
