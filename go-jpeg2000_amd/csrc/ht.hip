@@ -617,7 +617,6 @@ __device__ bool init_mel_ok(const uint8_t *data, long len, long lcup, long scup)
 #define HT_WALK_ROW 764                        /* LDS row: tail + 3 alignment bytes, 191 words (odd stride)          */
 #define HT_DEC_MWORDS (33 * HT_FAST_MAX_SAMPLES / 32 + 8)
 #define HT_WALK_REC 132                        /* words per block: 128 pair records + flags (+pad) */
-#define HT_FLAG_BIGU 1u                         /* some decoded u exceeds 32: the extraction must emulate the bit-counter wrap */
 #define HT_PAIR_SERIAL 0xFFFFFFFFu              /* record[0]: decode this block with the serial path */
 #define HT_PAIR_ZERO 0xFFFFFFFEu                /* record[0]: invalid stream -> output stays zero     */
 
@@ -867,14 +866,12 @@ __device__ uint32_t ht_loaded_bits(const HtDecShared &S, uint32_t nff, long segL
 
 // returns false when the block needs the bit-serial decoder (never on encoder output)
 __device__ bool ht_extract_fast(HtDecShared &S, const uint8_t *__restrict__ data, long len, long scup, int w, int h,
-                                int32_t *__restrict__ out, int lane, int phases, bool bigu) {
+                                int32_t *__restrict__ out, int lane, bool bigu) {
     const int quadCols = (w + 3) / 4, P = (quadCols + 1) / 2, R = (h + 3) / 4, N = R * P;
     const long lcup = len;
-    if (phases == 21) return true;
     for (int i = lane; i < HT_DEC_MWORDS; i += 64) S.mbuf[i] = 0;
     if (lane == 0) S.nff = 0;
     wave_sync();
-    if (phases == 22) return true;
     constexpr int PF = 4;   // prefetch 4 x 256 bytes (one aligned dword per lane each) before processing
     {
         const long segLen = lcup - scup;
@@ -934,7 +931,6 @@ __device__ bool ht_extract_fast(HtDecShared &S, const uint8_t *__restrict__ data
             }
         }
         wave_sync();
-        if (phases == 23) return true;
         if (bigu && (nb != segLen || S.nff > HT_MAX_FF)) return false;
         if (nb == segLen) {   // everything past the segment reads as ones (ht.go:407, 447-449, 462-464)
             const uint32_t wd0 = off >> 5;
@@ -943,7 +939,6 @@ __device__ bool ht_extract_fast(HtDecShared &S, const uint8_t *__restrict__ data
         }
     }
     wave_sync();
-    if (phases < 3 || phases > 20) return true;
     // ---- u > 32: the reference's uint32 bit counter wraps when it advances by more bits than it has loaded
     //      (ht.go:515-519); from then on the reader never refills and everything reads as zero.  Equivalent:
     //      the bit string is cut to zeros at L = "bits loaded when the first such advance happens".  Find L. ----
@@ -1046,7 +1041,7 @@ __device__ bool ht_extract_fast(HtDecShared &S, const uint8_t *__restrict__ data
 __global__ __launch_bounds__(256) void ht_decode_kernel(const BlockJob *__restrict__ jobs, int njobs,
                                                         const uint8_t *__restrict__ stream, const uint64_t *__restrict__ offs,
                                                         const uint32_t *__restrict__ lens, int32_t *__restrict__ decoded,
-                                                        const uint32_t *__restrict__ pairs, int phases) {
+                                                        const uint32_t *__restrict__ pairs) {
     __shared__ HtDecShared S4[4];
     HtDecShared &S = S4[threadIdx.x >> 6];
     const int jid = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1060,7 +1055,7 @@ __global__ __launch_bounds__(256) void ht_decode_kernel(const BlockJob *__restri
     const uint32_t *rec = pairs + (size_t)jid * HT_WALK_REC;
     const uint32_t r0 = rec[lane], r1 = rec[64 + lane];
     const uint32_t tag = __shfl(r0, 0);
-    const bool fast = (tag != HT_PAIR_ZERO) && (tag != HT_PAIR_SERIAL) && (phases & 0xFF) >= 2;
+    const bool fast = (tag != HT_PAIR_ZERO) && (tag != HT_PAIR_SERIAL);
     // fresh NewHTDecoder: zeroed data.  On the fast path the coded rows (y % 4 == 0) are written in full by the
     // extraction and the other rows are zeroed LAST (vmcnt retires in order: a load issued behind these
     // stores would wait for all of them).  Other paths zero everything up front.
@@ -1107,12 +1102,12 @@ __global__ __launch_bounds__(256) void ht_decode_kernel(const BlockJob *__restri
         bigu = __any(bigu);
     }
     wave_sync();
-    if (tag == HT_PAIR_ZERO || (phases & 0xFF) < 2 || (phases & 0xFF) == 20) return;
+    if (tag == HT_PAIR_ZERO) return;
     if (tag != HT_PAIR_SERIAL) {
         const uint8_t *fdata = stream + offs[jid];
         const long flen = (long)lens[jid];
         const long fscup = (long)__shfl(rec[HT_WALK_MAX_PAIRS], 0);   // validated by ht_vlcprep_kernel
-        if (ht_extract_fast(S, fdata, flen, fscup, w, h, out, lane, phases & 0xFF, bigu)) {
+        if (ht_extract_fast(S, fdata, flen, fscup, w, h, out, lane, bigu)) {
             zero_fill(true);
             return;
         }
@@ -1242,9 +1237,7 @@ hipError_t launch_ht_decode(hipStream_t s, const BlockJob *jobs, int njobs, cons
     if ((e = hipGetLastError()) != hipSuccess) return e;
     hipLaunchKernelGGL(ht_walk_kernel, dim3((njobs + 63) / 64), dim3(256), sizeof(HtWalkShared), s, jobs, njobs, vbits, pairs);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    static int phases = -1;   // debug knob (timing only): J2K_HT_DEC_PHASES=1 zero fill, 2 + MagSgn unstuffing, 3 everything
-    if (phases < 0) { const char *en = getenv("J2K_HT_DEC_PHASES"); phases = en ? atoi(en) : 3; }
-    hipLaunchKernelGGL(ht_decode_kernel, dim3((njobs + 3) / 4), dim3(256), 0, s, jobs, njobs, stream, offs, lens, decoded, pairs, phases);
+    hipLaunchKernelGGL(ht_decode_kernel, dim3((njobs + 3) / 4), dim3(256), 0, s, jobs, njobs, stream, offs, lens, decoded, pairs);
     return hipGetLastError();
 }
 
