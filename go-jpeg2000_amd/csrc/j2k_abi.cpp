@@ -29,6 +29,10 @@ hipError_t launch_t1_encode(hipStream_t s, const BlockJob *jobs, int njobs, cons
 hipError_t launch_t1_decode(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs,
                             const uint32_t *lens, const uint8_t *numbps, int32_t *decoded, uint8_t *work,
                             size_t work_per_job);
+hipError_t launch_mq_encode(hipStream_t s, const uint8_t *ctxs, const uint8_t *decs, size_t n, uint8_t *out, size_t cap, uint32_t *out_len, int *fault);
+hipError_t launch_mq_decode(hipStream_t s, const uint8_t *data, size_t len, const uint8_t *ctxs, size_t n, uint8_t *decs, int *fault);
+hipError_t launch_raw_encode(hipStream_t s, const uint8_t *bits, size_t n, uint8_t *out, size_t cap, uint32_t *out_len, int *fault);
+hipError_t launch_raw_decode(hipStream_t s, const uint8_t *data, size_t len, size_t n, uint8_t *bits);
 size_t t1_work_bytes(int w, int h);
 size_t t1_flag_bytes(int w, int h);
 hipError_t launch_compact(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *slots, const uint32_t *lens,
@@ -617,6 +621,58 @@ static int ensure(j2k_ctx *ctx, void **p, size_t bytes) {
     if (*p) return J2K_OK;
     HIPCHK(ctx, hipMalloc(p, std::max<size_t>(bytes, 16)));
     return J2K_OK;
+}
+
+// ---- stand-alone coders (mqc.go): host buffers through the staging slots ------------------------
+// slot 0: inputs (a | b), slot 1: output, slot 3: {fault, out_len}
+static int coder_call(j2k_ctx *ctx, int which, const uint8_t *a, size_t na, const uint8_t *b, size_t nb, size_t n, uint8_t *out, size_t cap,
+                      size_t *out_len) {
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int r = stage_reserve(ctx, 0, na + nb + 64);
+    if (r == J2K_OK) r = stage_reserve(ctx, 1, cap + 64);
+    if (r == J2K_OK) r = stage_reserve(ctx, 3, 256);
+    if (r != J2K_OK) return r;
+    uint8_t *d_a = (uint8_t *)ctx->stage[0], *d_b = d_a + ((na + 15) & ~size_t(15)), *d_out = (uint8_t *)ctx->stage[1];
+    r = stage_reserve(ctx, 0, ((na + 15) & ~size_t(15)) + nb + 64);
+    if (r != J2K_OK) return r;
+    d_a = (uint8_t *)ctx->stage[0]; d_b = d_a + ((na + 15) & ~size_t(15));
+    int *d_fault = (int *)ctx->stage[3];
+    uint32_t *d_len = (uint32_t *)ctx->stage[3] + 4;
+    HIPCHK(ctx, hipMemsetAsync(d_fault, 0, 32, ctx->stream));
+    if (na) HIPCHK(ctx, hipMemcpyAsync(d_a, a, na, hipMemcpyHostToDevice, ctx->stream));
+    if (nb) HIPCHK(ctx, hipMemcpyAsync(d_b, b, nb, hipMemcpyHostToDevice, ctx->stream));
+    switch (which) {
+    case 0: HIPCHK(ctx, launch_mq_encode(ctx->stream, d_a, d_b, n, d_out, cap, d_len, d_fault)); break;
+    case 1: HIPCHK(ctx, launch_mq_decode(ctx->stream, d_a, na, d_b, n, d_out, d_fault)); break;
+    case 2: HIPCHK(ctx, launch_raw_encode(ctx->stream, d_a, n, d_out, cap, d_len, d_fault)); break;
+    default: HIPCHK(ctx, launch_raw_decode(ctx->stream, d_a, na, n, d_out)); break;
+    }
+    int h[8] = {0};
+    HIPCHK(ctx, hipMemcpyAsync(h, d_fault, 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (h[0] == 3) return fail(ctx, J2K_ERR_GO_PANIC, "context index out of range (the Go coder panics)");
+    if (h[0] == 2) return fail(ctx, J2K_ERR_CAPACITY, "output buffer too small");
+    const size_t produced = (which == 0 || which == 2) ? (size_t)(uint32_t)h[4] : n;
+    if (out_len) *out_len = produced;
+    if (produced) HIPCHK(ctx, hipMemcpy(out, d_out, std::min(produced, cap), hipMemcpyDeviceToHost));
+    return J2K_OK;
+}
+
+extern "C" int j2k_mq_encode(j2k_ctx *ctx, const uint8_t *ctxs, const uint8_t *decisions, size_t n, uint8_t *out, size_t cap, size_t *out_len) {
+    if (!ctx || !out_len || (n && (!ctxs || !decisions)) || (cap && !out)) return J2K_ERR_INVALID_ARG;
+    return coder_call(ctx, 0, ctxs, n, decisions, n, n, out, cap, out_len);
+}
+extern "C" int j2k_mq_decode(j2k_ctx *ctx, const uint8_t *data, size_t len, const uint8_t *ctxs, size_t n, uint8_t *decisions) {
+    if (!ctx || (len && !data) || (n && (!ctxs || !decisions))) return J2K_ERR_INVALID_ARG;
+    return coder_call(ctx, 1, data, len, ctxs, n, n, decisions, n, nullptr);
+}
+extern "C" int j2k_raw_encode(j2k_ctx *ctx, const uint8_t *bits, size_t n, uint8_t *out, size_t cap, size_t *out_len) {
+    if (!ctx || !out_len || (n && !bits) || (cap && !out)) return J2K_ERR_INVALID_ARG;
+    return coder_call(ctx, 2, bits, n, nullptr, 0, n, out, cap, out_len);
+}
+extern "C" int j2k_raw_decode(j2k_ctx *ctx, const uint8_t *data, size_t len, size_t n, uint8_t *bits) {
+    if (!ctx || (len && !data) || (n && !bits)) return J2K_ERR_INVALID_ARG;
+    return coder_call(ctx, 3, data, len, nullptr, 0, n, bits, n, nullptr);
 }
 
 // ---- pixels at native width (encoder.go:79-213, decoder.go:417-588) ----------------------------

@@ -791,6 +791,110 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(const BlockJob *__restric
     }
 }
 
+// ---- stand-alone coders: the reference's MQEncoder / MQDecoder / RawEncoder / RawDecoder as batch calls ----
+// mqc.go:169-349: NewMQEncoder, n x Encode(ctx, decision), Flush.  One wavefront, the coder on lane 0 (a single chain).
+__global__ __launch_bounds__(64) void mq_encode_kernel(const uint8_t *__restrict__ ctxs, const uint8_t *__restrict__ decs, size_t n,
+                                                       uint8_t *__restrict__ out, long cap, uint32_t *__restrict__ out_len, int *__restrict__ fault) {
+    __shared__ T1Tables T;
+    build_tables(T, 0, threadIdx.x);
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    MqEnc e{0x8000, 0, 12, 0, 0, out, cap, 0};
+    for (size_t i = 0; i < n; i++) {
+        const int c = ctxs[i];
+        if (c >= NumContexts) { atomicMax(fault, 3); *out_len = 0; return; }      // Go: index out of range panic
+        mq_encode(e, T, c, decs[i]);                                              // uint8(decision) == mps: a decision > 1 never matches
+    }
+    const uint32_t tempC = e.C + e.A;                                             // setbits + Flush, mqc.go:313-341
+    e.C |= 0xFFFF;
+    if (e.C >= tempC) e.C -= 0x8000;
+    e.C <<= e.CT; mq_byte_out(e);
+    e.C <<= e.CT; mq_byte_out(e);
+    long end = e.bp + 1;
+    if (e.cur == 0xFF) end--;
+    else if (e.bp >= 1) { if (e.bp - 1 < e.cap) out[e.bp - 1] = (uint8_t)e.cur; else e.overflow = 1; }
+    if (e.overflow) atomicMax(fault, 2);
+    *out_len = end > 1 ? (uint32_t)(end - 1) : 0;
+}
+
+// mqc.go:352-497: NewMQDecoder(data), n x Decode(ctx)
+__global__ __launch_bounds__(64) void mq_decode_kernel(const uint8_t *__restrict__ data, long len, const uint8_t *__restrict__ ctxs, size_t n,
+                                                       uint8_t *__restrict__ decs, int *__restrict__ fault) {
+    __shared__ T1Tables T;
+    build_tables(T, 0, threadIdx.x);
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    MqDec d{0, 0x8000, 0, -1, len, data};
+    if (d.len == 0) d.C = 0xFFu << 16; else { d.bp = 0; d.C = (uint32_t)d.data[0] << 16; }
+    mq_byte_in(d);
+    d.C <<= 7; d.CT -= 7; d.A = 0x8000;
+    for (size_t i = 0; i < n; i++) {
+        const int c = ctxs[i];
+        if (c >= NumContexts) { atomicMax(fault, 3); return; }
+        decs[i] = (uint8_t)mq_decode(d, T, c);
+    }
+}
+
+// mqc.go:560-600: RawEncoder.EncodeBit x n + Flush (bit stuffing: after an 0xFF byte the next byte carries 7 bits)
+__global__ void raw_encode_kernel(const uint8_t *__restrict__ bits, size_t n, uint8_t *__restrict__ out, size_t cap,
+                                  uint32_t *__restrict__ out_len, int *__restrict__ fault) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t c = 0;
+    int ct = 8;
+    size_t pos = 0;
+    for (size_t i = 0; i < n; i++) {
+        ct--;
+        c += (uint32_t)(bits[i] & 1) << ct;
+        if (ct == 0) {
+            if (pos < cap) out[pos] = (uint8_t)c; else atomicMax(fault, 2);
+            pos++;
+            ct = ((uint8_t)c == 0xFF) ? 7 : 8;
+            c = 0;
+        }
+    }
+    if (ct < 8) { if (pos < cap) out[pos] = (uint8_t)c; else atomicMax(fault, 2); pos++; }
+    *out_len = (uint32_t)pos;
+}
+
+// mqc.go:516-557: RawDecoder.DecodeBit x n
+__global__ void raw_decode_kernel(const uint8_t *__restrict__ data, size_t len, size_t n, uint8_t *__restrict__ bits) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    size_t pos = 0;
+    uint32_t c = 0;
+    int ct = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (ct == 0) {
+            if (c == 0xFF) {
+                if (pos < len && data[pos] > 0x8F) { c = 0xFF; ct = 8; }
+                else if (pos < len) { c = data[pos++]; ct = 7; }
+                else { c = 0xFF; ct = 8; }
+            } else {
+                if (pos < len) { c = data[pos++]; ct = 8; }
+                else { c = 0xFF; ct = 8; }
+            }
+        }
+        ct--;
+        bits[i] = (uint8_t)((c >> ct) & 1);
+    }
+}
+
+hipError_t launch_mq_encode(hipStream_t s, const uint8_t *ctxs, const uint8_t *decs, size_t n, uint8_t *out, size_t cap, uint32_t *out_len, int *fault) {
+    hipLaunchKernelGGL(mq_encode_kernel, dim3(1), dim3(64), 0, s, ctxs, decs, n, out, (long)cap, out_len, fault);
+    return hipGetLastError();
+}
+hipError_t launch_mq_decode(hipStream_t s, const uint8_t *data, size_t len, const uint8_t *ctxs, size_t n, uint8_t *decs, int *fault) {
+    hipLaunchKernelGGL(mq_decode_kernel, dim3(1), dim3(64), 0, s, data, (long)len, ctxs, n, decs, fault);
+    return hipGetLastError();
+}
+hipError_t launch_raw_encode(hipStream_t s, const uint8_t *bits, size_t n, uint8_t *out, size_t cap, uint32_t *out_len, int *fault) {
+    hipLaunchKernelGGL(raw_encode_kernel, dim3(1), dim3(64), 0, s, bits, n, out, cap, out_len, fault);
+    return hipGetLastError();
+}
+hipError_t launch_raw_decode(hipStream_t s, const uint8_t *data, size_t len, size_t n, uint8_t *bits) {
+    hipLaunchKernelGGL(raw_decode_kernel, dim3(1), dim3(64), 0, s, data, len, n, bits);
+    return hipGetLastError();
+}
+
 static int lds_for(size_t work_per_job) {
     const size_t tab = (sizeof(T1Tables) + 15) & ~size_t(15);
     size_t wb = work_per_job;

@@ -152,3 +152,70 @@ def PutHTEncoder(e):
 
 def PutHTDecoder(d):
     pass
+
+
+# ---- stand-alone coders (internal/entropy/mqc.go) ---------------------------------------------------
+def _buf(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8).reshape(-1)
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+def mq_encode(ctxs, decisions, ctx=None):
+    """NewMQEncoder(); for i: Encode(ctxs[i], decisions[i]); Flush()  (mqc.go:169-349).  Returns bytes (b"" for nil)."""
+    ctx = ctx or default_context()
+    cs, pc = _buf(ctxs)
+    ds, pd = _buf(decisions)
+    assert cs.size == ds.size
+    out = np.zeros(cs.size * 2 + 64, dtype=np.uint8)
+    n = C.c_size_t(0)
+    ctx.check(ctx.L.j2k_mq_encode(ctx.h, pc, pd, C.c_size_t(cs.size), out.ctypes.data_as(C.c_void_p), C.c_size_t(out.size), C.byref(n)))
+    return out[:n.value].tobytes()
+
+
+def mq_decode(data, ctxs, ctx=None):
+    """NewMQDecoder(data); [Decode(c) for c in ctxs]  (mqc.go:352-497)."""
+    ctx = ctx or default_context()
+    dat, pdat = _buf(np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data)
+    cs, pc = _buf(ctxs)
+    out = np.zeros(max(cs.size, 1), dtype=np.uint8)
+    ctx.check(ctx.L.j2k_mq_decode(ctx.h, pdat, C.c_size_t(dat.size), pc, C.c_size_t(cs.size), out.ctypes.data_as(C.c_void_p)))
+    return out[:cs.size]
+
+
+def raw_encode(bits, ctx=None):
+    """NewRawEncoder(); EncodeBit(b) for b in bits; Flush()  (mqc.go:560-600)."""
+    ctx = ctx or default_context()
+    bs, pb = _buf(bits)
+    out = np.zeros(bs.size // 7 + 16, dtype=np.uint8)
+    n = C.c_size_t(0)
+    ctx.check(ctx.L.j2k_raw_encode(ctx.h, pb, C.c_size_t(bs.size), out.ctypes.data_as(C.c_void_p), C.c_size_t(out.size), C.byref(n)))
+    return out[:n.value].tobytes()
+
+
+def raw_decode(data, n, ctx=None):
+    """NewRawDecoder(data); [DecodeBit() for _ in range(n)]  (mqc.go:516-557)."""
+    ctx = ctx or default_context()
+    dat, pdat = _buf(np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data)
+    out = np.zeros(max(n, 1), dtype=np.uint8)
+    ctx.check(ctx.L.j2k_raw_decode(ctx.h, pdat, C.c_size_t(dat.size), C.c_size_t(n), out.ctypes.data_as(C.c_void_p)))
+    return out[:n]
+
+
+class MQEncoder:
+    """Same call sequence as the Go type; the symbols are coded on the device at Flush()."""
+
+    def __init__(self):
+        self._c, self._d = [], []
+
+    def Reset(self):
+        self._c, self._d = [], []
+
+    def Encode(self, ctx, decision):
+        self._c.append(int(ctx)); self._d.append(int(decision) & 0xFF)
+
+    def Flush(self):
+        return mq_encode(self._c, self._d)
+
+
+def NewMQEncoder():
+    return MQEncoder()

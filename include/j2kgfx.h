@@ -191,6 +191,18 @@ int j2k_plan_decode_blocks(j2k_plan *plan, const uint8_t *d_stream, const uint64
 /* job j's offset (in int32 elements) into d_decoded */
 int j2k_plan_get_decoded_offsets(const j2k_plan *plan, uint64_t *offs, size_t cap);
 
+/* ---- stand-alone arithmetic / bypass coders (internal/entropy/mqc.go), host buffers ------------
+ * MQEncoder: NewMQEncoder, n x Encode(ctxs[i], decisions[i]), Flush (mqc.go:169-349); *out_len = 0
+ * is Flush's nil.  A context >= 19 is the Go index panic (J2K_ERR_GO_PANIC). */
+int j2k_mq_encode(j2k_ctx *ctx, const uint8_t *ctxs, const uint8_t *decisions, size_t n,
+                  uint8_t *out, size_t cap, size_t *out_len);
+/* MQDecoder: NewMQDecoder(data), n x Decode(ctxs[i]) -> decisions[i] (mqc.go:352-497) */
+int j2k_mq_decode(j2k_ctx *ctx, const uint8_t *data, size_t len, const uint8_t *ctxs, size_t n,
+                  uint8_t *decisions);
+/* RawEncoder: n x EncodeBit(bits[i]), Flush (mqc.go:560-600); RawDecoder: n x DecodeBit (mqc.go:516-557) */
+int j2k_raw_encode(j2k_ctx *ctx, const uint8_t *bits, size_t n, uint8_t *out, size_t cap, size_t *out_len);
+int j2k_raw_decode(j2k_ctx *ctx, const uint8_t *data, size_t len, size_t n, uint8_t *bits);
+
 /* ---- pixels at native width ------------------------------------------------
  * encoder.extractImageData (encoder.go:79-213) and decoder.createImage (decoder.go:417-588): the
  * host loops on either side of the tile-component path.  Pixel buffers are Go image.* Pix layouts

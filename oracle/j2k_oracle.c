@@ -347,6 +347,42 @@ void orc_tcd_inverse_dwt(int32_t *d, int w, int h, int levels, int reversible) {
     free(f);
 }
 
+/* ---- RawEncoder / RawDecoder, mqc.go:516-600 ------------------------------------------------- */
+long orc_raw_encode(const uint8_t *bits, size_t n, uint8_t *out, size_t cap) {
+    uint32_t c = 0; int ct = 8; size_t pos = 0;
+    for (size_t i = 0; i < n; i++) {                                  /* EncodeBit, mqc.go:577-589 */
+        ct--;
+        c = c + ((uint32_t)(bits[i] & 1) << ct);
+        if (ct == 0) {
+            if (pos >= cap) return -1;
+            out[pos++] = (uint8_t)c;
+            ct = 8;
+            if ((uint8_t)c == 0xFF) ct = 7;
+            c = 0;
+        }
+    }
+    if (ct < 8) { if (pos >= cap) return -1; out[pos++] = (uint8_t)c; } /* Flush, mqc.go:592-599 */
+    return (long)pos;
+}
+
+void orc_raw_decode(const uint8_t *data, size_t len, size_t n, uint8_t *bits) {
+    size_t pos = 0; uint8_t c = 0; int ct = 0;
+    for (size_t i = 0; i < n; i++) {                                  /* DecodeBit, mqc.go:535-557 */
+        if (ct == 0) {
+            if (c == 0xFF) {
+                if (pos < len && data[pos] > 0x8F) { c = 0xFF; ct = 8; }
+                else if (pos < len) { c = data[pos++]; ct = 7; }
+                else { c = 0xFF; ct = 8; }
+            } else {
+                if (pos < len) { c = data[pos++]; ct = 8; }
+                else { c = 0xFF; ct = 8; }
+            }
+        }
+        ct--;
+        bits[i] = (uint8_t)((c >> ct) & 1);
+    }
+}
+
 /* ---- pixels: encoder.go:79-213, decoder.go:417-588 ------------------------------------------ */
 static int32_t go_mul32(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }   /* Go int32 multiply wraps */
 static int be16p(const uint8_t *p) { return (p[0] << 8) | p[1]; }

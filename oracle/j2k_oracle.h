@@ -61,6 +61,9 @@ void orc_tcd_forward_dwt(int32_t *d, int w, int h, int levels, int reversible);
 /* tcd.TileDecoder.ApplyInverseDWT (tcd.go:416-437): 9-7 path rounds int32(v+0.5) */
 void orc_tcd_inverse_dwt(int32_t *d, int w, int h, int levels, int reversible);
 /* decoder.decodeTiles tail (decoder.go:321-348): inverse MCT (if mct && C>=3) + DC shift (unsigned) */
+/* RawEncoder / RawDecoder (mqc.go:516-600): n bits in (one per byte) -> bytes; returns the byte count / fills bits */
+long orc_raw_encode(const uint8_t *bits, size_t n, uint8_t *out, size_t cap);
+void orc_raw_decode(const uint8_t *data, size_t len, size_t n, uint8_t *bits);
 /* encoder.extractImageData (encoder.go:79-213) / decoder.createImage (decoder.go:417-588) on Go image Pix layouts;
  * formats: 0 Gray 1 Gray16 2 RGBA 3 RGBA64 4 NRGBA 5 NRGBA64.  Return the component count (0 = bad argument). */
 int orc_extract_image_data(int format, const uint8_t *pix, size_t stride, int w, int h, int target_precision, int32_t **planes);

@@ -25,6 +25,7 @@ def lib():
             build()
         _LIB = C.CDLL(path)
         _LIB.orc_mq_encode.restype = C.c_long
+        _LIB.orc_raw_encode.restype = C.c_long
         _LIB.orc_t1_encode.restype = C.c_long
         _LIB.orc_ht_encode.restype = C.c_long
         _LIB.orc_ht_bound.restype = C.c_size_t
@@ -187,6 +188,21 @@ def mq_decode(data, ctx):
     out = np.zeros(ctx.size, dtype=np.uint8)
     lib().orc_mq_decode(_u8(data), C.c_size_t(data.size), _u8(ctx), C.c_size_t(ctx.size), _u8(out))
     return out
+
+
+def raw_encode(bits):
+    bits = np.ascontiguousarray(bits, dtype=np.uint8)
+    out = np.zeros(bits.size // 7 + 16, dtype=np.uint8)
+    n = lib().orc_raw_encode(_u8(bits), C.c_size_t(bits.size), _u8(out), C.c_size_t(out.size))
+    assert n >= 0
+    return out[:n].copy()
+
+
+def raw_decode(data, n):
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    out = np.zeros(max(n, 1), dtype=np.uint8)
+    lib().orc_raw_decode(_u8(data), C.c_size_t(data.size), C.c_size_t(n), _u8(out))
+    return out[:n]
 
 
 def mq_table():

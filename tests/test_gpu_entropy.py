@@ -161,3 +161,29 @@ def test_plan_decode_blocks_matches_decoders(oracle, coder):
         got = hd[int(doffs[j]):int(doffs[j]) + w * h].reshape(h, w)
         assert np.array_equal(got, want), j
         big += int(np.abs(want).max() >= (1 << 31) - 1) if want.size else 0
+
+
+def test_standalone_mq_and_raw_coders(ent, oracle):
+    """MQEncoder / MQDecoder / RawEncoder / RawDecoder as batch calls, byte-exact against the oracle."""
+    rng = np.random.default_rng(14)
+    for n, skew in [(0, 0.5), (1, 0.5), (50, 0.5), (5000, 0.5), (20000, 0.9), (20000, 0.02)]:
+        ctxs = rng.integers(0, 19, n).astype(np.uint8)
+        decs = (rng.random(n) < skew).astype(np.uint8)
+        want = oracle.mq_encode(ctxs, decs)
+        got = ent.mq_encode(ctxs, decs)
+        assert got == want.tobytes()
+        assert np.array_equal(ent.mq_decode(got, ctxs), oracle.mq_decode(want, ctxs))
+        junk = rng.integers(0, 256, max(n // 4, 3)).astype(np.uint8)                # arbitrary bytes decode the same way
+        assert np.array_equal(ent.mq_decode(junk, ctxs), oracle.mq_decode(junk, ctxs))
+        bits = (rng.random(n) < skew).astype(np.uint8)
+        wr = oracle.raw_encode(bits)
+        assert ent.raw_encode(bits) == wr.tobytes()
+        assert np.array_equal(ent.raw_decode(wr, n), bits)
+        assert np.array_equal(ent.raw_decode(junk, n + 5), oracle.raw_decode(junk, n + 5))
+    e = ent.NewMQEncoder()
+    for c, d in [(18, 1), (17, 0), (0, 1), (9, 1)]:
+        e.Encode(c, d)
+    assert e.Flush() == oracle.mq_encode([18, 17, 0, 9], [1, 0, 1, 1]).tobytes()
+    from j2kgfx import J2KError
+    with pytest.raises(J2KError):
+        ent.mq_encode([19], [0])                                                    # contexts [19]: Go index panic

@@ -58,3 +58,55 @@ def test_enumerate_blocks(oracle):
     # block counts stated in SURVEY.md 8a (a10)
     assert len(oracle.enumerate_blocks(3, 512, 512, 3, 256, 256)) == 21
     assert len(oracle.enumerate_blocks(3, 512, 512, 6, 64, 64)) == 210
+
+
+def test_raw_coders_oracle_vs_python_restatement():
+    """RawEncoder / RawDecoder (mqc.go:516-600): the C oracle against a literal Python restatement, and the property the
+    bit stuffing exists for (after an 0xFF byte the next byte carries 7 bits, so decode(encode(bits)) == bits)."""
+    import oracle as orc
+
+    def py_encode(bits):
+        buf, c, ct = [], 0, 8
+        for b in bits:
+            ct -= 1
+            c += (int(b) & 1) << ct
+            if ct == 0:
+                buf.append(c & 0xFF)
+                ct = 7 if (c & 0xFF) == 0xFF else 8
+                c = 0
+        if ct < 8:
+            buf.append(c & 0xFF)
+        return bytes(buf)
+
+    def py_decode(data, n):
+        out, pos, c, ct = [], 0, 0, 0
+        for _ in range(n):
+            if ct == 0:
+                if c == 0xFF:
+                    if pos < len(data) and data[pos] > 0x8F:
+                        c, ct = 0xFF, 8
+                    elif pos < len(data):
+                        c, ct = data[pos], 7
+                        pos += 1
+                    else:
+                        c, ct = 0xFF, 8
+                elif pos < len(data):
+                    c, ct = data[pos], 8
+                    pos += 1
+                else:
+                    c, ct = 0xFF, 8
+            ct -= 1
+            out.append((c >> ct) & 1)
+        return out
+
+    rng = np.random.default_rng(7)
+    for n, p1 in [(0, 0.5), (1, 0.5), (7, 0.5), (8, 1.0), (64, 1.0), (1000, 0.5), (1000, 0.97), (4099, 0.9)]:
+        bits = (rng.random(n) < p1).astype(np.uint8)
+        enc = orc.raw_encode(bits)
+        assert enc.tobytes() == py_encode(bits)
+        dec = orc.raw_decode(enc, n)
+        assert dec.tolist() == py_decode(enc.tobytes(), n)
+        assert dec.tolist() == bits.tolist()
+    assert orc.raw_encode(np.ones(8, np.uint8)).tolist() == [0xFF, 0x00]            # ct = 7 < 8 after an 0xFF: Flush appends c
+    assert orc.raw_encode(np.ones(15, np.uint8)).tolist() == [0xFF, 0x7F]          # second byte holds 7 bits
+    assert orc.raw_decode(np.array([], np.uint8), 9).tolist() == [1] * 9            # exhausted input feeds 0xFF
