@@ -187,3 +187,29 @@ def test_standalone_mq_and_raw_coders(ent, oracle):
     from j2kgfx import J2KError
     with pytest.raises(J2KError):
         ent.mq_encode([19], [0])                                                    # contexts [19]: Go index panic
+
+
+@pytest.mark.parametrize("reversible", [True, False])
+@pytest.mark.parametrize("htj2k", [False, True])
+def test_tcd_tile_encoder_decoder_mirror(oracle, reversible, htj2k):
+    """internal/tcd's hot-path methods through the Python mirror: forward DWT, one code-block out and back, inverse DWT."""
+    from j2kgfx import tcd
+    rng = np.random.default_rng(5)
+    w, h, levels = 96, 80, 3
+    src = rng.integers(-300, 300, w * h).astype(np.int32)
+    tc = tcd.TileComponent(0, 0, w, h, src.copy())
+    enc = tcd.TileEncoder(levels, reversible, htj2k)
+    enc.ApplyForwardDWT(tc)
+    assert np.array_equal(tc.Data, oracle.tcd_forward_dwt(src.copy(), w, h, levels, reversible).reshape(-1))
+    block = tc.Data.reshape(h, w)[:32, :32].copy()
+    cb = tcd.CodeBlock(0, 0, 32, 32)
+    enc.EncodeCodeBlock(cb, block, 1)
+    want = oracle.ht_encode(block, 32, 32) if htj2k else oracle.t1_encode(block, 32, 32, 1)[0]
+    assert (cb.Data or b"") == bytes(want)
+    dec = tcd.TileDecoder(levels, reversible, htj2k)
+    dec.DecodeCodeBlock(cb, 1)
+    wantd = oracle.ht_decode(want, 32, 32) if htj2k else oracle.t1_decode(want, cb.TotalBitPlanes, 1, 32, 32)
+    assert np.array_equal(cb.Coefficients.reshape(32, 32), wantd)
+    back = tcd.TileComponent(0, 0, w, h, tc.Data.copy())
+    dec.ApplyInverseDWT(back)
+    assert np.array_equal(back.Data, oracle.tcd_inverse_dwt(tc.Data.copy(), w, h, levels, reversible).reshape(-1))
