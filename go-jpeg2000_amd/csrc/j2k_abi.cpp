@@ -118,10 +118,24 @@ extern "C" void j2k_ctx_destroy(j2k_ctx *ctx) {
     delete ctx;
 }
 
+// The block-encode kernels report inputs outside the reference's domain (Go panic) or a slot overflow in a STICKY
+// device word (first int of stage[3]): it is armed by every encode launch, read and cleared at the next
+// synchronisation point (j2k_ctx_sync or a synchronous call), so the asynchronous plan calls fail loudly too.
+static int check_fault(j2k_ctx *ctx) {
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx->fault_armed || !ctx->stage[3]) return J2K_OK;
+    int f = 0;
+    HIPCHK(ctx, hipMemcpy(&f, ctx->stage[3], sizeof(int), hipMemcpyDeviceToHost));
+    ctx->fault_armed = false;
+    if (!f) return J2K_OK;
+    HIPCHK(ctx, hipMemset(ctx->stage[3], 0, sizeof(int)));
+    if (f == 1) return fail(ctx, J2K_ERR_GO_PANIC, "block coder: input on which the reference panics (stream buffer overrun / MinInt32)");
+    return fail(ctx, J2K_ERR_CAPACITY, "block coder: slot overflow");
+}
+
 extern "C" int j2k_ctx_sync(j2k_ctx *ctx) {
     if (!ctx) return J2K_ERR_INVALID_ARG;
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return J2K_OK;
+    return check_fault(ctx);
 }
 extern "C" void *j2k_ctx_stream(j2k_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
@@ -170,6 +184,7 @@ static int stage_reserve(j2k_ctx *ctx, int slot, size_t bytes) {
     size_t cap = std::max<size_t>(bytes, 1 << 20);
     HIPCHK(ctx, hipMalloc(&ctx->stage[slot], cap));
     ctx->stage_bytes[slot] = cap;
+    if (slot == 3) HIPCHK(ctx, hipMemset(ctx->stage[slot], 0, cap));   // holds the sticky fault word (check_fault)
     return J2K_OK;
 }
 
@@ -636,8 +651,8 @@ static int coder_call(j2k_ctx *ctx, int which, const uint8_t *a, size_t na, cons
     r = stage_reserve(ctx, 0, ((na + 15) & ~size_t(15)) + nb + 64);
     if (r != J2K_OK) return r;
     d_a = (uint8_t *)ctx->stage[0]; d_b = d_a + ((na + 15) & ~size_t(15));
-    int *d_fault = (int *)ctx->stage[3];
-    uint32_t *d_len = (uint32_t *)ctx->stage[3] + 4;
+    int *d_fault = (int *)ctx->stage[3] + 16;                                    // bytes 64..: word 0 is the plans' sticky fault word
+    uint32_t *d_len = (uint32_t *)ctx->stage[3] + 20;
     HIPCHK(ctx, hipMemsetAsync(d_fault, 0, 32, ctx->stream));
     if (na) HIPCHK(ctx, hipMemcpyAsync(d_a, a, na, hipMemcpyHostToDevice, ctx->stream));
     if (nb) HIPCHK(ctx, hipMemcpyAsync(d_b, b, nb, hipMemcpyHostToDevice, ctx->stream));
@@ -806,8 +821,8 @@ extern "C" int j2k_plan_encode_blocks(j2k_plan *P, const int32_t *d_coeff, uint8
     if (!n) return J2K_OK;
     int r = stage_reserve(ctx, 3, 256);
     if (r != J2K_OK) return r;
-    int *d_fault = (int *)ctx->stage[3];
-    HIPCHK(ctx, hipMemsetAsync(d_fault, 0, sizeof(int), ctx->stream));
+    int *d_fault = (int *)ctx->stage[3];                                         // sticky word: cleared when reported (check_fault)
+    ctx->fault_armed = true;
     if (P->spec.coder == J2K_CODER_HT) {
         HIPCHK(ctx, launch_ht_encode(ctx->stream, P->d_bjobs, n, d_coeff, d_slots, d_lens, d_numbps, d_fault));
     } else {
@@ -818,16 +833,6 @@ extern "C" int j2k_plan_encode_blocks(j2k_plan *P, const int32_t *d_coeff, uint8
         if (r != J2K_OK) return r;
         HIPCHK(ctx, launch_t1_encode(ctx->stream, P->d_bjobs, n, d_coeff, d_slots, d_lens, d_numbps, (uint8_t *)ctx->stage[2], wpj, d_fault, max_dim));
     }
-    return J2K_OK;
-}
-
-// reads the device fault word written by the encode kernels (after a sync)
-static int check_fault(j2k_ctx *ctx) {
-    int f = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&f, ctx->stage[3], sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (f == 1) return fail(ctx, J2K_ERR_GO_PANIC, "block coder: input on which the reference panics (stream buffer overrun / MinInt32)");
-    if (f) return fail(ctx, J2K_ERR_CAPACITY, "block coder: slot overflow");
     return J2K_OK;
 }
 

@@ -24,6 +24,7 @@ struct j2k_ctx {
     std::vector<j2k_plan *> cache;
     // host-call staging buffers (device)
     void *stage[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool fault_armed = false;  // a block-encode launch may have written the sticky fault word (stage[3]) since the last check
     size_t stage_bytes[4] = {0, 0, 0, 0};
     // level-0 kernel timing (j2k_ctx_profile_*)
     int profile = 0;

@@ -213,3 +213,23 @@ def test_tcd_tile_encoder_decoder_mirror(oracle, reversible, htj2k):
     back = tcd.TileComponent(0, 0, w, h, tc.Data.copy())
     dec.ApplyInverseDWT(back)
     assert np.array_equal(back.Data, oracle.tcd_inverse_dwt(tc.Data.copy(), w, h, levels, reversible).reshape(-1))
+
+
+def test_plan_encode_fault_is_reported_at_sync():
+    """The asynchronous plan calls fail loudly: a coefficient on which the Go HT encoder never returns (MinInt32,
+    ht.go:1159) is reported by the next synchronisation, once, and the context keeps working afterwards."""
+    import torch
+    from j2kgfx import J2KError
+    from j2kgfx.codec import FramePlan
+    plan = FramePlan(64, 64, 1, precision=8, lossless=True, num_resolutions=2, cb=(64, 64), coder=1)
+    coeff = plan.alloc_coeff()
+    coeff.zero_()
+    coeff[5] = -2147483648                                            # alone it would be an all-zero block (its int32 magnitude is negative)
+    coeff[6] = 3
+    plan.encode_blocks(coeff)
+    with pytest.raises(J2KError):
+        plan.ctx.sync()
+    coeff[5] = 7
+    slots, lens, nb = plan.encode_blocks(coeff)
+    plan.ctx.sync()                                                   # the fault word was cleared when it was reported
+    assert int(lens[0].item()) > 0
