@@ -128,7 +128,7 @@ def main():
                 self.pix = torch.from_numpy(np.ascontiguousarray(rgba.reshape(H, W * 4))).to(p.device)
                 self.back_pix = torch.empty_like(self.pix)
             self.coeff = p.alloc_coeff()
-            self.slots = p.empty(i.bytes_cap, torch.uint8); self.stream = p.empty(i.bytes_cap, torch.uint8)
+            self.stream = p.empty(i.bytes_cap, torch.uint8)
             self.lens = p.empty(self.n, torch.int32); self.numbps = p.empty(self.n, torch.uint8)
             self.offs = p.empty(self.n + 1, torch.int64)
             self.decoded = p.empty(i.decoded_elems, torch.int32)
@@ -141,8 +141,7 @@ def main():
                 p.forward_rgba8(self.pix, self.coeff)
             else:
                 p.forward(self.frame, self.coeff)
-            p.encode_blocks(self.coeff, self.slots, self.lens, self.numbps)
-            p.compact(self.slots, self.lens, self.offs, self.stream)
+            p.encode_stream(self.coeff, self.stream, self.offs, self.lens, self.numbps)   # block coding + compaction, one kernel
 
         def decode_side(self):
             p = self.plan

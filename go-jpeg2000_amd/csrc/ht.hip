@@ -149,14 +149,12 @@ __device__ __forceinline__ uint32_t get_bits8(const uint32_t *buf, uint32_t bitp
     return (uint32_t)(two >> sh) & 0xFF;
 }
 
-__device__ bool ht_encode_fast(const BlockJob &J, const int32_t *__restrict__ src, uint8_t *__restrict__ out, int lane,
-                               uint32_t *vbuf, uint32_t *mbuf, long &magLenOut, long &vlcLenOut) {
+// Part 1: every quad pair's code words and MagSgn fields deposited into the two LDS bit strings.  Returns false on the
+// reference's panic domain (MinInt32).  TM / TV = bits in the MagSgn / VLC strings.
+__device__ bool ht_form(const BlockJob &J, const int32_t *__restrict__ src, int lane, uint32_t *vbuf, uint32_t *mbuf,
+                        uint32_t &TMout, uint32_t &TVout) {
     const int w = J.w, h = J.h, stride = J.stride;
     const int quadCols = (w + 3) / 4, P = (quadCols + 1) / 2, R = (h + 3) / 4, N = R * P;
-    const size_t nsamp = (size_t)w * h;
-    const size_t maxSize = nsamp * 2 < 64 ? 64 : nsamp * 2;
-    const long msCap = (long)(maxSize / 2), vlcCap = (long)(maxSize / 2);
-    const size_t melLen = maxSize / 4;
     for (int i = lane; i < HT_VLC_WORDS; i += 64) vbuf[i] = 0;
     for (int i = lane; i < HT_MS_WORDS; i += 64) mbuf[i] = 0;
     __syncthreads();
@@ -245,6 +243,19 @@ __device__ bool ht_encode_fast(const BlockJob &J, const int32_t *__restrict__ sr
     bad = __any(bad);
     __syncthreads();
     if (bad) return false;
+    TMout = mbase; TVout = vbase;
+    return true;
+}
+
+// Part 2: the bytes.  WRITE = false only counts them (the fused encode + compact kernel needs the length of a block
+// before it knows where the block goes).
+template <bool WRITE>
+__device__ bool ht_emit(const BlockJob &J, uint8_t *__restrict__ out, int lane, const uint32_t *vbuf, const uint32_t *mbuf,
+                        uint32_t mbase, uint32_t vbase, long &magLenOut, long &vlcLenOut) {
+    const size_t nsamp = (size_t)J.w * J.h;
+    const size_t maxSize = nsamp * 2 < 64 ? 64 : nsamp * 2;
+    const long msCap = (long)(maxSize / 2), vlcCap = (long)(maxSize / 2);
+    const size_t melLen = maxSize / 4;
     // ---- MagSgn emission with 0xFF stuffing (ht.go:1303-1341) ----
     const uint32_t TM = mbase;
     uint32_t pos = 0, last = 0;
@@ -253,7 +264,7 @@ __device__ bool ht_encode_fast(const BlockJob &J, const int32_t *__restrict__ sr
         if (last == 0xFF) {                         // wave-uniform: one 7-bit byte
             const uint32_t b = get_bits8(mbuf, pos) & 0x7F;
             if (outpos >= msCap) return false;
-            if (lane == 0) out[outpos] = (uint8_t)b;
+            if (WRITE && lane == 0) out[outpos] = (uint8_t)b;
             outpos++; pos += 7; last = b;
             continue;
         }
@@ -265,13 +276,13 @@ __device__ bool ht_encode_fast(const BlockJob &J, const int32_t *__restrict__ sr
         const int first = fmask ? __ffsll((long long)fmask) - 1 : 64;
         const int count = min(nvalid, first + 1);
         if (outpos + count > msCap) return false;
-        if (lane < count) out[outpos + lane] = (uint8_t)b;
+        if (WRITE && lane < count) out[outpos + lane] = (uint8_t)b;
         outpos += count; pos += 8 * count;
         last = (first < nvalid) ? 0xFF : __shfl(b, count - 1);
     }
     if (TM > pos) {                                 // magSgnFlush: the remaining < 8 bits, no stuffing rule
         if (outpos >= msCap) return false;
-        if (lane == 0) out[outpos] = (uint8_t)get_bits8(mbuf, pos);
+        if (WRITE && lane == 0) out[outpos] = (uint8_t)get_bits8(mbuf, pos);
         outpos++;
     }
     const long magLen = outpos;
@@ -280,7 +291,7 @@ __device__ bool ht_encode_fast(const BlockJob &J, const int32_t *__restrict__ sr
     const long nfull = TV >> 3, vlcLen = (TV + 7) >> 3;
     if (vlcLen > vlcCap) return false;
     uint8_t *vout = out + magLen + melLen;
-    for (long i = lane; i < vlcLen; i += 64) {
+    for (long i = lane; WRITE && i < vlcLen; i += 64) {
         uint32_t b = get_bits8(vbuf, (uint32_t)(8 * i));
         if (i < nfull && (b & 0x7F) == 0x7F && i > 0) {
             // final value of the previous byte: walk back over the run of bytes whose low 7 bits are all ones
@@ -299,6 +310,14 @@ __device__ bool ht_encode_fast(const BlockJob &J, const int32_t *__restrict__ sr
     }
     magLenOut = magLen; vlcLenOut = vlcLen;
     return true;
+}
+
+
+__device__ bool ht_encode_fast(const BlockJob &J, const int32_t *__restrict__ src, uint8_t *__restrict__ out, int lane,
+                               uint32_t *vbuf, uint32_t *mbuf, long &magLenOut, long &vlcLenOut) {
+    uint32_t TM, TV;
+    if (!ht_form(J, src, lane, vbuf, mbuf, TM, TV)) return false;
+    return ht_emit<true>(J, out, lane, vbuf, mbuf, TM, TV, magLenOut, vlcLenOut);
 }
 
 __global__ __launch_bounds__(64) void ht_encode_kernel(const BlockJob *__restrict__ jobs, int njobs,
@@ -444,6 +463,109 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(const BlockJob *__restric
         out[total - 1] = (uint8_t)(scup & 0xFF);
         lens[jid] = (uint32_t)total;
         numbps[jid] = (uint8_t)(32 - __clz((uint32_t)maxMag));
+    }
+}
+
+// ================================================================================================
+// Encode + compact in one kernel (blocks on the parallel path only): the dense stream the reference builds with
+// `tileData = append(tileData, encoded...)` (encoder.go:684) without the slot -> stream copy.
+// A block's place is the sum of the lengths before it in job order.  Each workgroup learns its length BEFORE writing a
+// byte (ht_emit<false> counts), publishes it, and looks back over its predecessors' status words ("decoupled look-back":
+// a word holds either a block's own length or its inclusive prefix).  Only status words travel between workgroups --
+// relaxed agent-scope atomics, no fences -- and workgroups are dispatched in index order, so every predecessor a
+// workgroup waits for is already running: no deadlock; the wait is bounded anyway and reports a fault if it ever hits
+// the bound.  A launch is tagged with an epoch so the status array needs no clearing between launches.
+#define HT_ST_AGG 1ull
+#define HT_ST_PREFIX 2ull
+__device__ __forceinline__ unsigned long long ht_status(unsigned long long flag, uint32_t epoch, unsigned long long value) {
+    return flag << 62 | (unsigned long long)(epoch & 0x3FFFFF) << 40 | (value & 0xFFFFFFFFFFull);
+}
+
+__global__ __launch_bounds__(64) void ht_encode_stream_kernel(const BlockJob *__restrict__ jobs, int njobs,
+                                                              const int32_t *__restrict__ coef, uint8_t *__restrict__ stream,
+                                                              unsigned long long *__restrict__ offs, uint32_t *__restrict__ lens,
+                                                              uint8_t *__restrict__ numbps, unsigned long long *__restrict__ status,
+                                                              uint32_t epoch, int *__restrict__ fault) {
+    __shared__ uint32_t s_vbuf[HT_VLC_WORDS];
+    __shared__ uint32_t s_mbuf[HT_MS_WORDS];
+    const int jid = blockIdx.x;
+    if (jid >= njobs) return;
+    const int lane = threadIdx.x;
+    const BlockJob J = jobs[jid];
+    const int w = J.w, h = J.h, stride = J.stride;
+    const int32_t *src = coef + J.src_off;
+    int maxMag = 0;  // Go compares int32: -MinInt32 stays negative and never wins (ht.go:947-960)
+    if ((w & 3) == 0 && (stride & 3) == 0 && (J.src_off & 3) == 0) {
+        const int wq = w >> 2, nq = wq * h;
+        for (int e = lane; e < nq; e += 64) {
+            const int y = e / wq, xq = e - y * wq;
+            const int4 q = *reinterpret_cast<const int4 *>(src + (size_t)y * stride + 4 * xq);
+            const int a0 = q.x < 0 ? (int)(0u - (uint32_t)q.x) : q.x, a1 = q.y < 0 ? (int)(0u - (uint32_t)q.y) : q.y;
+            const int a2 = q.z < 0 ? (int)(0u - (uint32_t)q.z) : q.z, a3 = q.w < 0 ? (int)(0u - (uint32_t)q.w) : q.w;
+            maxMag = max(max(maxMag, max(a0, a1)), max(a2, a3));
+        }
+    } else {
+        for (int y = 0; y < h; y++)
+            for (int x = lane; x < w; x += 64) {
+                int v = src[(size_t)y * stride + x];
+                if (v < 0) v = (int)(0u - (uint32_t)v);
+                maxMag = max(maxMag, v);
+            }
+    }
+    for (int o = 32; o > 0; o >>= 1) maxMag = max(maxMag, __shfl_xor(maxMag, o));
+    const size_t nsamp = (size_t)w * h;
+    const size_t maxSize = nsamp * 2 < 64 ? 64 : nsamp * 2;
+    const size_t melLen = maxSize / 4;
+    uint32_t TM = 0, TV = 0;
+    long mLen = 0, vLen = 0;
+    unsigned long long total = 0;
+    if (maxMag != 0) {
+        bool ok = ht_form(J, src, lane, s_vbuf, s_mbuf, TM, TV);
+        if (ok) ok = ht_emit<false>(J, nullptr, lane, s_vbuf, s_mbuf, TM, TV, mLen, vLen);
+        if (ok) total = (unsigned long long)mLen + melLen + (unsigned long long)vLen + 2;
+        else if (lane == 0) atomicMax(fault, 1);                      // the reference panics on this input
+    }
+    // ---- decoupled look-back over the predecessors ----
+    if (lane == 0) __hip_atomic_store(&status[jid], ht_status(HT_ST_AGG, epoch, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long excl = 0;
+    int base = jid - 1;
+    uint32_t spins = 0;
+    while (base >= 0) {
+        const int idx = base - lane;
+        const unsigned long long v = idx >= 0 ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                              : ht_status(HT_ST_PREFIX, epoch, 0);
+        const unsigned long long flag = v >> 62;
+        const bool valid = flag != 0 && (uint32_t)((v >> 40) & 0x3FFFFF) == (epoch & 0x3FFFFF);
+        const unsigned long long inv = __ballot(!valid), pre = __ballot(valid && flag == HT_ST_PREFIX);
+        const int first_inv = inv ? __ffsll((long long)inv) - 1 : 64, first_pre = pre ? __ffsll((long long)pre) - 1 : 64;
+        if (first_inv < first_pre) {                                  // a predecessor this side of the nearest prefix has not published yet
+            if (++spins > (1u << 22)) { if (lane == 0) atomicMax(fault, 3); break; }
+            __builtin_amdgcn_s_sleep(8);
+            continue;
+        }
+        const int upto = min(first_pre, 63);
+        unsigned long long part = lane <= upto ? (v & 0xFFFFFFFFFFull) : 0ull;
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        excl += part;
+        if (first_pre < 64) break;
+        base -= 64;
+    }
+    if (lane == 0) {
+        __hip_atomic_store(&status[jid], ht_status(HT_ST_PREFIX, epoch, excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        offs[jid] = excl;
+        if (jid == njobs - 1) offs[njobs] = excl + total;
+        lens[jid] = (uint32_t)total;
+        numbps[jid] = total ? (uint8_t)(32 - __clz((uint32_t)maxMag)) : 0;
+    }
+    if (!total) return;
+    // ---- the bytes, straight into their final place ----
+    uint8_t *out = stream + excl;
+    ht_emit<true>(J, out, lane, s_vbuf, s_mbuf, TM, TV, mLen, vLen);
+    for (size_t i = lane; i < melLen; i += 64) out[mLen + i] = 0;
+    if (lane == 0) {
+        const size_t scup = melLen + (size_t)vLen + 2;
+        out[total - 2] = (uint8_t)(scup >> 8);
+        out[total - 1] = (uint8_t)(scup & 0xFF);
     }
 }
 
@@ -1223,6 +1345,19 @@ hipError_t launch_ht_encode(hipStream_t s, const BlockJob *jobs, int njobs, cons
     hipLaunchKernelGGL(ht_encode_kernel, dim3(njobs), dim3(64), 0, s, jobs, njobs, coef, slots, lens, numbps, fault);
     return hipGetLastError();
 }
+
+// every block of the batch must be on the parallel path ((h+3)/4 * w <= HT_FAST_MAX_SAMPLES); status = njobs u64 words
+// that are never cleared (epoch-tagged)
+hipError_t launch_ht_encode_stream(hipStream_t s, const BlockJob *jobs, int njobs, const int32_t *coef, uint8_t *stream,
+                                   uint64_t *offs, uint32_t *lens, uint8_t *numbps, uint64_t *status, uint32_t epoch, int *fault) {
+    if (njobs <= 0) return hipSuccess;
+    hipError_t e;
+    if ((e = ht_tables_ready(s)) != hipSuccess) return e;
+    hipLaunchKernelGGL(ht_encode_stream_kernel, dim3(njobs), dim3(64), 0, s, jobs, njobs, coef, stream,
+                       reinterpret_cast<unsigned long long *>(offs), lens, numbps, reinterpret_cast<unsigned long long *>(status), epoch, fault);
+    return hipGetLastError();
+}
+int ht_fast_max_samples() { return HT_FAST_MAX_SAMPLES; }
 
 // words of device scratch launch_ht_decode needs for njobs blocks: per-pair records + unstuffed VLC bit strings
 size_t ht_decode_scratch_words(int njobs) { return (size_t)njobs * (HT_WALK_REC + HT_VBITS_WORDS); }

@@ -24,6 +24,9 @@ hipError_t launch_ht_encode(hipStream_t s, const BlockJob *jobs, int njobs, cons
 hipError_t launch_ht_decode(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs,
                             const uint32_t *lens, int32_t *decoded, uint32_t *scratch);
 size_t ht_decode_scratch_words(int njobs);
+hipError_t launch_ht_encode_stream(hipStream_t s, const BlockJob *jobs, int njobs, const int32_t *coef, uint8_t *stream,
+                                   uint64_t *offs, uint32_t *lens, uint8_t *numbps, uint64_t *status, uint32_t epoch, int *fault);
+int ht_fast_max_samples();
 hipError_t launch_t1_encode(hipStream_t s, const BlockJob *jobs, int njobs, const int32_t *coef, uint8_t *slots,
                             uint32_t *lens, uint8_t *numbps, uint8_t *work, size_t work_per_job, int *fault, int max_dim);
 hipError_t launch_t1_decode(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs,
@@ -95,6 +98,7 @@ extern "C" int j2k_ctx_create(int device, j2k_ctx **out) {
     }
     if (const char *e = getenv("J2K_BAND_PROWS_97")) { int v = atoi(e); if (v >= 2 && v <= 4096) ctx->band_prows_97 = v; }
     if (const char *e = getenv("J2K_FORCE_NOVEC")) ctx->force_novec = atoi(e) != 0;
+    if (const char *e = getenv("J2K_FUSE_COMPACT")) ctx->fuse_compact = atoi(e) != 0;
     if (const char *e = getenv("J2K_FWD_LINK")) ctx->fwd_link = atoi(e) != 0;
     if (const char *e = getenv("J2K_INV_LINK")) ctx->inv_link = atoi(e) != 0;
     if (const char *e = getenv("J2K_BAND_PROWS_INV")) { int v = atoi(e); if (v >= 1 && v <= 4096) ctx->band_prows_inv = v; }
@@ -482,7 +486,7 @@ extern "C" void j2k_plan_destroy(j2k_plan *P) {
         for (auto &T : P->fwd[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); }
         for (auto &T : P->inv[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); }
     }
-    void *ptrs[] = {P->d_scrA, P->d_scrB, P->d_tail, P->d_bjobs, P->d_djobs, P->d_frame, P->d_coeff, P->d_slots, P->d_stream, P->d_lens, P->d_numbps, P->d_offs};
+    void *ptrs[] = {P->d_scrA, P->d_scrB, P->d_tail, P->d_bjobs, P->d_djobs, P->d_frame, P->d_coeff, P->d_slots, P->d_stream, P->d_lens, P->d_numbps, P->d_offs, P->d_status};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete P;
 }
@@ -834,6 +838,43 @@ extern "C" int j2k_plan_encode_blocks(j2k_plan *P, const int32_t *d_coeff, uint8
         HIPCHK(ctx, launch_t1_encode(ctx->stream, P->d_bjobs, n, d_coeff, d_slots, d_lens, d_numbps, (uint8_t *)ctx->stage[2], wpj, d_fault, max_dim));
     }
     return J2K_OK;
+}
+
+// encode_blocks + compact in one launch when every block is on the parallel HT path; otherwise the two steps through a
+// slot buffer owned by the context
+extern "C" int j2k_plan_encode_stream(j2k_plan *P, const int32_t *d_coeff, uint8_t *d_stream, uint64_t *d_offs, uint32_t *d_lens,
+                                      uint8_t *d_numbps) {
+    if (!P || !d_coeff || !d_stream || !d_offs || !d_lens || !d_numbps) return J2K_ERR_INVALID_ARG;
+    j2k_ctx *ctx = P->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int n = (int)P->blocks.size();
+    if (!n) { HIPCHK(ctx, hipMemsetAsync(d_offs, 0, 8, ctx->stream)); return J2K_OK; }
+    bool fused = P->spec.coder == J2K_CODER_HT && ctx->fuse_compact;
+    if (fused && !P->d_status) {
+        P->all_blocks_fast = true;
+        for (const j2k_block &b : P->blocks)
+            if ((int64_t)((b.h + 3) / 4) * b.w > ht_fast_max_samples()) P->all_blocks_fast = false;
+        if (P->all_blocks_fast) {
+            HIPCHK(ctx, hipMalloc((void **)&P->d_status, (size_t)n * 8));
+            HIPCHK(ctx, hipMemset(P->d_status, 0, (size_t)n * 8));
+        }
+    }
+    if (fused && P->all_blocks_fast && P->d_status) {
+        int r = stage_reserve(ctx, 3, 256);
+        if (r != J2K_OK) return r;
+        if ((++P->epoch & 0x3FFFFF) == 0) {          // the 22-bit tag wraps: clear the words once
+            HIPCHK(ctx, hipMemsetAsync(P->d_status, 0, (size_t)n * 8, ctx->stream));
+            P->epoch = 1;
+        }
+        ctx->fault_armed = true;
+        HIPCHK(ctx, launch_ht_encode_stream(ctx->stream, P->d_bjobs, n, d_coeff, d_stream, d_offs, d_lens, d_numbps, P->d_status,
+                                            P->epoch, (int *)ctx->stage[3]));
+        return J2K_OK;
+    }
+    if (!P->d_slots) HIPCHK(ctx, hipMalloc(&P->d_slots, (size_t)P->bytes_cap + 64));
+    int r = j2k_plan_encode_blocks(P, d_coeff, (uint8_t *)P->d_slots, d_lens, d_numbps);
+    if (r != J2K_OK) return r;
+    return j2k_plan_compact(P, (const uint8_t *)P->d_slots, d_lens, d_offs, d_stream);
 }
 
 extern "C" int j2k_plan_compact(j2k_plan *P, const uint8_t *d_slots, const uint32_t *d_lens, uint64_t *d_offs, uint8_t *d_stream) {

@@ -10,6 +10,8 @@ struct j2k_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
     std::string last_error;
+    int fuse_compact = 0;      // j2k_plan_encode_stream: encode + compact in ONE kernel (decoupled look-back; J2K_FUSE_COMPACT=1).
+                               // Measured slower than the three kernels it replaces (61.7 vs 58.6 us: the prefix chain crosses XCDs)
     int fwd_link = 1;          // forward 5-3: bands of one workgroup exchange halo rows through LDS (J2K_FWD_LINK)
     int inv_link = 1;          // same for the inverse kernels (J2K_INV_LINK)
     int band_prows_97 = 8;     // 9-7 kernels: 7 halo rows per band, so taller bands (J2K_BAND_PROWS_97)
@@ -104,4 +106,8 @@ struct j2k_plan {
     // device workspaces owned by the plan for j2k_encode_frame
     void *d_frame = nullptr, *d_coeff = nullptr, *d_slots = nullptr, *d_stream = nullptr;
     void *d_lens = nullptr, *d_numbps = nullptr, *d_offs = nullptr;
+    // fused encode + compact (j2k_plan_encode_stream): look-back status words, tagged with the launch epoch
+    uint64_t *d_status = nullptr;
+    uint32_t epoch = 0;
+    bool all_blocks_fast = false;           // every job on the parallel HT path
 };

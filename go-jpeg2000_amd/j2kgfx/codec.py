@@ -127,6 +127,18 @@ class FramePlan:
                                                          self._p(numbps)))
         return slots, lens, numbps
 
+    def encode_stream(self, coeff, stream=None, offs=None, lens=None, numbps=None):
+        """encode_blocks + compact in one call (one kernel for HT blocks up to 64x64): returns (stream, offs, lens, numbps)."""
+        t = _torch()
+        n = int(self.info.blocks)
+        stream = stream if stream is not None else self.empty(self.info.bytes_cap, t.uint8)
+        offs = offs if offs is not None else self.empty(n + 1, t.int64)
+        lens = lens if lens is not None else self.empty(n, t.int32)
+        numbps = numbps if numbps is not None else self.empty(n, t.uint8)
+        self.ctx.check(self.ctx.L.j2k_plan_encode_stream(self.h, self._p(coeff), self._p(stream), self._p(offs), self._p(lens),
+                                                         self._p(numbps)))
+        return stream, offs, lens, numbps
+
     def compact(self, slots, lens, offs=None, stream=None):
         t = _torch()
         n = int(self.info.blocks)

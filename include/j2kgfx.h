@@ -184,6 +184,12 @@ int j2k_plan_encode_blocks(j2k_plan *plan, const int32_t *d_coeff, uint8_t *d_sl
  * slots into the dense stream d_stream (concatenation in job order, encoder.go:684). */
 int j2k_plan_compact(j2k_plan *plan, const uint8_t *d_slots, const uint32_t *d_lens,
                      uint64_t *d_offs, uint8_t *d_stream);
+/* j2k_plan_encode_blocks + j2k_plan_compact in one call: the dense stream (job order), d_offs (u64
+ * per job + total), d_lens, d_numbps; the slot buffer in between is owned by the plan.  (With
+ * J2K_FUSE_COMPACT=1, the HT coder and blocks up to 64x64 it is one kernel with a decoupled look-back
+ * over the block lengths -- correct, but measured slower than the three kernels, so off by default.) */
+int j2k_plan_encode_stream(j2k_plan *plan, const int32_t *d_coeff, uint8_t *d_stream, uint64_t *d_offs,
+                           uint32_t *d_lens, uint8_t *d_numbps);
 /* tcd.TileDecoder.DecodeCodeBlock (tcd.go:393-413) for every job: dense stream + offsets
  * + lens + numbps -> d_decoded (decoded_elems int32, block j dense at its job offset). */
 int j2k_plan_decode_blocks(j2k_plan *plan, const uint8_t *d_stream, const uint64_t *d_offs,

@@ -233,3 +233,34 @@ def test_plan_encode_fault_is_reported_at_sync():
     slots, lens, nb = plan.encode_blocks(coeff)
     plan.ctx.sync()                                                   # the fault word was cleared when it was reported
     assert int(lens[0].item()) > 0
+
+
+@pytest.mark.parametrize("W,H,tile,cb,coder", [(3840, 2160, 512, 64, 1), (200, 96, 0, 32, 1), (100, 75, 64, 16, 1), (512, 512, 0, 256, 1),
+                                               (256, 128, 128, 64, 0)])
+@pytest.mark.parametrize("fuse", ["0", "1"])
+def test_encode_stream_equals_encode_blocks_plus_compact(W, H, tile, cb, coder, fuse, monkeypatch):
+    """j2k_plan_encode_stream (one kernel with a look-back for HT blocks up to 64x64, the two-step path otherwise) must
+    produce the stream, offsets, lengths and bit-plane counts of encode_blocks + compact -- also when launched again
+    and again on the same plan (the look-back words are epoch-tagged, never cleared)."""
+    import torch
+    from j2kgfx import Context
+    from j2kgfx.codec import FramePlan
+    monkeypatch.setenv("J2K_FUSE_COMPACT", fuse)                   # read when a context is created
+    rng = np.random.default_rng(W + cb)
+    frame = torch.from_numpy(rng.integers(0, 256, size=(3, H, W)).astype(np.int32))
+    plan = FramePlan(W, H, 3, precision=8, lossless=True, num_resolutions=6, cb=(cb, cb), tile=(tile, tile), coder=coder,
+                     ctx=Context(0))
+    d = frame.to(plan.device)
+    coeff = plan.forward(d)
+    slots, lens, nb = plan.encode_blocks(coeff)
+    offs, stream = plan.compact(slots, lens)
+    plan.ctx.sync()
+    n = int(plan.info.blocks)
+    tot = int(offs[n].item())
+    for rep in range(3):
+        s2, o2, l2, n2 = plan.encode_stream(coeff)
+        plan.ctx.sync()
+        assert int(o2[n].item()) == tot
+        assert torch.equal(o2[:n + 1], offs[:n + 1]) and torch.equal(l2[:n], lens[:n]) and torch.equal(n2[:n], nb[:n])
+        assert torch.equal(s2[:tot], stream[:tot]), rep
+        coeff = plan.forward(d)                                    # same values; keeps the launches back to back
