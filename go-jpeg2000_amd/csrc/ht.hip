@@ -143,6 +143,19 @@ __device__ __forceinline__ void or_bits(uint32_t *buf, uint32_t bitpos, uint64_t
     if ((uint32_t)hi) atomicOr(&buf[wd + 1], (uint32_t)hi);
     if ((uint32_t)(hi >> 32)) atomicOr(&buf[wd + 2], (uint32_t)(hi >> 32));
 }
+// n zero bytes at p (any alignment), one wavefront: bytes up to the next 16-byte boundary, 16-byte stores, tail bytes.
+// (The MEL segment is max(64, 2wh)/4 zero bytes -- 2 KB per 64x64 block; as 64 one-byte lanes per store it was 32 store
+// instructions per block and a measurable part of the encoder.)
+__device__ __forceinline__ void zero_bytes(uint8_t *p, size_t n, int lane) {
+    const size_t head = min(n, (size_t)((16 - ((uintptr_t)p & 15)) & 15));
+    if ((size_t)lane < head) p[lane] = 0;
+    uint8_t *q = p + head;
+    const size_t nv = (n - head) >> 4;
+    for (size_t i = lane; i < nv; i += 64) reinterpret_cast<uint4 *>(q)[i] = make_uint4(0, 0, 0, 0);
+    const size_t done = head + (nv << 4);
+    if (done + lane < n) p[done + lane] = 0;
+}
+
 __device__ __forceinline__ uint32_t get_bits8(const uint32_t *buf, uint32_t bitpos) {
     const uint32_t wd = bitpos >> 5, sh = bitpos & 31;
     const uint64_t two = (uint64_t)buf[wd] | ((uint64_t)buf[wd + 1] << 32);
@@ -367,7 +380,7 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(const BlockJob *__restric
             if (lane == 0) { atomicMax(fault, 1); lens[jid] = 0; numbps[jid] = 0; }
             return;
         }
-        for (size_t i = lane; i < melLen_; i += 64) out[mLen + i] = 0;
+        zero_bytes(out + mLen, melLen_, lane);
         if (lane == 0) {
             const size_t scup = melLen_ + (size_t)vLen + 2;
             const size_t total = (size_t)mLen + scup;
@@ -445,7 +458,7 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(const BlockJob *__restric
         return;
     }
     // ---- assemble: MagSgn | MEL zeros | VLC | SCUP (ht.go:1017-1042) ----
-    for (size_t i = lane; i < melLen; i += 64) out[magLen + i] = 0;
+    zero_bytes(out + magLen, melLen, lane);
     __syncthreads();  // single-wave block: orders the zero fill before the move below
     const size_t D = (size_t)magLen + melLen;                  // <= msCap + melLen: the move goes downward
     for (long base = 0; base < vlcLen; base += 64) {
@@ -561,7 +574,7 @@ __global__ __launch_bounds__(64) void ht_encode_stream_kernel(const BlockJob *__
     // ---- the bytes, straight into their final place ----
     uint8_t *out = stream + excl;
     ht_emit<true>(J, out, lane, s_vbuf, s_mbuf, TM, TV, mLen, vLen);
-    for (size_t i = lane; i < melLen; i += 64) out[mLen + i] = 0;
+    zero_bytes(out + mLen, melLen, lane);
     if (lane == 0) {
         const size_t scup = melLen + (size_t)vLen + 2;
         out[total - 2] = (uint8_t)(scup >> 8);
