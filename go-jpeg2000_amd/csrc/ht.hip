@@ -825,31 +825,41 @@ __global__ __launch_bounds__(256) void ht_vlcprep_kernel(const BlockJob *__restr
     const long size = scup - 2;
     const long maxbytes = (long)(46 * N + 7) / 8 + 8;
     const long nb = size < maxbytes ? size : maxbytes;
-    constexpr int PF = 8;
+    // Four stream bytes per lane per step: reverse-reader bytes k = 256c + 4l + 1 .. + 4 are the four bytes ENDING at
+    // data[lcup - 3 - 256c - 4l]; one (unaligned) 4-byte load, byte-swapped so that byte j is the j-th in reading order.
+    // A byte's width (7 or 8) needs only its predecessor; one prefix sum of the per-lane totals, one OR-deposit of the
+    // four bytes merged at their offsets (a 7-bit advance lets the next byte overlap the top bit: OR, as revRead does).
     uint32_t carry = b0 | 0x0F;                                      // "previous byte" of k = 1
-    for (long k0 = 1; k0 <= nb; k0 += 64 * PF) {
-        uint32_t raw[PF];
+    for (long k0 = 1; k0 <= nb; k0 += 256) {
+        const long k = k0 + 4 * lane;                                // first of this lane's four bytes
+        const long e = lcup - 2 - k;                                 // its address; the other three sit below it
+        uint32_t dw = 0;
+        if (k + 3 <= nb) {
+            __builtin_memcpy(&dw, data + e - 3, 4);
+            dw = __builtin_bswap32(dw);
+        } else {
 #pragma unroll
-        for (int c = 0; c < PF; c++) {
-            const long k = k0 + 64 * c + lane;
-            const uint32_t t = data[lcup - 2 - (k <= nb ? k : nb)];  // clamped: unconditional loads
-            raw[c] = (k <= nb) ? t : 0;
+            for (int j = 0; j < 4; j++)
+                if (k + j <= nb) dw |= (uint32_t)data[e - j] << (8 * j);
         }
+        uint32_t prev = __shfl_up(dw >> 24, 1);
+        if (lane == 0) prev = carry;
+        carry = __shfl(dw >> 24, 63);                                // only read again when all 256 bytes of this step exist
+        uint32_t wsum = 0;
+        uint64_t merged = 0;
 #pragma unroll
-        for (int c = 0; c < PF; c++) {
-            const long k = k0 + 64 * c + lane;
-            if (k0 + 64 * c > nb) break;
-            const uint32_t b = raw[c];
-            uint32_t prev = __shfl_up(b, 1);
-            if (lane == 0) prev = carry;
-            carry = __shfl(b, 63);
-            const uint32_t width = (k <= nb) ? ((prev > 0x8F && (b & 0x7F) == 0x7F) ? 7u : 8u) : 0u;
-            uint32_t ws = width;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const uint32_t a = __shfl_up(ws, o); if (lane >= o) ws += a; }
-            if (k <= nb && b) or_bits(vb, off + ws - width, (uint64_t)b);
-            off += __shfl(ws, 63);
+        for (int j = 0; j < 4; j++) {
+            const uint32_t bj = (dw >> (8 * j)) & 0xFF;
+            const uint32_t wj = (k + j <= nb) ? ((prev > 0x8F && (bj & 0x7F) == 0x7F) ? 7u : 8u) : 0u;
+            merged |= (uint64_t)bj << wsum;
+            wsum += wj;
+            prev = bj;
         }
+        uint32_t ws = wsum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t a2 = __shfl_up(ws, o); if (lane >= o) ws += a2; }
+        if (merged) or_bits(vb, off + ws - wsum, merged);
+        off += __shfl(ws, 63);
     }
     wave_sync();
     uint32_t *dst = vbits + (size_t)jid * HT_VBITS_WORDS;
