@@ -42,7 +42,8 @@ struct T1Tables {
     uint32_t mq[96];      // qe | nmps << 16 | nlps << 24
     uint8_t zc[256];      // lutZCCtx for this block's band (t1_luts.go:34-110)
     uint8_t sc[256];      // lutSignCtx | lutSignPred << 3 (t1_luts.go:153-230)
-    uint8_t ctx[32];      // MQ context states
+    uint8_t ctx[32];      // MQ context states (encoder)
+    uint32_t ent[32];     // decoder: the table entry of each context's current state
 };
 
 __device__ void build_tables(T1Tables &T, int band, int lane) {
@@ -85,6 +86,10 @@ __device__ void build_tables(T1Tables &T, int band, int lane) {
         T.sc[p] = (uint8_t)(sctx | pred << 3);
     }
     if (lane < NumContexts) T.ctx[lane] = (lane == CtxUni) ? 92 : 0;
+}
+// after build_tables + a barrier: the decoder's per-context entries (contexts start at state 0, UNI at 92)
+__device__ void init_dec_contexts(T1Tables &T, int lane) {
+    if (lane < NumContexts) T.ent[lane] = T.mq[lane == CtxUni ? 92 : 0];
 }
 
 // ---- MQ encoder with the "current byte" (buf[bp]) held in a register ---------------------
@@ -658,24 +663,29 @@ __device__ __forceinline__ void mq_renorm_dec(MqDec &d) {   // mqc.go:488-497
         d.A <<= 1; d.C <<= 1; d.CT--;
     } while ((d.A & 0x8000) == 0);
 }
-__device__ __forceinline__ int mq_decode(MqDec &d, T1Tables &T, int ctx) {   // mqc.go:443-485
-    const uint32_t st = T.ctx[ctx];
-    const uint32_t ent = T.mq[st];
+// mqc.go:443-485.  The per-context state is the state's TABLE ENTRY (T.mq word: qe | nmps << 16 | nlps << 24; the MPS
+// is the parity of nmps) kept in T.ent[], so a decision costs one LDS read unless the context changes state.
+__device__ __forceinline__ int mq_decode(MqDec &d, T1Tables &T, int ctx) {
+    const uint32_t ent = T.ent[ctx];
     const uint32_t qe = ent & 0xFFFF;
-    const int mps = st & 1;
+    const int mps = (ent >> 16) & 1;
     int dec;
     d.A -= qe;
     if ((d.C >> 16) < qe) {
-        if (d.A < qe) { dec = mps; T.ctx[ctx] = (uint8_t)((ent >> 16) & 0xFF); }
-        else { dec = 1 - mps; T.ctx[ctx] = (uint8_t)(ent >> 24); }
+        uint32_t nst;
+        if (d.A < qe) { dec = mps; nst = (ent >> 16) & 0xFF; }
+        else { dec = 1 - mps; nst = ent >> 24; }
+        T.ent[ctx] = T.mq[nst];
         d.A = qe;
         mq_renorm_dec(d);
         return dec;
     }
     d.C -= qe << 16;
     if ((d.A & 0x8000) == 0) {
-        if (d.A < qe) { dec = 1 - mps; T.ctx[ctx] = (uint8_t)(ent >> 24); }
-        else { dec = mps; T.ctx[ctx] = (uint8_t)((ent >> 16) & 0xFF); }
+        uint32_t nst;
+        if (d.A < qe) { dec = 1 - mps; nst = ent >> 24; }
+        else { dec = mps; nst = (ent >> 16) & 0xFF; }
+        T.ent[ctx] = T.mq[nst];
         mq_renorm_dec(d);
         return dec;
     }
@@ -711,6 +721,8 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(const BlockJob *__restric
     build_tables(T, J.band, lane);
     for (size_t i = lane; i < (size_t)(w + 2) * (h + 2); i += 64) flags[i] = 0;
     for (size_t i = lane; i < n; i += 64) out[i] = 0;
+    __syncthreads();
+    init_dec_contexts(T, lane);
     __syncthreads();
     if (lane == 0) {
         const int numBPS = numbps[jid];
@@ -822,6 +834,8 @@ __global__ __launch_bounds__(64) void mq_decode_kernel(const uint8_t *__restrict
                                                        uint8_t *__restrict__ decs, int *__restrict__ fault) {
     __shared__ T1Tables T;
     build_tables(T, 0, threadIdx.x);
+    __syncthreads();
+    init_dec_contexts(T, threadIdx.x);
     __syncthreads();
     if (threadIdx.x != 0) return;
     MqDec d{0, 0x8000, 0, -1, len, data};
