@@ -156,6 +156,11 @@ __device__ __forceinline__ void zero_bytes(uint8_t *p, size_t n, int lane) {
     if (done + lane < n) p[done + lane] = 0;
 }
 
+__device__ __forceinline__ uint32_t ms_bits32(const uint32_t *buf, uint32_t bitpos) {
+    const uint32_t wd = bitpos >> 5, sh = bitpos & 31;
+    const uint64_t two = (uint64_t)buf[wd] | ((uint64_t)buf[wd + 1] << 32);
+    return (uint32_t)(two >> sh);
+}
 __device__ __forceinline__ uint32_t get_bits8(const uint32_t *buf, uint32_t bitpos) {
     const uint32_t wd = bitpos >> 5, sh = bitpos & 31;
     const uint64_t two = (uint64_t)buf[wd] | ((uint64_t)buf[wd + 1] << 32);
@@ -281,17 +286,34 @@ __device__ bool ht_emit(const BlockJob &J, uint8_t *__restrict__ out, int lane, 
             outpos++; pos += 7; last = b;
             continue;
         }
-        const uint32_t p = pos + 8 * lane;
-        const bool valid = (p + 8 <= TM);
-        const uint32_t b = valid ? get_bits8(mbuf, p) : 0;
-        const unsigned long long vmask = __ballot(valid), fmask = __ballot(valid && b == 0xFF);
-        const int nvalid = __popcll(vmask);
-        const int first = fmask ? __ffsll((long long)fmask) - 1 : 64;
-        const int count = min(nvalid, first + 1);
+        // four bytes per lane, up to 256 per step; the step ends at the first 0xFF (the byte after it is 7 bits wide)
+        const uint32_t nbytes = min((TM - pos) >> 3, 256u);
+        const uint32_t mine = 4u * lane < nbytes ? min(nbytes - 4u * lane, 4u) : 0u;
+        const uint32_t dw = mine ? ms_bits32(mbuf, pos + 32 * lane) : 0u;
+        uint32_t ffj = 4;
+#pragma unroll
+        for (int j = 3; j >= 0; j--)
+            if ((uint32_t)j < mine && ((dw >> (8 * j)) & 0xFF) == 0xFF) ffj = j;
+        const unsigned long long fmask = __ballot(ffj < 4);
+        int first = 256;
+        if (fmask) {
+            const int fl = __ffsll((long long)fmask) - 1;
+            first = 4 * fl + (int)__shfl(ffj, fl);
+        }
+        const int count = min((int)nbytes, first + 1);
         if (outpos + count > msCap) return false;
-        if (WRITE && lane < count) out[outpos + lane] = (uint8_t)b;
+        if (WRITE) {
+            const int my0 = 4 * lane;
+            uint8_t *q = out + outpos + my0;
+            if (my0 + 4 <= count) __builtin_memcpy(q, &dw, 4);          // unaligned 4-byte store
+            else {
+#pragma unroll
+                for (int j = 0; j < 3; j++)
+                    if (my0 + j < count) q[j] = (uint8_t)(dw >> (8 * j));
+            }
+        }
+        last = (first < (int)nbytes) ? 0xFFu : ((__shfl(dw, (count - 1) >> 2) >> (8 * ((count - 1) & 3))) & 0xFF);
         outpos += count; pos += 8 * count;
-        last = (first < nvalid) ? 0xFF : __shfl(b, count - 1);
     }
     if (TM > pos) {                                 // magSgnFlush: the remaining < 8 bits, no stuffing rule
         if (outpos >= msCap) return false;
@@ -350,13 +372,17 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(const BlockJob *__restric
     // ---- max |x| over the WHOLE block: nil decision (ht.go:947-960) and numbps ----
     int maxMag = 0;  // Go compares int32: -MinInt32 stays negative and never wins
     if ((w & 3) == 0 && (stride & 3) == 0 && (J.src_off & 3) == 0) {
+        // (row, quad) kept incrementally: a division by the block width per load was a third of this loop's instructions
         const int wq = w >> 2, nq = wq * h;
+        const int dy = 64 / wq, dx = 64 - dy * wq;
+        int y = lane / wq, xq = lane - y * wq;
         for (int e = lane; e < nq; e += 64) {
-            const int y = e / wq, xq = e - y * wq;
             const int4 q = *reinterpret_cast<const int4 *>(src + (size_t)y * stride + 4 * xq);
             const int a0 = q.x < 0 ? (int)(0u - (uint32_t)q.x) : q.x, a1 = q.y < 0 ? (int)(0u - (uint32_t)q.y) : q.y;
             const int a2 = q.z < 0 ? (int)(0u - (uint32_t)q.z) : q.z, a3 = q.w < 0 ? (int)(0u - (uint32_t)q.w) : q.w;
             maxMag = max(max(maxMag, max(a0, a1)), max(a2, a3));
+            y += dy; xq += dx;
+            if (xq >= wq) { xq -= wq; y++; }
         }
     } else {
         for (int y = 0; y < h; y++)
@@ -509,13 +535,17 @@ __global__ __launch_bounds__(64) void ht_encode_stream_kernel(const BlockJob *__
     const int32_t *src = coef + J.src_off;
     int maxMag = 0;  // Go compares int32: -MinInt32 stays negative and never wins (ht.go:947-960)
     if ((w & 3) == 0 && (stride & 3) == 0 && (J.src_off & 3) == 0) {
+        // (row, quad) kept incrementally: a division by the block width per load was a third of this loop's instructions
         const int wq = w >> 2, nq = wq * h;
+        const int dy = 64 / wq, dx = 64 - dy * wq;
+        int y = lane / wq, xq = lane - y * wq;
         for (int e = lane; e < nq; e += 64) {
-            const int y = e / wq, xq = e - y * wq;
             const int4 q = *reinterpret_cast<const int4 *>(src + (size_t)y * stride + 4 * xq);
             const int a0 = q.x < 0 ? (int)(0u - (uint32_t)q.x) : q.x, a1 = q.y < 0 ? (int)(0u - (uint32_t)q.y) : q.y;
             const int a2 = q.z < 0 ? (int)(0u - (uint32_t)q.z) : q.z, a3 = q.w < 0 ? (int)(0u - (uint32_t)q.w) : q.w;
             maxMag = max(max(maxMag, max(a0, a1)), max(a2, a3));
+            y += dy; xq += dx;
+            if (xq >= wq) { xq -= wq; y++; }
         }
     } else {
         for (int y = 0; y < h; y++)
