@@ -67,15 +67,16 @@ def test_full_size_lossless_roundtrip(W, H, Cn, tile, prec):
     assert int(o2[n].item()) == tot and torch.equal(st2[:tot], a)
 
 
-def _sample_tile_parity(W, H, tile, prec, lossless, quality, coder, sample_tiles, frame):
+def _sample_tile_parity(W, H, tile, prec, lossless, quality, coder, sample_tiles, frame, ncomp=3):
     """GPU frame pipeline at full size vs the oracle's per-tile pipeline (encoder.preprocess + encodeTile body,
     encoder.go:198-281, 616-688) on a few sampled tiles: coefficients, block bytes, lengths, numBPS, and the block
     decoders' output for those blocks."""
     import torch
     import oracle as orc
     from j2kgfx.codec import FramePlan
-    plan = FramePlan(W, H, 3, precision=prec, lossless=lossless, quality=quality, num_resolutions=6, cb=(64, 64),
+    plan = FramePlan(W, H, ncomp, precision=prec, lossless=lossless, quality=quality, num_resolutions=6, cb=(64, 64),
                      tile=(tile, tile), coder=coder)
+    tile = tile or max(W, H)
     d = torch.from_numpy(frame).to(plan.device)
     torch.cuda.synchronize()
     coeff = plan.forward(d)
@@ -90,14 +91,14 @@ def _sample_tile_parity(W, H, tile, prec, lossless, quality, coder, sample_tiles
     tiles_x = (W + tile - 1) // tile
     first_block_of_tile = {}
     for j in range(n):
-        first_block_of_tile.setdefault(int(blocks[j]["plane"]) // 3, j)
+        first_block_of_tile.setdefault(int(blocks[j]["plane"]) // ncomp, j)
     for tl in sample_tiles:
         x0, y0 = (tl % tiles_x) * tile, (tl // tiles_x) * tile
         w, h = min(tile, W - x0), min(tile, H - y0)
-        crop = [np.ascontiguousarray(frame[c, y0:y0 + h, x0:x0 + w]) for c in range(3)]
+        crop = [np.ascontiguousarray(frame[c, y0:y0 + h, x0:x0 + w]) for c in range(ncomp)]
         want_c = orc.preprocess(crop, w, h, prec, lossless, 6, quality)
-        for c in range(3):
-            row = planes[tl * 3 + c]
+        for c in range(ncomp):
+            row = planes[tl * ncomp + c]
             assert (int(row[0]), int(row[1]), int(row[4]), int(row[5])) == (tl, c, w, h)
             got = hco[int(row[6]):int(row[6]) + w * h].reshape(h, w)
             assert np.array_equal(got, want_c[c]), ("coefficients", tl, c)
@@ -159,3 +160,24 @@ def test_bench_two_rank_control_flow_rehearsal():
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["frames_in_flight"] == 2 and d["value"] > 0
+
+
+def test_c4_full_size_sampled_tiles_match_oracle():
+    """BASELINE C4 geometry: 7680x4320 RGB rescaled to 10 bit (v*1023/255), 512^2 tiles (135; last row 224 high),
+    5-3 lossless + HT: first, interior, right-edge, bottom-row and corner tiles against the oracle."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    import bench
+    small = bench.synth_frame(np, 4)                                             # 3840x2160 pattern, tiled 2x2 into 8K
+    frame = np.tile(small, (1, 2, 2)).astype(np.int64) * 1023 // 255
+    frame = frame.astype(np.int32)
+    _sample_tile_parity(7680, 4320, 512, 10, True, 0, 1, [0, 52, 14, 125, 134], frame)
+
+
+def test_c5_full_size_frame_matches_oracle():
+    """BASELINE C5 unit: one 2048x2048 16-bit gray frame, untiled, 5-3 lossless (HT coder): the whole frame is one
+    tile-component -- coefficients, all 1024 block streams and sampled decoded blocks against the oracle."""
+    rng = np.random.default_rng(55)
+    yy, xx = np.mgrid[0:2048, 0:2048]
+    frame = np.clip((xx * 65535 // 2048 + yy * 65535 // 2048) // 2 + rng.integers(-2000, 2001, (2048, 2048)), 0, 65535).astype(np.int32)[None]
+    _sample_tile_parity(2048, 2048, 0, 16, True, 0, 1, [0], frame, ncomp=1)
