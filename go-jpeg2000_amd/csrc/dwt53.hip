@@ -14,8 +14,9 @@
 //     the adjacent lane by a DPP wave shift (no LDS, no barrier).
 //   * The wave then marches down its band: the vertical lifting is a 2-row sliding
 //     window kept in registers, so every sample is read from HBM once and written
-//     once -- algorithmic bytes = 2*4*w*h per level (plus a 3-row halo per band that
-//     is served by L2).  Row-contiguous loads and stores only; the reference's
+//     once -- algorithmic bytes = 2*4*w*h per level.  A band needs three halo rows of its
+//     neighbours; the four bands of a workgroup hand them over through LDS (linked bands,
+//     see dwt53_fwd_kernel), so only three rows per WORKGROUP are read twice.  Row-contiguous loads and stores only; the reference's
 //     4-byte-strided column gather (dwt.go:375-394) does not exist here.
 //   * De-interleave happens at the store: L -> column p, H -> column ceil(w/2)+p,
 //     low rows -> row q, high rows -> row ceil(h/2)+q.

@@ -11,11 +11,13 @@
 // UNMASKED 7-bit table index into the VLC stream while advancing by the entry's length; MEL is
 // never fed (max(64,2wh)/4 zero bytes); output = MagSgn | MEL zeros | VLC (write order) | SCUP.
 //
-// Kernel shape: one code-block per wavefront.  The wave scans the whole block for max|x|
-// (nil / numbps decision) with coalesced row loads; the bit-serial stream packing -- every
-// code word's position depends on all previous lengths and on byte stuffing -- runs on lane 0
-// straight into the block's output slot; the MEL zero fill and the final VLC move are done by
-// all 64 lanes.  Go semantics kept: uint32 wraparound, shifts >= 32 give 0.
+// Encoder shape: one code-block per wavefront.  The wave scans the whole block for max|x| (nil /
+// numbps decision); every quad pair's code words and MagSgn fields are formed by one lane, their
+// bit positions are prefix sums of the lengths, and they are OR-deposited into two LDS bit strings
+// (ht_form); the bytes are then cut from the strings 256 at a time with the 0xFF stuffing rules
+// (ht_emit).  Blocks with more than HT_FAST_MAX_SAMPLES coded samples take a bit-serial path on
+// lane 0.  Decoder shape: three kernels, see "parallel decoder" below.  Go semantics kept: uint32
+// wraparound, shifts >= 32 give 0.
 #include <cstdlib>
 
 #include "ht_tables.h"
@@ -761,15 +763,15 @@ __device__ bool init_mel_ok(const uint8_t *data, long len, long lcup, long scup)
     return true;
 }
 
-// ---- parallel decoder (fast path), two kernels -------------------------------------------------
+// ---- parallel decoder (fast path), three kernels ------------------------------------------------
 // The VLC stream is inherently sequential (each code word's length comes out of the table lookup of the
-// previous one), ~150 dependent instructions per quad pair.  Run as "one block per wavefront" that walk
-// saturates the CU's single scalar unit (measured: 36 us for one block, 290 us for 7005).  So:
-//   ht_walk_kernel   : one block per LANE.  The tail of every block's stream (where the VLC bytes live) is
-//                      staged into LDS with coalesced loads, then 64 lanes walk 64 blocks at once with the
-//                      reference's own reverse reader (initVLC/revRead, ht.go:276-396) and write one record
-//                      (rho, rho2, u0, u1) per quad pair to a global scratch.
-//   ht_decode_kernel : one block per WAVEFRONT.  Zero fill, parallel unstuffing of the MagSgn bytes into an
+// previous one).  Run as "one block per wavefront" that walk saturates the CU's single scalar unit
+// (measured: 36 us for one block, 290 us for 7005).  So:
+//   ht_vlcprep_kernel: one block per WAVEFRONT.  Validates SCUP / the MEL start and undoes the reverse reader's
+//                      byte stuffing in parallel: the VLC bytes become a linear bit string in a global scratch.
+//   ht_walk_kernel   : one block per LANE.  64 bit strings staged in LDS, 64 blocks walked at once; one record
+//                      (rho, rho2, u-VLC mode, the 16 stream bits at the u-VLC) per quad pair.
+//   ht_decode_kernel : one block per WAVEFRONT.  u values from the records, parallel unstuffing of the MagSgn bytes into an
 //                      LDS bit string (a byte is 7 bits wide iff its predecessor is 0xFF; prefix sum of
 //                      widths; OR-deposit because the reference ORs a full byte at a 7-bit advance,
 //                      ht.go:467-500; past the segment everything reads as ones), then every lane extracts
@@ -778,8 +780,6 @@ __device__ bool init_mel_ok(const uint8_t *data, long len, long lcup, long scup)
 // Blocks with more than HT_FAST_MAX_SAMPLES coded samples / HT_WALK_MAX_PAIRS pairs, or where a decoded u
 // exceeds 32 (the reference's uint32 bit counter then wraps, ht.go:515-519), take the bit-serial path.
 #define HT_WALK_MAX_PAIRS 128
-#define HT_WALK_TAIL 756                       /* staged stream tail: >= 46*128/8 + 2 + read-ahead slack          */
-#define HT_WALK_ROW 764                        /* LDS row: tail + 3 alignment bytes, 191 words (odd stride)          */
 #define HT_DEC_MWORDS (33 * HT_FAST_MAX_SAMPLES / 32 + 8)
 #define HT_WALK_REC 132                        /* words per block: 128 pair records + flags (+pad) */
 #define HT_PAIR_SERIAL 0xFFFFFFFFu              /* record[0]: decode this block with the serial path */
