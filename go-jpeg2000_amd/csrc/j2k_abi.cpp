@@ -197,7 +197,7 @@ static int stage_reserve(j2k_ctx *ctx, int slot, size_t bytes) {
 // ------------------------------------------------------------------------------
 bool PlanSpec::operator==(const PlanSpec &o) const {
     return W == o.W && H == o.H && C == o.C && tile_w == o.tile_w && tile_h == o.tile_h && levels == o.levels &&
-           wavelet == o.wavelet && dc_shift == o.dc_shift && mct == o.mct && quant == o.quant && quality == o.quality &&
+           wavelet == o.wavelet && precision == o.precision && dc_shift == o.dc_shift && mct == o.mct && quant == o.quant && quality == o.quality &&
            num_res_jobs == o.num_res_jobs && cb_w == o.cb_w && cb_h == o.cb_h && coder == o.coder &&
            tile_first == o.tile_first && tile_count == o.tile_count && frame_is_f64 == o.frame_is_f64;
 }
@@ -499,6 +499,7 @@ static int spec_from_params(j2k_ctx *ctx, const j2k_params *p, PlanSpec &S) {
     S.levels = p->num_resolutions - 1;
     if (S.levels <= 0) S.levels = 5;                                  // encoder.go:249-252
     S.wavelet = p->lossless ? W53 : W97;
+    S.precision = p->precision;
     S.dc_shift = (int)((uint32_t)1 << (p->precision - 1));            // mct.go:97
     if (p->is_signed) S.dc_shift = 0;                                 // decoder.go:345 (decode side only skips it)
     S.mct = p->ncomp >= 3;                                            // encoder.go:223
@@ -809,6 +810,32 @@ extern "C" int j2k_plan_inverse_rgba8(j2k_plan *P, const int32_t *d_coeff, void 
     r = plan_inverse_impl(P, d_coeff, ctx->stage[0]);
     if (r != J2K_OK) return r;
     return j2k_pack_pixels(ctx, (const int32_t *)ctx->stage[0], 3, 8, S.W, S.H, d_pix, stride);
+}
+
+extern "C" int j2k_plan_forward_pixels(j2k_plan *P, int format, const void *d_pix, size_t stride, int32_t *d_coeff) {
+    if (!P || !d_pix || !d_coeff) return J2K_ERR_INVALID_ARG;
+    j2k_ctx *ctx = P->ctx;
+    const PlanSpec &S = P->spec;
+    if (format < 0 || format >= 6) return fail(ctx, J2K_ERR_INVALID_ARG, "unknown pixel format");
+    if (kPixComp[format] != S.C) return fail(ctx, J2K_ERR_INVALID_ARG, "pixel format and plan disagree on the component count");
+    if (format == J2K_PIX_RGBA8 && S.precision == 8) return j2k_plan_forward_rgba8(P, d_pix, stride, d_coeff);
+    int r = stage_reserve(ctx, 0, (size_t)S.W * S.H * S.C * 4 + 64);       // int32 staging frame
+    if (r != J2K_OK) return r;
+    r = j2k_unpack_pixels(ctx, format, d_pix, stride, S.W, S.H, S.precision, (int32_t *)ctx->stage[0]);
+    if (r != J2K_OK) return r;
+    return plan_forward_impl(P, ctx->stage[0], d_coeff);
+}
+
+extern "C" int j2k_plan_inverse_pixels(j2k_plan *P, const int32_t *d_coeff, void *d_pix, size_t stride) {
+    if (!P || !d_pix || !d_coeff) return J2K_ERR_INVALID_ARG;
+    j2k_ctx *ctx = P->ctx;
+    const PlanSpec &S = P->spec;
+    if (S.C == 3 && S.precision == 8 && S.dc_shift == 128) return j2k_plan_inverse_rgba8(P, d_coeff, d_pix, stride);
+    int r = stage_reserve(ctx, 0, (size_t)S.W * S.H * S.C * 4 + 64);
+    if (r != J2K_OK) return r;
+    r = plan_inverse_impl(P, d_coeff, ctx->stage[0]);
+    if (r != J2K_OK) return r;
+    return j2k_pack_pixels(ctx, (const int32_t *)ctx->stage[0], S.C, S.precision, S.W, S.H, d_pix, stride);
 }
 
 static size_t t1_work_per_job(const j2k_plan *P) {

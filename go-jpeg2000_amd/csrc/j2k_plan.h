@@ -49,6 +49,7 @@ struct PlanSpec {
     int tile_w = 0, tile_h = 0;
     int levels = 1;            // DWT levels actually run
     int wavelet = W53;
+    int precision = 8;         // component precision of the plan (pixel pack / unpack)
     int dc_shift = 0;          // value subtracted on the way in / added on the way out
     int mct = 0;               // fused RCT (W53) / ICT (W97) on comps 0-2 when C>=3
     int quant = Q_NONE;

@@ -90,6 +90,9 @@ class FramePlan:
         return C.c_void_p(t.data_ptr())
 
     # ---- stages (asynchronous on the ctx stream) ------------------------------------
+    # The calls return before the kernels have run, and they run on the LIBRARY's stream, which torch's caching
+    # allocator knows nothing about: keep every tensor passed in alive (do not pass temporaries) until ctx.sync(), or
+    # order the streams yourself (torch.cuda.ExternalStream(ctx.stream).wait_stream / record_stream).
     def forward(self, frame, coeff=None):
         """encoder.preprocess for every tile-component: frame int32 [C,H,W] -> coefficient buffer."""
         coeff = coeff if coeff is not None else self.alloc_coeff()
@@ -126,6 +129,18 @@ class FramePlan:
         self.ctx.check(self.ctx.L.j2k_plan_encode_blocks(self.h, self._p(coeff), self._p(slots), self._p(lens),
                                                          self._p(numbps)))
         return slots, lens, numbps
+
+    def forward_pixels(self, fmt, pix, coeff=None):
+        """extractImageData (+ rescale to the plan's precision) + preprocess: pix = device uint8 [H, stride] in a Go Pix layout."""
+        coeff = coeff if coeff is not None else self.alloc_coeff()
+        assert pix.dim() == 2 and pix.shape[0] == self.height and pix.is_contiguous()
+        self.ctx.check(self.ctx.L.j2k_plan_forward_pixels(self.h, int(fmt), self._p(pix), C.c_size_t(int(pix.shape[1])), self._p(coeff)))
+        return coeff
+
+    def inverse_pixels(self, coeff, pix):
+        """inverse path + createImage for the plan's component count and precision into pix (device uint8 [H, stride])."""
+        self.ctx.check(self.ctx.L.j2k_plan_inverse_pixels(self.h, self._p(coeff), self._p(pix), C.c_size_t(int(pix.shape[1]))))
+        return pix
 
     def encode_stream(self, coeff, stream=None, offs=None, lens=None, numbps=None):
         """encode_blocks + compact in one call (one kernel for HT blocks up to 64x64): returns (stream, offs, lens, numbps)."""

@@ -244,6 +244,12 @@ int j2k_pack_pixels(j2k_ctx *ctx, const int32_t *d_planes, int ncomp, int precis
  * allows 16-byte accesses (otherwise the pixels pass through an int32 staging frame). */
 int j2k_plan_forward_rgba8(j2k_plan *plan, const void *d_pix, size_t stride, int32_t *d_coeff);
 int j2k_plan_inverse_rgba8(j2k_plan *plan, const int32_t *d_coeff, void *d_pix, size_t stride);
+/* Any pixel format: extractImageData (+ the rescale to the plan's precision) then j2k_plan_forward;
+ * j2k_plan_inverse then createImage for the plan's component count and precision.  The plan's
+ * component count must equal j2k_pixels_components(format) (forward) / be 1, 3 or 4 (inverse).
+ * J2K_PIX_RGBA8 into an 8-bit plan takes the fused kernels above. */
+int j2k_plan_forward_pixels(j2k_plan *plan, int format, const void *d_pix, size_t stride, int32_t *d_coeff);
+int j2k_plan_inverse_pixels(j2k_plan *plan, const int32_t *d_coeff, void *d_pix, size_t stride);
 
 /* Whole shard from HOST planes, mirroring encoder.preprocess + encodeTile
  * (encoder.go:216-281, 597-688): planes[c] = host int32 W*H, mutated in place to

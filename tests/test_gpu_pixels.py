@@ -80,3 +80,33 @@ def test_plan_forward_inverse_rgba8(oracle, W, H, tile, pad):
     want_pix = oracle.create_image([p for p in back.cpu().numpy()], 8)
     assert np.array_equal(bpix.cpu().numpy(), want_pix)
     assert np.array_equal(bpix.cpu().numpy().reshape(H, W, 4)[..., :3], pix[:, :W * 4].reshape(H, W, 4)[..., :3])   # lossless
+
+
+@pytest.mark.parametrize("fmt,prec", [(0, 8), (1, 16), (1, 12), (2, 8), (3, 16), (3, 12), (4, 8), (5, 16)])
+def test_plan_forward_inverse_pixels_all_formats(oracle, fmt, prec):
+    """j2k_plan_forward_pixels / j2k_plan_inverse_pixels for every pixel format (and the Options.Precision rescale
+    16 -> 12): coefficients equal extractImageData + preprocess, pixels equal the inverse path + createImage."""
+    import torch
+    from j2kgfx import pixels
+    from j2kgfx.codec import FramePlan
+    W, H = 256, 128
+    nc = pixels.components(fmt)
+    rng = np.random.default_rng(fmt * 10 + prec)
+    stride = W * BPP[fmt] + 16
+    pix = rng.integers(0, 256, (H, stride)).astype(np.uint8)
+    plan = FramePlan(W, H, nc, precision=prec, lossless=True, num_resolutions=4, cb=(64, 64), tile=(128, 128), coder=1)
+    planes = oracle.extract_image_data(pix, fmt, W, H, prec)
+    frame = torch.from_numpy(np.stack(planes)).to(plan.device)     # kept alive: the plan calls are asynchronous on the
+    dpix = torch.from_numpy(pix).to(plan.device)                   # library's own stream, torch may not recycle their inputs
+    torch.cuda.synchronize()
+    want = plan.forward(frame)
+    got = plan.forward_pixels(fmt, dpix)
+    plan.ctx.sync()
+    assert torch.equal(got, want)
+    if nc in (1, 3, 4):
+        back = plan.inverse(got)
+        bpp = (1 if nc == 1 else 4) * (2 if prec > 8 else 1)
+        out = torch.zeros((H, W * bpp), dtype=torch.uint8, device=plan.device)
+        plan.inverse_pixels(got, out)
+        plan.ctx.sync()
+        assert np.array_equal(out.cpu().numpy(), oracle.create_image([p for p in back.cpu().numpy()], prec))
