@@ -773,6 +773,40 @@ extern "C" int j2k_create_image(j2k_ctx *ctx, const int32_t *const *planes, int 
     return J2K_OK;
 }
 
+// ---- colour conversions (colorspace.go:54-480) ---------------------------------------------------
+static bool cs_applies(int cs, int ncomp) {
+    switch (cs) {
+    case J2K_CS_CMYK: case J2K_CS_YCCK: return ncomp >= 4;
+    case J2K_CS_SYCC: case J2K_CS_EYCC: case J2K_CS_YCBCR2: case J2K_CS_YCBCR3: case J2K_CS_PHOTOYCC: case J2K_CS_CMY:
+    case J2K_CS_CIELAB: case J2K_CS_CIEJAB: case J2K_CS_ESRGB: case J2K_CS_ROMMRGB: case J2K_CS_YPBPR60: case J2K_CS_YPBPR50:
+        return ncomp >= 3;
+    default: return false;
+    }
+}
+
+extern "C" int j2k_convert_colorspace_device(j2k_ctx *ctx, int cs, int32_t *d_planes, int ncomp, size_t n, int precision) {
+    if (!ctx || (n && !d_planes) || ncomp < 0 || precision < 1 || precision > 31) return J2K_ERR_INVALID_ARG;
+    if (!cs_applies(cs, ncomp) || !n) return J2K_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, launch_colorspace(ctx->stream, cs, d_planes, ncomp, n, precision));
+    return J2K_OK;
+}
+
+extern "C" int j2k_convert_colorspace(j2k_ctx *ctx, int cs, int32_t *const *planes, int ncomp, size_t n, int precision) {
+    if (!ctx || (n && ncomp > 0 && !planes) || ncomp < 0 || precision < 1 || precision > 31) return J2K_ERR_INVALID_ARG;
+    if (!cs_applies(cs, ncomp) || !n) return J2K_OK;
+    const int nc = (cs == J2K_CS_CMYK || cs == J2K_CS_YCCK) ? 4 : 3;      // the conversions touch only these
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int r = stage_reserve(ctx, 0, n * 4 * nc + 64);
+    if (r != J2K_OK) return r;
+    int32_t *d = (int32_t *)ctx->stage[0];
+    for (int c = 0; c < nc; c++) HIPCHK(ctx, hipMemcpyAsync(d + (size_t)c * n, planes[c], n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, launch_colorspace(ctx->stream, cs, d, nc, n, precision));
+    for (int c = 0; c < 3; c++) HIPCHK(ctx, hipMemcpyAsync(planes[c], d + (size_t)c * n, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return J2K_OK;
+}
+
 // can the level-0 5-3 + RCT kernels read / write packed RGBA8 directly?
 static bool rgba8_fusable(const j2k_plan *P, const void *d_pix, size_t stride, bool inverse) {
     const PlanSpec &S = P->spec;

@@ -74,6 +74,7 @@ hipError_t launch_dwt53_tail_inv(hipStream_t s, const TailPlane *planes, int npl
 
 hipError_t launch_unpack_pixels(hipStream_t s, const uint8_t *pix, size_t stride, int format, int w, int h, int src_max, int dst_max,
                                 int32_t *planes);
+hipError_t launch_colorspace(hipStream_t s, int cs, int32_t *planes, int ncomp, size_t n, int precision);
 hipError_t launch_pack_pixels(hipStream_t s, const int32_t *planes, int ncomp, int precision, int w, int h, uint8_t *pix, size_t stride);
 
 }  // namespace j2k

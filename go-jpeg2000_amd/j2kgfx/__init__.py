@@ -5,6 +5,7 @@ libj2kgfx.so (HIP, gfx950).  Same names and argument meaning as the reference:
     j2kgfx.dwt      <- internal/dwt      (Forward53, ..., DecomposeMultiLevel53, ReconstructMultiLevel97, ...)
     j2kgfx.entropy  <- internal/entropy  (T1, HTEncoder, HTDecoder, BandLL..BandHH)
     j2kgfx.tcd      <- internal/tcd      (TileEncoder/TileDecoder: ApplyForwardDWT, EncodeCodeBlock, ...)
+    j2kgfx.colorspace <- colorspace.go (decode-side conversions to sRGB)
     j2kgfx.pixels   <- encoder.extractImageData / decoder.createImage (pixel buffers at native width)
     j2kgfx.codec    <- encoder.preprocess / encodeTile / decoder.decodeTiles tail, batched per frame
     j2kgfx.dist     <- tile / frame sharding over ranks + gather of compressed blocks (torch.distributed)

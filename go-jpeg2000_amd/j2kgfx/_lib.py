@@ -53,6 +53,7 @@ SYMBOLS = [
     "j2k_plan_forward", "j2k_plan_inverse", "j2k_plan_encode_blocks", "j2k_plan_compact", "j2k_plan_encode_stream",
     "j2k_plan_decode_blocks", "j2k_plan_get_decoded_offsets", "j2k_encode_frame",
     "j2k_mq_encode", "j2k_mq_decode", "j2k_raw_encode", "j2k_raw_decode",
+    "j2k_convert_colorspace", "j2k_convert_colorspace_device",
     "j2k_pixels_components", "j2k_pixels_precision", "j2k_extract_image_data", "j2k_create_image",
     "j2k_unpack_pixels", "j2k_pack_pixels", "j2k_plan_forward_rgba8", "j2k_plan_inverse_rgba8",
     "j2k_plan_forward_pixels", "j2k_plan_inverse_pixels",

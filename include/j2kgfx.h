@@ -251,6 +251,22 @@ int j2k_plan_inverse_rgba8(j2k_plan *plan, const int32_t *d_coeff, void *d_pix, 
 int j2k_plan_forward_pixels(j2k_plan *plan, int format, const void *d_pix, size_t stride, int32_t *d_coeff);
 int j2k_plan_inverse_pixels(j2k_plan *plan, const int32_t *d_coeff, void *d_pix, size_t stride);
 
+/* ---- decode-side colour conversions to sRGB ---------------------------------
+ * getColorConversion(cs)(componentData, precision) (colorspace.go:54-480); the values are the
+ * reference's ColorSpace constants (jpeg2000.go:124-197).  Spaces without a conversion (sRGB, gray,
+ * bilevel, unknown, unspecified) and component counts below what a conversion needs (3; 4 for
+ * CMYK / YCCK) leave the data untouched, as the reference does. */
+enum {
+    J2K_CS_UNKNOWN = -1, J2K_CS_UNSPECIFIED = 0, J2K_CS_SRGB = 1, J2K_CS_GRAY = 2, J2K_CS_SYCC = 3, J2K_CS_EYCC = 4,
+    J2K_CS_CMYK = 5, J2K_CS_BILEVEL = 6, J2K_CS_YCBCR2 = 7, J2K_CS_YCBCR3 = 8, J2K_CS_PHOTOYCC = 9, J2K_CS_CMY = 10,
+    J2K_CS_YCCK = 11, J2K_CS_CIELAB = 12, J2K_CS_CIEJAB = 13, J2K_CS_ESRGB = 14, J2K_CS_ROMMRGB = 15,
+    J2K_CS_YPBPR60 = 16, J2K_CS_YPBPR50 = 17
+};
+/* host planes (ncomp pointers to n int32 each), converted in place */
+int j2k_convert_colorspace(j2k_ctx *ctx, int colorspace, int32_t *const *planes, int ncomp, size_t n, int precision);
+/* device planes, contiguous (ncomp x n int32), converted in place on the ctx stream */
+int j2k_convert_colorspace_device(j2k_ctx *ctx, int colorspace, int32_t *d_planes, int ncomp, size_t n, int precision);
+
 /* Whole shard from HOST planes, mirroring encoder.preprocess + encodeTile
  * (encoder.go:216-281, 597-688): planes[c] = host int32 W*H, mutated in place to
  * the coefficients like e.componentData when the frame is a single tile (with tiles

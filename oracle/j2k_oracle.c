@@ -11,6 +11,7 @@
 #include "j2k_oracle.h"
 #include "ht_tables.h"
 
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -345,6 +346,105 @@ void orc_tcd_inverse_dwt(int32_t *d, int w, int h, int levels, int reversible) {
     orc_reconstruct97(f, w, h, levels);
     for (size_t i = 0; i < n; i++) d[i] = (int32_t)(f[i] + 0.5);      /* trunc: negatives round toward + */
     free(f);
+}
+
+/* ---- colorspace.go:54-501 ---------------------------------------------------------------------- */
+static int32_t cs_go_int32(double v) {                               /* Go int32(float64) on amd64 */
+    if (v != v) return 0;
+    if (v > -2147483648.0 && v < 2147483648.0) return (int32_t)v;
+    if (v >= 9223372036854775808.0 || v < -9223372036854775808.0) return 0;
+    return (int32_t)(int64_t)v;
+}
+static int32_t cs_clamp_to_int32(double v, double lo, double hi) {   /* colorspace.go:483-491 */
+    if (v < lo) return cs_go_int32(lo);
+    if (v > hi) return cs_go_int32(hi);
+    return cs_go_int32(v + 0.5);
+}
+static double cs_clamp_f64(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static double cs_lab_inverse_f(double t) {                           /* :293-299 */
+    const double delta = 6.0 / 29.0;
+    if (t > delta) return t * t * t;
+    return 3 * delta * delta * (t - 4.0 / 29.0);
+}
+static double cs_srgb_gamma(double linear) {                         /* :302-307 */
+    if (linear <= 0.0031308) return 12.92 * linear;
+    return 1.055 * pow(linear, 1.0 / 2.4) - 0.055;
+}
+
+void orc_convert_colorspace(int cs, int32_t **planes, int ncomp, size_t n, int precision) {
+    const int need4 = (cs == 5 || cs == 11);
+    if (ncomp < (need4 ? 4 : 3)) return;
+    const double maxVal = (double)(int32_t)(((uint32_t)1 << precision) - 1);
+    const double halfVal = (double)(int32_t)((uint32_t)1 << (precision - 1));
+    int32_t *p0 = planes[0], *p1 = planes[1], *p2 = planes[2];
+    for (size_t i = 0; i < n; i++) {
+        double r, g, b;
+        switch (cs) {
+        case 3: case 16: case 17: case 4: {                          /* sYCC :92-116, YPbPr :429-452, e-sYCC :456-480 */
+            double y = (double)p0[i], cb = (double)p1[i] - halfVal, cr = (double)p2[i] - halfVal;
+            r = y + 1.5748 * cr; g = y - 0.1873 * cb - 0.4681 * cr; b = y + 1.8556 * cb;
+            break;
+        }
+        case 7: case 8: {                                            /* BT.601 :119-142 */
+            double y = (double)p0[i], cb = (double)p1[i] - halfVal, cr = (double)p2[i] - halfVal;
+            r = y + 1.402 * cr; g = y - 0.344136 * cb - 0.714136 * cr; b = y + 1.772 * cb;
+            break;
+        }
+        case 9: case 11: {                                           /* PhotoYCC :145-169, YCCK :218-247 */
+            double scale = maxVal / 255.0;
+            double y = (double)p0[i] / scale, c1 = (double)p1[i] / scale - 156.0, c2 = (double)p2[i] / scale - 156.0;
+            r = y + 1.3584 * c2; g = y - 0.4302 * c1 - 0.7915 * c2; b = y + 2.2179 * c1;
+            if (cs == 11) {
+                double k = (double)planes[3][i] / maxVal;
+                r = r * scale * (1 - k); g = g * scale * (1 - k); b = b * scale * (1 - k);
+            } else { r = r * scale; g = g * scale; b = b * scale; }
+            break;
+        }
+        case 10: {                                                   /* CMY :172-189 */
+            int32_t mv = (int32_t)(((uint32_t)1 << precision) - 1);
+            p0[i] = (int32_t)((uint32_t)mv - (uint32_t)p0[i]); p1[i] = (int32_t)((uint32_t)mv - (uint32_t)p1[i]);
+            p2[i] = (int32_t)((uint32_t)mv - (uint32_t)p2[i]);
+            continue;
+        }
+        case 5: {                                                    /* CMYK :192-215 */
+            double c = (double)p0[i] / maxVal, m = (double)p1[i] / maxVal, y = (double)p2[i] / maxVal, k = (double)planes[3][i] / maxVal;
+            r = (1 - c) * (1 - k) * maxVal; g = (1 - m) * (1 - k) * maxVal; b = (1 - y) * (1 - k) * maxVal;
+            break;
+        }
+        case 12: case 13: {                                          /* CIELab :250-290, CIEJab :319-359 */
+            double L = (double)p0[i] / maxVal * 100.0, a = (double)p1[i] / maxVal * 255.0 - 128.0, bb = (double)p2[i] / maxVal * 255.0 - 128.0;
+            double fy = (L + 16.0) / 116.0, fx = a / 500.0 + fy, fz = fy - bb / 200.0;
+            double x = 0.96422 * cs_lab_inverse_f(fx), y = 1.0 * cs_lab_inverse_f(fy), z = 0.82521 * cs_lab_inverse_f(fz);
+            double rl = 3.2404542 * x - 1.5371385 * y - 0.4985314 * z;
+            double gl = -0.9692660 * x + 1.8760108 * y + 0.0415560 * z;
+            double bl = 0.0556434 * x - 0.2040259 * y + 1.0572252 * z;
+            r = cs_srgb_gamma(rl) * maxVal; g = cs_srgb_gamma(gl) * maxVal; b = cs_srgb_gamma(bl) * maxVal;
+            break;
+        }
+        case 14: {                                                   /* e-sRGB :362-388 */
+            double er = (double)p0[i] / maxVal * 1.25 - 0.25, eg = (double)p1[i] / maxVal * 1.25 - 0.25, eb = (double)p2[i] / maxVal * 1.25 - 0.25;
+            r = cs_srgb_gamma(cs_clamp_f64(er, 0, 1)) * maxVal; g = cs_srgb_gamma(cs_clamp_f64(eg, 0, 1)) * maxVal;
+            b = cs_srgb_gamma(cs_clamp_f64(eb, 0, 1)) * maxVal;
+            break;
+        }
+        case 15: {                                                   /* ROMM-RGB :391-426 */
+            double rr = pow((double)p0[i] / maxVal, 1.8), gr = pow((double)p1[i] / maxVal, 1.8), br = pow((double)p2[i] / maxVal, 1.8);
+            double x = 0.7977 * rr + 0.1352 * gr + 0.0313 * br;
+            double y = 0.2880 * rr + 0.7119 * gr + 0.0001 * br;
+            double z = 0.0000 * rr + 0.0000 * gr + 0.8249 * br;
+            double rl = 3.2404542 * x - 1.5371385 * y - 0.4985314 * z;
+            double gl = -0.9692660 * x + 1.8760108 * y + 0.0415560 * z;
+            double bl = 0.0556434 * x - 0.2040259 * y + 1.0572252 * z;
+            r = cs_srgb_gamma(cs_clamp_f64(rl, 0, 1)) * maxVal; g = cs_srgb_gamma(cs_clamp_f64(gl, 0, 1)) * maxVal;
+            b = cs_srgb_gamma(cs_clamp_f64(bl, 0, 1)) * maxVal;
+            break;
+        }
+        default: return;                                             /* :86-89: no conversion */
+        }
+        p0[i] = cs_clamp_to_int32(r, 0, maxVal);
+        p1[i] = cs_clamp_to_int32(g, 0, maxVal);
+        p2[i] = cs_clamp_to_int32(b, 0, maxVal);
+    }
 }
 
 /* ---- RawEncoder / RawDecoder, mqc.go:516-600 ------------------------------------------------- */

@@ -61,6 +61,9 @@ void orc_tcd_forward_dwt(int32_t *d, int w, int h, int levels, int reversible);
 /* tcd.TileDecoder.ApplyInverseDWT (tcd.go:416-437): 9-7 path rounds int32(v+0.5) */
 void orc_tcd_inverse_dwt(int32_t *d, int w, int h, int levels, int reversible);
 /* decoder.decodeTiles tail (decoder.go:321-348): inverse MCT (if mct && C>=3) + DC shift (unsigned) */
+/* getColorConversion(cs)(componentData, precision), colorspace.go:54-480; cs = the reference's ColorSpace constants
+ * (jpeg2000.go:124-197).  In place; spaces / component counts without a conversion leave the data untouched. */
+void orc_convert_colorspace(int cs, int32_t **planes, int ncomp, size_t n, int precision);
 /* RawEncoder / RawDecoder (mqc.go:516-600): n bits in (one per byte) -> bytes; returns the byte count / fills bits */
 long orc_raw_encode(const uint8_t *bits, size_t n, uint8_t *out, size_t cap);
 void orc_raw_decode(const uint8_t *data, size_t len, size_t n, uint8_t *bits);

@@ -190,6 +190,14 @@ def mq_decode(data, ctx):
     return out
 
 
+def convert_colorspace(planes, cs, precision):
+    """getColorConversion(cs)(componentData, precision) (colorspace.go); returns new planes."""
+    shape = np.asarray(planes[0]).shape
+    planes = [_own_i32(p).reshape(-1) for p in planes]
+    lib().orc_convert_colorspace(int(cs), _plane_ptrs(planes), len(planes), C.c_size_t(planes[0].size), int(precision))
+    return [p.reshape(shape) for p in planes]
+
+
 def raw_encode(bits):
     bits = np.ascontiguousarray(bits, dtype=np.uint8)
     out = np.zeros(bits.size // 7 + 16, dtype=np.uint8)

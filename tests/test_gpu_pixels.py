@@ -110,3 +110,29 @@ def test_plan_forward_inverse_pixels_all_formats(oracle, fmt, prec):
         plan.inverse_pixels(got, out)
         plan.ctx.sync()
         assert np.array_equal(out.cpu().numpy(), oracle.create_image([p for p in back.cpu().numpy()], prec))
+
+
+@pytest.mark.parametrize("cs", range(-1, 18))
+@pytest.mark.parametrize("prec", [8, 12, 16])
+def test_colorspace_conversions(oracle, cs, prec):
+    """colorspace.go:54-480 for every ColorSpace constant: the matrix conversions bit-exact against the oracle, the four
+    that go through math.Pow (CIELab, CIEJab, e-sRGB, ROMM-RGB: 12..15) within one code value; 3 and 4 components."""
+    from j2kgfx import colorspace
+    rng = np.random.default_rng(cs * 7 + prec)
+    mx = (1 << prec) - 1
+    n = 5000
+    for nc in (3, 4):
+        planes = [rng.integers(0, mx + 1, n).astype(np.int32) for _ in range(nc)]
+        for p in planes[:3]:                                       # corners and out-of-range values for the matrix conversions
+            p[:4] = [0, mx, mx // 2, mx // 2 + 1]
+            if cs not in (12, 13, 14, 15):
+                p[4:8] = [-5, mx + 9, -2147483648, 2147483647]
+        want = oracle.convert_colorspace([p.copy() for p in planes], cs, prec)
+        got = colorspace.convert([p.copy() for p in planes], cs, prec)
+        for c in range(nc):
+            if cs in (12, 13, 14, 15) and c < 3:
+                assert np.max(np.abs(got[c].astype(np.int64) - want[c].astype(np.int64))) <= 1, (cs, c)
+            else:
+                assert np.array_equal(got[c], want[c]), (cs, c)
+    two = [np.arange(10, dtype=np.int32), np.arange(10, dtype=np.int32)]
+    assert np.array_equal(colorspace.convert([p.copy() for p in two], 3, prec)[0], two[0])   # fewer than 3 components: untouched

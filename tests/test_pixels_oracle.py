@@ -109,3 +109,22 @@ def test_create_image_matches_numpy(nc, prec):
     got = orc.create_image(planes, prec, stride)
     want = np_create(planes, prec, stride)
     assert np.array_equal(got, want)
+
+
+def test_colorspace_oracle_hand_values():
+    """colorspace.go by hand: sYCC neutral grey stays grey; CMY is the integer complement; CMYK with K = max is black;
+    BT.601 red; an unknown space and a 2-component image are untouched."""
+    import oracle as orc
+    g = [np.array([100], np.int32), np.array([128], np.int32), np.array([128], np.int32)]
+    assert [int(p[0]) for p in orc.convert_colorspace(g, 3, 8)] == [100, 100, 100]
+    c = [np.array([0, 255, 10], np.int32), np.array([255, 0, 20], np.int32), np.array([5, 5, 30], np.int32)]
+    out = orc.convert_colorspace(c, 10, 8)
+    assert out[0].tolist() == [255, 0, 245] and out[1].tolist() == [0, 255, 235] and out[2].tolist() == [250, 250, 225]
+    k = [np.array([10], np.int32), np.array([20], np.int32), np.array([30], np.int32), np.array([255], np.int32)]
+    assert [int(p[0]) for p in orc.convert_colorspace(k, 5, 8)[:3]] == [0, 0, 0]
+    y = [np.array([76], np.int32), np.array([85], np.int32), np.array([255], np.int32)]      # Y, Cb, Cr of pure red (BT.601)
+    r, gg, b = [int(p[0]) for p in orc.convert_colorspace(y, 7, 8)]
+    assert r == 254 and gg == 0 and b == 0      # 76 + 1.402*127 = 254.05 -> 254; g = 76 + 14.8 - 90.7 = 0.1 -> 0; b = 76 - 76.2 -> clamp 0
+    same = [np.array([1, 2, 3], np.int32)] * 3
+    assert orc.convert_colorspace([p.copy() for p in same], 1, 8)[0].tolist() == [1, 2, 3]
+    assert orc.convert_colorspace([np.array([9], np.int32)] * 2, 3, 8)[0].tolist() == [9]
