@@ -136,3 +136,27 @@ def test_ht_basic_properties(oracle):                            # ht_test.go:7-
     for data in (np.zeros(0, np.uint8), np.zeros(1, np.uint8), np.zeros(2, np.uint8)):
         assert not oracle.ht_decode(data, 8, 8).any()             # nil / 1-byte / 2-byte inputs -> zeros
     assert oracle.ht_encode(np.zeros(16, np.int32), 4, 4).size == 0
+
+
+def test_colorspace_reference_test_expectations():
+    """The assertions of the reference's own colorspace_test.go (:48-300, 391-500) hold for the oracle's restatement of
+    colorspace.go: neutral inputs stay neutral (+-2), CMY / CMYK white and black are exact, Lab mid-grey is grey within
+    20, results stay in range, too few components leave the data untouched."""
+    import oracle as orc
+
+    def one(cs, vals, prec=8):
+        return [int(p[0]) for p in orc.convert_colorspace([np.array([v], np.int32) for v in vals], cs, prec)]
+
+    for cs in (3, 7, 8, 16, 17, 4):                                  # TestConvertSYCC / YCbCr601 / YPbPr709 / EYCC
+        r, g, b = one(cs, [128, 128, 128])
+        assert abs(r - 128) <= 2 and abs(g - 128) <= 2 and abs(b - 128) <= 2
+    assert one(10, [0, 0, 0]) == [255, 255, 255] and one(10, [255, 255, 255]) == [0, 0, 0]           # TestConvertCMYToRGB
+    assert one(5, [0, 0, 0, 0])[:3] == [255, 255, 255] and one(5, [0, 0, 0, 255])[0] == 0              # TestConvertCMYKToRGB
+    r, g, b = one(12, [128, 128, 128])                                                                 # TestConvertCIELabToRGB
+    assert abs(r - g) <= 20 and abs(g - b) <= 20
+    for cs in (14, 15, 13, 9):                                                                         # e-sRGB, ROMM, Jab, PhotoYCC
+        assert all(0 <= v <= 255 for v in one(cs, [128, 128, 128]))
+    assert all(0 <= v <= 65535 for v in one(3, [32768, 32768, 32768], 16))                             # 16bit_precision
+    two = [np.array([128], np.int32), np.array([128], np.int32)]
+    assert [int(p[0]) for p in orc.convert_colorspace(two, 3, 8)] == [128, 128]                        # insufficient_components
+    assert all(0 <= v <= 255 for v in one(11, [128, 156, 156, 0])[:3])                                 # TestConvertYCCKToRGB range
