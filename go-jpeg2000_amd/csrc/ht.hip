@@ -897,8 +897,11 @@ __global__ __launch_bounds__(256) void ht_vlcprep_kernel(const BlockJob *__restr
     if (lane == 0) { rec[0] = 0; rec[HT_WALK_MAX_PAIRS] = (uint32_t)scup; }   // not a tag; SCUP travels in the flag word
 }
 
+#ifndef HT_WALK_BLOCKS
+#define HT_WALK_BLOCKS 64                      /* blocks (= walking lanes) per workgroup: 64 or 32 */
+#endif
 struct HtWalkShared {
-    uint32_t vb[64][HT_VROW];
+    uint32_t vb[HT_WALK_BLOCKS][HT_VROW];
     uint16_t pair1[16384];
     uint16_t tbl0[512], tbl1[512];
 };
@@ -924,27 +927,28 @@ __global__ __launch_bounds__(256) void ht_walk_kernel(const BlockJob *__restrict
     extern __shared__ __align__(16) unsigned char walk_smem[];
     HtWalkShared &S = *reinterpret_cast<HtWalkShared *>(walk_smem);
     const int tid = threadIdx.x, lane = tid & 63;
-    const int jid0 = blockIdx.x * 64;
+    const int jid0 = blockIdx.x * HT_WALK_BLOCKS;
     const int jid = jid0 + lane;
-    const bool have = jid < njobs;
+    const bool have = lane < HT_WALK_BLOCKS && jid < njobs;
 #ifdef J2K_WALK_STAMP
     const long long st0 = __builtin_amdgcn_s_memtime();
 #endif
     // Staging by all four wavefronts, every load issued before the first use (a lone wavefront doing this in
     // dependent batches spent 40% of the kernel here): 32 KiB pair table = 8 x 16 B per thread, 64 blocks x 192 words
     // = 12 x 16 B per thread, the two 1 KiB tables.  Afterwards only wavefront 0 walks.
-    const int nblk = min(64, njobs - jid0);
+    const int nblk = min(HT_WALK_BLOCKS, njobs - jid0);
     // the walking wavefront's own inputs ride along with the staging loads
     uint32_t *rec = pairs + (size_t)jid * HT_WALK_REC;
     uint32_t tag = HT_PAIR_ZERO;
     int w = 0, h = 0;
     if (tid < 64 && have) { tag = rec[0]; w = jobs[jid].w; h = jobs[jid].h; }
     {
-        uint4 t[8], v[12];
+        constexpr int NV = HT_WALK_BLOCKS * 48 / 256;          // 16-byte pieces of bit string per thread
+        uint4 t[8], v[NV];
 #pragma unroll
         for (int j = 0; j < 8; j++) t[j] = reinterpret_cast<const uint4 *>(g_vlc_pair1)[j * 256 + tid];
 #pragma unroll
-        for (int j = 0; j < 12; j++) {
+        for (int j = 0; j < NV; j++) {
             const int q = j * 256 + tid;                      // 16-byte piece q: block q / 48, words 4 * (q % 48) ..
             const int bsel = min(q / 48, nblk - 1);
             v[j] = reinterpret_cast<const uint4 *>(vbits + (size_t)(jid0 + bsel) * HT_VBITS_WORDS)[q % 48];
@@ -954,7 +958,7 @@ __global__ __launch_bounds__(256) void ht_walk_kernel(const BlockJob *__restrict
 #pragma unroll
         for (int j = 0; j < 8; j++) reinterpret_cast<uint4 *>(S.pair1)[j * 256 + tid] = t[j];
 #pragma unroll
-        for (int j = 0; j < 12; j++) {
+        for (int j = 0; j < NV; j++) {
             const int q = j * 256 + tid;
             uint32_t *d = &S.vb[q / 48][4 * (q % 48)];        // rows have an odd word stride: four 4-byte stores
             d[0] = v[j].x; d[1] = v[j].y; d[2] = v[j].z; d[3] = v[j].w;
@@ -1423,7 +1427,7 @@ hipError_t launch_ht_decode(hipStream_t s, const BlockJob *jobs, int njobs, cons
     uint32_t *pairs = scratch, *vbits = scratch + (size_t)njobs * HT_WALK_REC;
     hipLaunchKernelGGL(ht_vlcprep_kernel, dim3((njobs + 3) / 4), dim3(256), 0, s, jobs, njobs, stream, offs, lens, vbits, pairs);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    hipLaunchKernelGGL(ht_walk_kernel, dim3((njobs + 63) / 64), dim3(256), sizeof(HtWalkShared), s, jobs, njobs, vbits, pairs);
+    hipLaunchKernelGGL(ht_walk_kernel, dim3((njobs + HT_WALK_BLOCKS - 1) / HT_WALK_BLOCKS), dim3(256), sizeof(HtWalkShared), s, jobs, njobs, vbits, pairs);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     hipLaunchKernelGGL(ht_decode_kernel, dim3((njobs + 3) / 4), dim3(256), 0, s, jobs, njobs, stream, offs, lens, decoded, pairs);
     return hipGetLastError();
