@@ -648,14 +648,12 @@ static int ensure(j2k_ctx *ctx, void **p, size_t bytes) {
 static int coder_call(j2k_ctx *ctx, int which, const uint8_t *a, size_t na, const uint8_t *b, size_t nb, size_t n, uint8_t *out, size_t cap,
                       size_t *out_len) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    int r = stage_reserve(ctx, 0, na + nb + 64);
+    const size_t na16 = (na + 15) & ~size_t(15);
+    int r = stage_reserve(ctx, 0, na16 + nb + 64);
     if (r == J2K_OK) r = stage_reserve(ctx, 1, cap + 64);
     if (r == J2K_OK) r = stage_reserve(ctx, 3, 256);
     if (r != J2K_OK) return r;
-    uint8_t *d_a = (uint8_t *)ctx->stage[0], *d_b = d_a + ((na + 15) & ~size_t(15)), *d_out = (uint8_t *)ctx->stage[1];
-    r = stage_reserve(ctx, 0, ((na + 15) & ~size_t(15)) + nb + 64);
-    if (r != J2K_OK) return r;
-    d_a = (uint8_t *)ctx->stage[0]; d_b = d_a + ((na + 15) & ~size_t(15));
+    uint8_t *d_a = (uint8_t *)ctx->stage[0], *d_b = d_a + na16, *d_out = (uint8_t *)ctx->stage[1];
     int *d_fault = (int *)ctx->stage[3] + 16;                                    // bytes 64..: word 0 is the plans' sticky fault word
     uint32_t *d_len = (uint32_t *)ctx->stage[3] + 20;
     HIPCHK(ctx, hipMemsetAsync(d_fault, 0, 32, ctx->stream));
