@@ -96,6 +96,7 @@ extern "C" int j2k_ctx_create(int device, j2k_ctx **out) {
         int v = atoi(e);
         if (v >= 1 && v <= 4096) ctx->band_prows = v;
     }
+    if (const char *e = getenv("J2K_BAND_PROWS_PIX")) { int v = atoi(e); if (v >= 1 && v <= 4096) ctx->band_prows_pix = v; }
     if (const char *e = getenv("J2K_BAND_PROWS_97")) { int v = atoi(e); if (v >= 2 && v <= 4096) ctx->band_prows_97 = v; }
     if (const char *e = getenv("J2K_FORCE_NOVEC")) ctx->force_novec = atoi(e) != 0;
     if (const char *e = getenv("J2K_FUSE_COMPACT")) ctx->fuse_compact = atoi(e) != 0;
@@ -374,45 +375,55 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                 const int halo = (S.wavelet == W97 && cpl < 4) ? 2 : 1;
                 const int band53 = (dir == 1 && ctx->band_prows_inv > 0) ? ctx->band_prows_inv : ctx->band_prows;
                 const int band = (S.wavelet == W97) ? ctx->band_prows_97 : band53;
-                std::vector<DwtJob> jobs;
-                for (size_t i = 0; i < planes.size(); i++) {
-                    make_jobs(jobs, (int)i, pw[i], ph[i], cpl, band, halo);
-                    T.alg_bytes += (int64_t)2 * esz * pw[i] * ph[i] * T.ncomp;
-                }
-                if (ctx->xcd_map && jobs.size() >= 64) {
-                    // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one), so the
-                    // wavefronts of one plane -- whose bands share halo rows -- are placed in workgroups = x (mod 8):
-                    // the halo re-reads then hit that XCD's L2 instead of going back to HBM.  Speed only.
-                    std::vector<std::vector<DwtJob>> per(8);
-                    for (const DwtJob &j : jobs) per[j.plane % 8].push_back(j);
-                    size_t m = 0;
-                    for (auto &v : per) m = std::max(m, v.size());
-                    m = (m + 3) & ~size_t(3);
-                    std::vector<DwtJob> perm(m * 8, DwtJob{-1, 0, 0, 0});
-                    for (int x = 0; x < 8; x++)
-                        for (size_t i = 0; i < per[x].size(); i++) perm[((i / 4) * 8 + x) * 4 + (i % 4)] = per[x][i];
-                    jobs.swap(perm);
-                }
-                if (S.wavelet == W53 && (dir == 0 ? ctx->fwd_link : ctx->inv_link)) {
-                    // link vertically adjacent bands that share a workgroup (4 consecutive jobs): see dwt53_fwd_kernel
-                    for (size_t i = 1; i < jobs.size(); i++) {
-                        if (i % 4 == 0) continue;
-                        DwtJob &a = jobs[i - 1], &b = jobs[i];
-                        if (a.plane < 0 || a.plane != b.plane || a.col0 != b.col0) continue;
-                        const int w = pw[a.plane], h = ph[a.plane], halfH = (h + 1) / 2;
-                        if (w < 2 || h < 2) continue;
-                        const int an = a.nprow & 0xffff, bn = b.nprow & 0xffff;
-                        if (a.prow0 + an != b.prow0) continue;
-                        if (std::min(an, halfH - a.prow0) < 2 || std::min(bn, halfH - b.prow0) < 2) continue;
-                        if (2 * b.prow0 + 1 >= h) continue;      // the band below must own a real odd row
-                        a.nprow |= J2K_LINK_DOWN;
-                        b.nprow |= J2K_LINK_UP;
+                auto build_jobs = [&](int band_) {
+                    std::vector<DwtJob> jobs;
+                    for (size_t i = 0; i < planes.size(); i++) make_jobs(jobs, (int)i, pw[i], ph[i], cpl, band_, halo);
+                    if (ctx->xcd_map && jobs.size() >= 64) {
+                        // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one), so the
+                        // wavefronts of one plane -- whose bands share halo rows -- are placed in workgroups = x (mod 8):
+                        // the halo re-reads then hit that XCD's L2 instead of going back to HBM.  Speed only.
+                        std::vector<std::vector<DwtJob>> per(8);
+                        for (const DwtJob &j : jobs) per[j.plane % 8].push_back(j);
+                        size_t m = 0;
+                        for (auto &v : per) m = std::max(m, v.size());
+                        m = (m + 3) & ~size_t(3);
+                        std::vector<DwtJob> perm(m * 8, DwtJob{-1, 0, 0, 0});
+                        for (int x = 0; x < 8; x++)
+                            for (size_t i = 0; i < per[x].size(); i++) perm[((i / 4) * 8 + x) * 4 + (i % 4)] = per[x][i];
+                        jobs.swap(perm);
                     }
-                }
+                    if (S.wavelet == W53 && (dir == 0 ? ctx->fwd_link : ctx->inv_link)) {
+                        // link vertically adjacent bands that share a workgroup (4 consecutive jobs): see dwt53_fwd_kernel
+                        for (size_t i = 1; i < jobs.size(); i++) {
+                            if (i % 4 == 0) continue;
+                            DwtJob &a = jobs[i - 1], &b = jobs[i];
+                            if (a.plane < 0 || a.plane != b.plane || a.col0 != b.col0) continue;
+                            const int w = pw[a.plane], h = ph[a.plane], halfH = (h + 1) / 2;
+                            if (w < 2 || h < 2) continue;
+                            const int an = a.nprow & 0xffff, bn = b.nprow & 0xffff;
+                            if (a.prow0 + an != b.prow0) continue;
+                            if (std::min(an, halfH - a.prow0) < 2 || std::min(bn, halfH - b.prow0) < 2) continue;
+                            if (2 * b.prow0 + 1 >= h) continue;      // the band below must own a real odd row
+                            a.nprow |= J2K_LINK_DOWN;
+                            b.nprow |= J2K_LINK_UP;
+                        }
+                    }
+                    return jobs;
+                };
+                for (size_t i = 0; i < planes.size(); i++) T.alg_bytes += (int64_t)2 * esz * pw[i] * ph[i] * T.ncomp;
+                std::vector<DwtJob> jobs = build_jobs(band);
                 T.njobs = (int)jobs.size();
                 int r = upload(ctx, &T.d_planes, planes);
                 if (r == J2K_OK) r = upload(ctx, &T.d_jobs, jobs);
                 if (r != J2K_OK) { j2k_plan_destroy(P); return r; }
+                if (dir == 0 && l == 0 && cls == 1 && S.wavelet == W53 && vec_ok && cpl == 8) {
+                    // the packed-pixel forward (j2k_plan_forward_rgba8) moves a third of the bytes per row on the read side
+                    // and likes shorter bands: its own job table (measured: 3 pair-rows 29.6 us, 5 pair-rows 31.9 us)
+                    std::vector<DwtJob> pj = build_jobs(ctx->band_prows_pix);
+                    P->fwd_pix_njobs = (int)pj.size();
+                    r = upload(ctx, &P->d_fwd_pix_jobs, pj);
+                    if (r != J2K_OK) { j2k_plan_destroy(P); return r; }
+                }
                 if (dir == 0) {
                     P->dwt_bytes += T.alg_bytes;
                     if (l == 0) P->dwt_level0_bytes += T.alg_bytes;
@@ -486,7 +497,7 @@ extern "C" void j2k_plan_destroy(j2k_plan *P) {
         for (auto &T : P->fwd[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); }
         for (auto &T : P->inv[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); }
     }
-    void *ptrs[] = {P->d_scrA, P->d_scrB, P->d_tail, P->d_bjobs, P->d_djobs, P->d_frame, P->d_coeff, P->d_slots, P->d_stream, P->d_lens, P->d_numbps, P->d_offs, P->d_status};
+    void *ptrs[] = {P->d_scrA, P->d_scrB, P->d_tail, P->d_bjobs, P->d_djobs, P->d_frame, P->d_coeff, P->d_slots, P->d_stream, P->d_lens, P->d_numbps, P->d_offs, P->d_status, P->d_fwd_pix_jobs};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete P;
 }
@@ -579,7 +590,10 @@ static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff, in
             if (!T.njobs) continue;
             if (S.wavelet == W53) {
                 LevelLaunch L = mk(T, ctx->fwd_pf);
-                if (l == 0 && cls == 1) L.pix_stride = pix_stride;        // packed RGBA8 frame (j2k_plan_forward_rgba8)
+                if (l == 0 && cls == 1 && pix_stride > 0) {               // packed RGBA8 frame (j2k_plan_forward_rgba8)
+                    L.pix_stride = pix_stride;
+                    if (P->d_fwd_pix_jobs) { L.jobs = P->d_fwd_pix_jobs; L.njobs = P->fwd_pix_njobs; }
+                }
                 if (l == 0 && cls == 1 && ev1) { L.ev_start = ev0; L.ev_stop = ev1; }
                 HIPCHK(ctx, launch_dwt53_fwd(ctx->stream, L, (const int32_t *)in, (int32_t *)d_coeff, (int32_t *)nx, l == 0 ? S.dc_shift : 0));
             } else {

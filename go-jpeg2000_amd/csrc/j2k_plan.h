@@ -14,6 +14,7 @@ struct j2k_ctx {
                                // Measured slower than the three kernels it replaces (61.7 vs 58.6 us: the prefix chain crosses XCDs)
     int fwd_link = 1;          // forward 5-3: bands of one workgroup exchange halo rows through LDS (J2K_FWD_LINK)
     int inv_link = 1;          // same for the inverse kernels (J2K_INV_LINK)
+    int band_prows_pix = 3;    // packed-pixel level-0 forward (J2K_BAND_PROWS_PIX)
     int band_prows_97 = 8;     // 9-7 kernels: 7 halo rows per band, so taller bands (J2K_BAND_PROWS_97)
     int band_prows_inv = 0;    // 0: same as band_prows (J2K_BAND_PROWS_INV)
     int fwd_pf = 0;            // forward 5-3 level kernels: software prefetch of the next pair-row (J2K_FWD_PF)
@@ -108,6 +109,8 @@ struct j2k_plan {
     void *d_frame = nullptr, *d_coeff = nullptr, *d_slots = nullptr, *d_stream = nullptr;
     void *d_lens = nullptr, *d_numbps = nullptr, *d_offs = nullptr;
     // fused encode + compact (j2k_plan_encode_stream): look-back status words, tagged with the launch epoch
+    j2k::DwtJob *d_fwd_pix_jobs = nullptr;  // level-0 forward job table of the packed-pixel path (shorter bands)
+    int fwd_pix_njobs = 0;
     uint64_t *d_status = nullptr;
     uint32_t epoch = 0;
     bool all_blocks_fast = false;           // every job on the parallel HT path
