@@ -50,55 +50,61 @@ __global__ __launch_bounds__(1024) void scan_lens_kernel(const uint32_t *__restr
     if (tid == 0) offs[n] = carry;
 }
 
-// one wavefront per job: the slot is 16-byte aligned, the destination is not -- destination-aligned 16-byte stores
-// whose dwords are assembled from two aligned source dwords (v_alignbyte)
+// n bytes src -> dst, any alignment on both sides, one wavefront: bytes up to the destination's next 16-byte boundary,
+// then aligned 16-byte stores of (possibly unaligned) 16-byte loads, then the tail bytes
+__device__ __forceinline__ void copy_bytes(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, uint32_t n, int lane) {
+    const uint32_t head = min(n, (uint32_t)((16 - ((uintptr_t)dst & 15)) & 15));
+    if ((uint32_t)lane < head) dst[lane] = src[lane];
+    const uint32_t nv = (n - head) >> 4;
+    for (uint32_t i = lane; i < nv; i += 64) {
+        uint4 v;
+        __builtin_memcpy(&v, src + head + 16 * (size_t)i, 16);
+        *reinterpret_cast<uint4 *>(dst + head + 16 * (size_t)i) = v;
+    }
+    const uint32_t done = head + (nv << 4);
+    if (done + lane < n) dst[done + lane] = src[done + lane];
+}
+__device__ __forceinline__ void zero_run(uint8_t *__restrict__ dst, uint32_t n, int lane) {
+    const uint32_t head = min(n, (uint32_t)((16 - ((uintptr_t)dst & 15)) & 15));
+    if ((uint32_t)lane < head) dst[lane] = 0;
+    const uint32_t nv = (n - head) >> 4;
+    for (uint32_t i = lane; i < nv; i += 64) *reinterpret_cast<uint4 *>(dst + head + 16 * (size_t)i) = make_uint4(0, 0, 0, 0);
+    const uint32_t done = head + (nv << 4);
+    if (done + lane < n) dst[done + lane] = 0;
+}
+
+// one wavefront per job.  maglens != NULL (HT blocks coded by j2k_plan_encode_stream): the slot holds
+// MagSgn | <hole> | VLC | SCUP -- the MEL segment of max(64, 2wh)/4 zero bytes (ht.go:978, 1019) was never written to the
+// slot and is produced here as zeros, so two thirds of a 64x64 block's bytes are neither stored twice nor read back.
 __global__ __launch_bounds__(256) void gather_kernel(const BlockJob *__restrict__ jobs, int njobs, const uint8_t *__restrict__ slots,
                                                      const uint32_t *__restrict__ lens, const uint64_t *__restrict__ offs,
-                                                     uint8_t *__restrict__ stream) {
+                                                     uint8_t *__restrict__ stream, const uint32_t *__restrict__ maglens) {
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= njobs) return;
     const int lane = threadIdx.x & 63;
     const uint32_t len = lens[j];
-    const uint8_t *src = slots + jobs[j].out_off;   // 16-byte aligned
-    uint8_t *dst = stream + offs[j];
     if (len == 0) return;
-    // head bytes up to 4-byte alignment of dst, then dwords, then the tail
-    uint32_t head = (uint32_t)((4 - ((uintptr_t)dst & 3)) & 3);
-    if (head > len) head = len;
-    if (lane < (int)head) dst[lane] = src[lane];
-    const uint32_t nd = (len - head) >> 2;          // destination dword i holds source bytes head + 4i .. head + 4i + 3
-    const uint32_t *S = reinterpret_cast<const uint32_t *>(src);
-    const uint32_t last = (len - 1) >> 2;            // last source dword that holds job bytes
-    uint32_t *D = reinterpret_cast<uint32_t *>(dst + head);
-    const uint32_t sh = 8 * head;
-    for (uint32_t i = 4 * lane; i < nd; i += 256) {
-        const uint4 a = *reinterpret_cast<const uint4 *>(S + i);               // i is a multiple of 4: aligned
-        const uint32_t e = S[min(i + 4, last)];
-        uint32_t d0 = a.x, d1 = a.y, d2 = a.z, d3 = a.w;
-        if (head) {
-            d0 = (uint32_t)(((uint64_t)a.y << 32 | a.x) >> sh);
-            d1 = (uint32_t)(((uint64_t)a.z << 32 | a.y) >> sh);
-            d2 = (uint32_t)(((uint64_t)a.w << 32 | a.z) >> sh);
-            d3 = (uint32_t)(((uint64_t)e << 32 | a.w) >> sh);
-        }
-        if (i + 4 <= nd) {
-            D[i] = d0; D[i + 1] = d1; D[i + 2] = d2; D[i + 3] = d3;
-        } else {
-            D[i] = d0;
-            if (i + 1 < nd) D[i + 1] = d1;
-            if (i + 2 < nd) D[i + 2] = d2;
-        }
+    const BlockJob J = jobs[j];
+    const uint8_t *src = slots + J.out_off;
+    uint8_t *dst = stream + offs[j];
+    if (!maglens) {
+        copy_bytes(dst, src, len, lane);
+        return;
     }
-    const uint32_t done = head + 4 * nd;
-    if (done + lane < len) dst[done + lane] = src[done + lane];
+    const uint32_t mag = maglens[j];
+    const size_t nsamp = (size_t)J.w * J.h;
+    const uint32_t mel = (uint32_t)((nsamp * 2 < 64 ? 64 : nsamp * 2) / 4);
+    copy_bytes(dst, src, mag, lane);
+    zero_run(dst + mag, mel, lane);
+    copy_bytes(dst + mag + mel, src + mag + mel, len - mag - mel, lane);
 }
 
 hipError_t launch_compact(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *slots, const uint32_t *lens,
-                          uint64_t *offs, uint8_t *stream, void *) {
+                          uint64_t *offs, uint8_t *stream, const uint32_t *maglens) {
     hipLaunchKernelGGL(scan_lens_kernel, dim3(1), dim3(1024), 0, s, lens, njobs, offs);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || njobs <= 0) return e;
-    hipLaunchKernelGGL(gather_kernel, dim3((njobs + 3) / 4), dim3(256), 0, s, jobs, njobs, slots, lens, offs, stream);
+    hipLaunchKernelGGL(gather_kernel, dim3((njobs + 3) / 4), dim3(256), 0, s, jobs, njobs, slots, lens, offs, stream, maglens);
     return hipGetLastError();
 }
 

@@ -360,7 +360,9 @@ __device__ bool ht_encode_fast(const BlockJob &J, const int32_t *__restrict__ sr
 __global__ __launch_bounds__(64) void ht_encode_kernel(const BlockJob *__restrict__ jobs, int njobs,
                                                        const int32_t *__restrict__ coef, uint8_t *__restrict__ slots,
                                                        uint32_t *__restrict__ lens, uint8_t *__restrict__ numbps,
-                                                       int *__restrict__ fault) {
+                                                       int *__restrict__ fault, uint32_t *__restrict__ maglens) {
+    // maglens != NULL (j2k_plan_encode_stream): also report where the MagSgn bytes end, and do NOT write the MEL
+    // segment's zero bytes into the slot -- the gather puts zeros straight into the stream instead of copying them
     __shared__ uint32_t s_vbuf[HT_VLC_WORDS];
     __shared__ uint32_t s_mbuf[HT_MS_WORDS];
     const int jid = blockIdx.x;
@@ -408,8 +410,9 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(const BlockJob *__restric
             if (lane == 0) { atomicMax(fault, 1); lens[jid] = 0; numbps[jid] = 0; }
             return;
         }
-        zero_bytes(out + mLen, melLen_, lane);
+        if (!maglens) zero_bytes(out + mLen, melLen_, lane);
         if (lane == 0) {
+            if (maglens) maglens[jid] = (uint32_t)mLen;
             const size_t scup = melLen_ + (size_t)vLen + 2;
             const size_t total = (size_t)mLen + scup;
             out[total - 2] = (uint8_t)(scup >> 8);
@@ -504,6 +507,7 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(const BlockJob *__restric
         out[total - 1] = (uint8_t)(scup & 0xFF);
         lens[jid] = (uint32_t)total;
         numbps[jid] = (uint8_t)(32 - __clz((uint32_t)maxMag));
+        if (maglens) maglens[jid] = (uint32_t)magLen;
     }
 }
 
@@ -1395,11 +1399,11 @@ static hipError_t ht_tables_ready(hipStream_t s) {
 }
 
 hipError_t launch_ht_encode(hipStream_t s, const BlockJob *jobs, int njobs, const int32_t *coef, uint8_t *slots,
-                            uint32_t *lens, uint8_t *numbps, int *fault) {
+                            uint32_t *lens, uint8_t *numbps, int *fault, uint32_t *maglens) {
     if (njobs <= 0) return hipSuccess;
     hipError_t e;
     if ((e = ht_tables_ready(s)) != hipSuccess) return e;
-    hipLaunchKernelGGL(ht_encode_kernel, dim3(njobs), dim3(64), 0, s, jobs, njobs, coef, slots, lens, numbps, fault);
+    hipLaunchKernelGGL(ht_encode_kernel, dim3(njobs), dim3(64), 0, s, jobs, njobs, coef, slots, lens, numbps, fault, maglens);
     return hipGetLastError();
 }
 

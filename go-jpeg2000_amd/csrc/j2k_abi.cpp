@@ -20,7 +20,7 @@ hipError_t launch_dwt97_fwd(hipStream_t s, const LevelLaunch &L, const void *src
 hipError_t launch_dwt97_inv(hipStream_t s, const LevelLaunch &L, const void *coef, int coef_is_f64, const double *prev,
                             void *dst, int dc_shift, int final_level, int dst_mode, int mct);
 hipError_t launch_ht_encode(hipStream_t s, const BlockJob *jobs, int njobs, const int32_t *coef, uint8_t *slots,
-                            uint32_t *lens, uint8_t *numbps, int *fault);
+                            uint32_t *lens, uint8_t *numbps, int *fault, uint32_t *maglens = nullptr);
 hipError_t launch_ht_decode(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs,
                             const uint32_t *lens, int32_t *decoded, uint32_t *scratch);
 size_t ht_decode_scratch_words(int njobs);
@@ -39,7 +39,7 @@ hipError_t launch_raw_decode(hipStream_t s, const uint8_t *data, size_t len, siz
 size_t t1_work_bytes(int w, int h);
 size_t t1_flag_bytes(int w, int h);
 hipError_t launch_compact(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *slots, const uint32_t *lens,
-                          uint64_t *offs, uint8_t *stream, void *scan_tmp);
+                          uint64_t *offs, uint8_t *stream, const uint32_t *maglens);
 }  // namespace j2k
 
 // ------------------------------------------------------------------------------
@@ -497,7 +497,7 @@ extern "C" void j2k_plan_destroy(j2k_plan *P) {
         for (auto &T : P->fwd[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); }
         for (auto &T : P->inv[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); }
     }
-    void *ptrs[] = {P->d_scrA, P->d_scrB, P->d_tail, P->d_bjobs, P->d_djobs, P->d_frame, P->d_coeff, P->d_slots, P->d_stream, P->d_lens, P->d_numbps, P->d_offs, P->d_status, P->d_fwd_pix_jobs};
+    void *ptrs[] = {P->d_scrA, P->d_scrB, P->d_tail, P->d_bjobs, P->d_djobs, P->d_frame, P->d_coeff, P->d_slots, P->d_stream, P->d_lens, P->d_numbps, P->d_offs, P->d_status, P->d_fwd_pix_jobs, P->d_maglens};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete P;
 }
@@ -945,6 +945,17 @@ extern "C" int j2k_plan_encode_stream(j2k_plan *P, const int32_t *d_coeff, uint8
         return J2K_OK;
     }
     if (!P->d_slots) HIPCHK(ctx, hipMalloc(&P->d_slots, (size_t)P->bytes_cap + 64));
+    if (P->spec.coder == J2K_CODER_HT) {
+        // the slot buffer is private here: the MEL zero bytes are not written into it, the gather emits them (compact.hip)
+        if (!P->d_maglens) HIPCHK(ctx, hipMalloc((void **)&P->d_maglens, (size_t)n * 4));
+        int r = stage_reserve(ctx, 3, 256);
+        if (r != J2K_OK) return r;
+        ctx->fault_armed = true;
+        HIPCHK(ctx, launch_ht_encode(ctx->stream, P->d_bjobs, n, d_coeff, (uint8_t *)P->d_slots, d_lens, d_numbps, (int *)ctx->stage[3],
+                                     P->d_maglens));
+        HIPCHK(ctx, launch_compact(ctx->stream, P->d_bjobs, n, (const uint8_t *)P->d_slots, d_lens, d_offs, d_stream, P->d_maglens));
+        return J2K_OK;
+    }
     int r = j2k_plan_encode_blocks(P, d_coeff, (uint8_t *)P->d_slots, d_lens, d_numbps);
     if (r != J2K_OK) return r;
     return j2k_plan_compact(P, (const uint8_t *)P->d_slots, d_lens, d_offs, d_stream);
@@ -957,7 +968,7 @@ extern "C" int j2k_plan_compact(j2k_plan *P, const uint8_t *d_slots, const uint3
     const int n = (int)P->blocks.size();
     int r = stage_reserve(ctx, 1, 4096);
     if (r != J2K_OK) return r;
-    HIPCHK(ctx, launch_compact(ctx->stream, P->d_bjobs, n, d_slots, d_lens, d_offs, d_stream, ctx->stage[1]));
+    HIPCHK(ctx, launch_compact(ctx->stream, P->d_bjobs, n, d_slots, d_lens, d_offs, d_stream, nullptr));
     return J2K_OK;
 }
 

@@ -111,6 +111,7 @@ struct j2k_plan {
     // fused encode + compact (j2k_plan_encode_stream): look-back status words, tagged with the launch epoch
     j2k::DwtJob *d_fwd_pix_jobs = nullptr;  // level-0 forward job table of the packed-pixel path (shorter bands)
     int fwd_pix_njobs = 0;
+    uint32_t *d_maglens = nullptr;          // j2k_plan_encode_stream: end of each block's MagSgn bytes (the MEL hole starts there)
     uint64_t *d_status = nullptr;
     uint32_t epoch = 0;
     bool all_blocks_fast = false;           // every job on the parallel HT path
