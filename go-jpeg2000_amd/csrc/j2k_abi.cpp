@@ -28,7 +28,9 @@ hipError_t launch_ht_encode_stream(hipStream_t s, const BlockJob *jobs, int njob
                                    uint64_t *offs, uint32_t *lens, uint8_t *numbps, uint64_t *status, uint32_t epoch, int *fault);
 int ht_fast_max_samples();
 hipError_t launch_t1_encode(hipStream_t s, const BlockJob *jobs, int njobs, const int32_t *coef, uint8_t *slots,
-                            uint32_t *lens, uint8_t *numbps, uint8_t *work, size_t work_per_job, int *fault, int max_dim);
+                            uint32_t *lens, uint8_t *numbps, uint8_t *work, size_t work_per_job, int *fault, int max_dim,
+                            uint8_t *sym, size_t sym_stride, uint32_t *nsyms, int lanes);
+size_t t1_sym_stride(int planes);
 hipError_t launch_t1_decode(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs,
                             const uint32_t *lens, const uint8_t *numbps, int32_t *decoded, uint8_t *work,
                             size_t work_per_job);
@@ -106,6 +108,9 @@ extern "C" int j2k_ctx_create(int device, j2k_ctx **out) {
     if (const char *e = getenv("J2K_FWD_PF")) ctx->fwd_pf = atoi(e) != 0;
     if (const char *e = getenv("J2K_TAIL")) ctx->use_tail = atoi(e) != 0;
     if (const char *e = getenv("J2K_XCD_MAP")) ctx->xcd_map = atoi(e) != 0;
+    if (const char *e = getenv("J2K_T1_SPLIT")) ctx->t1_split = atoi(e) != 0;
+    if (const char *e = getenv("J2K_T1_SYM_MB")) { long v = atol(e); if (v >= 0) ctx->t1_sym_mb = v; }
+    if (const char *e = getenv("J2K_T1_LANES")) { int v = atoi(e); if (v >= 0 && v <= 64) ctx->t1_lanes = v; }
     if (const char *e = getenv("J2K_CPL0")) { int v = atoi(e); if (v == 2 || v == 4 || v == 8) ctx->cpl0 = v; }
     *out = ctx;
     return J2K_OK;
@@ -884,6 +889,27 @@ extern "C" int j2k_plan_inverse_pixels(j2k_plan *P, const int32_t *d_coeff, void
     return j2k_pack_pixels(ctx, (const int32_t *)ctx->stage[0], S.C, S.precision, S.W, S.H, d_pix, stride);
 }
 
+// Workspace of the T1 encoder: [serial-kernel work: wpj * n] [nsyms: n words] [symbol lists: n * stride].  The symbol
+// lists cover 31 bit planes when that fits ctx->t1_sym_mb (default 8192 MiB), fewer otherwise (blocks with more planes
+// take the one-kernel path on the device); ctx->t1_split = 0 turns the two-kernel path off.
+struct T1Workspace { size_t off_nsyms, off_sym, stride, total; };
+static T1Workspace t1_workspace(const j2k_ctx *ctx, size_t n, size_t wpj) {
+    const long limit_mb = ctx->t1_sym_mb;
+    const int split = ctx->t1_split;
+    T1Workspace W{};
+    W.off_nsyms = (wpj * n + 255) & ~size_t(255);
+    W.off_sym = (W.off_nsyms + n * 4 + 255) & ~size_t(255);
+    W.stride = 0;
+    if (split && n) {
+        int planes = 31;
+        const size_t limit = (size_t)limit_mb << 20;
+        while (planes >= 8 && j2k::t1_sym_stride(planes) * n > limit) planes--;
+        if (planes >= 8) W.stride = j2k::t1_sym_stride(planes);
+    }
+    W.total = W.off_sym + W.stride * n + 256;
+    return W;
+}
+
 static size_t t1_work_per_job(const j2k_plan *P) {
     size_t m = 0;
     for (const j2k_block &b : P->blocks) m = std::max(m, t1_work_bytes(b.w, b.h));
@@ -906,9 +932,12 @@ extern "C" int j2k_plan_encode_blocks(j2k_plan *P, const int32_t *d_coeff, uint8
         int max_dim = 0;
         for (const j2k_block &b : P->blocks) max_dim = std::max(max_dim, std::max(b.w, b.h));
         const size_t wpj = max_dim > 64 ? t1_work_per_job(P) : 0;     // only the serial kernel (blocks > 64) needs a workspace
-        r = stage_reserve(ctx, 2, wpj * (size_t)n + 256);
+        const T1Workspace W = t1_workspace(ctx, (size_t)n, wpj);
+        r = stage_reserve(ctx, 2, W.total);
         if (r != J2K_OK) return r;
-        HIPCHK(ctx, launch_t1_encode(ctx->stream, P->d_bjobs, n, d_coeff, d_slots, d_lens, d_numbps, (uint8_t *)ctx->stage[2], wpj, d_fault, max_dim));
+        uint8_t *ws = (uint8_t *)ctx->stage[2];
+        HIPCHK(ctx, launch_t1_encode(ctx->stream, P->d_bjobs, n, d_coeff, d_slots, d_lens, d_numbps, ws, wpj, d_fault, max_dim,
+                                     W.stride ? ws + W.off_sym : nullptr, W.stride, (uint32_t *)(ws + W.off_nsyms), ctx->t1_lanes));
     }
     return J2K_OK;
 }
@@ -1151,11 +1180,14 @@ extern "C" int j2k_encode_blocks(j2k_ctx *ctx, int coder, const int32_t *const *
     if (coder == J2K_CODER_HT) {
         TRY(launch_ht_encode(ctx->stream, (BlockJob *)d_jobs, (int)nblocks, (int32_t *)d_coef, (uint8_t *)d_slots, (uint32_t *)d_lens, (uint8_t *)d_nb, (int *)d_fault));
     } else {
-        TRY(hipMalloc(&d_work, wpj * nblocks + 256));
         int max_dim = 0;
         for (size_t j = 0; j < nblocks; j++) max_dim = std::max(max_dim, std::max(bj[j].w, bj[j].h));
+        if (max_dim <= 64) wpj = 0;
+        const T1Workspace W = t1_workspace(ctx, nblocks, wpj);
+        TRY(hipMalloc(&d_work, W.total));
+        uint8_t *ws = (uint8_t *)d_work;
         TRY(launch_t1_encode(ctx->stream, (BlockJob *)d_jobs, (int)nblocks, (int32_t *)d_coef, (uint8_t *)d_slots, (uint32_t *)d_lens, (uint8_t *)d_nb,
-                             (uint8_t *)d_work, wpj, (int *)d_fault, max_dim));
+                             ws, wpj, (int *)d_fault, max_dim, W.stride ? ws + W.off_sym : nullptr, W.stride, (uint32_t *)(ws + W.off_nsyms), ctx->t1_lanes));
     }
     std::vector<uint32_t> hl(nblocks);
     std::vector<uint8_t> hn(nblocks);

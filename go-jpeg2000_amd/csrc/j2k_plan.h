@@ -23,6 +23,9 @@ struct j2k_ctx {
     int xcd_map = 0;           // J2K_XCD_MAP=0: plain job order (A/B)
     int cpl0 = 0;              // J2K_CPL0: force columns-per-lane of the level-0 5-3 kernels (tuning)
     int force_novec = 0;       // J2K_FORCE_NOVEC=1: always take the scalar-access kernels (testing)
+    int t1_split = 1;          // J2K_T1_SPLIT=0: T1 encoder as one kernel (contexts + MQ chain on lane 0) instead of two
+    long t1_sym_mb = 8192;     // J2K_T1_SYM_MB: cap of the T1 symbol workspace; blocks with more bit planes than fit take the one-kernel path
+    int t1_lanes = 0;          // J2K_T1_LANES: blocks per wavefront of the lane-parallel MQ kernel (0: njobs / 2048, at least 1)
     // cached single-plane plans for the host (unit) calls
     std::vector<j2k_plan *> cache;
     // host-call staging buffers (device)

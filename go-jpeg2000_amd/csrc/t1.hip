@@ -352,8 +352,10 @@ struct T1Fast {
     T1Tables T;
     uint8_t zc2[256];          // ZC context by this kernel's index: NW | N<<1 | NE<<2 | SW<<3 | S<<4 | SE<<5 | W<<6 | E<<7
     uint32_t ctxent[32];       // per context: the MQ table entry of its current state
-    uint8_t sym[T1F_SYM_CAP];  // ctx | decision << 5
+    alignas(16) uint8_t sym[T1F_SYM_CAP];  // ctx | decision << 5
 };
+#define T1F_NULL_SYM 31u     /* context 31 is a no-op for the lane-parallel MQ kernel (Qe = 0): pads a chunk to 16 symbols */
+#define T1F_SKIPPED 0xFFFFFFFFu   /* nsyms[] mark: block over the symbol-plane budget, left to the one-kernel path */
 
 __device__ __forceinline__ uint64_t rl64(uint64_t v, int r) {      // row mask of lane r, broadcast (r wave-uniform)
     const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, r), hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), r);
@@ -402,16 +404,27 @@ __device__ __forceinline__ void mq_run(MqEnc &e, const uint32_t *mqtab, uint32_t
     e.A = A; e.C = C; e.CT = CT;
 }
 
+// SPLIT = false: contexts + MQ coder in this kernel (lane 0 codes each chunk of symbols).  only_skipped != null: just the
+//                 blocks the split path marked T1F_SKIPPED.
+// SPLIT = true : the symbols go to `gsym` (job j at j * sym_stride, chunks padded to 16 with no-op symbols, count in
+//                nsyms[j]) for t1_mq_lanes_kernel; blocks with more than `plane_budget` bit planes are marked T1F_SKIPPED.
+template <bool SPLIT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void t1_encode64_kernel(const BlockJob *__restrict__ jobs, int njobs, const int32_t *__restrict__ coef,
                                                          uint8_t *__restrict__ slots, uint32_t *__restrict__ lens,
-                                                         uint8_t *__restrict__ numbps, int *__restrict__ fault) {
+                                                         uint8_t *__restrict__ numbps, int *__restrict__ fault,
+                                                         uint8_t *__restrict__ gsym, size_t sym_stride, uint32_t *__restrict__ nsyms,
+                                                         int plane_budget, const uint32_t *__restrict__ only_skipped) {
     __shared__ T1Fast F;
     const int jid = blockIdx.x;
     if (jid >= njobs) return;
+    if (!SPLIT && only_skipped && only_skipped[jid] != T1F_SKIPPED) return;
     const int lane = threadIdx.x;
     const BlockJob J = jobs[jid];
     const int w = J.w, h = J.h;
-    if (w > 64 || h > 64) return;                 // the serial kernel takes these
+    if (w > 64 || h > 64) {                       // the serial kernel takes these
+        if (SPLIT && lane == 0) nsyms[jid] = 0;
+        return;
+    }
     const size_t n = (size_t)w * h;
     build_tables(F.T, J.band, lane);
     __syncthreads();
@@ -440,10 +453,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
         maxVal = (uint32_t)m;
     }
     if (maxVal == 0) {
-        if (lane == 0) { lens[jid] = 0; numbps[jid] = 0; }
+        if (lane == 0) { lens[jid] = 0; numbps[jid] = 0; if (SPLIT) nsyms[jid] = 0; }
         return;
     }
     const int numBPS = 32 - __clz(maxVal);
+    if (SPLIT && numBPS > plane_budget) {
+        if (lane == 0) nsyms[jid] = T1F_SKIPPED;
+        return;
+    }
+    uint8_t *gdst = SPLIT ? gsym + (size_t)jid * sym_stride : nullptr;
+    uint32_t gtotal = 0;
+    bool govf = false;
     // row masks of one bit of the samples (bit 31 = sign): loads with lanes = columns, a ballot per row, kept by lane = row.
     // Re-read from L2 for every plane (16 KB per block) rather than parked in LDS: LDS is what limits how many of the
     // serial MQ chains a SIMD can interleave.
@@ -474,8 +494,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
     uint32_t nsym = 0;
 #define T1F_DRAIN()                                           \
     do {                                                      \
-        __syncthreads();                                      \
-        if (lane == 0) mq_run(e, F.T.mq, F.ctxent, F.sym, nsym); \
+        if (SPLIT) {                                          \
+            const uint32_t npad = (nsym + 15u) & ~15u;        \
+            if (nsym + lane < npad) F.sym[nsym + lane] = (uint8_t)T1F_NULL_SYM; \
+            __syncthreads();                                  \
+            if ((size_t)gtotal + npad > sym_stride) govf = true; \
+            else {                                            \
+                for (uint32_t i = (uint32_t)lane * 16; i < npad; i += 1024) \
+                    *reinterpret_cast<uint4 *>(gdst + gtotal + i) = *reinterpret_cast<const uint4 *>(F.sym + i); \
+                gtotal += npad;                               \
+            }                                                 \
+        } else {                                              \
+            __syncthreads();                                  \
+            if (lane == 0) mq_run(e, F.T.mq, F.ctxent, F.sym, nsym); \
+        }                                                     \
         nsym = 0;                                             \
         __syncthreads();                                      \
     } while (0)
@@ -631,6 +663,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
 #undef T1F_DRAIN
 #undef T1F_ROOM
     if (lane != 0) return;
+    if (SPLIT) {
+        if (govf) atomicMax(fault, 2);
+        nsyms[jid] = govf ? 0u : gtotal;
+        if (govf) lens[jid] = 0;
+        numbps[jid] = (uint8_t)numBPS;
+        return;
+    }
     // ---- flush (t1_fast5.go:878-898) ----
     const uint32_t tempC = e.C + e.A;
     e.C |= 0xFFFF;
@@ -643,6 +682,124 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
     if (e.overflow) atomicMax(fault, 2);
     lens[jid] = end > 1 ? (uint32_t)(end - 1) : 0;
     numbps[jid] = (uint8_t)numBPS;
+}
+
+// ---- MQ coder, K blocks per wavefront in lock step (mqc.go:224-267, flush t1_fast5.go:878-898) ----
+// t1_encode64_kernel<true> leaves every block's (context, decision) list in memory; here LANE l of workgroup g codes the
+// list of block g*K + l.  One serial chain per block is bound by instruction issue (≈45 wave instructions per symbol,
+// most of them on the CU's one scalar unit); K chains per wavefront share every instruction, so the issue cost per
+// symbol falls by K and the kernel runs at the latency of one chain.  All lane-varying state is in registers (A, C, CT,
+// the pending byte) or in a lane-interleaved LDS array (the table entry of each context's current state).  Lanes whose
+// list has ended are fed the no-op symbol (context 31: Qe = 0, never renormalises).
+__global__ __launch_bounds__(64) void t1_mq_lanes_kernel(const BlockJob *__restrict__ jobs, int njobs, int K, const uint8_t *__restrict__ gsym,
+                                                         size_t sym_stride, const uint32_t *__restrict__ nsyms, uint8_t *__restrict__ slots,
+                                                         uint32_t *__restrict__ lens, int *__restrict__ fault) {
+    __shared__ uint32_t mqtab[96];
+    __shared__ uint32_t ce[32 * 64];
+    const int lane = threadIdx.x;
+    const long jid = (long)blockIdx.x * K + lane;
+    const bool live = lane < K && jid < njobs;
+    for (int s = lane; s < 94; s += 64) {
+        const int i = s >> 1, m = s & 1;
+        const uint32_t nm = 2 * c_iso_nmps[i] + m;
+        const uint32_t nl = 2 * c_iso_nlps[i] + (c_iso_switch[i] ? 1 - m : m);
+        mqtab[s] = (uint32_t)c_iso_qe[i] | nm << 16 | nl << 24;
+    }
+    __syncthreads();
+    for (int c = 0; c < 32; c++) ce[c * 64 + lane] = c < NumContexts ? mqtab[c == CtxUni ? 92 : 0] : 0u;
+    uint32_t n = live ? nsyms[jid] : 0u;
+    if (n == T1F_SKIPPED) n = 0;
+    uint32_t nmax = n;
+    for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, o));
+    if (nmax == 0) return;
+    const BlockJob J = jobs[live ? jid : 0];
+    const uint8_t *src = gsym + (size_t)(live ? jid : 0) * sym_stride;
+    uint8_t *const out = slots + J.out_off;
+    const uint32_t cap = (uint32_t)J.w * J.h * 2 + 1024;
+    uint32_t A = 0x8000, C = 0, CT = 12;
+    uint32_t curb = 0, bp = 0, ovf = 0;            // pending byte buf[bp]; byte k >= 1 goes to out[k - 1] (t1_fast.go:11-34)
+    // One byte leaves C (mqc.go:270-299 as t1_fast.go restates it), select-only: the pending byte takes the carry unless it
+    // is 0xFF; a pending 0xFF makes the next byte a 7-bit one.
+    auto byte_out = [&](bool on) {
+        const bool carry = curb != 0xFF && (C & 0x8000000u);
+        const uint32_t emit = curb + (carry ? 1u : 0u);
+        const uint32_t Cm = carry ? (C & 0x7FFFFFFu) : C;
+        const bool ff = emit == 0xFF;
+        const bool room = bp - 1u < cap;               // bp == 0: the byte before the stream, never stored (wraps to "no room")
+        if (on && room) out[bp - 1] = (uint8_t)emit;
+        ovf |= (on && bp >= 1 && !room) ? 1u : 0u;
+        const uint32_t sh = ff ? 20u : 19u;
+        if (on) {
+            bp++;
+            curb = (Cm >> sh) & 0xFF;
+            C = Cm & ((1u << sh) - 1u);
+            CT = ff ? 7u : 8u;
+        }
+    };
+    const uint4 null16 = make_uint4(0x1F1F1F1Fu, 0x1F1F1F1Fu, 0x1F1F1F1Fu, 0x1F1F1F1Fu);
+    const uint32_t nclamp = n ? n - 16u : 0u;
+    auto fetch = [&](uint32_t i0) -> uint4 {      // unconditional load from a clamped offset, then select (n is a multiple of 16)
+        uint4 v;
+        __builtin_memcpy(&v, src + min(i0, nclamp), 16);
+        const bool in = i0 < n;
+        return make_uint4(in ? v.x : null16.x, in ? v.y : null16.y, in ? v.z : null16.z, in ? v.w : null16.w);
+    };
+    uint4 cur = fetch(0);
+    uint32_t idx = (cur.x & 31u) * 64 + lane;
+    uint32_t ent = ce[idx];
+    for (uint32_t i0 = 0; i0 < nmax; i0 += 16) {
+        const uint4 nxt = fetch(i0 + 16);
+        const uint32_t words[5] = {cur.x, cur.y, cur.z, cur.w, nxt.x};
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const uint32_t sy = words[q >> 2] >> ((q & 3) * 8);
+            const uint32_t syn = words[(q + 1) >> 2] >> (((q + 1) & 3) * 8);
+            const uint32_t d = (sy >> 5) & 1;
+            // the next symbol's entry is read BEFORE this symbol's update is written and patched below if it is the same
+            // context: the LDS round trip of the state update stays off the chain of the following symbol
+            const uint32_t idxn = (syn & 31u) * 64 + lane;
+            const uint32_t entn = ce[idxn];
+            const uint32_t qe = ent & 0xFFFF;
+            const uint32_t A1 = A - qe;
+            const bool isM = d == ((ent >> 16) & 1);
+            const bool lt = A1 < qe;
+            C += (isM != lt) ? qe : 0u;                 // MPS: C += qe unless A < qe; LPS: only if A < qe
+            A = (isM == lt) ? qe : A1;
+            uint32_t shift = (uint32_t)__builtin_clz(A) - 16;   // A != 0; 0 when the interval is still >= 0x8000
+            if (__any(shift != 0)) {
+                const uint32_t ne = mqtab[isM ? ((ent >> 16) & 0xFF) : (ent >> 24)];
+                const bool upd = shift != 0;            // a context changes state exactly when it renormalises
+                const uint32_t nent = upd ? ne : ent;
+                ce[idx] = nent;
+                ent = idxn == idx ? nent : entn;
+                A <<= shift;
+                uint32_t s1 = min(shift, CT);
+                C <<= s1; CT -= s1; shift -= s1;
+                while (__any(CT == 0)) {                // a byte leaves the register (at most twice per symbol)
+                    const bool on = CT == 0;
+                    byte_out(on);
+                    s1 = on ? min(shift, CT) : 0u;
+                    C <<= s1; CT -= s1; shift -= s1;
+                }
+            } else {
+                ent = entn;
+            }
+            idx = idxn;
+        }
+        cur = nxt;
+    }
+    if (n == 0) return;
+    // ---- flush (t1_fast5.go:878-898) ----
+    const uint32_t tempC = C + A;
+    C |= 0xFFFF;
+    if (C >= tempC) C -= 0x8000;
+    C <<= CT; byte_out(true);
+    C <<= CT; byte_out(true);
+    uint32_t end = bp + 1;
+    if (curb == 0xFF) end--;
+    else if (bp >= 1) { if (bp - 1 < cap) out[bp - 1] = (uint8_t)curb; else ovf = 1; }
+    if (ovf) atomicMax(fault, 2);
+    lens[jid] = end > 1 ? (uint32_t)(end - 1) : 0;
 }
 
 // ---- MQ decoder (mqc.go:352-497) --------------------------------------------------------------
@@ -916,14 +1073,39 @@ static int lds_for(size_t work_per_job) {
     return (int)wb;
 }
 
-// max_dim: largest block width or height among the jobs (<= 64: every block takes the wave-parallel kernel)
+// symbol workspace of the split path: bytes per job for blocks up to 64x64 with `planes` bit planes.  A block emits at
+// most one decision per sample and plane, one sign per sample, and two extra symbols per run-length hit (a 4-sample
+// column can be hit once): (planes + 1.5) * 4096, plus the padding of each drained chunk.
+size_t t1_sym_stride(int planes) { return ((size_t)(planes + 2) * 4096 + 1024 + 15) & ~size_t(15); }
+
+// max_dim: largest block width or height among the jobs (<= 64: every block takes the wave-parallel kernels).
+// sym != null: context formation and MQ coding as two kernels through the symbol workspace (sym_stride bytes per job,
+// nsyms = njobs words); blocks with more bit planes than the stride allows fall back to the one-kernel path.
 hipError_t launch_t1_encode(hipStream_t s, const BlockJob *jobs, int njobs, const int32_t *coef, uint8_t *slots,
-                            uint32_t *lens, uint8_t *numbps, uint8_t *work, size_t work_per_job, int *fault, int max_dim) {
+                            uint32_t *lens, uint8_t *numbps, uint8_t *work, size_t work_per_job, int *fault, int max_dim,
+                            uint8_t *sym, size_t sym_stride, uint32_t *nsyms, int lanes) {
     if (njobs <= 0) return hipSuccess;
     static int serial_only = -1;   // J2K_T1_SERIAL=1: A/B against the serial kernel
     if (serial_only < 0) { const char *en = getenv("J2K_T1_SERIAL"); serial_only = en ? atoi(en) : 0; }
     if (!serial_only) {
-        hipLaunchKernelGGL(t1_encode64_kernel, dim3(njobs), dim3(64), 0, s, jobs, njobs, coef, slots, lens, numbps, fault);
+        if (sym && nsyms) {
+            int planes = (int)((sym_stride - 1024) / 4096) - 2;
+            if (planes > 31) planes = 31;
+            hipLaunchKernelGGL(t1_encode64_kernel<true>, dim3(njobs), dim3(64), 0, s, jobs, njobs, coef, slots, lens, numbps, fault,
+                               sym, sym_stride, nsyms, planes, (const uint32_t *)nullptr);
+            // blocks per wavefront: the kernel runs at the latency of one chain while there are no more than about two
+            // wavefronts per SIMD (1024 SIMDs); measured on a 4K 12-bit frame (7005 blocks): K = 4 is the optimum
+            int K = lanes > 0 ? lanes : (njobs + 2047) / 2048;
+            K = std::min(64, std::max(1, K));
+            hipLaunchKernelGGL(t1_mq_lanes_kernel, dim3((njobs + K - 1) / K), dim3(64), 0, s, jobs, njobs, K, sym, sym_stride, nsyms,
+                               slots, lens, fault);
+            if (planes < 31)
+                hipLaunchKernelGGL(t1_encode64_kernel<false>, dim3(njobs), dim3(64), 0, s, jobs, njobs, coef, slots, lens, numbps, fault,
+                                   (uint8_t *)nullptr, (size_t)0, (uint32_t *)nullptr, 0, (const uint32_t *)nsyms);
+        } else {
+            hipLaunchKernelGGL(t1_encode64_kernel<false>, dim3(njobs), dim3(64), 0, s, jobs, njobs, coef, slots, lens, numbps, fault,
+                               (uint8_t *)nullptr, (size_t)0, (uint32_t *)nullptr, 0, (const uint32_t *)nullptr);
+        }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess || max_dim <= 64) return e;
     }

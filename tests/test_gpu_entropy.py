@@ -63,6 +63,49 @@ def test_t1_large_block_global_workspace(ent, oracle):
     assert np.array_equal(ent.NewT1(256, 256).Decode(got, nb, 3).reshape(256, 256), x)
 
 
+@pytest.mark.parametrize("env", [{}, {"J2K_T1_SPLIT": "0"}, {"J2K_T1_LANES": "64"}, {"J2K_T1_LANES": "3"}, {"J2K_T1_SYM_MB": "2"},
+                                 {"J2K_T1_SYM_MB": "0"}])
+def test_t1_batch_all_encoder_paths(ent, oracle, env, monkeypatch):
+    """One batch of blocks of mixed size, band and bit depth through every arrangement of the T1 encoder: contexts and MQ
+    coder as two kernels with K blocks per wavefront in lock step (default; K forced to 3 and 64), as one kernel
+    (J2K_T1_SPLIT=0), and with a symbol workspace too small for the deep blocks (they fall back to the one-kernel path on
+    the device; 0 MiB: all of them).  Every block's bytes and numBPS must be the oracle's."""
+    from j2kgfx import Context
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)                                   # read when a context is created
+    ctx = Context(0)
+    rng = np.random.default_rng(77)
+    PW, PH = 520, 330
+    plane = np.zeros((PH, PW), np.int32)
+    dims = [(64, 64), (33, 64), (64, 7), (5, 3), (1, 1), (64, 64), (16, 16), (64, 64), (8, 64), (64, 33)]
+    blocks = []
+    for gy in range(5):
+        for gx in range(8):
+            w, h = dims[(gy * 8 + gx) % len(dims)]
+            x0, y0 = gx * 65, gy * 66
+            kind = (gy * 8 + gx) % 7
+            if kind == 0:
+                v = np.zeros((h, w), np.int64)                                     # all-zero block: nil stream
+            elif kind == 1:
+                v = rng.integers(-3, 4, (h, w))                                    # 2 bit planes
+            elif kind == 2:
+                v = rng.integers(-100, 101, (h, w))                                # 25 bit planes, few deep samples (the
+                v[rng.integers(0, h), rng.integers(0, w)] = (1 << 24) + 12345      # slot bound is 2 bytes per sample)
+            elif kind == 3:
+                v = np.where(rng.random((h, w)) < 0.02, rng.integers(-5000, 5000, (h, w)), 0)   # sparse: run-length mode
+            else:
+                v = rng.integers(-900, 901, (h, w))
+            plane[y0:y0 + h, x0:x0 + w] = v
+            blocks.append((0, (gy + gx) % 4, x0, y0, w, h))
+    blk = np.array(blocks, dtype=ent.BLOCK_DTYPE)
+    stream, offs, lens, nb = ent.encode_blocks(0, [plane], blk, ctx=ctx)
+    for j, (_, band, x0, y0, w, h) in enumerate(blocks):
+        want, wnb = oracle.t1_encode(plane[y0:y0 + h, x0:x0 + w], w, h, band)
+        got = stream[int(offs[j]):int(offs[j]) + int(lens[j])]
+        assert int(lens[j]) == want.size and int(nb[j]) == wnb, (j, env)
+        assert np.array_equal(got, want), (j, env)
+
+
 HT_SHAPES = [(4, 4), (8, 8), (16, 16), (64, 64), (32, 32), (8, 5), (13, 9), (7, 4), (5, 8), (12, 16), (64, 7), (3, 16), (128, 128)]
 
 
