@@ -759,6 +759,8 @@ __global__ __launch_bounds__(64) void t1_mq_lanes_kernel(const BlockJob *__restr
             // context: the LDS round trip of the state update stays off the chain of the following symbol
             const uint32_t idxn = (syn & 31u) * 64 + lane;
             const uint32_t entn = ce[idxn];
+            // both successor entries, read while the interval arithmetic runs (the pick waits for isM and the renormalisation)
+            const uint32_t candM = mqtab[(ent >> 16) & 0xFF], candL = mqtab[ent >> 24];
             const uint32_t qe = ent & 0xFFFF;
             const uint32_t A1 = A - qe;
             const bool isM = d == ((ent >> 16) & 1);
@@ -766,8 +768,10 @@ __global__ __launch_bounds__(64) void t1_mq_lanes_kernel(const BlockJob *__restr
             C += (isM != lt) ? qe : 0u;                 // MPS: C += qe unless A < qe; LPS: only if A < qe
             A = (isM == lt) ? qe : A1;
             uint32_t shift = (uint32_t)__builtin_clz(A) - 16;   // A != 0; 0 when the interval is still >= 0x8000
-            if (__any(shift != 0)) {
-                const uint32_t ne = mqtab[isM ? ((ent >> 16) & 0xFF) : (ent >> 24)];
+            // no wave-level branch around the renormalisation (with K lanes some lane nearly always renormalises, and a
+            // taken branch costs more than the dozen instructions it would skip): shift = 0 lanes pass through unchanged
+            {
+                const uint32_t ne = isM ? candM : candL;
                 const bool upd = shift != 0;            // a context changes state exactly when it renormalises
                 const uint32_t nent = upd ? ne : ent;
                 ce[idx] = nent;
@@ -775,14 +779,18 @@ __global__ __launch_bounds__(64) void t1_mq_lanes_kernel(const BlockJob *__restr
                 A <<= shift;
                 uint32_t s1 = min(shift, CT);
                 C <<= s1; CT -= s1; shift -= s1;
-                while (__any(CT == 0)) {                // a byte leaves the register (at most twice per symbol)
-                    const bool on = CT == 0;
+                if (__any(CT == 0)) {                   // a byte leaves the register (at most three times per symbol)
+                    bool on = CT == 0;
                     byte_out(on);
                     s1 = on ? min(shift, CT) : 0u;
                     C <<= s1; CT -= s1; shift -= s1;
+                    while (__any(CT == 0)) {
+                        on = CT == 0;
+                        byte_out(on);
+                        s1 = on ? min(shift, CT) : 0u;
+                        C <<= s1; CT -= s1; shift -= s1;
+                    }
                 }
-            } else {
-                ent = entn;
             }
             idx = idxn;
         }
