@@ -153,6 +153,16 @@ __device__ __forceinline__ void set_significant(uint8_t *f, int x, int y, int w,
     if (x > 0) f[-1] |= T1SigE;
     if (x < w - 1) f[1] |= T1SigW;
 }
+// Decoder only: the directional bits are not read there (contexts come from the neighbours' T1Sig), so bit 16 means
+// "one of my 8 neighbours is significant", set when the neighbour turns significant.  The scans of T1.Decode then test
+// one flag byte per sample instead of nine (any_sig8 below); the flag array has a border, so no bounds checks.
+enum { T1HasNb = 16 };
+__device__ __forceinline__ void set_significant_dec(uint8_t *f, int stride) {
+    *f |= T1Sig;
+    f[-stride - 1] |= T1HasNb; f[-stride] |= T1HasNb; f[-stride + 1] |= T1HasNb;
+    f[-1] |= T1HasNb; f[1] |= T1HasNb;
+    f[stride - 1] |= T1HasNb; f[stride] |= T1HasNb; f[stride + 1] |= T1HasNb;
+}
 __device__ __forceinline__ bool any_sig8(const uint8_t *f, int stride) {
     return ((f[-1] | f[1] | f[-stride] | f[stride] | f[-stride - 1] | f[-stride + 1] | f[stride - 1] | f[stride + 1]) & T1Sig) != 0;
 }
@@ -900,12 +910,11 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(const BlockJob *__restric
             for (int y = 0; y < h; y++)                                   // t1.go:1295-1319
                 for (int x = 0; x < w; x++) {
                     uint8_t *f = flags + (size_t)(y + 1) * stride + x + 1;
-                    if (*f & T1Sig) continue;
-                    if (!any_sig8(f, stride)) continue;
+                    if ((*f & (T1Sig | T1HasNb)) != T1HasNb) continue;       // not significant, a significant neighbour
                     if (mq_decode(d, T, T.zc[zc_packed(f, stride)])) {
                         data[(size_t)y * w + x] = bit;
                         dec_sign(d, T, f, stride);
-                        set_significant(f, x, y, w, h, stride);
+                        set_significant_dec(f, stride);
                     }
                     *f |= T1Visit;
                 }
@@ -914,7 +923,7 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(const BlockJob *__restric
                     uint8_t *f = flags + (size_t)(y + 1) * stride + x + 1;
                     const uint32_t fv = *f;
                     if ((fv & T1Sig) == 0 || (fv & T1Visit) != 0) continue;
-                    const int ctx = (fv & T1Refine) ? CtxMag2 : (any_sig8(f, stride) ? CtxMag1 : CtxMag0);
+                    const int ctx = (fv & T1Refine) ? CtxMag2 : ((fv & T1HasNb) ? CtxMag1 : CtxMag0);
                     if (mq_decode(d, T, ctx)) atomicOr(&data[(size_t)y * w + x], bit);
                     *f = (uint8_t)(fv | T1Refine);
                 }
@@ -924,7 +933,7 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(const BlockJob *__restric
                     if (canRL)
                         for (int yy = y; yy < y + 4; yy++) {
                             const uint8_t *f = flags + (size_t)(yy + 1) * stride + x + 1;
-                            if ((*f & (T1Sig | T1Visit)) || any_sig8(f, stride)) { canRL = false; break; }
+                            if (*f & (T1Sig | T1Visit | T1HasNb)) { canRL = false; break; }
                         }
                     if (canRL) {
                         if (mq_decode(d, T, CtxRL) == 0) continue;
@@ -934,14 +943,14 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(const BlockJob *__restric
                             uint8_t *f = flags + (size_t)(y + pos + 1) * stride + x + 1;
                             data[(size_t)(y + pos) * w + x] = bit;
                             dec_sign(d, T, f, stride);
-                            set_significant(f, x, y + pos, w, h, stride);
+                            set_significant_dec(f, stride);
                         }
                         for (int i = pos + 1; i < 4 && y + i < h; i++) {
                             uint8_t *f = flags + (size_t)(y + i + 1) * stride + x + 1;
                             if (mq_decode(d, T, T.zc[zc_packed(f, stride)])) {
                                 data[(size_t)(y + i) * w + x] = bit;
                                 dec_sign(d, T, f, stride);
-                                set_significant(f, x, y + i, w, h, stride);
+                                set_significant_dec(f, stride);
                             }
                         }
                         continue;
@@ -954,7 +963,7 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(const BlockJob *__restric
                         if (mq_decode(d, T, T.zc[zc_packed(f, stride)])) {
                             data[(size_t)yy * w + x] = bit;
                             dec_sign(d, T, f, stride);
-                            set_significant(f, x, yy, w, h, stride);
+                            set_significant_dec(f, stride);
                         }
                     }
                 }
