@@ -175,6 +175,9 @@ size_t t1_work_bytes(int w, int h) {
 
 #define T1_LDS_LIMIT (60 * 1024)
 
+// LDSW: the flag / magnitude workspace is in LDS (every block fits) or in `work`; a template parameter so that the
+// accesses compile to ds_* / global_* instead of flat_* (a pointer chosen at run time is a flat pointer).
+template <bool LDSW>
 __global__ __launch_bounds__(64) void t1_encode_kernel(const BlockJob *__restrict__ jobs, int njobs, const int32_t *__restrict__ coef,
                                                        uint8_t *__restrict__ slots, uint32_t *__restrict__ lens,
                                                        uint8_t *__restrict__ numbps, uint8_t *__restrict__ work, size_t work_per_job,
@@ -189,8 +192,7 @@ __global__ __launch_bounds__(64) void t1_encode_kernel(const BlockJob *__restric
     const size_t n = (size_t)w * h;
     T1Tables &T = *reinterpret_cast<T1Tables *>(smem);
     const size_t flag_bytes = ((size_t)(w + 2) * (h + 2) + 15) & ~size_t(15);
-    const bool in_lds = (flag_bytes + n * 4) <= (size_t)lds_work_bytes;
-    uint8_t *wk = in_lds ? smem + ((sizeof(T1Tables) + 15) & ~size_t(15)) : work + (size_t)jid * work_per_job;
+    uint8_t *wk = LDSW ? smem + ((sizeof(T1Tables) + 15) & ~size_t(15)) : work + (size_t)jid * work_per_job;
     uint8_t *flags = wk;
     int32_t *data = reinterpret_cast<int32_t *>(wk + flag_bytes);
 
@@ -838,19 +840,19 @@ __device__ __forceinline__ void mq_renorm_dec(MqDec &d) {   // mqc.go:488-497
         d.A <<= 1; d.C <<= 1; d.CT--;
     } while ((d.A & 0x8000) == 0);
 }
-// mqc.go:443-485.  The per-context state is the state's TABLE ENTRY (T.mq word: qe | nmps << 16 | nlps << 24; the MPS
-// is the parity of nmps) kept in T.ent[], so a decision costs one LDS read unless the context changes state.
-__device__ __forceinline__ int mq_decode(MqDec &d, T1Tables &T, int ctx) {
-    const uint32_t ent = T.ent[ctx];
-    const uint32_t qe = ent & 0xFFFF;
-    const int mps = (ent >> 16) & 1;
+// mqc.go:443-485.  The per-context state is the state's TABLE ENTRY (mq word: qe | nmps << 16 | nlps << 24; the MPS
+// is the parity of nmps) kept in ent[], so a decision costs one LDS read unless the context changes state.
+__device__ __forceinline__ int mq_decode(MqDec &d, uint32_t *ent, const uint32_t *mq, int ctx) {
+    const uint32_t e = ent[ctx];
+    const uint32_t qe = e & 0xFFFF;
+    const int mps = (e >> 16) & 1;
     int dec;
     d.A -= qe;
     if ((d.C >> 16) < qe) {
         uint32_t nst;
-        if (d.A < qe) { dec = mps; nst = (ent >> 16) & 0xFF; }
-        else { dec = 1 - mps; nst = ent >> 24; }
-        T.ent[ctx] = T.mq[nst];
+        if (d.A < qe) { dec = mps; nst = (e >> 16) & 0xFF; }
+        else { dec = 1 - mps; nst = e >> 24; }
+        ent[ctx] = mq[nst];
         d.A = qe;
         mq_renorm_dec(d);
         return dec;
@@ -858,40 +860,125 @@ __device__ __forceinline__ int mq_decode(MqDec &d, T1Tables &T, int ctx) {
     d.C -= qe << 16;
     if ((d.A & 0x8000) == 0) {
         uint32_t nst;
-        if (d.A < qe) { dec = 1 - mps; nst = ent >> 24; }
-        else { dec = mps; nst = (ent >> 16) & 0xFF; }
-        T.ent[ctx] = T.mq[nst];
+        if (d.A < qe) { dec = 1 - mps; nst = e >> 24; }
+        else { dec = mps; nst = (e >> 16) & 0xFF; }
+        ent[ctx] = mq[nst];
         mq_renorm_dec(d);
         return dec;
     }
     return mps;
 }
+__device__ __forceinline__ int mq_decode(MqDec &d, T1Tables &T, int ctx) { return mq_decode(d, T.ent, T.mq, ctx); }
 
-__device__ __forceinline__ void dec_sign(MqDec &d, T1Tables &T, uint8_t *f, int stride) {   // t1.go:1322-1328
-    const uint32_t sc = T.sc[sc_index(f[-1], f[1], f[-stride], f[stride])];
-    if (mq_decode(d, T, CtxSC0 + (sc & 7)) ^ (int)(sc >> 3)) *f |= T1SignNeg;
+// One block, one lane: T.Decode's three passes per bit plane (t1.go:1291-1410) on byte flags (`flags` has a 1-sample
+// border, `stride` = w + 2).  ent = this lane's context entries, mq / zc / sc = the shared tables (zc for this block's band).
+struct T1DecLane {
+    MqDec d;
+    uint32_t *ent;
+    const uint32_t *mq;
+    const uint8_t *zc, *sc;
+    uint8_t *flags;
+    int32_t *data;
+    int w, h, stride;
+};
+__device__ __forceinline__ void dec_sign(T1DecLane &L, uint8_t *f) {   // t1.go:1322-1328
+    const uint32_t sc = L.sc[sc_index(f[-1], f[1], f[-L.stride], f[L.stride])];
+    if (mq_decode(L.d, L.ent, L.mq, CtxSC0 + (sc & 7)) ^ (int)(sc >> 3)) *f |= T1SignNeg;
+}
+__device__ __forceinline__ void t1_decode_passes(T1DecLane &L, int numBPS) {
+    const int w = L.w, h = L.h, stride = L.stride;
+    uint8_t *const flags = L.flags;
+    int32_t *const data = L.data;
+    for (int bp = numBPS - 1; bp >= 0; bp--) {
+        const int32_t bit = bp < 32 ? (int32_t)(1u << bp) : 0;
+        for (int y = 0; y < h; y++)                                   // t1.go:1295-1319
+            for (int x = 0; x < w; x++) {
+                uint8_t *f = flags + (size_t)(y + 1) * stride + x + 1;
+                if ((*f & (T1Sig | T1HasNb)) != T1HasNb) continue;       // not significant, a significant neighbour
+                if (mq_decode(L.d, L.ent, L.mq, L.zc[zc_packed(f, stride)])) {
+                    data[(size_t)y * w + x] = bit;
+                    dec_sign(L, f);
+                    set_significant_dec(f, stride);
+                }
+                *f |= T1Visit;
+            }
+        for (int y = 0; y < h; y++)                                   // t1.go:1331-1347
+            for (int x = 0; x < w; x++) {
+                uint8_t *f = flags + (size_t)(y + 1) * stride + x + 1;
+                const uint32_t fv = *f;
+                if ((fv & T1Sig) == 0 || (fv & T1Visit) != 0) continue;
+                const int ctx = (fv & T1Refine) ? CtxMag2 : ((fv & T1HasNb) ? CtxMag1 : CtxMag0);
+                if (mq_decode(L.d, L.ent, L.mq, ctx)) atomicOr(&data[(size_t)y * w + x], bit);
+                *f = (uint8_t)(fv | T1Refine);
+            }
+        for (int y = 0; y < h; y += 4)                                // t1.go:1350-1410
+            for (int x = 0; x < w; x++) {
+                bool canRL = (y + 4 <= h);
+                if (canRL)
+                    for (int yy = y; yy < y + 4; yy++) {
+                        const uint8_t *f = flags + (size_t)(yy + 1) * stride + x + 1;
+                        if (*f & (T1Sig | T1Visit | T1HasNb)) { canRL = false; break; }
+                    }
+                if (canRL) {
+                    if (mq_decode(L.d, L.ent, L.mq, CtxRL) == 0) continue;
+                    int pos = mq_decode(L.d, L.ent, L.mq, CtxUni) << 1;
+                    pos |= mq_decode(L.d, L.ent, L.mq, CtxUni);
+                    {
+                        uint8_t *f = flags + (size_t)(y + pos + 1) * stride + x + 1;
+                        data[(size_t)(y + pos) * w + x] = bit;
+                        dec_sign(L, f);
+                        set_significant_dec(f, stride);
+                    }
+                    for (int i = pos + 1; i < 4 && y + i < h; i++) {
+                        uint8_t *f = flags + (size_t)(y + i + 1) * stride + x + 1;
+                        if (mq_decode(L.d, L.ent, L.mq, L.zc[zc_packed(f, stride)])) {
+                            data[(size_t)(y + i) * w + x] = bit;
+                            dec_sign(L, f);
+                            set_significant_dec(f, stride);
+                        }
+                    }
+                    continue;
+                }
+                for (int yy = y; yy < y + 4 && yy < h; yy++) {
+                    uint8_t *f = flags + (size_t)(yy + 1) * stride + x + 1;
+                    const uint32_t fv = *f;
+                    if (fv & T1Visit) { *f = (uint8_t)(fv & ~T1Visit); continue; }
+                    if (fv & T1Sig) continue;
+                    if (mq_decode(L.d, L.ent, L.mq, L.zc[zc_packed(f, stride)])) {
+                        data[(size_t)yy * w + x] = bit;
+                        dec_sign(L, f);
+                        set_significant_dec(f, stride);
+                    }
+                }
+            }
+    }
+}
+__device__ __forceinline__ void mq_dec_init(MqDec &d, const uint8_t *data, long len) {   // NewMQDecoder mqc.go:370-399
+    d = MqDec{0, 0x8000, 0, -1, len, data};
+    if (d.len == 0) d.C = 0xFFu << 16; else { d.bp = 0; d.C = (uint32_t)d.data[0] << 16; }
+    mq_byte_in(d);
+    d.C <<= 7; d.CT -= 7; d.A = 0x8000;
 }
 
+template <bool LDSW>
 __global__ __launch_bounds__(64) void t1_decode_kernel(const BlockJob *__restrict__ jobs, int njobs, const uint8_t *__restrict__ stream,
                                                        const uint64_t *__restrict__ offs, const uint32_t *__restrict__ lens,
                                                        const uint8_t *__restrict__ numbps, int32_t *__restrict__ decoded,
-                                                       uint8_t *__restrict__ work, size_t work_per_job, int lds_work_bytes) {
+                                                       uint8_t *__restrict__ work, size_t work_per_job, int lds_work_bytes, int skip_small) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int jid = blockIdx.x;
     if (jid >= njobs) return;
     const int lane = threadIdx.x;
     const BlockJob J = jobs[jid];
+    if (skip_small && J.w <= 64 && J.h <= 64) return;             // t1_decode_multi_kernel takes these
     const int w = J.w, h = J.h, stride = w + 2;
     const size_t n = (size_t)w * h;
     T1Tables &T = *reinterpret_cast<T1Tables *>(smem);
     // Only the flags live in the workspace (LDS when they fit): the magnitudes are built in the output buffer itself
     // (first significance = plain store, refinement = fire-and-forget atomic OR), so LDS does not limit how many of
     // these serial chains a SIMD interleaves.
-    const size_t flag_bytes = ((size_t)(w + 2) * (h + 2) + 15) & ~size_t(15);
-    const bool in_lds = flag_bytes <= (size_t)lds_work_bytes;
-    uint8_t *flags = in_lds ? smem + ((sizeof(T1Tables) + 15) & ~size_t(15)) : work + (size_t)jid * work_per_job;
+    uint8_t *flags = LDSW ? smem + ((sizeof(T1Tables) + 15) & ~size_t(15)) : work + (size_t)jid * work_per_job;
     int32_t *out = decoded + J.out_off;
-    int32_t *data = out;
 
     build_tables(T, J.band, lane);
     for (size_t i = lane; i < (size_t)(w + 2) * (h + 2); i += 64) flags[i] = 0;
@@ -900,80 +987,88 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(const BlockJob *__restric
     init_dec_contexts(T, lane);
     __syncthreads();
     if (lane == 0) {
-        const int numBPS = numbps[jid];
-        MqDec d{0, 0x8000, 0, -1, (long)lens[jid], stream + offs[jid]};   // NewMQDecoder mqc.go:370-399
-        if (d.len == 0) d.C = 0xFFu << 16; else { d.bp = 0; d.C = (uint32_t)d.data[0] << 16; }
-        mq_byte_in(d);
-        d.C <<= 7; d.CT -= 7; d.A = 0x8000;
-        for (int bp = numBPS - 1; bp >= 0; bp--) {
-            const int32_t bit = bp < 32 ? (int32_t)(1u << bp) : 0;
-            for (int y = 0; y < h; y++)                                   // t1.go:1295-1319
-                for (int x = 0; x < w; x++) {
-                    uint8_t *f = flags + (size_t)(y + 1) * stride + x + 1;
-                    if ((*f & (T1Sig | T1HasNb)) != T1HasNb) continue;       // not significant, a significant neighbour
-                    if (mq_decode(d, T, T.zc[zc_packed(f, stride)])) {
-                        data[(size_t)y * w + x] = bit;
-                        dec_sign(d, T, f, stride);
-                        set_significant_dec(f, stride);
-                    }
-                    *f |= T1Visit;
-                }
-            for (int y = 0; y < h; y++)                                   // t1.go:1331-1347
-                for (int x = 0; x < w; x++) {
-                    uint8_t *f = flags + (size_t)(y + 1) * stride + x + 1;
-                    const uint32_t fv = *f;
-                    if ((fv & T1Sig) == 0 || (fv & T1Visit) != 0) continue;
-                    const int ctx = (fv & T1Refine) ? CtxMag2 : ((fv & T1HasNb) ? CtxMag1 : CtxMag0);
-                    if (mq_decode(d, T, ctx)) atomicOr(&data[(size_t)y * w + x], bit);
-                    *f = (uint8_t)(fv | T1Refine);
-                }
-            for (int y = 0; y < h; y += 4)                                // t1.go:1350-1410
-                for (int x = 0; x < w; x++) {
-                    bool canRL = (y + 4 <= h);
-                    if (canRL)
-                        for (int yy = y; yy < y + 4; yy++) {
-                            const uint8_t *f = flags + (size_t)(yy + 1) * stride + x + 1;
-                            if (*f & (T1Sig | T1Visit | T1HasNb)) { canRL = false; break; }
-                        }
-                    if (canRL) {
-                        if (mq_decode(d, T, CtxRL) == 0) continue;
-                        int pos = mq_decode(d, T, CtxUni) << 1;
-                        pos |= mq_decode(d, T, CtxUni);
-                        {
-                            uint8_t *f = flags + (size_t)(y + pos + 1) * stride + x + 1;
-                            data[(size_t)(y + pos) * w + x] = bit;
-                            dec_sign(d, T, f, stride);
-                            set_significant_dec(f, stride);
-                        }
-                        for (int i = pos + 1; i < 4 && y + i < h; i++) {
-                            uint8_t *f = flags + (size_t)(y + i + 1) * stride + x + 1;
-                            if (mq_decode(d, T, T.zc[zc_packed(f, stride)])) {
-                                data[(size_t)(y + i) * w + x] = bit;
-                                dec_sign(d, T, f, stride);
-                                set_significant_dec(f, stride);
-                            }
-                        }
-                        continue;
-                    }
-                    for (int yy = y; yy < y + 4 && yy < h; yy++) {
-                        uint8_t *f = flags + (size_t)(yy + 1) * stride + x + 1;
-                        const uint32_t fv = *f;
-                        if (fv & T1Visit) { *f = (uint8_t)(fv & ~T1Visit); continue; }
-                        if (fv & T1Sig) continue;
-                        if (mq_decode(d, T, T.zc[zc_packed(f, stride)])) {
-                            data[(size_t)yy * w + x] = bit;
-                            dec_sign(d, T, f, stride);
-                            set_significant_dec(f, stride);
-                        }
-                    }
-                }
-        }
+        T1DecLane L;
+        mq_dec_init(L.d, stream + offs[jid], (long)lens[jid]);
+        L.ent = T.ent; L.mq = T.mq; L.zc = T.zc; L.sc = T.sc; L.flags = flags; L.data = out; L.w = w; L.h = h; L.stride = stride;
+        t1_decode_passes(L, numbps[jid]);
     }
     __syncthreads();                                                      // includes the wait for lane 0's stores and atomics
     for (size_t i = lane; i < n; i += 64) {                               // t1.go:1281-1289
         if (!(flags[(i / w + 1) * stride + (i % w) + 1] & T1SignNeg)) continue;
         const int v = __hip_atomic_load(&out[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // L2, not this CU's L1
         out[i] = (int32_t)(0u - (uint32_t)v);
+    }
+}
+
+// K blocks (each <= 64x64) per wavefront, lane l on block g*K + l, every lane running T1.Decode's loops on its own
+// flag array in LDS.  The loops are the same for every block -- three scans of all samples per bit plane -- so the lanes
+// stay position-synchronous: the scan overhead is shared, and where several blocks take a decision at the same sample of
+// the same pass (the dense passes: Cleanup on the high planes, MagRef on the low ones) they share the decoder's
+// instructions too.  A chain on its own lane is bound by instruction issue (7 one-lane wavefronts per SIMD); here the
+// issue slots per block fall with K.
+#define T1M_FLAGS (66 * 66)          /* bytes per lane: 1089 dwords, so lanes fall on consecutive LDS banks */
+#define T1M_ENT 33                   /* words per lane */
+struct T1MultiShared {
+    uint32_t mq[96];
+    uint8_t zc[4][256];              // by band
+    uint8_t sc[256];
+};
+size_t t1_dec_multi_lds(int K) { return sizeof(T1MultiShared) + (size_t)K * (T1M_ENT * 4 + T1M_FLAGS); }
+
+__global__ __launch_bounds__(64) void t1_decode_multi_kernel(const BlockJob *__restrict__ jobs, int njobs, int K, const uint8_t *__restrict__ stream,
+                                                             const uint64_t *__restrict__ offs, const uint32_t *__restrict__ lens,
+                                                             const uint8_t *__restrict__ numbps, int32_t *__restrict__ decoded) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    T1MultiShared &S = *reinterpret_cast<T1MultiShared *>(smem);
+    uint32_t *ent = reinterpret_cast<uint32_t *>(smem + sizeof(T1MultiShared));           // [K][T1M_ENT]
+    uint8_t *flags = reinterpret_cast<uint8_t *>(ent + (size_t)K * T1M_ENT);             // [K][T1M_FLAGS]
+    const int lane = threadIdx.x;
+    const long j0 = (long)blockIdx.x * K;
+    {
+        T1Tables &T = *reinterpret_cast<T1Tables *>(flags);          // scratch: the flag area is cleared below
+        for (int band = 0; band < 4; band++) {
+            build_tables(T, band, lane);
+            __syncthreads();
+            for (int p = lane; p < 256; p += 64) S.zc[band][p] = T.zc[p];
+            if (band == 0) {
+                for (int p = lane; p < 256; p += 64) S.sc[p] = T.sc[p];
+                for (int p = lane; p < 94; p += 64) S.mq[p] = T.mq[p];
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = lane; i < K * T1M_FLAGS / 4; i += 64) reinterpret_cast<uint32_t *>(flags)[i] = 0;
+    for (int i = lane; i < K * T1M_ENT; i += 64) ent[i] = (i % T1M_ENT) < NumContexts ? S.mq[(i % T1M_ENT) == CtxUni ? 92 : 0] : 0u;
+    for (int b = 0; b < K && j0 + b < njobs; b++) {                  // the output blocks start as zeros
+        const BlockJob Jb = jobs[j0 + b];
+        if (Jb.w > 64 || Jb.h > 64) continue;
+        int32_t *o = decoded + Jb.out_off;
+        for (int i = lane; i < Jb.w * Jb.h; i += 64) o[i] = 0;
+    }
+    __syncthreads();
+    const long jid = j0 + lane;
+    if (lane < K && jid < njobs) {
+        const BlockJob J = jobs[jid];
+        if (J.w <= 64 && J.h <= 64) {                                // the one-block kernel takes the others
+            T1DecLane L;
+            mq_dec_init(L.d, stream + offs[jid], (long)lens[jid]);
+            L.ent = ent + (size_t)lane * T1M_ENT; L.mq = S.mq; L.zc = S.zc[J.band & 3]; L.sc = S.sc;
+            L.flags = flags + (size_t)lane * T1M_FLAGS; L.data = decoded + J.out_off; L.w = J.w; L.h = J.h; L.stride = J.w + 2;
+            t1_decode_passes(L, numbps[jid]);
+        }
+    }
+    __syncthreads();                                                      // includes the wait for the stores and atomics above
+    for (int b = 0; b < K && j0 + b < njobs; b++) {                       // t1.go:1281-1289: signs
+        const BlockJob Jb = jobs[j0 + b];
+        if (Jb.w > 64 || Jb.h > 64) continue;
+        int32_t *o = decoded + Jb.out_off;
+        const uint8_t *fb = flags + (size_t)b * T1M_FLAGS;
+        const int st = Jb.w + 2;
+        for (int i = lane; i < Jb.w * Jb.h; i += 64) {
+            if (!(fb[(i / Jb.w + 1) * st + (i % Jb.w) + 1] & T1SignNeg)) continue;
+            const int v = __hip_atomic_load(&o[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // L2, not this CU's L1
+            o[i] = (int32_t)(0u - (uint32_t)v);
+        }
     }
 }
 
@@ -1128,18 +1223,32 @@ hipError_t launch_t1_encode(hipStream_t s, const BlockJob *jobs, int njobs, cons
     }
     const int wb = lds_for(work_per_job);
     const size_t lds = ((sizeof(T1Tables) + 15) & ~size_t(15)) + (size_t)wb;
-    hipLaunchKernelGGL(t1_encode_kernel, dim3(njobs), dim3(64), lds, s, jobs, njobs, coef, slots, lens, numbps, work,
-                       work_per_job, wb, fault, serial_only ? 0 : 1);
+    if (wb) hipLaunchKernelGGL(t1_encode_kernel<true>, dim3(njobs), dim3(64), lds, s, jobs, njobs, coef, slots, lens, numbps, work,
+                               work_per_job, wb, fault, serial_only ? 0 : 1);
+    else hipLaunchKernelGGL(t1_encode_kernel<false>, dim3(njobs), dim3(64), lds, s, jobs, njobs, coef, slots, lens, numbps, work,
+                            work_per_job, wb, fault, serial_only ? 0 : 1);
     return hipGetLastError();
 }
 
+// lanes: blocks per wavefront for blocks up to 64x64 in t1_decode_multi_kernel (0 = 1; up to 12); < 0: the general
+// one-block kernel for every block
 hipError_t launch_t1_decode(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs,
-                            const uint32_t *lens, const uint8_t *numbps, int32_t *decoded, uint8_t *work, size_t work_per_job) {
+                            const uint32_t *lens, const uint8_t *numbps, int32_t *decoded, uint8_t *work, size_t work_per_job,
+                            int max_dim, int lanes) {
     if (njobs <= 0) return hipSuccess;
+    if (lanes >= 0) {
+        const int K = std::min(12, std::max(1, lanes));        // measured (C3): 1 -> 58.6 ms, 2 -> 62.7, 4 -> 96.9, 12 -> 138; 12 blocks = 54 KB of LDS
+        hipLaunchKernelGGL(t1_decode_multi_kernel, dim3((njobs + K - 1) / K), dim3(64), t1_dec_multi_lds(K), s, jobs, njobs, K, stream,
+                           offs, lens, numbps, decoded);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess || max_dim <= 64) return e;
+    }
     const int wb = lds_for(work_per_job);     // work_per_job = flag bytes of the largest block
     const size_t lds = ((sizeof(T1Tables) + 15) & ~size_t(15)) + (size_t)wb;
-    hipLaunchKernelGGL(t1_decode_kernel, dim3(njobs), dim3(64), lds, s, jobs, njobs, stream, offs, lens, numbps, decoded,
-                       work, work_per_job, wb);
+    if (wb) hipLaunchKernelGGL(t1_decode_kernel<true>, dim3(njobs), dim3(64), lds, s, jobs, njobs, stream, offs, lens, numbps, decoded,
+                               work, work_per_job, wb, lanes >= 0 ? 1 : 0);
+    else hipLaunchKernelGGL(t1_decode_kernel<false>, dim3(njobs), dim3(64), lds, s, jobs, njobs, stream, offs, lens, numbps, decoded,
+                            work, work_per_job, wb, lanes >= 0 ? 1 : 0);
     return hipGetLastError();
 }
 
