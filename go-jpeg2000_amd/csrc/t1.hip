@@ -167,7 +167,11 @@ __device__ __forceinline__ bool any_sig8(const uint8_t *f, int stride) {
     return ((f[-1] | f[1] | f[-stride] | f[stride] | f[-stride - 1] | f[-stride + 1] | f[stride - 1] | f[stride + 1]) & T1Sig) != 0;
 }
 
-size_t t1_flag_bytes(int w, int h) { return ((size_t)(w + 2) * (h + 2) + 15) & ~size_t(15); }
+// Decoder flag layout: rows of T1D_STRIDE(w) bytes, sample (x, y) at (y + 1) * stride + T1D_XO + x, one border sample on
+// every side.  (Rows aligned to 8 bytes with the scans testing 8 samples per load were slower: 58 -> 61 ms on C3.)
+#define T1D_XO 1
+#define T1D_STRIDE(w) ((w) + 2)
+size_t t1_flag_bytes(int w, int h) { return ((size_t)T1D_STRIDE(w) * (h + 2) + 15) & ~size_t(15); }
 size_t t1_work_bytes(int w, int h) {
     const size_t flags = ((size_t)(w + 2) * (h + 2) + 15) & ~size_t(15);
     return flags + (size_t)w * h * 4;
@@ -893,7 +897,7 @@ __device__ __forceinline__ void t1_decode_passes(T1DecLane &L, int numBPS) {
         const int32_t bit = bp < 32 ? (int32_t)(1u << bp) : 0;
         for (int y = 0; y < h; y++)                                   // t1.go:1295-1319
             for (int x = 0; x < w; x++) {
-                uint8_t *f = flags + (size_t)(y + 1) * stride + x + 1;
+                uint8_t *f = flags + (size_t)(y + 1) * stride + T1D_XO + x;
                 if ((*f & (T1Sig | T1HasNb)) != T1HasNb) continue;       // not significant, a significant neighbour
                 if (mq_decode(L.d, L.ent, L.mq, L.zc[zc_packed(f, stride)])) {
                     data[(size_t)y * w + x] = bit;
@@ -904,7 +908,7 @@ __device__ __forceinline__ void t1_decode_passes(T1DecLane &L, int numBPS) {
             }
         for (int y = 0; y < h; y++)                                   // t1.go:1331-1347
             for (int x = 0; x < w; x++) {
-                uint8_t *f = flags + (size_t)(y + 1) * stride + x + 1;
+                uint8_t *f = flags + (size_t)(y + 1) * stride + T1D_XO + x;
                 const uint32_t fv = *f;
                 if ((fv & T1Sig) == 0 || (fv & T1Visit) != 0) continue;
                 const int ctx = (fv & T1Refine) ? CtxMag2 : ((fv & T1HasNb) ? CtxMag1 : CtxMag0);
@@ -916,7 +920,7 @@ __device__ __forceinline__ void t1_decode_passes(T1DecLane &L, int numBPS) {
                 bool canRL = (y + 4 <= h);
                 if (canRL)
                     for (int yy = y; yy < y + 4; yy++) {
-                        const uint8_t *f = flags + (size_t)(yy + 1) * stride + x + 1;
+                        const uint8_t *f = flags + (size_t)(yy + 1) * stride + T1D_XO + x;
                         if (*f & (T1Sig | T1Visit | T1HasNb)) { canRL = false; break; }
                     }
                 if (canRL) {
@@ -924,13 +928,13 @@ __device__ __forceinline__ void t1_decode_passes(T1DecLane &L, int numBPS) {
                     int pos = mq_decode(L.d, L.ent, L.mq, CtxUni) << 1;
                     pos |= mq_decode(L.d, L.ent, L.mq, CtxUni);
                     {
-                        uint8_t *f = flags + (size_t)(y + pos + 1) * stride + x + 1;
+                        uint8_t *f = flags + (size_t)(y + pos + 1) * stride + T1D_XO + x;
                         data[(size_t)(y + pos) * w + x] = bit;
                         dec_sign(L, f);
                         set_significant_dec(f, stride);
                     }
                     for (int i = pos + 1; i < 4 && y + i < h; i++) {
-                        uint8_t *f = flags + (size_t)(y + i + 1) * stride + x + 1;
+                        uint8_t *f = flags + (size_t)(y + i + 1) * stride + T1D_XO + x;
                         if (mq_decode(L.d, L.ent, L.mq, L.zc[zc_packed(f, stride)])) {
                             data[(size_t)(y + i) * w + x] = bit;
                             dec_sign(L, f);
@@ -940,7 +944,7 @@ __device__ __forceinline__ void t1_decode_passes(T1DecLane &L, int numBPS) {
                     continue;
                 }
                 for (int yy = y; yy < y + 4 && yy < h; yy++) {
-                    uint8_t *f = flags + (size_t)(yy + 1) * stride + x + 1;
+                    uint8_t *f = flags + (size_t)(yy + 1) * stride + T1D_XO + x;
                     const uint32_t fv = *f;
                     if (fv & T1Visit) { *f = (uint8_t)(fv & ~T1Visit); continue; }
                     if (fv & T1Sig) continue;
@@ -970,8 +974,8 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(const BlockJob *__restric
     if (jid >= njobs) return;
     const int lane = threadIdx.x;
     const BlockJob J = jobs[jid];
-    if (skip_small && J.w <= 64 && J.h <= 64) return;             // t1_decode_multi_kernel takes these
-    const int w = J.w, h = J.h, stride = w + 2;
+    if (skip_small && J.w <= 64 && J.h <= 64) return;             // t1_decode64_kernel takes these
+    const int w = J.w, h = J.h, stride = T1D_STRIDE(w);
     const size_t n = (size_t)w * h;
     T1Tables &T = *reinterpret_cast<T1Tables *>(smem);
     // Only the flags live in the workspace (LDS when they fit): the magnitudes are built in the output buffer itself
@@ -981,7 +985,7 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(const BlockJob *__restric
     int32_t *out = decoded + J.out_off;
 
     build_tables(T, J.band, lane);
-    for (size_t i = lane; i < (size_t)(w + 2) * (h + 2); i += 64) flags[i] = 0;
+    for (size_t i = lane; i < (size_t)stride * (h + 2); i += 64) flags[i] = 0;
     for (size_t i = lane; i < n; i += 64) out[i] = 0;
     __syncthreads();
     init_dec_contexts(T, lane);
@@ -994,81 +998,57 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(const BlockJob *__restric
     }
     __syncthreads();                                                      // includes the wait for lane 0's stores and atomics
     for (size_t i = lane; i < n; i += 64) {                               // t1.go:1281-1289
-        if (!(flags[(i / w + 1) * stride + (i % w) + 1] & T1SignNeg)) continue;
+        if (!(flags[(i / w + 1) * stride + T1D_XO + (i % w)] & T1SignNeg)) continue;
         const int v = __hip_atomic_load(&out[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // L2, not this CU's L1
         out[i] = (int32_t)(0u - (uint32_t)v);
     }
 }
 
-// K blocks (each <= 64x64) per wavefront, lane l on block g*K + l, every lane running T1.Decode's loops on its own
-// flag array in LDS.  The loops are the same for every block -- three scans of all samples per bit plane -- so the lanes
-// stay position-synchronous: the scan overhead is shared, and where several blocks take a decision at the same sample of
-// the same pass (the dense passes: Cleanup on the high planes, MagRef on the low ones) they share the decoder's
-// instructions too.  A chain on its own lane is bound by instruction issue (7 one-lane wavefronts per SIMD); here the
-// issue slots per block fall with K.
-#define T1M_FLAGS (66 * 66)          /* bytes per lane: 1089 dwords, so lanes fall on consecutive LDS banks */
-#define T1M_ENT 33                   /* words per lane */
-struct T1MultiShared {
-    uint32_t mq[96];
-    uint8_t zc[4][256];              // by band
-    uint8_t sc[256];
+// The same for blocks up to 64x64 with the flags in LDS BY CONSTRUCTION: a workspace pointer chosen at run time (LDS or
+// `work`) is a flat pointer, and flat loads / stores cost the serial chain far more than ds_* ones (C3: 84 -> 58 ms).
+// (Tried and removed: K blocks per wavefront on K lanes of this same code -- the loops are the same for every block, so
+// lanes stay position-synchronous and share the scans -- K = 2: 62.7 ms, 4: 96.9, 12: 138: two blocks rarely take a
+// decision at the same sample of the same pass, so the decoder's instructions are not shared, only serialised.)
+#define T1D64_FLAGS ((66 * T1D_STRIDE(64) + 15) & ~15)
+struct T1Dec64Shared {
+    T1Tables T;
+    alignas(16) uint8_t flags[T1D64_FLAGS];
 };
-size_t t1_dec_multi_lds(int K) { return sizeof(T1MultiShared) + (size_t)K * (T1M_ENT * 4 + T1M_FLAGS); }
-
-__global__ __launch_bounds__(64) void t1_decode_multi_kernel(const BlockJob *__restrict__ jobs, int njobs, int K, const uint8_t *__restrict__ stream,
-                                                             const uint64_t *__restrict__ offs, const uint32_t *__restrict__ lens,
-                                                             const uint8_t *__restrict__ numbps, int32_t *__restrict__ decoded) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    T1MultiShared &S = *reinterpret_cast<T1MultiShared *>(smem);
-    uint32_t *ent = reinterpret_cast<uint32_t *>(smem + sizeof(T1MultiShared));           // [K][T1M_ENT]
-    uint8_t *flags = reinterpret_cast<uint8_t *>(ent + (size_t)K * T1M_ENT);             // [K][T1M_FLAGS]
+__global__ __launch_bounds__(64) void t1_decode64_kernel(const BlockJob *__restrict__ jobs, int njobs, const uint8_t *__restrict__ stream,
+                                                         const uint64_t *__restrict__ offs, const uint32_t *__restrict__ lens,
+                                                         const uint8_t *__restrict__ numbps, int32_t *__restrict__ decoded) {
+    __shared__ T1Dec64Shared S;
+    if ((int)blockIdx.x >= njobs) return;
     const int lane = threadIdx.x;
-    const long j0 = (long)blockIdx.x * K;
-    {
-        T1Tables &T = *reinterpret_cast<T1Tables *>(flags);          // scratch: the flag area is cleared below
-        for (int band = 0; band < 4; band++) {
-            build_tables(T, band, lane);
-            __syncthreads();
-            for (int p = lane; p < 256; p += 64) S.zc[band][p] = T.zc[p];
-            if (band == 0) {
-                for (int p = lane; p < 256; p += 64) S.sc[p] = T.sc[p];
-                for (int p = lane; p < 94; p += 64) S.mq[p] = T.mq[p];
-            }
-            __syncthreads();
-        }
-    }
-    for (int i = lane; i < K * T1M_FLAGS / 4; i += 64) reinterpret_cast<uint32_t *>(flags)[i] = 0;
-    for (int i = lane; i < K * T1M_ENT; i += 64) ent[i] = (i % T1M_ENT) < NumContexts ? S.mq[(i % T1M_ENT) == CtxUni ? 92 : 0] : 0u;
-    for (int b = 0; b < K && j0 + b < njobs; b++) {                  // the output blocks start as zeros
-        const BlockJob Jb = jobs[j0 + b];
-        if (Jb.w > 64 || Jb.h > 64) continue;
-        int32_t *o = decoded + Jb.out_off;
-        for (int i = lane; i < Jb.w * Jb.h; i += 64) o[i] = 0;
-    }
+    // The block index as a VECTOR value the compiler cannot prove uniform: everything derived from it (block size, loop
+    // counters, flag addresses) then lives in VGPRs and runs on the SIMD's own ALU.  As uniform values they go to the
+    // scalar unit, which all four SIMDs of a CU share -- with 28 serial chains per CU that unit is the bottleneck
+    // (C3: 67.7 ms with scalar loop control, 58 ms with vector).
+    int vzero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+    const int jid = (int)blockIdx.x + vzero;
+    const BlockJob J = jobs[jid];
+    const int w = J.w, h = J.h, stride = T1D_STRIDE(w);
+    if (w > 64 || h > 64) return;                                    // the general kernel takes these
+    const int n = w * h;
+    int32_t *out = decoded + J.out_off;
+    build_tables(S.T, J.band, lane);
+    for (int i = lane; i < (stride * (h + 2) + 3) / 4; i += 64) reinterpret_cast<uint32_t *>(S.flags)[i] = 0;
+    for (int i = lane; i < n; i += 64) out[i] = 0;
     __syncthreads();
-    const long jid = j0 + lane;
-    if (lane < K && jid < njobs) {
-        const BlockJob J = jobs[jid];
-        if (J.w <= 64 && J.h <= 64) {                                // the one-block kernel takes the others
-            T1DecLane L;
-            mq_dec_init(L.d, stream + offs[jid], (long)lens[jid]);
-            L.ent = ent + (size_t)lane * T1M_ENT; L.mq = S.mq; L.zc = S.zc[J.band & 3]; L.sc = S.sc;
-            L.flags = flags + (size_t)lane * T1M_FLAGS; L.data = decoded + J.out_off; L.w = J.w; L.h = J.h; L.stride = J.w + 2;
-            t1_decode_passes(L, numbps[jid]);
-        }
+    init_dec_contexts(S.T, lane);
+    __syncthreads();
+    if (lane == 0) {
+        T1DecLane L;
+        mq_dec_init(L.d, stream + offs[jid], (long)lens[jid]);
+        L.ent = S.T.ent; L.mq = S.T.mq; L.zc = S.T.zc; L.sc = S.T.sc; L.flags = S.flags; L.data = out; L.w = w; L.h = h; L.stride = stride;
+        t1_decode_passes(L, numbps[jid]);
     }
-    __syncthreads();                                                      // includes the wait for the stores and atomics above
-    for (int b = 0; b < K && j0 + b < njobs; b++) {                       // t1.go:1281-1289: signs
-        const BlockJob Jb = jobs[j0 + b];
-        if (Jb.w > 64 || Jb.h > 64) continue;
-        int32_t *o = decoded + Jb.out_off;
-        const uint8_t *fb = flags + (size_t)b * T1M_FLAGS;
-        const int st = Jb.w + 2;
-        for (int i = lane; i < Jb.w * Jb.h; i += 64) {
-            if (!(fb[(i / Jb.w + 1) * st + (i % Jb.w) + 1] & T1SignNeg)) continue;
-            const int v = __hip_atomic_load(&o[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // L2, not this CU's L1
-            o[i] = (int32_t)(0u - (uint32_t)v);
-        }
+    __syncthreads();                                                      // includes the wait for lane 0's stores and atomics
+    for (int i = lane; i < n; i += 64) {                                  // t1.go:1281-1289
+        if (!(S.flags[(i / w + 1) * stride + T1D_XO + (i % w)] & T1SignNeg)) continue;
+        const int v = __hip_atomic_load(&out[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // L2, not this CU's L1
+        out[i] = (int32_t)(0u - (uint32_t)v);
     }
 }
 
@@ -1230,25 +1210,22 @@ hipError_t launch_t1_encode(hipStream_t s, const BlockJob *jobs, int njobs, cons
     return hipGetLastError();
 }
 
-// lanes: blocks per wavefront for blocks up to 64x64 in t1_decode_multi_kernel (0 = 1; up to 12); < 0: the general
-// one-block kernel for every block
+// general_only: every block on the general kernel (A/B knob); otherwise blocks up to 64x64 take t1_decode64_kernel
 hipError_t launch_t1_decode(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs,
                             const uint32_t *lens, const uint8_t *numbps, int32_t *decoded, uint8_t *work, size_t work_per_job,
-                            int max_dim, int lanes) {
+                            int max_dim, int general_only) {
     if (njobs <= 0) return hipSuccess;
-    if (lanes >= 0) {
-        const int K = std::min(12, std::max(1, lanes));        // measured (C3): 1 -> 58.6 ms, 2 -> 62.7, 4 -> 96.9, 12 -> 138; 12 blocks = 54 KB of LDS
-        hipLaunchKernelGGL(t1_decode_multi_kernel, dim3((njobs + K - 1) / K), dim3(64), t1_dec_multi_lds(K), s, jobs, njobs, K, stream,
-                           offs, lens, numbps, decoded);
+    if (!general_only) {
+        hipLaunchKernelGGL(t1_decode64_kernel, dim3(njobs), dim3(64), 0, s, jobs, njobs, stream, offs, lens, numbps, decoded);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess || max_dim <= 64) return e;
     }
     const int wb = lds_for(work_per_job);     // work_per_job = flag bytes of the largest block
     const size_t lds = ((sizeof(T1Tables) + 15) & ~size_t(15)) + (size_t)wb;
     if (wb) hipLaunchKernelGGL(t1_decode_kernel<true>, dim3(njobs), dim3(64), lds, s, jobs, njobs, stream, offs, lens, numbps, decoded,
-                               work, work_per_job, wb, lanes >= 0 ? 1 : 0);
+                               work, work_per_job, wb, general_only ? 0 : 1);
     else hipLaunchKernelGGL(t1_decode_kernel<false>, dim3(njobs), dim3(64), lds, s, jobs, njobs, stream, offs, lens, numbps, decoded,
-                            work, work_per_job, wb, lanes >= 0 ? 1 : 0);
+                            work, work_per_job, wb, general_only ? 0 : 1);
     return hipGetLastError();
 }
 

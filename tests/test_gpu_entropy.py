@@ -106,6 +106,34 @@ def test_t1_batch_all_encoder_paths(ent, oracle, env, monkeypatch):
         assert np.array_equal(got, want), (j, env)
 
 
+@pytest.mark.parametrize("general", ["0", "1"])
+def test_t1_batch_both_decoder_kernels(ent, oracle, general, monkeypatch):
+    """Blocks of mixed size (some wider than 64) through T1.Decode on the <= 64x64 kernel + the general kernel (default)
+    and on the general kernel alone (J2K_T1_DEC_GENERAL=1): encoder output and arbitrary bytes, against the oracle."""
+    from j2kgfx import Context
+    monkeypatch.setenv("J2K_T1_DEC_GENERAL", general)              # read when a context is created
+    ctx = Context(0)
+    rng = np.random.default_rng(5)
+    dims = [(64, 64), (33, 64), (64, 7), (5, 3), (1, 1), (9, 64), (128, 32), (16, 16), (64, 64), (70, 9), (8, 8), (17, 5)]
+    blocks, streams, nbs, wants = [], [], [], []
+    for j, (w, h) in enumerate(dims * 2):
+        band = j % 4
+        if j % 3 == 2:                                             # not encoder output
+            g = rng.integers(0, 256, int(rng.integers(0, 300))).astype(np.uint8)
+            nb = int(rng.integers(1, 14))
+        else:
+            x = rng.integers(-700, 701, (h, w)).astype(np.int32)
+            g, nb = oracle.t1_encode(x, w, h, band)
+        blocks.append((0, band, 0, 0, w, h)); streams.append(np.asarray(g, np.uint8)); nbs.append(nb)
+        wants.append(oracle.t1_decode(streams[-1], nb, band, w, h).reshape(h, w))
+    blk = np.array(blocks, dtype=ent.BLOCK_DTYPE)
+    lens = np.array([g.size for g in streams], np.uint32)
+    offs = np.concatenate(([0], np.cumsum(lens)[:-1])).astype(np.uint64)
+    got = ent.decode_blocks(0, np.concatenate(streams), offs, lens, np.array(nbs, np.uint8), blk, ctx=ctx)
+    for j in range(len(blocks)):
+        assert np.array_equal(got[j], wants[j]), (j, blocks[j], general)
+
+
 HT_SHAPES = [(4, 4), (8, 8), (16, 16), (64, 64), (32, 32), (8, 5), (13, 9), (7, 4), (5, 8), (12, 16), (64, 7), (3, 16), (128, 128)]
 
 
