@@ -1060,9 +1060,9 @@ __device__ bool ht_extract_fast(HtDecShared &S, const uint8_t *__restrict__ data
         const long segLen = lcup - scup;
         const long maxbytes = (long)HT_DEC_MWORDS * 4 - 16;
         const long nb = segLen < maxbytes ? segLen : maxbytes;
-        const uintptr_t a0 = (uintptr_t)data & ~(uintptr_t)3;
-        const long d = (long)((uintptr_t)data - a0);               // segment byte k lives at aligned byte d + k
-        const uint32_t *wsrc = reinterpret_cast<const uint32_t *>(a0);
+        const long d = (long)((uintptr_t)data & 3);                // segment byte k lives at aligned byte d + k
+        // (pointer arithmetic, not an integer round trip: a pointer made from an integer is a flat pointer)
+        const uint32_t *wsrc = reinterpret_cast<const uint32_t *>(data - d);
         const long ndw = (d + nb + 3) >> 2;                          // aligned dwords covering the segment
         uint32_t off = 0, carry = 0;
         for (long j0 = 0; j0 < ndw; j0 += 64 * PF) {
