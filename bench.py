@@ -128,24 +128,28 @@ def main():
                 self.pix = torch.from_numpy(np.ascontiguousarray(rgba.reshape(H, W * 4))).to(p.device)
                 self.back_pix = torch.empty_like(self.pix)
             self.coeff = p.alloc_coeff()
-            self.stream = p.empty(i.bytes_cap, torch.uint8)
-            self.lens = p.empty(self.n, torch.int32); self.numbps = p.empty(self.n, torch.uint8)
-            self.offs = p.empty(self.n + 1, torch.int64)
+            # two sets of stream buffers at N > 1: step k + 1 encodes into one set while RCCL still reads step k's
+            nb = 2 if world > 1 else 1
+            self.streams = [p.empty(i.bytes_cap, torch.uint8) for _ in range(nb)]
+            self.lenss = [p.empty(self.n, torch.int32) for _ in range(nb)]
+            self.numbpss = [p.empty(self.n, torch.uint8) for _ in range(nb)]
+            self.offss = [p.empty(self.n + 1, torch.int64) for _ in range(nb)]
+            self.stream, self.lens, self.numbps, self.offs = self.streams[0], self.lenss[0], self.numbpss[0], self.offss[0]
             self.decoded = p.empty(i.decoded_elems, torch.int32)
             self.back = p.alloc_frame()
-            self.gather_buf = None
+            self.gather_bufs = [None] * nb
 
-        def encode_side(self):
+        def encode_side(self, b=0):
             p = self.plan
             if args.io == "rgba8":
                 p.forward_rgba8(self.pix, self.coeff)
             else:
                 p.forward(self.frame, self.coeff)
-            p.encode_stream(self.coeff, self.stream, self.offs, self.lens, self.numbps)   # block coding + compaction, one kernel
+            p.encode_stream(self.coeff, self.streams[b], self.offss[b], self.lenss[b], self.numbpss[b])   # block coding + compaction
 
-        def decode_side(self):
+        def decode_side(self, b=0):
             p = self.plan
-            p.decode_blocks(self.stream, self.offs, self.lens, self.numbps, self.decoded)
+            p.decode_blocks(self.streams[b], self.offss[b], self.lenss[b], self.numbpss[b], self.decoded)
             if args.io == "rgba8":
                 p.inverse_rgba8(self.coeff, self.back_pix)
             else:
@@ -162,31 +166,49 @@ def main():
 
     exts = [torch.cuda.ExternalStream(ln.ctx.stream) for ln in lanes]
 
+    enc_done = [torch.cuda.Event() for _ in lanes]
+    pending = [None, None]          # the gather that still reads buffer set b
+    stepno = [0]
+
+    def finish_gather(b):
+        """The transfers that read buffer set b are complete (and the library streams know it)."""
+        g = pending[b]
+        if g is None:
+            return
+        for ln, (buf, _) in zip(lanes, g.wait()):
+            ln.gather_bufs[b] = buf
+        cur = torch.cuda.current_stream()
+        for e in exts:
+            e.wait_stream(cur)
+        pending[b] = None
+
     def step():
         if world == 1:
             for ln in lanes:
                 ln.code()
             return
-        # N > 1: encode every frame in flight, hand all their streams to RCCL in ONE size exchange + ONE batch of
-        # peer->root transfers, decode while the bytes travel, then make the library streams wait for the transfers
-        # before the next step rewrites the send buffers.
+        # N > 1, software-pipelined over two sets of stream buffers: encode + decode of this step are queued on the
+        # library streams first; the host then waits for the ENCODES only (an event per stream), exchanges the sizes and
+        # hands all frames' streams to RCCL in one batch of peer->root transfers -- which run while this step's decodes
+        # and the next step's kernels execute.  A buffer set is rewritten only after the gather that read it has finished.
+        b = stepno[0] & 1
+        stepno[0] += 1
+        finish_gather(b)
+        for ln, ev, e in zip(lanes, enc_done, exts):
+            ln.encode_side(b)
+            ev.record(e)
         for ln in lanes:
-            ln.encode_side()
-        for ln in lanes:
-            ln.ctx.sync()                               # bytes must be complete before RCCL reads them
-        items = [(ln.stream, int(ln.offs[ln.n].item())) for ln in lanes]
+            ln.decode_side(b)
+        for ev in enc_done:
+            ev.synchronize()                            # the bytes are complete before RCCL reads them
+        items = [(ln.streams[b], int(ln.offss[b][ln.n].item())) for ln in lanes]
         if os.environ.get("J2K_BENCH_BACKEND", "nccl") != "nccl":
             items = [(t[:n_].cpu(), n_) for t, n_ in items]
-        g = jdist.gather_streams_start(items, outs=[ln.gather_buf for ln in lanes])
-        for ln in lanes:
-            ln.decode_side()
-        for ln, (buf, _) in zip(lanes, g.wait()):
-            ln.gather_buf = buf
-        cur = torch.cuda.current_stream()
-        for e in exts:
-            e.wait_stream(cur)
+        pending[b] = jdist.gather_streams_start(items, outs=[ln.gather_bufs[b] for ln in lanes])
 
     def barrier():
+        finish_gather(0)
+        finish_gather(1)
         for ln in lanes:
             ln.ctx.sync()
         torch.cuda.synchronize()

@@ -142,7 +142,7 @@ def test_c3_full_size_sampled_tiles_match_oracle():
 
 def test_bench_two_rank_control_flow_rehearsal():
     """bench.py's N > 1 step (encode all frames in flight -> one batched gather to rank 0 -> decode while the bytes
-    travel -> streams wait for the transfers) with two ranks sharing this box's GPU over gloo (RCCL refuses two ranks
+    travel; two sets of stream buffers, a set is rewritten only after its gather has finished) with two ranks sharing this box's GPU over gloo (RCCL refuses two ranks
     on one device): control flow only, the JSON line must come out and the round trips inside bench.py must hold."""
     import json
     import os
@@ -153,7 +153,7 @@ def test_bench_two_rank_control_flow_rehearsal():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, J2K_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
            "--no-cpu-baseline", "--inflight", "2"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
