@@ -138,6 +138,13 @@ def main():
             self.decoded = p.empty(i.decoded_elems, torch.int32)
             self.back = p.alloc_frame()
             self.gather_bufs = [None] * nb
+            # N > 1: what travels is the transport form of the stream (j2k_plan_pack_stream: the blocks without the
+            # reference's MEL zero runs, a third of the bytes); rank 0 rebuilds every peer's dense stream from it
+            self.packs = [p.empty(p.pack_bound(), torch.uint8) for _ in range(nb)] if world > 1 else []
+            self.assembled = None
+            if world > 1 and rank == 0:
+                self.assembled = [(p.empty(i.bytes_cap, torch.uint8), p.empty(self.n + 1, torch.int64), p.empty(self.n, torch.int32),
+                                   p.empty(self.n, torch.uint8)) for _ in range(world - 1)]
 
         def encode_side(self, b=0):
             p = self.plan
@@ -146,6 +153,8 @@ def main():
             else:
                 p.forward(self.frame, self.coeff)
             p.encode_stream(self.coeff, self.streams[b], self.offss[b], self.lenss[b], self.numbpss[b])   # block coding + compaction
+            if world > 1 and rank != 0:
+                p.pack_stream(self.streams[b], self.offss[b], self.lenss[b], self.numbpss[b], self.packs[b])
 
         def decode_side(self, b=0):
             p = self.plan
@@ -167,6 +176,8 @@ def main():
     exts = [torch.cuda.ExternalStream(ln.ctx.stream) for ln in lanes]
 
     enc_done = [torch.cuda.Event() for _ in lanes]
+    unpacked = [[torch.cuda.Event() for _ in lanes] for _ in range(2)]
+    keep = [None, None]
     pending = [None, None]          # the gather that still reads buffer set b
     stepno = [0]
 
@@ -175,11 +186,25 @@ def main():
         g = pending[b]
         if g is None:
             return
-        for ln, (buf, _) in zip(lanes, g.wait()):
+        res = g.wait()
+        staged = []
+        for ln, (buf, offsets) in zip(lanes, res):
             ln.gather_bufs[b] = buf
+            if rank == 0:
+                pks = [buf[int(offsets[r]):int(offsets[r + 1])] for r in range(1, world)]
+                if not buf.is_cuda:                     # gloo rehearsal: the packs arrive in host memory
+                    pks = [pk.to(ln.plan.device) for pk in pks]
+                staged.append(pks)
         cur = torch.cuda.current_stream()
-        for e in exts:
+        for e in exts:                                  # the library streams wait for the transfers (and any staging copy)
             e.wait_stream(cur)
+        for ln, pks in zip(lanes, staged):              # rank 0: rebuild every peer's dense stream (+ offsets, lengths, bit planes)
+            for r, pk in enumerate(pks):
+                ln.plan.unpack_stream(pk, *ln.assembled[r])
+        keep[b] = staged                                # alive until this set's next turn
+        if rank == 0:                                   # the next gather into this receive buffer waits for these unpacks
+            for ev, e in zip(unpacked[b], exts):
+                ev.record(e)
         pending[b] = None
 
     def step():
@@ -201,9 +226,14 @@ def main():
             ln.decode_side(b)
         for ev in enc_done:
             ev.synchronize()                            # the bytes are complete before RCCL reads them
-        items = [(ln.streams[b], int(ln.offss[b][ln.n].item())) for ln in lanes]
+        # rank 0's own frames stay where they are (it sends nothing); a peer sends the pack, whose first word is its length
+        items = [(ln.packs[b], 0 if rank == 0 else int(ln.packs[b][:8].view(torch.int64)[0].item())) for ln in lanes]
         if os.environ.get("J2K_BENCH_BACKEND", "nccl") != "nccl":
             items = [(t[:n_].cpu(), n_) for t, n_ in items]
+        if rank == 0 and stepno[0] > 2:
+            cur = torch.cuda.current_stream()
+            for ev in unpacked[b]:
+                cur.wait_event(ev)
         pending[b] = jdist.gather_streams_start(items, outs=[ln.gather_bufs[b] for ln in lanes])
 
     def barrier():
@@ -274,6 +304,18 @@ def main():
         else:
             assert torch.equal(ln.back, ln.frame), "lossless round trip failed"
     total_bytes = int(lanes[0].offs[n].item())
+    if world > 1 and rank == 0:
+        # what rank 0 assembled for rank 1's frame == that frame coded here, byte for byte (stream, offsets, lengths, bit planes)
+        ln = lanes[0]
+        fr1 = torch.from_numpy(synth_frame(np, 1)).to(plan.device)     # kept alive until the sync: the calls are asynchronous
+        torch.cuda.synchronize()
+        co = plan.forward(fr1)
+        s_, o_, l_, n_ = plan.encode_stream(co)
+        ctx.sync()
+        a_s, a_o, a_l, a_n = ln.assembled[0]
+        tot1 = int(o_[n].item())
+        assert torch.equal(a_o[:n + 1], o_[:n + 1]) and torch.equal(a_l[:n], l_[:n]) and torch.equal(a_n[:n], n_[:n]), "gathered arrays differ"
+        assert torch.equal(a_s[:tot1], s_[:tot1]), "gathered stream differs"
 
     if rank == 0:
         px = W * H
@@ -291,7 +333,8 @@ def main():
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "3840x2160 sRGB 8-bit, 512x512 tiles, 5-3 lossless + HT block coder, 64x64 code-blocks, "
                                    "6 resolutions (BASELINE configs[1]); frames_in_flight independent frames per rank per step, "
-                                   "each on its own HIP stream; N>1 gathers the compressed streams to rank 0 over RCCL",
+                                   "each on its own HIP stream; N>1 gathers the compressed streams to rank 0 over RCCL (sent without "
+                                   "the reference's MEL zero runs, rebuilt byte for byte at rank 0 inside the timed region)",
                        "tiles": int(info.tiles), "code_blocks": n, "compressed_bytes_per_frame": total_bytes,
                        "frames_in_flight": F, "frame_io": args.io,
                        "parallelism": "frames/rank" if world > 1 else "single GPU"},

@@ -99,6 +99,121 @@ __global__ __launch_bounds__(256) void gather_kernel(const BlockJob *__restrict_
     copy_bytes(dst + mag + mel, src + mag + mel, len - mag - mel, lane);
 }
 
+// ---- transport form of a stream (multi-GPU gather) ----
+// The reference's HT block is  MagSgn | MEL | VLC | SCUP  with MEL = max(64, 2wh)/4 ZERO bytes (ht.go:978, 1019): two
+// thirds of a 64x64 block.  A rank that sends its stream to the root over one xGMI link sends the blocks without those
+// runs, preceded by the per-block arrays the root needs to put them back (and to assemble packets): the pack is
+//   [total bytes u64 | payload bytes u64 | n u32 | mel flag u32 | pad to 64] lens u32[n] | maglens u32[n] | numbps u8[n] |
+//   offs u64[n+1] | toffs u64[n+1] | payload      (every section 16-byte aligned)
+// and j2k_plan_unpack_stream at the root rebuilds the dense stream, byte for byte.
+__host__ __device__ inline size_t pack_a16(size_t x) { return (x + 15) & ~size_t(15); }
+struct PackLayout { size_t lens, mag, nb, offs, toffs, payload; };
+__host__ __device__ inline PackLayout pack_layout(size_t n) {
+    PackLayout L;
+    L.lens = 64;
+    L.mag = pack_a16(L.lens + 4 * n);
+    L.nb = pack_a16(L.mag + 4 * n);
+    L.offs = pack_a16(L.nb + n);
+    L.toffs = pack_a16(L.offs + 8 * (n + 1));
+    L.payload = pack_a16(L.toffs + 8 * (n + 1));
+    return L;
+}
+size_t pack_header_bytes(size_t n) { return pack_layout(n).payload; }
+
+__device__ __forceinline__ uint32_t mel_bytes(const BlockJob &J) {
+    const size_t nsamp = (size_t)J.w * J.h;
+    return (uint32_t)((nsamp * 2 < 64 ? 64 : nsamp * 2) / 4);
+}
+
+// header arrays + the transport length of every block (tl: u32 per job, scratch)
+__global__ void pack_meta_kernel(const BlockJob *__restrict__ jobs, int n, const uint32_t *__restrict__ lens, const uint32_t *__restrict__ maglens,
+                                 const uint8_t *__restrict__ numbps, const uint64_t *__restrict__ offs, uint8_t *__restrict__ pack,
+                                 uint32_t *__restrict__ tl) {
+    const PackLayout L = pack_layout((size_t)n);
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > n) return;
+    reinterpret_cast<uint64_t *>(pack + L.offs)[j] = offs[j];
+    if (j == n) return;
+    const uint32_t len = lens[j];
+    const uint32_t mel = (maglens && len) ? mel_bytes(jobs[j]) : 0u;
+    reinterpret_cast<uint32_t *>(pack + L.lens)[j] = len;
+    reinterpret_cast<uint32_t *>(pack + L.mag)[j] = maglens ? maglens[j] : len;
+    pack[L.nb + j] = numbps[j];
+    tl[j] = len - mel;
+}
+__global__ __launch_bounds__(256) void pack_payload_kernel(const BlockJob *__restrict__ jobs, int n, const uint8_t *__restrict__ stream,
+                                                           int has_mel, uint8_t *__restrict__ pack) {
+    const PackLayout L = pack_layout((size_t)n);
+    const uint64_t *toffs = reinterpret_cast<const uint64_t *>(pack + L.toffs);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        uint64_t *h = reinterpret_cast<uint64_t *>(pack);
+        h[0] = (uint64_t)L.payload + toffs[n];
+        h[1] = toffs[n];
+        reinterpret_cast<uint32_t *>(pack)[4] = (uint32_t)n;
+        reinterpret_cast<uint32_t *>(pack)[5] = (uint32_t)has_mel;
+    }
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= n) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t len = reinterpret_cast<const uint32_t *>(pack + L.lens)[j];
+    if (len == 0) return;
+    const uint32_t mag = reinterpret_cast<const uint32_t *>(pack + L.mag)[j];
+    const uint32_t mel = has_mel ? mel_bytes(jobs[j]) : 0u;
+    const uint8_t *src = stream + reinterpret_cast<const uint64_t *>(pack + L.offs)[j];
+    uint8_t *dst = pack + L.payload + toffs[j];
+    copy_bytes(dst, src, mag, lane);
+    copy_bytes(dst + mag, src + mag + mel, len - mag - mel, lane);
+}
+// root side: pack -> dense stream + offs / lens / numbps.  fault: 4 = the pack does not belong to this plan
+__global__ __launch_bounds__(256) void unpack_kernel(const BlockJob *__restrict__ jobs, int n, const uint8_t *__restrict__ pack,
+                                                     uint8_t *__restrict__ stream, uint64_t stream_cap, uint64_t *__restrict__ offs,
+                                                     uint32_t *__restrict__ lens, uint8_t *__restrict__ numbps, int *__restrict__ fault) {
+    const PackLayout L = pack_layout((size_t)n);
+    if (reinterpret_cast<const uint32_t *>(pack)[4] != (uint32_t)n) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(fault, 4);
+        return;
+    }
+    const int has_mel = (int)reinterpret_cast<const uint32_t *>(pack)[5];
+    const uint64_t *poffs = reinterpret_cast<const uint64_t *>(pack + L.offs);
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j > n) return;
+    const int lane = threadIdx.x & 63;
+    if (lane == 0) offs[j] = poffs[j];
+    if (j == n) return;
+    const uint32_t len = reinterpret_cast<const uint32_t *>(pack + L.lens)[j];
+    if (lane == 0) { lens[j] = len; numbps[j] = pack[L.nb + j]; }
+    if (len == 0) return;
+    const uint32_t mag = reinterpret_cast<const uint32_t *>(pack + L.mag)[j];
+    const uint32_t mel = has_mel ? mel_bytes(jobs[j]) : 0u;
+    const uint64_t toff = reinterpret_cast<const uint64_t *>(pack + L.toffs)[j];
+    // a pack is foreign input: nothing is copied unless the block's pieces fit the pack and the stream
+    if (mag > len || mel > len - mag || toff + (len - mel) > reinterpret_cast<const uint64_t *>(pack)[1] ||
+        poffs[j] + len > poffs[n] || poffs[n] > stream_cap) {
+        if (lane == 0) atomicMax(fault, 4);
+        return;
+    }
+    const uint8_t *src = pack + L.payload + toff;
+    uint8_t *dst = stream + poffs[j];
+    copy_bytes(dst, src, mag, lane);
+    zero_run(dst + mag, mel, lane);
+    copy_bytes(dst + mag + mel, src + mag, len - mag - mel, lane);
+}
+
+hipError_t launch_pack(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs, const uint32_t *lens,
+                       const uint8_t *numbps, const uint32_t *maglens, uint8_t *pack, uint32_t *tl_scratch) {
+    const PackLayout L = pack_layout((size_t)njobs);
+    hipLaunchKernelGGL(pack_meta_kernel, dim3((njobs + 1 + 255) / 256), dim3(256), 0, s, jobs, njobs, lens, maglens, numbps, offs, pack, tl_scratch);
+    hipLaunchKernelGGL(scan_lens_kernel, dim3(1), dim3(1024), 0, s, tl_scratch, njobs, reinterpret_cast<uint64_t *>(pack + L.toffs));
+    hipLaunchKernelGGL(pack_payload_kernel, dim3((njobs + 3) / 4), dim3(256), 0, s, jobs, njobs, stream, maglens ? 1 : 0, pack);
+    return hipGetLastError();
+}
+hipError_t launch_unpack(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *pack, uint8_t *stream, size_t stream_cap,
+                         uint64_t *offs, uint32_t *lens, uint8_t *numbps, int *fault) {
+    hipLaunchKernelGGL(unpack_kernel, dim3((njobs + 1 + 3) / 4), dim3(256), 0, s, jobs, njobs, pack, stream, (uint64_t)stream_cap, offs, lens,
+                       numbps, fault);
+    return hipGetLastError();
+}
+
 hipError_t launch_compact(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *slots, const uint32_t *lens,
                           uint64_t *offs, uint8_t *stream, const uint32_t *maglens) {
     hipLaunchKernelGGL(scan_lens_kernel, dim3(1), dim3(1024), 0, s, lens, njobs, offs);

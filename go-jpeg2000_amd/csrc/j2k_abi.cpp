@@ -42,6 +42,11 @@ size_t t1_work_bytes(int w, int h);
 size_t t1_flag_bytes(int w, int h);
 hipError_t launch_compact(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *slots, const uint32_t *lens,
                           uint64_t *offs, uint8_t *stream, const uint32_t *maglens);
+size_t pack_header_bytes(size_t n);
+hipError_t launch_pack(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs, const uint32_t *lens,
+                       const uint8_t *numbps, const uint32_t *maglens, uint8_t *pack, uint32_t *tl_scratch);
+hipError_t launch_unpack(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *pack, uint8_t *stream, size_t stream_cap,
+                         uint64_t *offs, uint32_t *lens, uint8_t *numbps, int *fault);
 }  // namespace j2k
 
 // ------------------------------------------------------------------------------
@@ -141,6 +146,7 @@ static int check_fault(j2k_ctx *ctx) {
     if (!f) return J2K_OK;
     HIPCHK(ctx, hipMemset(ctx->stage[3], 0, sizeof(int)));
     if (f == 1) return fail(ctx, J2K_ERR_GO_PANIC, "block coder: input on which the reference panics (stream buffer overrun / MinInt32)");
+    if (f == 4) return fail(ctx, J2K_ERR_INVALID_ARG, "unpack_stream: the pack was not made by a plan of this geometry");
     return fail(ctx, J2K_ERR_CAPACITY, "block coder: slot overflow");
 }
 
@@ -989,6 +995,39 @@ extern "C" int j2k_plan_encode_stream(j2k_plan *P, const int32_t *d_coeff, uint8
     int r = j2k_plan_encode_blocks(P, d_coeff, (uint8_t *)P->d_slots, d_lens, d_numbps);
     if (r != J2K_OK) return r;
     return j2k_plan_compact(P, (const uint8_t *)P->d_slots, d_lens, d_offs, d_stream);
+}
+
+extern "C" size_t j2k_plan_pack_bound(const j2k_plan *P) {
+    if (!P) return 0;
+    return pack_header_bytes(P->blocks.size()) + (size_t)P->bytes_cap + 64;
+}
+
+extern "C" int j2k_plan_pack_stream(j2k_plan *P, const uint8_t *d_stream, const uint64_t *d_offs, const uint32_t *d_lens,
+                                    const uint8_t *d_numbps, uint8_t *d_pack) {
+    if (!P || !d_stream || !d_offs || !d_lens || !d_numbps || !d_pack) return J2K_ERR_INVALID_ARG;
+    j2k_ctx *ctx = P->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int n = (int)P->blocks.size();
+    const bool ht = P->spec.coder == J2K_CODER_HT;
+    if (ht && !P->d_maglens) return fail(ctx, J2K_ERR_UNSUPPORTED, "pack_stream: no j2k_plan_encode_stream (three-kernel path) ran on this plan");
+    int r = stage_reserve(ctx, 1, (size_t)n * 4 + 4096);
+    if (r != J2K_OK) return r;
+    HIPCHK(ctx, launch_pack(ctx->stream, P->d_bjobs, n, d_stream, d_offs, d_lens, d_numbps, ht ? P->d_maglens : nullptr, d_pack,
+                            (uint32_t *)ctx->stage[1]));
+    return J2K_OK;
+}
+
+extern "C" int j2k_plan_unpack_stream(j2k_plan *P, const uint8_t *d_pack, uint8_t *d_stream, uint64_t *d_offs, uint32_t *d_lens,
+                                      uint8_t *d_numbps) {
+    if (!P || !d_pack || !d_stream || !d_offs || !d_lens || !d_numbps) return J2K_ERR_INVALID_ARG;
+    j2k_ctx *ctx = P->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int n = (int)P->blocks.size();
+    int r = stage_reserve(ctx, 3, 256);
+    if (r != J2K_OK) return r;
+    ctx->fault_armed = true;
+    HIPCHK(ctx, launch_unpack(ctx->stream, P->d_bjobs, n, d_pack, d_stream, (size_t)P->bytes_cap, d_offs, d_lens, d_numbps, (int *)ctx->stage[3]));
+    return J2K_OK;
 }
 
 extern "C" int j2k_plan_compact(j2k_plan *P, const uint8_t *d_slots, const uint32_t *d_lens, uint64_t *d_offs, uint8_t *d_stream) {

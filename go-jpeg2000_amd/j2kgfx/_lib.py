@@ -57,6 +57,7 @@ SYMBOLS = [
     "j2k_pixels_components", "j2k_pixels_precision", "j2k_extract_image_data", "j2k_create_image",
     "j2k_unpack_pixels", "j2k_pack_pixels", "j2k_plan_forward_rgba8", "j2k_plan_inverse_rgba8",
     "j2k_plan_forward_pixels", "j2k_plan_inverse_pixels",
+    "j2k_plan_pack_bound", "j2k_plan_pack_stream", "j2k_plan_unpack_stream",
 ]
 PIX_GRAY8, PIX_GRAY16, PIX_RGBA8, PIX_RGBA64, PIX_NRGBA8, PIX_NRGBA64 = range(6)
 
@@ -92,5 +93,7 @@ def lib():
         L.j2k_ctx_sync.argtypes = [C.c_void_p]
         L.j2k_plan_destroy.argtypes = [C.c_void_p]
         L.j2k_plan_destroy.restype = None
+        L.j2k_plan_pack_bound.restype = C.c_size_t
+        L.j2k_plan_pack_bound.argtypes = [C.c_void_p]
         _lib = L
     return _lib

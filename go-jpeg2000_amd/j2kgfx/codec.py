@@ -154,6 +154,30 @@ class FramePlan:
                                                          self._p(numbps)))
         return stream, offs, lens, numbps
 
+    def pack_bound(self):
+        return int(self.ctx.L.j2k_plan_pack_bound(self.h))
+
+    def pack_stream(self, stream, offs, lens, numbps, pack=None):
+        """Transport form (blocks without the reference's MEL zero runs + the per-block arrays) of the stream the LAST
+        encode_stream call on this plan produced; the first int64 of the pack is its length in bytes."""
+        t = _torch()
+        pack = pack if pack is not None else self.empty(self.pack_bound(), t.uint8)
+        self.ctx.check(self.ctx.L.j2k_plan_pack_stream(self.h, self._p(stream), self._p(offs), self._p(lens), self._p(numbps),
+                                                       self._p(pack)))
+        return pack
+
+    def unpack_stream(self, pack, stream=None, offs=None, lens=None, numbps=None):
+        """Root side of the gather: pack -> (stream, offs, lens, numbps), byte for byte what encode_stream produced."""
+        t = _torch()
+        n = int(self.info.blocks)
+        stream = stream if stream is not None else self.empty(self.info.bytes_cap, t.uint8)
+        offs = offs if offs is not None else self.empty(n + 1, t.int64)
+        lens = lens if lens is not None else self.empty(n, t.int32)
+        numbps = numbps if numbps is not None else self.empty(n, t.uint8)
+        self.ctx.check(self.ctx.L.j2k_plan_unpack_stream(self.h, self._p(pack), self._p(stream), self._p(offs), self._p(lens),
+                                                         self._p(numbps)))
+        return stream, offs, lens, numbps
+
     def compact(self, slots, lens, offs=None, stream=None):
         t = _torch()
         n = int(self.info.blocks)

@@ -190,6 +190,20 @@ int j2k_plan_compact(j2k_plan *plan, const uint8_t *d_slots, const uint32_t *d_l
  * over the block lengths -- correct, but measured slower than the three kernels, so off by default.) */
 int j2k_plan_encode_stream(j2k_plan *plan, const int32_t *d_coeff, uint8_t *d_stream, uint64_t *d_offs,
                            uint32_t *d_lens, uint8_t *d_numbps);
+/* Transport form of a stream for the multi-GPU gather (the compressed packets go to rank 0 for codestream
+ * assembly, encoder.go:568-579, 746-760).  The reference's HT block carries max(64, 2wh)/4 zero bytes of MEL segment
+ * (ht.go:978, 1019) -- two thirds of a 64x64 block -- and every peer has ONE xGMI link to the root, so a peer sends
+ *   header | lens u32[n] | maglens u32[n] | numbps u8[n] | offs u64[n+1] | toffs u64[n+1] | blocks without the MEL runs
+ * (j2k_plan_pack_bound bytes at most; the first u64 of the pack is its length) and the root rebuilds the dense stream,
+ * d_offs (n + 1), d_lens and d_numbps byte for byte with j2k_plan_unpack_stream on a plan of the same geometry (any
+ * other pack is reported as J2K_ERR_INVALID_ARG at the next sync).  j2k_plan_pack_stream packs the stream made by the
+ * LAST j2k_plan_encode_stream call on this plan (the plan remembers where each block's MagSgn bytes end); MQ streams
+ * have no zero runs and are packed as they are. */
+size_t j2k_plan_pack_bound(const j2k_plan *plan);
+int j2k_plan_pack_stream(j2k_plan *plan, const uint8_t *d_stream, const uint64_t *d_offs, const uint32_t *d_lens,
+                         const uint8_t *d_numbps, uint8_t *d_pack);
+int j2k_plan_unpack_stream(j2k_plan *plan, const uint8_t *d_pack, uint8_t *d_stream, uint64_t *d_offs,
+                           uint32_t *d_lens, uint8_t *d_numbps);
 /* tcd.TileDecoder.DecodeCodeBlock (tcd.go:393-413) for every job: dense stream + offsets
  * + lens + numbps -> d_decoded (decoded_elems int32, block j dense at its job offset). */
 int j2k_plan_decode_blocks(j2k_plan *plan, const uint8_t *d_stream, const uint64_t *d_offs,

@@ -335,3 +335,42 @@ def test_encode_stream_equals_encode_blocks_plus_compact(W, H, tile, cb, coder, 
         assert torch.equal(o2[:n + 1], offs[:n + 1]) and torch.equal(l2[:n], lens[:n]) and torch.equal(n2[:n], nb[:n])
         assert torch.equal(s2[:tot], stream[:tot]), rep
         coeff = plan.forward(d)                                    # same values; keeps the launches back to back
+
+
+@pytest.mark.parametrize("W,H,tile,cb,coder", [(3840, 2160, 512, 64, 1), (200, 96, 0, 32, 1), (100, 75, 64, 16, 1), (512, 512, 0, 256, 1),
+                                               (256, 128, 128, 64, 0), (64, 64, 0, 64, 1)])
+def test_pack_unpack_stream_round_trip(W, H, tile, cb, coder):
+    """Transport form of a stream for the multi-GPU gather: unpack(pack(x)) must give back the dense stream, the offsets,
+    the lengths and the bit-plane counts byte for byte (on ANOTHER plan of the same geometry, as the root has), the pack
+    must be smaller than the stream by the MEL zero runs (HT), and a pack of another geometry must be refused."""
+    import torch
+    from j2kgfx import Context, J2KError
+    from j2kgfx.codec import FramePlan
+    rng = np.random.default_rng(W * 3 + cb + coder)
+    frame = torch.from_numpy(rng.integers(0, 256, size=(3, H, W)).astype(np.int32))
+    kw = dict(precision=8, lossless=True, num_resolutions=6, cb=(cb, cb), tile=(tile, tile), coder=coder)
+    plan = FramePlan(W, H, 3, ctx=Context(0), **kw)
+    root = FramePlan(W, H, 3, ctx=Context(0), **kw)
+    d = frame.to(plan.device)
+    coeff = plan.forward(d)
+    stream, offs, lens, nb = plan.encode_stream(coeff)
+    pack = plan.pack_stream(stream, offs, lens, nb)
+    plan.ctx.sync()
+    n = int(plan.info.blocks)
+    tot = int(offs[n].item())
+    pbytes = int(pack[:8].view(torch.int64)[0].item())
+    assert 0 < pbytes <= plan.pack_bound()
+    sent = pack[:pbytes].clone()                                   # what would travel
+    s2, o2, l2, n2 = root.unpack_stream(sent)
+    root.ctx.sync()
+    assert torch.equal(o2[:n + 1], offs[:n + 1]) and torch.equal(l2[:n], lens[:n]) and torch.equal(n2[:n], nb[:n])
+    assert torch.equal(s2[:tot], stream[:tot])
+    if coder == 1:
+        blocks = plan.blocks()
+        mel = sum(max(64, 2 * int(b["w"]) * int(b["h"])) // 4 for b, ln in zip(blocks, lens.cpu().numpy()[:n]) if ln)
+        payload = int(pack[8:16].view(torch.int64)[0].item())
+        assert payload == tot - mel
+    other = FramePlan(W + 64, H, 3, ctx=Context(0), **kw)
+    other.unpack_stream(sent)
+    with pytest.raises(J2KError):
+        other.ctx.sync()
