@@ -167,11 +167,12 @@ __device__ __forceinline__ bool any_sig8(const uint8_t *f, int stride) {
     return ((f[-1] | f[1] | f[-stride] | f[stride] | f[-stride - 1] | f[-stride + 1] | f[stride - 1] | f[stride + 1]) & T1Sig) != 0;
 }
 
-// Decoder flag layout: rows of T1D_STRIDE(w) bytes, sample (x, y) at (y + 1) * stride + T1D_XO + x, one border sample on
-// every side.  (Rows aligned to 8 bytes with the scans testing 8 samples per load were slower: 58 -> 61 ms on C3.)
-#define T1D_XO 1
-#define T1D_STRIDE(w) ((w) + 2)
-size_t t1_flag_bytes(int w, int h) { return ((size_t)T1D_STRIDE(w) * (h + 2) + 15) & ~size_t(15); }
+// Decoder flag layout: rows of T1D_STRIDE(w) bytes (a multiple of 4), sample (x, y) at (y + 1) * stride + T1D_XO + x: rows
+// start on a 4-byte boundary so the SigProp / MagRef scans test four samples with one load; border samples on every side
+// (x = -1 at offset 3; x = w in the row's padding or, for w % 4 == 0, at offset 0 of the next row, which no row uses).
+#define T1D_XO 4
+#define T1D_STRIDE(w) (((w) + T1D_XO + 3) & ~3)
+size_t t1_flag_bytes(int w, int h) { return ((size_t)T1D_STRIDE(w) * (h + 2) + 4 + 15) & ~size_t(15); }
 size_t t1_work_bytes(int w, int h) {
     const size_t flags = ((size_t)(w + 2) * (h + 2) + 15) & ~size_t(15);
     return flags + (size_t)w * h * 4;
@@ -895,26 +896,48 @@ __device__ __forceinline__ void t1_decode_passes(T1DecLane &L, int numBPS) {
     int32_t *const data = L.data;
     for (int bp = numBPS - 1; bp >= 0; bp--) {
         const int32_t bit = bp < 32 ? (int32_t)(1u << bp) : 0;
-        for (int y = 0; y < h; y++)                                   // t1.go:1295-1319
-            for (int x = 0; x < w; x++) {
-                uint8_t *f = flags + (size_t)(y + 1) * stride + T1D_XO + x;
-                if ((*f & (T1Sig | T1HasNb)) != T1HasNb) continue;       // not significant, a significant neighbour
-                if (mq_decode(L.d, L.ent, L.mq, L.zc[zc_packed(f, stride)])) {
-                    data[(size_t)y * w + x] = bit;
-                    dec_sign(L, f);
-                    set_significant_dec(f, stride);
+        // SigProp and MagRef look at four samples per load and step from candidate to candidate with find-first-set; a
+        // sample that turns significant changes its right-hand neighbour's flags, so the group is read again after it
+        for (int y = 0; y < h; y++) {                                 // t1.go:1295-1319
+            uint8_t *const row = flags + (size_t)(y + 1) * stride + T1D_XO;
+            for (int x0 = 0; x0 < w; x0 += 4) {
+                const uint32_t inrow = x0 + 4 <= w ? 0x01010101u : (0x01010101u >> (8 * (x0 + 4 - w)));
+                uint32_t v = *reinterpret_cast<const uint32_t *>(row + x0);
+                uint32_t cand = (v >> 4) & ~v & inrow;               // bit 0 of a byte: has a significant neighbour, not significant
+                while (cand) {
+                    const int k = (__ffs((int)cand) - 1) >> 3, x = x0 + k;
+                    uint8_t *f = row + x;
+                    const bool sig = mq_decode(L.d, L.ent, L.mq, L.zc[zc_packed(f, stride)]) != 0;
+                    if (sig) {
+                        data[(size_t)y * w + x] = bit;
+                        dec_sign(L, f);
+                        set_significant_dec(f, stride);
+                    }
+                    *f |= T1Visit;
+                    const uint32_t later = k == 3 ? 0u : (0xFFFFFFFFu << (8 * (k + 1)));
+                    if (sig) {
+                        v = *reinterpret_cast<const uint32_t *>(row + x0);
+                        cand = (v >> 4) & ~v & inrow & later;
+                    } else cand &= later;
                 }
-                *f |= T1Visit;
             }
-        for (int y = 0; y < h; y++)                                   // t1.go:1331-1347
-            for (int x = 0; x < w; x++) {
-                uint8_t *f = flags + (size_t)(y + 1) * stride + T1D_XO + x;
-                const uint32_t fv = *f;
-                if ((fv & T1Sig) == 0 || (fv & T1Visit) != 0) continue;
-                const int ctx = (fv & T1Refine) ? CtxMag2 : ((fv & T1HasNb) ? CtxMag1 : CtxMag0);
-                if (mq_decode(L.d, L.ent, L.mq, ctx)) atomicOr(&data[(size_t)y * w + x], bit);
-                *f = (uint8_t)(fv | T1Refine);
+        }
+        for (int y = 0; y < h; y++) {                                 // t1.go:1331-1347
+            uint8_t *const row = flags + (size_t)(y + 1) * stride + T1D_XO;
+            for (int x0 = 0; x0 < w; x0 += 4) {
+                const uint32_t inrow = x0 + 4 <= w ? 0x01010101u : (0x01010101u >> (8 * (x0 + 4 - w)));
+                const uint32_t v = *reinterpret_cast<const uint32_t *>(row + x0);
+                uint32_t memb = v & ~(v >> 1) & inrow;               // significant and not visited
+                while (memb) {
+                    const int k = (__ffs((int)memb) - 1) >> 3, x = x0 + k;
+                    memb &= memb - 1;
+                    const uint32_t fv = (v >> (8 * k)) & 0xFF;
+                    const int ctx = (fv & T1Refine) ? CtxMag2 : ((fv & T1HasNb) ? CtxMag1 : CtxMag0);
+                    if (mq_decode(L.d, L.ent, L.mq, ctx)) atomicOr(&data[(size_t)y * w + x], bit);
+                    row[x] = (uint8_t)(fv | T1Refine);
+                }
             }
+        }
         for (int y = 0; y < h; y += 4)                                // t1.go:1350-1410
             for (int x = 0; x < w; x++) {
                 bool canRL = (y + 4 <= h);
@@ -987,7 +1010,7 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(const BlockJob *__restric
     int32_t *out = decoded + J.out_off;
 
     build_tables(T, J.band, lane);
-    for (size_t i = lane; i < (size_t)stride * (h + 2); i += 64) flags[i] = 0;
+    for (size_t i = lane; i < (size_t)stride * (h + 2) + 4; i += 64) flags[i] = 0;
     for (size_t i = lane; i < n; i += 64) out[i] = 0;
     __syncthreads();
     init_dec_contexts(T, lane);
@@ -1011,11 +1034,17 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(const BlockJob *__restric
 // (Tried and removed: K blocks per wavefront on K lanes of this same code -- the loops are the same for every block, so
 // lanes stay position-synchronous and share the scans -- K = 2: 62.7 ms, 4: 96.9, 12: 138: two blocks rarely take a
 // decision at the same sample of the same pass, so the decoder's instructions are not shared, only serialised.)
-#define T1D64_FLAGS ((66 * T1D_STRIDE(64) + 15) & ~15)
+// LDS per block decides how many chains are resident: 7005 blocks of a 4K frame need 28 workgroups per CU, i.e. at most
+// 5632 bytes each (LDS is handed out in 512-byte granules) -- hence tables without the encoder's fields.
+#define T1D64_FLAGS ((66 * T1D_STRIDE(64) + 4 + 15) & ~15)
 struct T1Dec64Shared {
-    T1Tables T;
-    alignas(16) uint8_t flags[T1D64_FLAGS];
+    uint32_t mq[94];
+    uint32_t ent[20];
+    uint8_t zc[256];
+    uint8_t sc[256];
+    alignas(16) uint8_t flags[T1D64_FLAGS];      // doubles as the scratch the tables are built in
 };
+static_assert(sizeof(T1Dec64Shared) <= 5632, "t1_decode64_kernel: LDS per block above 11 granules");
 __global__ __launch_bounds__(64) void t1_decode64_kernel(const BlockJob *__restrict__ jobs, int njobs, const uint8_t *__restrict__ stream,
                                                          const uint64_t *__restrict__ offs, const uint32_t *__restrict__ lens,
                                                          const uint8_t *__restrict__ numbps, int32_t *__restrict__ decoded) {
@@ -1034,16 +1063,22 @@ __global__ __launch_bounds__(64) void t1_decode64_kernel(const BlockJob *__restr
     if (w > 64 || h > 64) return;                                    // the general kernel takes these
     const int n = w * h;
     int32_t *out = decoded + J.out_off;
-    build_tables(S.T, J.band, lane);
-    for (int i = lane; i < (stride * (h + 2) + 3) / 4; i += 64) reinterpret_cast<uint32_t *>(S.flags)[i] = 0;
+    {
+        T1Tables &T = *reinterpret_cast<T1Tables *>(S.flags);
+        build_tables(T, J.band, lane);
+        __syncthreads();
+        for (int p = lane; p < 256; p += 64) { S.zc[p] = T.zc[p]; S.sc[p] = T.sc[p]; }
+        for (int p = lane; p < 94; p += 64) S.mq[p] = T.mq[p];
+        if (lane < 20) S.ent[lane] = lane < NumContexts ? T.mq[lane == CtxUni ? 92 : 0] : 0u;
+        __syncthreads();
+    }
+    for (int i = lane; i < (stride * (h + 2) + 4 + 3) / 4; i += 64) reinterpret_cast<uint32_t *>(S.flags)[i] = 0;
     for (int i = lane; i < n; i += 64) out[i] = 0;
-    __syncthreads();
-    init_dec_contexts(S.T, lane);
     __syncthreads();
     if (lane == 0) {
         T1DecLane L;
         mq_dec_init(L.d, stream + offs[jid], (long)lens[jid]);
-        L.ent = S.T.ent; L.mq = S.T.mq; L.zc = S.T.zc; L.sc = S.T.sc; L.flags = S.flags; L.data = out; L.w = w; L.h = h; L.stride = stride;
+        L.ent = S.ent; L.mq = S.mq; L.zc = S.zc; L.sc = S.sc; L.flags = S.flags; L.data = out; L.w = w; L.h = h; L.stride = stride;
         t1_decode_passes(L, numbps[jid]);
     }
     __syncthreads();                                                      // includes the wait for lane 0's stores and atomics
