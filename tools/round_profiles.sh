@@ -10,3 +10,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --inflight 1 > $O/pmc_$c.log 2>&1
 done
 tail -1 $O/stats_default.log; tail -1 $O/stats_inflight1.log
+# C3-like frame (9-7, 12 bit, MQ coder): per-stage kernel stats of tools/bench_c3.py (T1 encoder / decoder kernels)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c3 -- python $R/tools/bench_c3.py 0 0 > $O/stats_c3.log 2>&1
+tail -7 $O/stats_c3.log
