@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void pack_payload_kernel(const BlockJob *__res
     const uint64_t *toffs = reinterpret_cast<const uint64_t *>(pack + L.toffs);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         uint64_t *h = reinterpret_cast<uint64_t *>(pack);
-        h[0] = (uint64_t)L.payload + toffs[n];
+        h[0] = ((uint64_t)L.payload + toffs[n] + 15) & ~uint64_t(15);     // packs laid end to end stay 16-byte aligned
         h[1] = toffs[n];
         reinterpret_cast<uint32_t *>(pack)[4] = (uint32_t)n;
         reinterpret_cast<uint32_t *>(pack)[5] = (uint32_t)has_mel;
