@@ -199,8 +199,7 @@ def main():
         for e in exts:                                  # the library streams wait for the transfers (and any staging copy)
             e.wait_stream(cur)
         for ln, pks in zip(lanes, staged):              # rank 0: rebuild every peer's dense stream (+ offsets, lengths, bit planes)
-            for r, pk in enumerate(pks):
-                ln.plan.unpack_stream(pk, *ln.assembled[r])
+            ln.plan.unpack_streams(pks, ln.assembled)   # one launch for the N - 1 packs of this frame slot
         keep[b] = staged                                # alive until this set's next turn
         if rank == 0:                                   # the next gather into this receive buffer waits for these unpacks
             for ev, e in zip(unpacked[b], exts):

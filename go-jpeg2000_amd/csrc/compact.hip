@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void gather_kernel(const BlockJob *__restrict_
 //   [total bytes u64 | payload bytes u64 | n u32 | mel flag u32 | pad to 64] lens u32[n] | maglens u32[n] | numbps u8[n] |
 //   offs u64[n+1] | toffs u64[n+1] | payload      (every section 16-byte aligned)
 // and j2k_plan_unpack_stream at the root rebuilds the dense stream, byte for byte.
+#define UNPACK_BATCH 16
 __host__ __device__ inline size_t pack_a16(size_t x) { return (x + 15) & ~size_t(15); }
 struct PackLayout { size_t lens, mag, nb, offs, toffs, payload; };
 __host__ __device__ inline PackLayout pack_layout(size_t n) {
@@ -164,10 +165,23 @@ __global__ __launch_bounds__(256) void pack_payload_kernel(const BlockJob *__res
     copy_bytes(dst, src, mag, lane);
     copy_bytes(dst + mag, src + mag + mel, len - mag - mel, lane);
 }
-// root side: pack -> dense stream + offs / lens / numbps.  fault: 4 = the pack does not belong to this plan
-__global__ __launch_bounds__(256) void unpack_kernel(const BlockJob *__restrict__ jobs, int n, const uint8_t *__restrict__ pack,
-                                                     uint8_t *__restrict__ stream, uint64_t stream_cap, uint64_t *__restrict__ offs,
-                                                     uint32_t *__restrict__ lens, uint8_t *__restrict__ numbps, int *__restrict__ fault) {
+// root side: pack -> dense stream + offs / lens / numbps, up to UNPACK_BATCH packs of the same geometry per launch
+// (blockIdx.y = which pack: at N = 8 the root rebuilds 7 peers' streams per frame slot, and one launch keeps far more
+// copies in flight than seven).  fault: 4 = a pack does not belong to this plan / its pieces do not fit
+struct UnpackBatch {
+    const uint8_t *pack[UNPACK_BATCH];
+    uint8_t *stream[UNPACK_BATCH];
+    uint64_t *offs[UNPACK_BATCH];
+    uint32_t *lens[UNPACK_BATCH];
+    uint8_t *numbps[UNPACK_BATCH];
+};
+__global__ __launch_bounds__(256) void unpack_kernel(const BlockJob *__restrict__ jobs, int n, UnpackBatch B, uint64_t stream_cap,
+                                                     int *__restrict__ fault) {
+    const uint8_t *__restrict__ pack = B.pack[blockIdx.y];
+    uint8_t *__restrict__ stream = B.stream[blockIdx.y];
+    uint64_t *__restrict__ offs = B.offs[blockIdx.y];
+    uint32_t *__restrict__ lens = B.lens[blockIdx.y];
+    uint8_t *__restrict__ numbps = B.numbps[blockIdx.y];
     const PackLayout L = pack_layout((size_t)n);
     if (reinterpret_cast<const uint32_t *>(pack)[4] != (uint32_t)n) {
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(fault, 4);
@@ -207,10 +221,17 @@ hipError_t launch_pack(hipStream_t s, const BlockJob *jobs, int njobs, const uin
     hipLaunchKernelGGL(pack_payload_kernel, dim3((njobs + 3) / 4), dim3(256), 0, s, jobs, njobs, stream, maglens ? 1 : 0, pack);
     return hipGetLastError();
 }
-hipError_t launch_unpack(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *pack, uint8_t *stream, size_t stream_cap,
-                         uint64_t *offs, uint32_t *lens, uint8_t *numbps, int *fault) {
-    hipLaunchKernelGGL(unpack_kernel, dim3((njobs + 1 + 3) / 4), dim3(256), 0, s, jobs, njobs, pack, stream, (uint64_t)stream_cap, offs, lens,
-                       numbps, fault);
+hipError_t launch_unpack(hipStream_t s, const BlockJob *jobs, int njobs, int count, const uint8_t *const *packs, uint8_t *const *streams,
+                         size_t stream_cap, uint64_t *const *offs, uint32_t *const *lens, uint8_t *const *numbps, int *fault) {
+    for (int c0 = 0; c0 < count; c0 += UNPACK_BATCH) {
+        UnpackBatch B{};
+        const int m = count - c0 < UNPACK_BATCH ? count - c0 : UNPACK_BATCH;
+        for (int i = 0; i < m; i++) {
+            B.pack[i] = packs[c0 + i]; B.stream[i] = streams[c0 + i]; B.offs[i] = offs[c0 + i]; B.lens[i] = lens[c0 + i];
+            B.numbps[i] = numbps[c0 + i];
+        }
+        hipLaunchKernelGGL(unpack_kernel, dim3((njobs + 1 + 3) / 4, m), dim3(256), 0, s, jobs, njobs, B, (uint64_t)stream_cap, fault);
+    }
     return hipGetLastError();
 }
 

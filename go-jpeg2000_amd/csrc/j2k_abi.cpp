@@ -45,8 +45,8 @@ hipError_t launch_compact(hipStream_t s, const BlockJob *jobs, int njobs, const 
 size_t pack_header_bytes(size_t n);
 hipError_t launch_pack(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs, const uint32_t *lens,
                        const uint8_t *numbps, const uint32_t *maglens, uint8_t *pack, uint32_t *tl_scratch);
-hipError_t launch_unpack(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *pack, uint8_t *stream, size_t stream_cap,
-                         uint64_t *offs, uint32_t *lens, uint8_t *numbps, int *fault);
+hipError_t launch_unpack(hipStream_t s, const BlockJob *jobs, int njobs, int count, const uint8_t *const *packs, uint8_t *const *streams,
+                         size_t stream_cap, uint64_t *const *offs, uint32_t *const *lens, uint8_t *const *numbps, int *fault);
 }  // namespace j2k
 
 // ------------------------------------------------------------------------------
@@ -1017,17 +1017,26 @@ extern "C" int j2k_plan_pack_stream(j2k_plan *P, const uint8_t *d_stream, const 
     return J2K_OK;
 }
 
-extern "C" int j2k_plan_unpack_stream(j2k_plan *P, const uint8_t *d_pack, uint8_t *d_stream, uint64_t *d_offs, uint32_t *d_lens,
-                                      uint8_t *d_numbps) {
-    if (!P || !d_pack || !d_stream || !d_offs || !d_lens || !d_numbps) return J2K_ERR_INVALID_ARG;
+extern "C" int j2k_plan_unpack_streams(j2k_plan *P, int count, const uint8_t *const *d_packs, uint8_t *const *d_streams,
+                                       uint64_t *const *d_offs, uint32_t *const *d_lens, uint8_t *const *d_numbps) {
+    if (!P || count < 0 || (count && (!d_packs || !d_streams || !d_offs || !d_lens || !d_numbps))) return J2K_ERR_INVALID_ARG;
+    for (int i = 0; i < count; i++)
+        if (!d_packs[i] || !d_streams[i] || !d_offs[i] || !d_lens[i] || !d_numbps[i]) return J2K_ERR_INVALID_ARG;
     j2k_ctx *ctx = P->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!count) return J2K_OK;
     const int n = (int)P->blocks.size();
     int r = stage_reserve(ctx, 3, 256);
     if (r != J2K_OK) return r;
     ctx->fault_armed = true;
-    HIPCHK(ctx, launch_unpack(ctx->stream, P->d_bjobs, n, d_pack, d_stream, (size_t)P->bytes_cap, d_offs, d_lens, d_numbps, (int *)ctx->stage[3]));
+    HIPCHK(ctx, launch_unpack(ctx->stream, P->d_bjobs, n, count, d_packs, d_streams, (size_t)P->bytes_cap, d_offs, d_lens, d_numbps,
+                              (int *)ctx->stage[3]));
     return J2K_OK;
+}
+
+extern "C" int j2k_plan_unpack_stream(j2k_plan *P, const uint8_t *d_pack, uint8_t *d_stream, uint64_t *d_offs, uint32_t *d_lens,
+                                      uint8_t *d_numbps) {
+    return j2k_plan_unpack_streams(P, 1, &d_pack, &d_stream, &d_offs, &d_lens, &d_numbps);
 }
 
 extern "C" int j2k_plan_compact(j2k_plan *P, const uint8_t *d_slots, const uint32_t *d_lens, uint64_t *d_offs, uint8_t *d_stream) {

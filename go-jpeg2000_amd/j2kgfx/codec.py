@@ -178,6 +178,17 @@ class FramePlan:
                                                          self._p(numbps)))
         return stream, offs, lens, numbps
 
+    def unpack_streams(self, packs, outs):
+        """unpack_stream for several packs of this geometry in ONE launch: packs = list of uint8 tensors, outs = list of
+        (stream, offs, lens, numbps) tuples to fill."""
+        k = len(packs)
+        assert k == len(outs)
+        VP = C.c_void_p * k
+        cols = list(zip(*outs)) if k else [(), (), (), ()]
+        arrs = [VP(*[int(t_.data_ptr()) for t_ in col]) for col in ([*packs],) + tuple(cols)]
+        self.ctx.check(self.ctx.L.j2k_plan_unpack_streams(self.h, C.c_int(k), *arrs))
+        return outs
+
     def compact(self, slots, lens, offs=None, stream=None):
         t = _torch()
         n = int(self.info.blocks)

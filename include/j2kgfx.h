@@ -204,6 +204,10 @@ int j2k_plan_pack_stream(j2k_plan *plan, const uint8_t *d_stream, const uint64_t
                          const uint8_t *d_numbps, uint8_t *d_pack);
 int j2k_plan_unpack_stream(j2k_plan *plan, const uint8_t *d_pack, uint8_t *d_stream, uint64_t *d_offs,
                            uint32_t *d_lens, uint8_t *d_numbps);
+/* the same for `count` packs of this geometry in one launch (host arrays of device pointers): the root of an N-GPU
+ * gather rebuilds the N-1 peers' streams of a frame slot at once */
+int j2k_plan_unpack_streams(j2k_plan *plan, int count, const uint8_t *const *d_packs, uint8_t *const *d_streams,
+                            uint64_t *const *d_offs, uint32_t *const *d_lens, uint8_t *const *d_numbps);
 /* tcd.TileDecoder.DecodeCodeBlock (tcd.go:393-413) for every job: dense stream + offsets
  * + lens + numbps -> d_decoded (decoded_elems int32, block j dense at its job offset). */
 int j2k_plan_decode_blocks(j2k_plan *plan, const uint8_t *d_stream, const uint64_t *d_offs,

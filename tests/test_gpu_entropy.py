@@ -370,6 +370,14 @@ def test_pack_unpack_stream_round_trip(W, H, tile, cb, coder):
         mel = sum(max(64, 2 * int(b["w"]) * int(b["h"])) // 4 for b, ln in zip(blocks, lens.cpu().numpy()[:n]) if ln)
         payload = int(pack[8:16].view(torch.int64)[0].item())
         assert payload == tot - mel
+    # several packs in one launch (what the root of an N-GPU gather does per frame slot)
+    outs = [(root.empty(root.info.bytes_cap, torch.uint8), root.empty(n + 1, torch.int64), root.empty(n, torch.int32),
+             root.empty(n, torch.uint8)) for _ in range(3)]
+    root.unpack_streams([sent, sent.clone(), sent], outs)
+    root.ctx.sync()
+    for s3, o3, l3, n3 in outs:
+        assert torch.equal(o3[:n + 1], offs[:n + 1]) and torch.equal(l3[:n], lens[:n]) and torch.equal(n3[:n], nb[:n])
+        assert torch.equal(s3[:tot], stream[:tot])
     other = FramePlan(W + 64, H, 3, ctx=Context(0), **kw)
     other.unpack_stream(sent)
     with pytest.raises(J2KError):

@@ -13,9 +13,14 @@ out = p.unpack_stream(pk)
 p.ctx.sync()
 n = int(p.info.blocks)
 print("stream %d bytes, pack %d bytes" % (int(o[n].item()), int(pk[:8].view(torch.int64)[0].item())))
-for name, f in (("pack", lambda: p.pack_stream(s, o, l, nb, pk)), ("unpack", lambda: p.unpack_stream(pk, *out))):
+outs7 = [tuple(t.clone() for t in out) for _ in range(7)]
+pk7 = [pk.clone() for _ in range(7)]
+def seven_launches():
+    for a, b in zip(pk7, outs7): p.unpack_stream(a, *b)
+for name, f in (("pack", lambda: p.pack_stream(s, o, l, nb, pk)), ("unpack", lambda: p.unpack_stream(pk, *out)),
+                ("7 unpacks, 7 launches", seven_launches), ("7 unpacks, 1 launch", lambda: p.unpack_streams(pk7, outs7))):
     f(); p.ctx.sync()
     t0 = time.perf_counter()
     for _ in range(50): f()
     p.ctx.sync()
-    print("%-7s %7.1f us" % (name, (time.perf_counter() - t0) / 50 * 1e6))
+    print("%-22s %7.1f us" % (name, (time.perf_counter() - t0) / 50 * 1e6))
