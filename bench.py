@@ -76,8 +76,8 @@ def cpu_baseline(np, frame, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--io", choices=["planes", "rgba8"], default=os.environ.get("J2K_BENCH_IO", "rgba8"),
                     help="frame format at the boundary: packed 8-bit RGBA pixels (image.RGBA.Pix) read / written directly by "
