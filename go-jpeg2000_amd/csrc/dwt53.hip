@@ -209,6 +209,22 @@ __device__ __forceinline__ void fwd_issue_row(const int32_t *__restrict__ src, c
             return;
         }
     }
+    if constexpr (PIX && NC == 1 && CPL == 8 && VEC) {
+        {
+            // packed Gray16 source (image.Gray16.Pix: two bytes per pixel, high byte first; encoder.go:94-105 fused):
+            // eight pixels = one 16-byte load instead of two
+            const int cc = (c < P.w) ? c : 0;
+            const uint16_t *p = reinterpret_cast<const uint16_t *>(src) + pix_row0 + (int64_t)r * pix_stride + cc;
+            const int4 a = ld4(reinterpret_cast<const int32_t *>(p), false);
+            const uint32_t dw[4] = {(uint32_t)a.x, (uint32_t)a.y, (uint32_t)a.z, (uint32_t)a.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {     // bytes b0 b1 b2 b3 -> pixels (b0 << 8 | b1), (b2 << 8 | b3)
+                R.x[0][2 * i] = (int)(((dw[i] & 0xFF) << 8) | ((dw[i] >> 8) & 0xFF));
+                R.x[0][2 * i + 1] = (int)(((dw[i] >> 8) & 0xFF00) | (dw[i] >> 24));
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int k = 0; k < NC; k++) {
         const int32_t *p = src + P.src_off[k] + (int64_t)r * P.src_stride;
@@ -635,6 +651,24 @@ __device__ __forceinline__ void inv_finish_row(int32_t *__restrict__ dst, const 
             return;
         }
     }
+    if constexpr (PIX && NC == 1 && CPL == 8 && VEC) {
+        {
+            // DCLevelShiftInverse + decoder.createImage for one component at 16 bit (decoder.go:434-451): clamp to
+            // 0..65535, then the reference's rescale v * 65535 / 65535 in int32 -- which WRAPS for v >= 32769 -- and
+            // uint16() of that; high byte first, eight pixels = one 16-byte store instead of two
+            uint32_t dw[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int a0 = min(max(wadd(x[0][2 * i], dc_shift), 0), 65535), b0 = min(max(wadd(x[0][2 * i + 1], dc_shift), 0), 65535);
+                const uint32_t a = (uint32_t)((int)((uint32_t)a0 * 65535u) / 65535) & 0xFFFFu;
+                const uint32_t b = (uint32_t)((int)((uint32_t)b0 * 65535u) / 65535) & 0xFFFFu;
+                dw[i] = (a >> 8) | ((a & 0xFF) << 8) | ((b >> 8) << 16) | ((b & 0xFF) << 24);
+            }
+            uint16_t *p = reinterpret_cast<uint16_t *>(dst) + pix0 + (int64_t)ro * pix_stride + c;
+            *reinterpret_cast<uint4 *>(p) = make_uint4(dw[0], dw[1], dw[2], dw[3]);
+            return;
+        }
+    }
     const int stride = final_level ? P.out_stride : P.w;
 #pragma unroll
     for (int k = 0; k < NC; k++) {
@@ -982,8 +1016,8 @@ hipError_t launch_dwt53_tail_inv(hipStream_t s, const TailPlane *planes, int npl
 template <int CPL, int NC, bool VEC>
 static hipError_t fwd_go(hipStream_t s, const LevelLaunch &L, const int32_t *src, int32_t *out, int32_t *nxt, int dc) {
     const int blocks = (L.njobs + 3) / 4;
-    if constexpr (CPL == 8 && NC == 3 && VEC) {
-        if (L.pix_stride > 0) {   // packed RGBA8 frame: its own instantiation, so the planar kernel is untouched
+    if constexpr (CPL == 8 && (NC == 3 || NC == 1) && VEC) {
+        if (L.pix_stride > 0) {   // packed RGBA8 / Gray16 frame: its own instantiation, so the planar kernel is untouched
             if (L.pf) hipExtLaunchKernelGGL((dwt53_fwd_kernel<CPL, NC, VEC, true, true>), dim3(blocks), dim3(256), 0, s, L.ev_start, L.ev_stop, 0,
                                             L.jobs, L.njobs, L.planes, src, out, nxt, dc, L.pix_stride);
             else hipExtLaunchKernelGGL((dwt53_fwd_kernel<CPL, NC, VEC, false, true>), dim3(blocks), dim3(256), 0, s, L.ev_start, L.ev_stop, 0,
@@ -1001,7 +1035,7 @@ static hipError_t fwd_go(hipStream_t s, const LevelLaunch &L, const int32_t *src
 template <int CPL, int NC, bool VEC>
 static hipError_t inv_go(hipStream_t s, const LevelLaunch &L, const int32_t *coef, const int32_t *prev, int32_t *dst, int dc, int fin) {
     const int blocks = (L.njobs + 3) / 4;
-    if constexpr (CPL == 8 && NC == 3 && VEC) {
+    if constexpr (CPL == 8 && (NC == 3 || NC == 1) && VEC) {
         if (L.pix_stride > 0) {
             hipLaunchKernelGGL((dwt53_inv_kernel<CPL, NC, VEC, true>), dim3(blocks), dim3(256), 0, s, L.jobs, L.njobs, L.planes, coef, prev, dst, dc, fin, L.pix_stride);
             return hipGetLastError();

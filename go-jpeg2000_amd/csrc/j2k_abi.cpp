@@ -584,7 +584,8 @@ extern "C" int j2k_plan_get_decoded_offsets(const j2k_plan *P, uint64_t *offs, s
 // ------------------------------------------------------------------------------
 static LevelLaunch mk(const LevelTab &T, int pf = 0) { return LevelLaunch{T.d_jobs, T.njobs, T.d_planes, T.cpl, T.vec, T.ncomp, pf}; }
 
-static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff, int pix_stride = 0) {
+// pix_stride > 0: d_frame is a packed-pixel frame read by the level-0 kernels of class pix_cls (1: RGBA8 triples, 0: Gray16 planes)
+static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff, int pix_stride = 0, int pix_cls = 1) {
     j2k_ctx *ctx = P->ctx;
     const PlanSpec &S = P->spec;
     if (((uintptr_t)d_frame & 15) || ((uintptr_t)d_coeff & 15)) return fail(ctx, J2K_ERR_INVALID_ARG, "device pointers must be 16-byte aligned");
@@ -602,9 +603,9 @@ static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff, in
             if (!T.njobs) continue;
             if (S.wavelet == W53) {
                 LevelLaunch L = mk(T, ctx->fwd_pf);
-                if (l == 0 && cls == 1 && pix_stride > 0) {               // packed RGBA8 frame (j2k_plan_forward_rgba8)
+                if (l == 0 && cls == pix_cls && pix_stride > 0) {         // packed frame (j2k_plan_forward_rgba8 / _pixels)
                     L.pix_stride = pix_stride;
-                    if (P->d_fwd_pix_jobs) { L.jobs = P->d_fwd_pix_jobs; L.njobs = P->fwd_pix_njobs; }
+                    if (cls == 1 && P->d_fwd_pix_jobs) { L.jobs = P->d_fwd_pix_jobs; L.njobs = P->fwd_pix_njobs; }
                 }
                 if (l == 0 && cls == 1 && ev1) { L.ev_start = ev0; L.ev_stop = ev1; }
                 HIPCHK(ctx, launch_dwt53_fwd(ctx->stream, L, (const int32_t *)in, (int32_t *)d_coeff, (int32_t *)nx, l == 0 ? S.dc_shift : 0));
@@ -621,7 +622,7 @@ static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff, in
     return J2K_OK;
 }
 
-static int plan_inverse_impl(j2k_plan *P, const void *d_coeff, void *d_frame, int pix_stride = 0) {
+static int plan_inverse_impl(j2k_plan *P, const void *d_coeff, void *d_frame, int pix_stride = 0, int pix_cls = 1) {
     j2k_ctx *ctx = P->ctx;
     const PlanSpec &S = P->spec;
     if (((uintptr_t)d_frame & 15) || ((uintptr_t)d_coeff & 15)) return fail(ctx, J2K_ERR_INVALID_ARG, "device pointers must be 16-byte aligned");
@@ -637,7 +638,7 @@ static int plan_inverse_impl(j2k_plan *P, const void *d_coeff, void *d_frame, in
             if (!T.njobs) continue;
             if (S.wavelet == W53) {
                 LevelLaunch L = mk(T);
-                if (l == 0 && cls == 1) L.pix_stride = pix_stride;        // packed RGBA8 frame (j2k_plan_inverse_rgba8)
+                if (l == 0 && cls == pix_cls) L.pix_stride = pix_stride;  // packed frame (j2k_plan_inverse_rgba8 / _pixels)
                 HIPCHK(ctx, launch_dwt53_inv(ctx->stream, L, (const int32_t *)d_coeff, (const int32_t *)prev, (int32_t *)dst,
                                              l == 0 ? S.dc_shift : 0, l == 0));
             } else {
@@ -841,6 +842,16 @@ static bool rgba8_fusable(const j2k_plan *P, const void *d_pix, size_t stride, b
     return !(((uintptr_t)d_pix | stride) & 15);
 }
 
+// can the level-0 5-3 kernels of a one-component 16-bit plan read / write packed Gray16 (big-endian) directly?
+static bool gray16_fusable(const j2k_plan *P, const void *d_pix, size_t stride, bool inverse) {
+    const PlanSpec &S = P->spec;
+    if (S.wavelet != W53 || S.C != 1 || S.levels < 1 || S.precision != 16 || S.dc_shift != 32768) return false;
+    const LevelTab &T = (inverse ? P->inv : P->fwd)[0][0];
+    if (!T.njobs || !T.vec || T.cpl != 8 || (inverse ? P->inv : P->fwd)[1][0].njobs) return false;
+    if (P->tail_l0 == 0) return false;
+    return !(((uintptr_t)d_pix | stride) & 15);
+}
+
 extern "C" int j2k_plan_forward_rgba8(j2k_plan *P, const void *d_pix, size_t stride, int32_t *d_coeff) {
     if (!P || !d_pix || !d_coeff) return J2K_ERR_INVALID_ARG;
     j2k_ctx *ctx = P->ctx;
@@ -877,6 +888,8 @@ extern "C" int j2k_plan_forward_pixels(j2k_plan *P, int format, const void *d_pi
     if (format < 0 || format >= 6) return fail(ctx, J2K_ERR_INVALID_ARG, "unknown pixel format");
     if (kPixComp[format] != S.C) return fail(ctx, J2K_ERR_INVALID_ARG, "pixel format and plan disagree on the component count");
     if (format == J2K_PIX_RGBA8 && S.precision == 8) return j2k_plan_forward_rgba8(P, d_pix, stride, d_coeff);
+    if (format == J2K_PIX_GRAY16 && stride >= (size_t)S.W * 2 && gray16_fusable(P, d_pix, stride, false))
+        return plan_forward_impl(P, d_pix, d_coeff, (int)(stride / 2), 0);
     int r = stage_reserve(ctx, 0, (size_t)S.W * S.H * S.C * 4 + 64);       // int32 staging frame
     if (r != J2K_OK) return r;
     r = j2k_unpack_pixels(ctx, format, d_pix, stride, S.W, S.H, S.precision, (int32_t *)ctx->stage[0]);
@@ -889,6 +902,7 @@ extern "C" int j2k_plan_inverse_pixels(j2k_plan *P, const int32_t *d_coeff, void
     j2k_ctx *ctx = P->ctx;
     const PlanSpec &S = P->spec;
     if (S.C == 3 && S.precision == 8 && S.dc_shift == 128) return j2k_plan_inverse_rgba8(P, d_coeff, d_pix, stride);
+    if (stride >= (size_t)S.W * 2 && gray16_fusable(P, d_pix, stride, true)) return plan_inverse_impl(P, d_coeff, d_pix, (int)(stride / 2), 0);
     int r = stage_reserve(ctx, 0, (size_t)S.W * S.H * S.C * 4 + 64);
     if (r != J2K_OK) return r;
     r = plan_inverse_impl(P, d_coeff, ctx->stage[0]);

@@ -82,6 +82,35 @@ def test_plan_forward_inverse_rgba8(oracle, W, H, tile, pad):
     assert np.array_equal(bpix.cpu().numpy().reshape(H, W, 4)[..., :3], pix[:, :W * 4].reshape(H, W, 4)[..., :3])   # lossless
 
 
+@pytest.mark.parametrize("W,H,tile,pad", [(2048, 2048, 0, 0), (1024, 256, 512, 32), (512, 64, 0, 16), (200, 96, 0, 0), (100, 75, 64, 6)])
+def test_plan_forward_inverse_gray16(oracle, W, H, tile, pad):
+    """BASELINE C5's input format: image.Gray16 at 16 bit.  The level-0 kernels read / write the big-endian pixels
+    themselves where the geometry allows (the 2048^2 frame, 512^2 tiles) and the staging path takes the rest:
+    coefficients identical to extractImageData + preprocess, pixels identical to the inverse path + createImage --
+    including the reference's int32 wrap in v * 65535 / 65535 for v >= 32769 (decoder.go:434-451)."""
+    import torch
+    from j2kgfx.codec import FramePlan
+    rng = np.random.default_rng(W + pad)
+    stride = W * 2 + pad
+    pix = rng.integers(0, 256, (H, stride)).astype(np.uint8)
+    plan = FramePlan(W, H, 1, precision=16, lossless=True, num_resolutions=6, cb=(64, 64), tile=(tile, tile), coder=1)
+    dpix = torch.from_numpy(pix).to(plan.device)
+    planes = oracle.extract_image_data(pix, 1, W, H, 16)
+    frame = torch.from_numpy(np.stack(planes)).to(plan.device)
+    torch.cuda.synchronize()
+    want = plan.forward(frame)
+    got = plan.forward_pixels(1, dpix)
+    plan.ctx.sync()
+    assert torch.equal(got, want)
+    back = plan.inverse(got)
+    out = torch.zeros((H, stride), dtype=torch.uint8, device=plan.device)
+    plan.inverse_pixels(got, out)
+    plan.ctx.sync()
+    want_pix = oracle.create_image([p for p in back.cpu().numpy()], 16)
+    assert np.array_equal(out.cpu().numpy()[:, :W * 2], want_pix)
+    assert np.array_equal(back.cpu().numpy().reshape(H, W), planes[0])      # the transform itself is lossless
+
+
 @pytest.mark.parametrize("fmt,prec", [(0, 8), (1, 16), (1, 12), (2, 8), (3, 16), (3, 12), (4, 8), (5, 16)])
 def test_plan_forward_inverse_pixels_all_formats(oracle, fmt, prec):
     """j2k_plan_forward_pixels / j2k_plan_inverse_pixels for every pixel format (and the Options.Precision rescale
