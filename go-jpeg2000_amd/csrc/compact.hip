@@ -218,7 +218,7 @@ hipError_t launch_pack(hipStream_t s, const BlockJob *jobs, int njobs, const uin
     const PackLayout L = pack_layout((size_t)njobs);
     hipLaunchKernelGGL(pack_meta_kernel, dim3((njobs + 1 + 255) / 256), dim3(256), 0, s, jobs, njobs, lens, maglens, numbps, offs, pack, tl_scratch);
     hipLaunchKernelGGL(scan_lens_kernel, dim3(1), dim3(1024), 0, s, tl_scratch, njobs, reinterpret_cast<uint64_t *>(pack + L.toffs));
-    hipLaunchKernelGGL(pack_payload_kernel, dim3((njobs + 3) / 4), dim3(256), 0, s, jobs, njobs, stream, maglens ? 1 : 0, pack);
+    hipLaunchKernelGGL(pack_payload_kernel, dim3(njobs > 0 ? (njobs + 3) / 4 : 1), dim3(256), 0, s, jobs, njobs, stream, maglens ? 1 : 0, pack);   // (block 0 writes the header even for an empty plan)
     return hipGetLastError();
 }
 hipError_t launch_unpack(hipStream_t s, const BlockJob *jobs, int njobs, int count, const uint8_t *const *packs, uint8_t *const *streams,
