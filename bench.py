@@ -226,7 +226,11 @@ def main():
         for ev in enc_done:
             ev.synchronize()                            # the bytes are complete before RCCL reads them
         # rank 0's own frames stay where they are (it sends nothing); a peer sends the pack, whose first word is its length
-        items = [(ln.packs[b], 0 if rank == 0 else int(ln.packs[b][:8].view(torch.int64)[0].item())) for ln in lanes]
+        if rank == 0:
+            sizes = [0] * len(lanes)
+        else:                                           # one device-to-host copy for all frames' pack lengths
+            sizes = torch.stack([ln.packs[b][:8].view(torch.int64)[0] for ln in lanes]).cpu().tolist()
+        items = [(ln.packs[b], int(sz)) for ln, sz in zip(lanes, sizes)]
         if os.environ.get("J2K_BENCH_BACKEND", "nccl") != "nccl":
             items = [(t[:n_].cpu(), n_) for t, n_ in items]
         if rank == 0 and stepno[0] > 2:
