@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("J2K_BENCH_INFLIGHT", "3")),
                     help="independent frames coded concurrently per step, each on its own context/stream")
     args = ap.parse_args()
+    import faulthandler
+    faulthandler.enable()           # a native crash in a rank prints its Python stack
 
     import numpy as np
     import torch
@@ -102,18 +104,29 @@ def main():
     if os.environ.get("J2K_BENCH_BACKEND", "nccl") != "nccl":
         local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
-    if world > 1:
+    # J2K_BENCH_PEER_REHEARSAL=1 (dev, one GPU): run the N > 1 step as a PEER would -- pack, wait for the encodes only,
+    # size exchange -- with a one-rank group and nothing to transfer, to see what the host side of that step costs
+    pr_mode = os.environ.get("J2K_BENCH_PEER_REHEARSAL", "0") if world == 1 else "0"   # 1: all of it; 2: no pack; 3: no exchange
+    peer_rehearsal = pr_mode in ("1", "2", "3", "4")   # 4: pack, but the sizes are not read back (dev)
+    multi = world > 1 or peer_rehearsal
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         # J2K_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks (ranks share
         # devices; the streams are staged through host memory for the gather) -- not a measurement mode
         backend = os.environ.get("J2K_BENCH_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            # the per-step size exchange goes through a gloo group: host integers, no GPU kernel in the host's way
+            size_group = dist.new_group(backend="gloo") if os.environ.get("J2K_BENCH_SIZE_GROUP", "gloo") == "gloo" else None
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+            size_group = None
 
     F = max(1, args.inflight)
     frame_h = synth_frame(np, rank)
+
+    NSETS = 3     # N > 1: stream / pack buffer sets in rotation (see step())
 
     class Lane:   # one frame in flight: its own context (= HIP stream), plan and buffers
         def __init__(self):
@@ -129,7 +142,7 @@ def main():
                 self.back_pix = torch.empty_like(self.pix)
             self.coeff = p.alloc_coeff()
             # two sets of stream buffers at N > 1: step k + 1 encodes into one set while RCCL still reads step k's
-            nb = 2 if world > 1 else 1
+            nb = NSETS if multi else 1
             self.streams = [p.empty(i.bytes_cap, torch.uint8) for _ in range(nb)]
             self.lenss = [p.empty(self.n, torch.int32) for _ in range(nb)]
             self.numbpss = [p.empty(self.n, torch.uint8) for _ in range(nb)]
@@ -140,7 +153,7 @@ def main():
             self.gather_bufs = [None] * nb
             # N > 1: what travels is the transport form of the stream (j2k_plan_pack_stream: the blocks without the
             # reference's MEL zero runs, a third of the bytes); rank 0 rebuilds every peer's dense stream from it
-            self.packs = [p.empty(p.pack_bound(), torch.uint8) for _ in range(nb)] if world > 1 else []
+            self.packs = [p.empty(p.pack_bound(), torch.uint8) for _ in range(nb)] if multi else []
             self.assembled = None
             if world > 1 and rank == 0:
                 self.assembled = [(p.empty(i.bytes_cap, torch.uint8), p.empty(self.n + 1, torch.int64), p.empty(self.n, torch.int32),
@@ -153,7 +166,7 @@ def main():
             else:
                 p.forward(self.frame, self.coeff)
             p.encode_stream(self.coeff, self.streams[b], self.offss[b], self.lenss[b], self.numbpss[b])   # block coding + compaction
-            if world > 1 and rank != 0:
+            if multi and (rank != 0 or pr_mode in ("1", "3", "4")):
                 p.pack_stream(self.streams[b], self.offss[b], self.lenss[b], self.numbpss[b], self.packs[b])
 
         def decode_side(self, b=0):
@@ -175,14 +188,21 @@ def main():
 
     exts = [torch.cuda.ExternalStream(ln.ctx.stream) for ln in lanes]
 
-    enc_done = [torch.cuda.Event() for _ in lanes]
-    unpacked = [[torch.cuda.Event() for _ in lanes] for _ in range(2)]
-    keep = [None, None]
-    pending = [None, None]          # the gather that still reads buffer set b
+    enc_done = [[torch.cuda.Event() for _ in lanes] for _ in range(NSETS)]
+    size_pin = [torch.zeros(len(lanes), dtype=torch.int64).pin_memory() for _ in range(NSETS)]
+    size_done = [torch.cuda.Event() for _ in range(NSETS)]
+    copy_stream = torch.cuda.Stream()                   # torch-owned: pinned memory stays away from the library's streams
+    unpacked = [[torch.cuda.Event() for _ in lanes] for _ in range(NSETS)]
+    keep = [None] * NSETS
+    pending = [None] * NSETS        # the gather that still reads buffer set b
+    coded = [False] * NSETS         # set b holds a step's streams whose exchange has not been started yet
     stepno = [0]
 
     def finish_gather(b):
         """The transfers that read buffer set b are complete (and the library streams know it)."""
+        xdone[b].wait()                                 # the helper has started (or never had) this set's exchange
+        if xerr:
+            raise xerr[0]
         g = pending[b]
         if g is None:
             return
@@ -199,49 +219,105 @@ def main():
         for e in exts:                                  # the library streams wait for the transfers (and any staging copy)
             e.wait_stream(cur)
         for ln, pks in zip(lanes, staged):              # rank 0: rebuild every peer's dense stream (+ offsets, lengths, bit planes)
-            ln.plan.unpack_streams(pks, ln.assembled)   # one launch for the N - 1 packs of this frame slot
+            if pks:
+                ln.plan.unpack_streams(pks, ln.assembled)   # one launch for the N - 1 packs of this frame slot
         keep[b] = staged                                # alive until this set's next turn
         if rank == 0:                                   # the next gather into this receive buffer waits for these unpacks
             for ev, e in zip(unpacked[b], exts):
                 ev.record(e)
         pending[b] = None
 
+    def exchange(b):
+        """Exchange of the step whose streams are in set b: its encodes are awaited (an event per library stream), the
+        sizes exchanged, and all frames' packs handed to RCCL in one batch of peer->root transfers."""
+        for ev in enc_done[b]:
+            ev.synchronize()                            # the bytes are complete before RCCL reads them
+        if rank != 0 or pr_mode == "1":
+            # the packs' lengths (their first words) -> pinned host memory by ASYNCHRONOUS copies on a torch-owned stream and
+            # an event wait: a blocking read-back here (hipMemcpy) holds up the kernel launches of the main thread
+            with torch.cuda.stream(copy_stream):
+                for f, ln in enumerate(lanes):
+                    size_pin[b][f:f + 1].copy_(ln.packs[b][:8].view(torch.int64), non_blocking=True)
+                size_done[b].record(copy_stream)
+            size_done[b].synchronize()
+        if pr_mode == "3":
+            return
+        # rank 0's own frames stay where they are (it sends nothing); a peer sends the pack, whose first word is its length
+        if rank == 0 and pr_mode != "1":
+            sizes = [0] * len(lanes)                    # (also the dev modes 2 and 4)
+        else:                                           # written by the asynchronous copies queued before enc_done
+            sizes = size_pin[b].tolist()
+        items = [(ln.packs[b], int(sz)) for ln, sz in zip(lanes, sizes)]
+        if os.environ.get("J2K_BENCH_BACKEND", "nccl") != "nccl":
+            items = [(t[:n_].cpu(), n_) for t, n_ in items]
+        if rank == 0 and keep[b] is not None:
+            cur = torch.cuda.current_stream()
+            for ev in unpacked[b]:
+                cur.wait_event(ev)
+        pending[b] = jdist.gather_streams_start(items, outs=[ln.gather_bufs[b] for ln in lanes], size_group=size_group)
+
+    # The exchange runs on a helper thread: its waits (encode events, the size exchange) would otherwise sit between two
+    # batches of kernel launches of the main thread, and at ~0.5 ms of GPU work per step the host has no slack for that
+    # (measured on one GPU with J2K_BENCH_PEER_REHEARSAL: 52.2 -> 46.0 Gpx/s inline).  Every rank's helper handles the
+    # steps in the same order, so the collectives line up.
+    import queue
+    import threading
+    xq = queue.Queue()
+    xdone = [threading.Event() for _ in range(NSETS)]
+    xerr = []
+    for ev_ in xdone:
+        ev_.set()
+
+    def helper():
+        torch.cuda.set_device(local)
+        while True:
+            b = xq.get()
+            if b is None:
+                return
+            try:
+                exchange(b)
+            except BaseException as exc:                # surfaced by the main thread at its next wait
+                xerr.append(exc)
+            finally:
+                xdone[b].set()
+
+    xthread = threading.Thread(target=helper, daemon=True)
+    if multi:
+        xthread.start()
+
+    def start_gather(b):
+        if not coded[b]:
+            return
+        coded[b] = False
+        xdone[b].clear()
+        xq.put(b)
+
     def step():
-        if world == 1:
+        if not multi:
             for ln in lanes:
                 ln.code()
             return
-        # N > 1, software-pipelined over two sets of stream buffers: encode + decode of this step are queued on the
-        # library streams first; the host then waits for the ENCODES only (an event per stream), exchanges the sizes and
-        # hands all frames' streams to RCCL in one batch of peer->root transfers -- which run while this step's decodes
-        # and the next step's kernels execute.  A buffer set is rewritten only after the gather that read it has finished.
-        b = stepno[0] & 1
+        # N > 1, software-pipelined over three sets of stream buffers.  Step k queues its encodes (+ packs) and decodes on
+        # the library streams into set k % 3 and only THEN runs the exchange of step k - 1 (whose encodes finished while
+        # the host was queueing), so the host never waits for work it has just launched; the transfers of step k - 1 run
+        # under the kernels of steps k and k + 1, and set (k - 1) % 3 is rewritten at step k + 2, after its gather finished.
+        k = stepno[0]
         stepno[0] += 1
+        b = k % NSETS
         finish_gather(b)
-        for ln, ev, e in zip(lanes, enc_done, exts):
+        for ln, ev, e in zip(lanes, enc_done[b], exts):
             ln.encode_side(b)
             ev.record(e)
         for ln in lanes:
             ln.decode_side(b)
-        for ev in enc_done:
-            ev.synchronize()                            # the bytes are complete before RCCL reads them
-        # rank 0's own frames stay where they are (it sends nothing); a peer sends the pack, whose first word is its length
-        if rank == 0:
-            sizes = [0] * len(lanes)
-        else:                                           # one device-to-host copy for all frames' pack lengths
-            sizes = torch.stack([ln.packs[b][:8].view(torch.int64)[0] for ln in lanes]).cpu().tolist()
-        items = [(ln.packs[b], int(sz)) for ln, sz in zip(lanes, sizes)]
-        if os.environ.get("J2K_BENCH_BACKEND", "nccl") != "nccl":
-            items = [(t[:n_].cpu(), n_) for t, n_ in items]
-        if rank == 0 and stepno[0] > 2:
-            cur = torch.cuda.current_stream()
-            for ev in unpacked[b]:
-                cur.wait_event(ev)
-        pending[b] = jdist.gather_streams_start(items, outs=[ln.gather_bufs[b] for ln in lanes])
+        coded[b] = True
+        start_gather((k - 1) % NSETS)
 
     def barrier():
-        finish_gather(0)
-        finish_gather(1)
+        for b in range(NSETS):
+            start_gather(b)
+        for b in range(NSETS):
+            finish_gather(b)
         for ln in lanes:
             ln.ctx.sync()
         torch.cuda.synchronize()
@@ -359,7 +435,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(np, frame_h)
         print(json.dumps(out))
-    if world > 1:
+    if multi:
+        xq.put(None)
+        xthread.join()
         dist.barrier()
         dist.destroy_process_group()
 

@@ -7,14 +7,17 @@ namespace j2k {
 
 // single workgroup; eight lengths per thread per pass (one pass up to 8192 jobs), every load issued before the first
 // use, one barrier per pass; offs[n] = total
-__global__ __launch_bounds__(1024) void scan_lens_kernel(const uint32_t *__restrict__ lens, int n, uint64_t *__restrict__ offs) {
-    __shared__ uint64_t wave_sum[2][16];
+// mels / toffs (both or neither): also the exclusive scan of the TRANSPORT lengths (a block's length without its
+// mels[j] bytes of MEL zero run; see the pack kernels below) -- the same pass, a second running sum.
+__global__ __launch_bounds__(1024) void scan_lens_kernel(const uint32_t *__restrict__ lens, int n, uint64_t *__restrict__ offs,
+                                                         const uint32_t *__restrict__ mels, uint64_t *__restrict__ toffs) {
+    __shared__ uint64_t wave_sum[2][16], wave_sum2[2][16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    uint64_t carry = 0;
+    uint64_t carry = 0, carry2 = 0;
     int par = 0;
     for (int base = 0; base < n; base += 8192, par ^= 1) {
         const int i0 = base + tid * 8;
-        uint32_t v[8];
+        uint32_t v[8], m[8];
         if (i0 + 8 <= n) {
             const uint4 a = *reinterpret_cast<const uint4 *>(lens + i0), b = *reinterpret_cast<const uint4 *>(lens + i0 + 4);
             v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
@@ -22,32 +25,34 @@ __global__ __launch_bounds__(1024) void scan_lens_kernel(const uint32_t *__restr
 #pragma unroll
             for (int k = 0; k < 8; k++) v[k] = (i0 + k < n) ? lens[i0 + k] : 0u;
         }
-        uint64_t t = 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) t += v[k];
-        uint64_t x = t;
+        for (int k = 0; k < 8; k++) m[k] = (mels && i0 + k < n && v[k]) ? mels[i0 + k] : 0u;
+        uint64_t t = 0, t2 = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { t += v[k]; t2 += v[k] - m[k]; }
+        uint64_t x = t, x2 = t2;
         for (int o = 1; o < 64; o <<= 1) {
-            const uint64_t y = __shfl_up(x, o);
-            if (lane >= o) x += y;
+            const uint64_t y = __shfl_up(x, o), y2 = __shfl_up(x2, o);
+            if (lane >= o) { x += y; x2 += y2; }
         }
-        if (lane == 63) wave_sum[par][wv] = x;
+        if (lane == 63) { wave_sum[par][wv] = x; wave_sum2[par][wv] = x2; }
         __syncthreads();
-        uint64_t pre = carry, all = carry;
+        uint64_t pre = carry, all = carry, pre2 = carry2, all2 = carry2;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            const uint64_t ws = wave_sum[par][k];
-            if (k < wv) pre += ws;
-            all += ws;
+            const uint64_t ws = wave_sum[par][k], ws2 = wave_sum2[par][k];
+            if (k < wv) { pre += ws; pre2 += ws2; }
+            all += ws; all2 += ws2;
         }
-        uint64_t o = pre + x - t;
+        uint64_t o = pre + x - t, o2 = pre2 + x2 - t2;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            if (i0 + k < n) offs[i0 + k] = o;
-            o += v[k];
+            if (i0 + k < n) { offs[i0 + k] = o; if (toffs) toffs[i0 + k] = o2; }
+            o += v[k]; o2 += v[k] - m[k];
         }
-        carry = all;
+        carry = all; carry2 = all2;
     }
-    if (tid == 0) offs[n] = carry;
+    if (tid == 0) { offs[n] = carry; if (toffs) toffs[n] = carry2; }
 }
 
 // n bytes src -> dst, any alignment on both sides, one wavefront: bytes up to the destination's next 16-byte boundary,
@@ -126,26 +131,14 @@ __device__ __forceinline__ uint32_t mel_bytes(const BlockJob &J) {
     return (uint32_t)((nsamp * 2 < 64 ? 64 : nsamp * 2) / 4);
 }
 
-// header arrays + the transport length of every block (tl: u32 per job, scratch)
-__global__ void pack_meta_kernel(const BlockJob *__restrict__ jobs, int n, const uint32_t *__restrict__ lens, const uint32_t *__restrict__ maglens,
-                                 const uint8_t *__restrict__ numbps, const uint64_t *__restrict__ offs, uint8_t *__restrict__ pack,
-                                 uint32_t *__restrict__ tl) {
+// one wavefront per block: its header entries and its bytes; toffs = the exclusive scan of the transport lengths that
+// j2k_plan_encode_stream's scan left in the plan (for a stream without MEL runs: offs itself)
+__global__ __launch_bounds__(256) void pack_kernel(const BlockJob *__restrict__ jobs, int n, const uint8_t *__restrict__ stream,
+                                                   const uint64_t *__restrict__ offs, const uint64_t *__restrict__ toffs,
+                                                   const uint32_t *__restrict__ lens, const uint32_t *__restrict__ maglens,
+                                                   const uint8_t *__restrict__ numbps, uint8_t *__restrict__ pack) {
     const PackLayout L = pack_layout((size_t)n);
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j > n) return;
-    reinterpret_cast<uint64_t *>(pack + L.offs)[j] = offs[j];
-    if (j == n) return;
-    const uint32_t len = lens[j];
-    const uint32_t mel = (maglens && len) ? mel_bytes(jobs[j]) : 0u;
-    reinterpret_cast<uint32_t *>(pack + L.lens)[j] = len;
-    reinterpret_cast<uint32_t *>(pack + L.mag)[j] = maglens ? maglens[j] : len;
-    pack[L.nb + j] = numbps[j];
-    tl[j] = len - mel;
-}
-__global__ __launch_bounds__(256) void pack_payload_kernel(const BlockJob *__restrict__ jobs, int n, const uint8_t *__restrict__ stream,
-                                                           int has_mel, uint8_t *__restrict__ pack) {
-    const PackLayout L = pack_layout((size_t)n);
-    const uint64_t *toffs = reinterpret_cast<const uint64_t *>(pack + L.toffs);
+    const int has_mel = maglens != nullptr;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         uint64_t *h = reinterpret_cast<uint64_t *>(pack);
         h[0] = ((uint64_t)L.payload + toffs[n] + 15) & ~uint64_t(15);     // packs laid end to end stay 16-byte aligned
@@ -154,16 +147,32 @@ __global__ __launch_bounds__(256) void pack_payload_kernel(const BlockJob *__res
         reinterpret_cast<uint32_t *>(pack)[5] = (uint32_t)has_mel;
     }
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (j >= n) return;
+    if (j > n) return;
     const int lane = threadIdx.x & 63;
-    const uint32_t len = reinterpret_cast<const uint32_t *>(pack + L.lens)[j];
+    const uint64_t off = offs[j], toff = toffs[j];
+    if (lane == 0) {
+        reinterpret_cast<uint64_t *>(pack + L.offs)[j] = off;
+        reinterpret_cast<uint64_t *>(pack + L.toffs)[j] = toff;
+    }
+    if (j == n) return;
+    const uint32_t len = lens[j];
+    const uint32_t mag = has_mel ? maglens[j] : len;
+    if (lane == 0) {
+        reinterpret_cast<uint32_t *>(pack + L.lens)[j] = len;
+        reinterpret_cast<uint32_t *>(pack + L.mag)[j] = mag;
+        pack[L.nb + j] = numbps[j];
+    }
     if (len == 0) return;
-    const uint32_t mag = reinterpret_cast<const uint32_t *>(pack + L.mag)[j];
     const uint32_t mel = has_mel ? mel_bytes(jobs[j]) : 0u;
-    const uint8_t *src = stream + reinterpret_cast<const uint64_t *>(pack + L.offs)[j];
-    uint8_t *dst = pack + L.payload + toffs[j];
+    const uint8_t *src = stream + off;
+    uint8_t *dst = pack + L.payload + toff;
     copy_bytes(dst, src, mag, lane);
     copy_bytes(dst + mag, src + mag + mel, len - mag - mel, lane);
+}
+// per-job MEL run length (plan build): max(64, 2wh) / 4
+__global__ void mel_table_kernel(const BlockJob *__restrict__ jobs, int n, uint32_t *__restrict__ mels) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) mels[j] = mel_bytes(jobs[j]);
 }
 // root side: pack -> dense stream + offs / lens / numbps, up to UNPACK_BATCH packs of the same geometry per launch
 // (blockIdx.y = which pack: at N = 8 the root rebuilds 7 peers' streams per frame slot, and one launch keeps far more
@@ -213,12 +222,14 @@ __global__ __launch_bounds__(256) void unpack_kernel(const BlockJob *__restrict_
     copy_bytes(dst + mag + mel, src + mag, len - mag - mel, lane);
 }
 
-hipError_t launch_pack(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs, const uint32_t *lens,
-                       const uint8_t *numbps, const uint32_t *maglens, uint8_t *pack, uint32_t *tl_scratch) {
-    const PackLayout L = pack_layout((size_t)njobs);
-    hipLaunchKernelGGL(pack_meta_kernel, dim3((njobs + 1 + 255) / 256), dim3(256), 0, s, jobs, njobs, lens, maglens, numbps, offs, pack, tl_scratch);
-    hipLaunchKernelGGL(scan_lens_kernel, dim3(1), dim3(1024), 0, s, tl_scratch, njobs, reinterpret_cast<uint64_t *>(pack + L.toffs));
-    hipLaunchKernelGGL(pack_payload_kernel, dim3(njobs > 0 ? (njobs + 3) / 4 : 1), dim3(256), 0, s, jobs, njobs, stream, maglens ? 1 : 0, pack);   // (block 0 writes the header even for an empty plan)
+hipError_t launch_pack(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs, const uint64_t *toffs,
+                       const uint32_t *lens, const uint8_t *numbps, const uint32_t *maglens, uint8_t *pack) {
+    hipLaunchKernelGGL(pack_kernel, dim3((njobs + 1 + 3) / 4), dim3(256), 0, s, jobs, njobs, stream, offs, toffs, lens, maglens, numbps, pack);
+    return hipGetLastError();
+}
+hipError_t launch_mel_table(hipStream_t s, const BlockJob *jobs, int njobs, uint32_t *mels) {
+    if (njobs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(mel_table_kernel, dim3((njobs + 255) / 256), dim3(256), 0, s, jobs, njobs, mels);
     return hipGetLastError();
 }
 hipError_t launch_unpack(hipStream_t s, const BlockJob *jobs, int njobs, int count, const uint8_t *const *packs, uint8_t *const *streams,
@@ -236,8 +247,8 @@ hipError_t launch_unpack(hipStream_t s, const BlockJob *jobs, int njobs, int cou
 }
 
 hipError_t launch_compact(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *slots, const uint32_t *lens,
-                          uint64_t *offs, uint8_t *stream, const uint32_t *maglens) {
-    hipLaunchKernelGGL(scan_lens_kernel, dim3(1), dim3(1024), 0, s, lens, njobs, offs);
+                          uint64_t *offs, uint8_t *stream, const uint32_t *maglens, const uint32_t *mels, uint64_t *toffs) {
+    hipLaunchKernelGGL(scan_lens_kernel, dim3(1), dim3(1024), 0, s, lens, njobs, offs, mels, toffs);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || njobs <= 0) return e;
     hipLaunchKernelGGL(gather_kernel, dim3((njobs + 3) / 4), dim3(256), 0, s, jobs, njobs, slots, lens, offs, stream, maglens);

@@ -41,10 +41,11 @@ hipError_t launch_raw_decode(hipStream_t s, const uint8_t *data, size_t len, siz
 size_t t1_work_bytes(int w, int h);
 size_t t1_flag_bytes(int w, int h);
 hipError_t launch_compact(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *slots, const uint32_t *lens,
-                          uint64_t *offs, uint8_t *stream, const uint32_t *maglens);
+                          uint64_t *offs, uint8_t *stream, const uint32_t *maglens, const uint32_t *mels = nullptr, uint64_t *toffs = nullptr);
+hipError_t launch_mel_table(hipStream_t s, const BlockJob *jobs, int njobs, uint32_t *mels);
 size_t pack_header_bytes(size_t n);
-hipError_t launch_pack(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs, const uint32_t *lens,
-                       const uint8_t *numbps, const uint32_t *maglens, uint8_t *pack, uint32_t *tl_scratch);
+hipError_t launch_pack(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs, const uint64_t *toffs,
+                       const uint32_t *lens, const uint8_t *numbps, const uint32_t *maglens, uint8_t *pack);
 hipError_t launch_unpack(hipStream_t s, const BlockJob *jobs, int njobs, int count, const uint8_t *const *packs, uint8_t *const *streams,
                          size_t stream_cap, uint64_t *const *offs, uint32_t *const *lens, uint8_t *const *numbps, int *fault);
 }  // namespace j2k
@@ -509,7 +510,7 @@ extern "C" void j2k_plan_destroy(j2k_plan *P) {
         for (auto &T : P->fwd[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); }
         for (auto &T : P->inv[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); }
     }
-    void *ptrs[] = {P->d_scrA, P->d_scrB, P->d_tail, P->d_bjobs, P->d_djobs, P->d_frame, P->d_coeff, P->d_slots, P->d_stream, P->d_lens, P->d_numbps, P->d_offs, P->d_status, P->d_fwd_pix_jobs, P->d_maglens};
+    void *ptrs[] = {P->d_scrA, P->d_scrB, P->d_tail, P->d_bjobs, P->d_djobs, P->d_frame, P->d_coeff, P->d_slots, P->d_stream, P->d_lens, P->d_numbps, P->d_offs, P->d_status, P->d_fwd_pix_jobs, P->d_maglens, P->d_mels, P->d_toffs};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete P;
 }
@@ -997,13 +998,19 @@ extern "C" int j2k_plan_encode_stream(j2k_plan *P, const int32_t *d_coeff, uint8
     if (!P->d_slots) HIPCHK(ctx, hipMalloc(&P->d_slots, (size_t)P->bytes_cap + 64));
     if (P->spec.coder == J2K_CODER_HT) {
         // the slot buffer is private here: the MEL zero bytes are not written into it, the gather emits them (compact.hip)
-        if (!P->d_maglens) HIPCHK(ctx, hipMalloc((void **)&P->d_maglens, (size_t)n * 4));
+        if (!P->d_maglens) {
+            HIPCHK(ctx, hipMalloc((void **)&P->d_maglens, (size_t)n * 4));
+            HIPCHK(ctx, hipMalloc((void **)&P->d_mels, (size_t)n * 4));
+            HIPCHK(ctx, hipMalloc((void **)&P->d_toffs, ((size_t)n + 1) * 8));
+            HIPCHK(ctx, launch_mel_table(ctx->stream, P->d_bjobs, n, P->d_mels));
+        }
         int r = stage_reserve(ctx, 3, 256);
         if (r != J2K_OK) return r;
         ctx->fault_armed = true;
         HIPCHK(ctx, launch_ht_encode(ctx->stream, P->d_bjobs, n, d_coeff, (uint8_t *)P->d_slots, d_lens, d_numbps, (int *)ctx->stage[3],
                                      P->d_maglens));
-        HIPCHK(ctx, launch_compact(ctx->stream, P->d_bjobs, n, (const uint8_t *)P->d_slots, d_lens, d_offs, d_stream, P->d_maglens));
+        HIPCHK(ctx, launch_compact(ctx->stream, P->d_bjobs, n, (const uint8_t *)P->d_slots, d_lens, d_offs, d_stream, P->d_maglens,
+                                   P->d_mels, P->d_toffs));
         return J2K_OK;
     }
     int r = j2k_plan_encode_blocks(P, d_coeff, (uint8_t *)P->d_slots, d_lens, d_numbps);
@@ -1024,10 +1031,8 @@ extern "C" int j2k_plan_pack_stream(j2k_plan *P, const uint8_t *d_stream, const 
     const int n = (int)P->blocks.size();
     const bool ht = P->spec.coder == J2K_CODER_HT;
     if (ht && !P->d_maglens) return fail(ctx, J2K_ERR_UNSUPPORTED, "pack_stream: no j2k_plan_encode_stream (three-kernel path) ran on this plan");
-    int r = stage_reserve(ctx, 1, (size_t)n * 4 + 4096);
-    if (r != J2K_OK) return r;
-    HIPCHK(ctx, launch_pack(ctx->stream, P->d_bjobs, n, d_stream, d_offs, d_lens, d_numbps, ht ? P->d_maglens : nullptr, d_pack,
-                            (uint32_t *)ctx->stage[1]));
+    HIPCHK(ctx, launch_pack(ctx->stream, P->d_bjobs, n, d_stream, d_offs, ht ? P->d_toffs : d_offs, d_lens, d_numbps,
+                            ht ? P->d_maglens : nullptr, d_pack));
     return J2K_OK;
 }
 

@@ -116,6 +116,8 @@ struct j2k_plan {
     j2k::DwtJob *d_fwd_pix_jobs = nullptr;  // level-0 forward job table of the packed-pixel path (shorter bands)
     int fwd_pix_njobs = 0;
     uint32_t *d_maglens = nullptr;          // j2k_plan_encode_stream: end of each block's MagSgn bytes (the MEL hole starts there)
+    uint32_t *d_mels = nullptr;      // per job: bytes of MEL zero run of an HT block (max(64, 2wh) / 4), built with d_maglens
+    uint64_t *d_toffs = nullptr;     // n + 1: exclusive scan of the transport lengths of the last j2k_plan_encode_stream (pack_stream)
     uint64_t *d_status = nullptr;
     uint32_t epoch = 0;
     bool all_blocks_fast = false;           // every job on the parallel HT path

@@ -82,22 +82,30 @@ class StreamGather:
         return self._results
 
 
-def gather_streams_start(items, group=None, outs=None):
+def gather_streams_start(items, group=None, outs=None, size_group=None):
     """Gather SEVERAL streams to rank 0 with one size exchange and one batch of point-to-point transfers, without
     waiting for the bytes: `items` = [(uint8 tensor, nbytes), ...] (e.g. one per frame in flight), `outs` = optional
     list of reusable receive buffers on rank 0.  The caller overlaps other work and then calls .wait().
     The source tensors (and `outs`) must not be rewritten before .wait() has returned and, on nccl, before the
-    streams that rewrite them have been made to wait for the current stream."""
+    streams that rewrite them have been made to wait for the current stream.
+    size_group: a gloo group of the same ranks for the size exchange.  The sizes are host integers on both ends; sent
+    through RCCL they would cost a kernel that queues behind everything the GPU is busy with while the host waits."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     F = len(items)
     dev = items[0][0].device
-    mine = torch.tensor([int(n) for _, n in items], dtype=torch.int64, device=dev)
-    totals = torch.empty(world * F, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(totals, mine, group=group)
-    totals_h = totals.cpu().numpy().reshape(world, F)
+    if size_group is not None:
+        mine = torch.tensor([int(n) for _, n in items], dtype=torch.int64)
+        totals = torch.empty(world * F, dtype=torch.int64)
+        dist.all_gather_into_tensor(totals, mine, group=size_group)
+        totals_h = totals.numpy().reshape(world, F)
+    else:
+        mine = torch.tensor([int(n) for _, n in items], dtype=torch.int64, device=dev)
+        totals = torch.empty(world * F, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(totals, mine, group=group)
+        totals_h = totals.cpu().numpy().reshape(world, F)
     results, ops = [], []
     outs = list(outs) if outs is not None else [None] * F
     for f, (stream, nbytes) in enumerate(items):
