@@ -108,6 +108,9 @@ def main():
     # size exchange -- with a one-rank group and nothing to transfer, to see what the host side of that step costs
     pr_mode = os.environ.get("J2K_BENCH_PEER_REHEARSAL", "0") if world == 1 else "0"   # 1: all of it; 2: no pack; 3: no exchange
     peer_rehearsal = pr_mode in ("1", "2", "3", "4")   # 4: pack, but the sizes are not read back (dev)
+    # J2K_BENCH_ROOT_REHEARSAL=N (dev, one GPU): the GPU work of rank 0 in an N-GPU run -- its own frames plus the rebuild of
+    # N - 1 peers' streams per frame slot (its own pack stands in for theirs) -- with nothing transferred
+    root_n = int(os.environ.get("J2K_BENCH_ROOT_REHEARSAL", "0")) if world == 1 else 0
     multi = world > 1 or peer_rehearsal
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -155,6 +158,10 @@ def main():
             # reference's MEL zero runs, a third of the bytes); rank 0 rebuilds every peer's dense stream from it
             self.packs = [p.empty(p.pack_bound(), torch.uint8) for _ in range(nb)] if multi else []
             self.assembled = None
+            if root_n > 1:
+                self.packs = [p.empty(p.pack_bound(), torch.uint8)]
+                self.assembled = [(p.empty(i.bytes_cap, torch.uint8), p.empty(self.n + 1, torch.int64), p.empty(self.n, torch.int32),
+                                   p.empty(self.n, torch.uint8)) for _ in range(root_n - 1)]
             if world > 1 and rank == 0:
                 self.assembled = [(p.empty(i.bytes_cap, torch.uint8), p.empty(self.n + 1, torch.int64), p.empty(self.n, torch.int32),
                                    p.empty(self.n, torch.uint8)) for _ in range(world - 1)]
@@ -293,6 +300,13 @@ def main():
         xq.put(b)
 
     def step():
+        if root_n > 1:
+            for ln in lanes:
+                ln.encode_side()
+                ln.plan.pack_stream(ln.stream, ln.offs, ln.lens, ln.numbps, ln.packs[0])
+                ln.plan.unpack_streams([ln.packs[0]] * (root_n - 1), ln.assembled)
+                ln.decode_side()
+            return
         if not multi:
             for ln in lanes:
                 ln.code()
