@@ -71,12 +71,20 @@ def _worker_batched(rank, world, port, lens, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         outs = None
+        side = dist.new_group(backend="gloo")                             # bench.py: the sizes travel through a side group,
         for step in range(2):                                             # second step reuses the receive buffers
             items = []
             for f, n in enumerate(lens[rank]):
                 rng = np.random.default_rng(1000 * rank + 10 * step + f)
                 items.append((torch.from_numpy(rng.integers(0, 256, n + 5).astype(np.uint8)), n))
-            g = jd.gather_streams_start(items, outs=outs)
+            if step == 0:
+                g = jd.gather_streams_start(items, outs=outs)
+            else:                                                         # ... and the exchange runs on a helper thread
+                import threading
+                box = []
+                th = threading.Thread(target=lambda: box.append(jd.gather_streams_start(items, outs=outs, size_group=side)))
+                th.start(); th.join()
+                g = box[0]
             res = g.wait()
             if rank == 0:
                 outs = [b for b, _ in res]
