@@ -9,6 +9,7 @@ namespace j2k {
 // use, one barrier per pass; offs[n] = total
 // mels / toffs (both or neither): also the exclusive scan of the TRANSPORT lengths (a block's length without its
 // mels[j] bytes of MEL zero run; see the pack kernels below) -- the same pass, a second running sum.
+template <bool TWO>
 __global__ __launch_bounds__(1024) void scan_lens_kernel(const uint32_t *__restrict__ lens, int n, uint64_t *__restrict__ offs,
                                                          const uint32_t *__restrict__ mels, uint64_t *__restrict__ toffs) {
     __shared__ uint64_t wave_sum[2][16], wave_sum2[2][16];
@@ -25,34 +26,45 @@ __global__ __launch_bounds__(1024) void scan_lens_kernel(const uint32_t *__restr
 #pragma unroll
             for (int k = 0; k < 8; k++) v[k] = (i0 + k < n) ? lens[i0 + k] : 0u;
         }
+        if (TWO && i0 + 8 <= n) {                       // both vectors in flight with the lens above: no serialised loads
+            const uint4 a = *reinterpret_cast<const uint4 *>(mels + i0), b = *reinterpret_cast<const uint4 *>(mels + i0 + 4);
+            m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w; m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
+        } else {
 #pragma unroll
-        for (int k = 0; k < 8; k++) m[k] = (mels && i0 + k < n && v[k]) ? mels[i0 + k] : 0u;
+            for (int k = 0; k < 8; k++) m[k] = (TWO && i0 + k < n) ? mels[i0 + k] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) m[k] = v[k] ? m[k] : 0u;
         uint64_t t = 0, t2 = 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) { t += v[k]; t2 += v[k] - m[k]; }
+        for (int k = 0; k < 8; k++) { t += v[k]; if (TWO) t2 += v[k] - m[k]; }
         uint64_t x = t, x2 = t2;
         for (int o = 1; o < 64; o <<= 1) {
-            const uint64_t y = __shfl_up(x, o), y2 = __shfl_up(x2, o);
-            if (lane >= o) { x += y; x2 += y2; }
+            const uint64_t y = __shfl_up(x, o);
+            if (lane >= o) x += y;
+            if (TWO) {
+                const uint64_t y2 = __shfl_up(x2, o);
+                if (lane >= o) x2 += y2;
+            }
         }
-        if (lane == 63) { wave_sum[par][wv] = x; wave_sum2[par][wv] = x2; }
+        if (lane == 63) { wave_sum[par][wv] = x; if (TWO) wave_sum2[par][wv] = x2; }
         __syncthreads();
         uint64_t pre = carry, all = carry, pre2 = carry2, all2 = carry2;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            const uint64_t ws = wave_sum[par][k], ws2 = wave_sum2[par][k];
+            const uint64_t ws = wave_sum[par][k], ws2 = TWO ? wave_sum2[par][k] : 0;
             if (k < wv) { pre += ws; pre2 += ws2; }
             all += ws; all2 += ws2;
         }
         uint64_t o = pre + x - t, o2 = pre2 + x2 - t2;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            if (i0 + k < n) { offs[i0 + k] = o; if (toffs) toffs[i0 + k] = o2; }
+            if (i0 + k < n) { offs[i0 + k] = o; if (TWO) toffs[i0 + k] = o2; }
             o += v[k]; o2 += v[k] - m[k];
         }
         carry = all; carry2 = all2;
     }
-    if (tid == 0) { offs[n] = carry; if (toffs) toffs[n] = carry2; }
+    if (tid == 0) { offs[n] = carry; if (TWO) toffs[n] = carry2; }
 }
 
 // n bytes src -> dst, any alignment on both sides, one wavefront: bytes up to the destination's next 16-byte boundary,
@@ -222,6 +234,11 @@ __global__ __launch_bounds__(256) void unpack_kernel(const BlockJob *__restrict_
     copy_bytes(dst + mag + mel, src + mag, len - mag - mel, lane);
 }
 
+hipError_t launch_scan(hipStream_t s, const uint32_t *lens, int njobs, uint64_t *offs, const uint32_t *mels, uint64_t *toffs) {
+    if (mels && toffs) hipLaunchKernelGGL(scan_lens_kernel<true>, dim3(1), dim3(1024), 0, s, lens, njobs, offs, mels, toffs);
+    else hipLaunchKernelGGL(scan_lens_kernel<false>, dim3(1), dim3(1024), 0, s, lens, njobs, offs, mels, toffs);
+    return hipGetLastError();
+}
 hipError_t launch_pack(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs, const uint64_t *toffs,
                        const uint32_t *lens, const uint8_t *numbps, const uint32_t *maglens, uint8_t *pack) {
     hipLaunchKernelGGL(pack_kernel, dim3((njobs + 1 + 3) / 4), dim3(256), 0, s, jobs, njobs, stream, offs, toffs, lens, maglens, numbps, pack);
@@ -248,8 +265,7 @@ hipError_t launch_unpack(hipStream_t s, const BlockJob *jobs, int njobs, int cou
 
 hipError_t launch_compact(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *slots, const uint32_t *lens,
                           uint64_t *offs, uint8_t *stream, const uint32_t *maglens, const uint32_t *mels, uint64_t *toffs) {
-    hipLaunchKernelGGL(scan_lens_kernel, dim3(1), dim3(1024), 0, s, lens, njobs, offs, mels, toffs);
-    hipError_t e = hipGetLastError();
+    hipError_t e = launch_scan(s, lens, njobs, offs, mels, toffs);
     if (e != hipSuccess || njobs <= 0) return e;
     hipLaunchKernelGGL(gather_kernel, dim3((njobs + 3) / 4), dim3(256), 0, s, jobs, njobs, slots, lens, offs, stream, maglens);
     return hipGetLastError();

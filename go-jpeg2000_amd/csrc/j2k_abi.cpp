@@ -43,6 +43,7 @@ size_t t1_flag_bytes(int w, int h);
 hipError_t launch_compact(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *slots, const uint32_t *lens,
                           uint64_t *offs, uint8_t *stream, const uint32_t *maglens, const uint32_t *mels = nullptr, uint64_t *toffs = nullptr);
 hipError_t launch_mel_table(hipStream_t s, const BlockJob *jobs, int njobs, uint32_t *mels);
+hipError_t launch_scan(hipStream_t s, const uint32_t *lens, int njobs, uint64_t *offs, const uint32_t *mels, uint64_t *toffs);
 size_t pack_header_bytes(size_t n);
 hipError_t launch_pack(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs, const uint64_t *toffs,
                        const uint32_t *lens, const uint8_t *numbps, const uint32_t *maglens, uint8_t *pack);
@@ -1009,8 +1010,10 @@ extern "C" int j2k_plan_encode_stream(j2k_plan *P, const int32_t *d_coeff, uint8
         ctx->fault_armed = true;
         HIPCHK(ctx, launch_ht_encode(ctx->stream, P->d_bjobs, n, d_coeff, (uint8_t *)P->d_slots, d_lens, d_numbps, (int *)ctx->stage[3],
                                      P->d_maglens));
+        // the transport offsets (a second running sum in the scan, +4 us) only once j2k_plan_pack_stream has asked for them
         HIPCHK(ctx, launch_compact(ctx->stream, P->d_bjobs, n, (const uint8_t *)P->d_slots, d_lens, d_offs, d_stream, P->d_maglens,
-                                   P->d_mels, P->d_toffs));
+                                   P->want_toffs ? P->d_mels : nullptr, P->want_toffs ? P->d_toffs : nullptr));
+        P->toffs_valid = P->want_toffs;
         return J2K_OK;
     }
     int r = j2k_plan_encode_blocks(P, d_coeff, (uint8_t *)P->d_slots, d_lens, d_numbps);
@@ -1031,6 +1034,13 @@ extern "C" int j2k_plan_pack_stream(j2k_plan *P, const uint8_t *d_stream, const 
     const int n = (int)P->blocks.size();
     const bool ht = P->spec.coder == J2K_CODER_HT;
     if (ht && !P->d_maglens) return fail(ctx, J2K_ERR_UNSUPPORTED, "pack_stream: no j2k_plan_encode_stream (three-kernel path) ran on this plan");
+    if (ht && !P->toffs_valid) {      // first pack on this plan: scan the transport lengths now, and with every encode from here on
+        int r = stage_reserve(ctx, 1, ((size_t)n + 1) * 8 + 4096);
+        if (r != J2K_OK) return r;
+        HIPCHK(ctx, launch_scan(ctx->stream, d_lens, n, (uint64_t *)ctx->stage[1], P->d_mels, P->d_toffs));
+        P->want_toffs = true;
+        P->toffs_valid = true;
+    }
     HIPCHK(ctx, launch_pack(ctx->stream, P->d_bjobs, n, d_stream, d_offs, ht ? P->d_toffs : d_offs, d_lens, d_numbps,
                             ht ? P->d_maglens : nullptr, d_pack));
     return J2K_OK;

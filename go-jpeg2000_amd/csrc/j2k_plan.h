@@ -117,6 +117,7 @@ struct j2k_plan {
     int fwd_pix_njobs = 0;
     uint32_t *d_maglens = nullptr;          // j2k_plan_encode_stream: end of each block's MagSgn bytes (the MEL hole starts there)
     uint32_t *d_mels = nullptr;      // per job: bytes of MEL zero run of an HT block (max(64, 2wh) / 4), built with d_maglens
+    bool want_toffs = false, toffs_valid = false;   // pack_stream has been used on this plan / d_toffs belongs to the last encode_stream
     uint64_t *d_toffs = nullptr;     // n + 1: exclusive scan of the transport lengths of the last j2k_plan_encode_stream (pack_stream)
     uint64_t *d_status = nullptr;
     uint32_t epoch = 0;
