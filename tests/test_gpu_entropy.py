@@ -335,6 +335,7 @@ def test_encode_stream_equals_encode_blocks_plus_compact(W, H, tile, cb, coder, 
         assert torch.equal(o2[:n + 1], offs[:n + 1]) and torch.equal(l2[:n], lens[:n]) and torch.equal(n2[:n], nb[:n])
         assert torch.equal(s2[:tot], stream[:tot]), rep
         coeff = plan.forward(d)                                    # same values; keeps the launches back to back
+    plan.ctx.sync()                                                # nothing in flight when the tensors go out of scope
 
 
 @pytest.mark.parametrize("W,H,tile,cb,coder", [(3840, 2160, 512, 64, 1), (200, 96, 0, 32, 1), (100, 75, 64, 16, 1), (512, 512, 0, 256, 1),
@@ -356,11 +357,13 @@ def test_pack_unpack_stream_round_trip(W, H, tile, cb, coder):
     stream, offs, lens, nb = plan.encode_stream(coeff)
     pack = plan.pack_stream(stream, offs, lens, nb)
     plan.ctx.sync()
+    torch.cuda.synchronize()
     n = int(plan.info.blocks)
     tot = int(offs[n].item())
     pbytes = int(pack[:8].view(torch.int64)[0].item())
     assert 0 < pbytes <= plan.pack_bound()
     sent = pack[:pbytes].clone()                                   # what would travel
+    torch.cuda.synchronize()                                       # (the copy ran on torch's stream, the plans have their own)
     s2, o2, l2, n2 = root.unpack_stream(sent)
     root.ctx.sync()
     assert torch.equal(o2[:n + 1], offs[:n + 1]) and torch.equal(l2[:n], lens[:n]) and torch.equal(n2[:n], nb[:n])
@@ -373,12 +376,16 @@ def test_pack_unpack_stream_round_trip(W, H, tile, cb, coder):
     # several packs in one launch (what the root of an N-GPU gather does per frame slot)
     outs = [(root.empty(root.info.bytes_cap, torch.uint8), root.empty(n + 1, torch.int64), root.empty(n, torch.int32),
              root.empty(n, torch.uint8)) for _ in range(3)]
-    root.unpack_streams([sent, sent.clone(), sent], outs)
+    sent2 = sent.clone()
+    torch.cuda.synchronize()
+    root.unpack_streams([sent, sent2, sent], outs)
     root.ctx.sync()
     for s3, o3, l3, n3 in outs:
         assert torch.equal(o3[:n + 1], offs[:n + 1]) and torch.equal(l3[:n], lens[:n]) and torch.equal(n3[:n], nb[:n])
         assert torch.equal(s3[:tot], stream[:tot])
     other = FramePlan(W + 64, H, 3, ctx=Context(0), **kw)
-    other.unpack_stream(sent)
+    kept = other.unpack_stream(sent)                               # (outputs kept alive until the sync: the call is asynchronous)
     with pytest.raises(J2KError):
         other.ctx.sync()
+    del kept
+    torch.cuda.synchronize()
