@@ -146,7 +146,7 @@ static int check_fault(j2k_ctx *ctx) {
     HIPCHK(ctx, hipMemcpy(&f, ctx->stage[3], sizeof(int), hipMemcpyDeviceToHost));
     ctx->fault_armed = false;
     if (!f) return J2K_OK;
-    HIPCHK(ctx, hipMemset(ctx->stage[3], 0, sizeof(int)));
+    HIPCHK(ctx, hipMemsetAsync(ctx->stage[3], 0, sizeof(int), ctx->stream));   // ordered with the next launches on this stream
     if (f == 1) return fail(ctx, J2K_ERR_GO_PANIC, "block coder: input on which the reference panics (stream buffer overrun / MinInt32)");
     if (f == 4) return fail(ctx, J2K_ERR_INVALID_ARG, "unpack_stream: the pack was not made by a plan of this geometry");
     return fail(ctx, J2K_ERR_CAPACITY, "block coder: slot overflow");
@@ -203,7 +203,9 @@ static int stage_reserve(j2k_ctx *ctx, int slot, size_t bytes) {
     size_t cap = std::max<size_t>(bytes, 1 << 20);
     HIPCHK(ctx, hipMalloc(&ctx->stage[slot], cap));
     ctx->stage_bytes[slot] = cap;
-    if (slot == 3) HIPCHK(ctx, hipMemset(ctx->stage[slot], 0, cap));   // holds the sticky fault word (check_fault)
+    // slot 3 holds the sticky fault word (check_fault): cleared ON THE CONTEXT'S STREAM, i.e. before any kernel that may
+    // set it -- a hipMemset on the null stream is not ordered with a non-blocking stream and could clear a fault afterwards
+    if (slot == 3) HIPCHK(ctx, hipMemsetAsync(ctx->stage[slot], 0, cap, ctx->stream));
     return J2K_OK;
 }
 
@@ -981,7 +983,7 @@ extern "C" int j2k_plan_encode_stream(j2k_plan *P, const int32_t *d_coeff, uint8
             if ((int64_t)((b.h + 3) / 4) * b.w > ht_fast_max_samples()) P->all_blocks_fast = false;
         if (P->all_blocks_fast) {
             HIPCHK(ctx, hipMalloc((void **)&P->d_status, (size_t)n * 8));
-            HIPCHK(ctx, hipMemset(P->d_status, 0, (size_t)n * 8));
+            HIPCHK(ctx, hipMemsetAsync(P->d_status, 0, (size_t)n * 8, ctx->stream));
         }
     }
     if (fused && P->all_blocks_fast && P->d_status) {
