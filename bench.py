@@ -107,7 +107,8 @@ def main():
     # J2K_BENCH_PEER_REHEARSAL=1 (dev, one GPU): run the N > 1 step as a PEER would -- pack, wait for the encodes only,
     # size exchange -- with a one-rank group and nothing to transfer, to see what the host side of that step costs
     pr_mode = os.environ.get("J2K_BENCH_PEER_REHEARSAL", "0") if world == 1 else "0"   # 1: all of it; 2: no pack; 3: no exchange
-    peer_rehearsal = pr_mode in ("1", "2", "3", "4")   # 4: pack, but the sizes are not read back (dev)
+    peer_rehearsal = pr_mode in ("1", "2", "3", "4", "5")   # 4: pack, but the sizes are not read back; 5: as 1, and the lone
+    # rank sends its packs to itself through RCCL and rebuilds them (the transfer calls, on one GPU)
     # J2K_BENCH_ROOT_REHEARSAL=N (dev, one GPU): the GPU work of rank 0 in an N-GPU run -- its own frames plus the rebuild of
     # N - 1 peers' streams per frame slot (its own pack stands in for theirs) -- with nothing transferred
     root_n = int(os.environ.get("J2K_BENCH_ROOT_REHEARSAL", "0")) if world == 1 else 0
@@ -158,6 +159,9 @@ def main():
             # reference's MEL zero runs, a third of the bytes); rank 0 rebuilds every peer's dense stream from it
             self.packs = [p.empty(p.pack_bound(), torch.uint8) for _ in range(nb)] if multi else []
             self.assembled = None
+            if pr_mode == "5":
+                self.assembled = [(p.empty(i.bytes_cap, torch.uint8), p.empty(self.n + 1, torch.int64), p.empty(self.n, torch.int32),
+                                   p.empty(self.n, torch.uint8))]
             if root_n > 1:
                 self.packs = [p.empty(p.pack_bound(), torch.uint8)]
                 self.assembled = [(p.empty(i.bytes_cap, torch.uint8), p.empty(self.n + 1, torch.int64), p.empty(self.n, torch.int32),
@@ -173,7 +177,7 @@ def main():
             else:
                 p.forward(self.frame, self.coeff)
             p.encode_stream(self.coeff, self.streams[b], self.offss[b], self.lenss[b], self.numbpss[b])   # block coding + compaction
-            if multi and (rank != 0 or pr_mode in ("1", "3", "4")):
+            if multi and (rank != 0 or pr_mode in ("1", "3", "4", "5")):
                 p.pack_stream(self.streams[b], self.offss[b], self.lenss[b], self.numbpss[b], self.packs[b])
 
         def decode_side(self, b=0):
@@ -226,7 +230,10 @@ def main():
         staged = []
         for ln, (buf, offsets) in zip(lanes, res):
             ln.gather_bufs[b] = buf
-            if rank == 0:
+            if pr_mode == "5":
+                pks = [buf[:int(offsets[1])]]
+                staged.append(pks)
+            elif rank == 0:
                 pks = [buf[int(offsets[r]):int(offsets[r + 1])] for r in range(1, world)]
                 if not buf.is_cuda:                     # gloo rehearsal: the packs arrive in host memory
                     pks = [pk.to(ln.plan.device) for pk in pks]
@@ -248,7 +255,7 @@ def main():
         sizes exchanged, and all frames' packs handed to RCCL in one batch of peer->root transfers."""
         for ev in enc_done[b]:
             ev.synchronize()                            # the bytes are complete before RCCL reads them
-        if rank != 0 or pr_mode == "1":
+        if rank != 0 or pr_mode in ("1", "5"):
             # the packs' lengths (their first words) -> pinned host memory by ASYNCHRONOUS copies on a torch-owned stream and
             # an event wait: a blocking read-back here (hipMemcpy) holds up the kernel launches of the main thread
             with torch.cuda.stream(copy_stream):
@@ -259,7 +266,7 @@ def main():
         if pr_mode == "3":
             return
         # rank 0's own frames stay where they are (it sends nothing); a peer sends the pack, whose first word is its length
-        if rank == 0 and pr_mode != "1":
+        if rank == 0 and pr_mode not in ("1", "5"):
             sizes = [0] * len(lanes)                    # (also the dev modes 2 and 4)
         else:                                           # written by the asynchronous copies queued before enc_done
             sizes = size_pin[b].tolist()
@@ -270,7 +277,8 @@ def main():
             cur = torch.cuda.current_stream()
             for ev in unpacked[b]:
                 cur.wait_event(ev)
-        pending[b] = jdist.gather_streams_start(items, outs=[ln.gather_bufs[b] for ln in lanes], size_group=size_group)
+        pending[b] = jdist.gather_streams_start(items, outs=[ln.gather_bufs[b] for ln in lanes], size_group=size_group,
+                                                self_loop=pr_mode == "5")
 
     # The exchange runs on a helper thread: its waits (encode events, the size exchange) would otherwise sit between two
     # batches of kernel launches of the main thread, and at ~0.5 ms of GPU work per step the host has no slack for that
@@ -410,6 +418,11 @@ def main():
         else:
             assert torch.equal(ln.back, ln.frame), "lossless round trip failed"
     total_bytes = int(lanes[0].offs[n].item())
+    if pr_mode == "5":                                   # the packs came back through RCCL and were rebuilt: same bytes
+        ln = lanes[0]
+        a_s, a_o, a_l, a_n = ln.assembled[0]
+        assert torch.equal(a_o[:n + 1], ln.offs[:n + 1]) and torch.equal(a_l[:n], ln.lens[:n]) and torch.equal(a_n[:n], ln.numbps[:n])
+        assert torch.equal(a_s[:total_bytes], ln.stream[:total_bytes]), "self-loop stream differs"
     if world > 1 and rank == 0:
         # what rank 0 assembled for rank 1's frame == that frame coded here, byte for byte (stream, offsets, lengths, bit planes)
         ln = lanes[0]

@@ -82,14 +82,15 @@ class StreamGather:
         return self._results
 
 
-def gather_streams_start(items, group=None, outs=None, size_group=None):
+def gather_streams_start(items, group=None, outs=None, size_group=None, self_loop=False):
     """Gather SEVERAL streams to rank 0 with one size exchange and one batch of point-to-point transfers, without
     waiting for the bytes: `items` = [(uint8 tensor, nbytes), ...] (e.g. one per frame in flight), `outs` = optional
     list of reusable receive buffers on rank 0.  The caller overlaps other work and then calls .wait().
     The source tensors (and `outs`) must not be rewritten before .wait() has returned and, on nccl, before the
     streams that rewrite them have been made to wait for the current stream.
     size_group: a gloo group of the same ranks for the size exchange.  The sizes are host integers on both ends; sent
-    through RCCL they would cost a kernel that queues behind everything the GPU is busy with while the host waits."""
+    through RCCL they would cost a kernel that queues behind everything the GPU is busy with while the host waits.
+    self_loop (dev, one rank): the lone rank sends every stream to itself, to exercise the transfer calls on one GPU."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -110,6 +111,15 @@ def gather_streams_start(items, group=None, outs=None, size_group=None):
     outs = list(outs) if outs is not None else [None] * F
     for f, (stream, nbytes) in enumerate(items):
         offsets = np.concatenate(([0], np.cumsum(totals_h[:, f]))).astype(np.int64)
+        if world == 1 and self_loop:
+            out = outs[f]
+            if out is None or out.numel() < int(nbytes):
+                out = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=dev)
+            if int(nbytes):
+                ops.append(dist.P2POp(dist.irecv, out[:int(nbytes)], 0, group))
+                ops.append(dist.P2POp(dist.isend, stream[:int(nbytes)], 0, group))
+            results.append((out, offsets))
+            continue
         if world == 1:
             results.append((stream[:int(nbytes)], offsets))
             continue
