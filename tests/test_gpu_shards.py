@@ -162,6 +162,27 @@ def test_bench_two_rank_control_flow_rehearsal():
     assert d["n_gpus"] == 2 and d["config"]["frames_in_flight"] == 2 and d["value"] > 0
 
 
+def test_bench_rccl_self_loop_rehearsal():
+    """The transfer calls of bench.py's N > 1 step on this box's one GPU: a one-rank RCCL group, the rank sends its packs
+    to itself (batched isend / irecv issued from the helper thread), rebuilds them and bench.py asserts the rebuilt
+    stream, offsets, lengths and bit-plane counts equal the originals."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, J2K_BENCH_PEER_REHEARSAL="5", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0
+
+
 def test_c4_full_size_sampled_tiles_match_oracle():
     """BASELINE C4 geometry: 7680x4320 RGB rescaled to 10 bit (v*1023/255), 512^2 tiles (135; last row 224 high),
     5-3 lossless + HT: first, interior, right-edge, bottom-row and corner tiles against the oracle."""
