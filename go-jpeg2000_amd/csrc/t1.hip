@@ -890,94 +890,112 @@ __device__ __forceinline__ void dec_sign(T1DecLane &L, uint8_t *f) {   // t1.go:
     const uint32_t sc = L.sc[sc_index(f[-1], f[1], f[-L.stride], f[L.stride])];
     if (mq_decode(L.d, L.ent, L.mq, CtxSC0 + (sc & 7)) ^ (int)(sc >> 3)) *f |= T1SignNeg;
 }
-__device__ __forceinline__ void t1_decode_passes(T1DecLane &L, int numBPS) {
+__device__ __forceinline__ void t1_dec_sigprop(T1DecLane &L, int32_t bit) {
     const int w = L.w, h = L.h, stride = L.stride;
     uint8_t *const flags = L.flags;
     int32_t *const data = L.data;
+    (void)w; (void)h; (void)stride; (void)flags; (void)data;
+    // SigProp and MagRef look at four samples per load and step from candidate to candidate with find-first-set; a
+    // sample that turns significant changes its right-hand neighbour's flags, so the group is read again after it
+    for (int y = 0; y < h; y++) {                                 // t1.go:1295-1319
+        uint8_t *const row = flags + (size_t)(y + 1) * stride + T1D_XO;
+        for (int x0 = 0; x0 < w; x0 += 4) {
+            const uint32_t inrow = x0 + 4 <= w ? 0x01010101u : (0x01010101u >> (8 * (x0 + 4 - w)));
+            uint32_t v = *reinterpret_cast<const uint32_t *>(row + x0);
+            uint32_t cand = (v >> 4) & ~v & inrow;               // bit 0 of a byte: has a significant neighbour, not significant
+            while (cand) {
+                const int k = (__ffs((int)cand) - 1) >> 3, x = x0 + k;
+                uint8_t *f = row + x;
+                const bool sig = mq_decode(L.d, L.ent, L.mq, L.zc[zc_packed(f, stride)]) != 0;
+                if (sig) {
+                    data[(size_t)y * w + x] = bit;
+                    dec_sign(L, f);
+                    set_significant_dec(f, stride);
+                }
+                *f |= T1Visit;
+                const uint32_t later = k == 3 ? 0u : (0xFFFFFFFFu << (8 * (k + 1)));
+                if (sig) {
+                    v = *reinterpret_cast<const uint32_t *>(row + x0);
+                    cand = (v >> 4) & ~v & inrow & later;
+                } else cand &= later;
+            }
+        }
+    }
+}
+__device__ __forceinline__ void t1_dec_magref(T1DecLane &L, int32_t bit) {
+    const int w = L.w, h = L.h, stride = L.stride;
+    uint8_t *const flags = L.flags;
+    int32_t *const data = L.data;
+    (void)w; (void)h; (void)stride; (void)flags; (void)data;
+    for (int y = 0; y < h; y++) {                                 // t1.go:1331-1347
+        uint8_t *const row = flags + (size_t)(y + 1) * stride + T1D_XO;
+        for (int x0 = 0; x0 < w; x0 += 4) {
+            const uint32_t inrow = x0 + 4 <= w ? 0x01010101u : (0x01010101u >> (8 * (x0 + 4 - w)));
+            const uint32_t v = *reinterpret_cast<const uint32_t *>(row + x0);
+            uint32_t memb = v & ~(v >> 1) & inrow;               // significant and not visited
+            while (memb) {
+                const int k = (__ffs((int)memb) - 1) >> 3, x = x0 + k;
+                memb &= memb - 1;
+                const uint32_t fv = (v >> (8 * k)) & 0xFF;
+                const int ctx = (fv & T1Refine) ? CtxMag2 : ((fv & T1HasNb) ? CtxMag1 : CtxMag0);
+                if (mq_decode(L.d, L.ent, L.mq, ctx)) atomicOr(&data[(size_t)y * w + x], bit);
+                row[x] = (uint8_t)(fv | T1Refine);
+            }
+        }
+    }
+}
+__device__ __forceinline__ void t1_dec_cleanup(T1DecLane &L, int32_t bit) {
+    const int w = L.w, h = L.h, stride = L.stride;
+    uint8_t *const flags = L.flags;
+    int32_t *const data = L.data;
+    (void)w; (void)h; (void)stride; (void)flags; (void)data;
+    for (int y = 0; y < h; y += 4)                                // t1.go:1350-1410
+        for (int x = 0; x < w; x++) {
+            bool canRL = (y + 4 <= h);
+            if (canRL)
+                for (int yy = y; yy < y + 4; yy++) {
+                    const uint8_t *f = flags + (size_t)(yy + 1) * stride + T1D_XO + x;
+                    if (*f & (T1Sig | T1Visit | T1HasNb)) { canRL = false; break; }
+                }
+            if (canRL) {
+                if (mq_decode(L.d, L.ent, L.mq, CtxRL) == 0) continue;
+                int pos = mq_decode(L.d, L.ent, L.mq, CtxUni) << 1;
+                pos |= mq_decode(L.d, L.ent, L.mq, CtxUni);
+                {
+                    uint8_t *f = flags + (size_t)(y + pos + 1) * stride + T1D_XO + x;
+                    data[(size_t)(y + pos) * w + x] = bit;
+                    dec_sign(L, f);
+                    set_significant_dec(f, stride);
+                }
+                for (int i = pos + 1; i < 4 && y + i < h; i++) {
+                    uint8_t *f = flags + (size_t)(y + i + 1) * stride + T1D_XO + x;
+                    if (mq_decode(L.d, L.ent, L.mq, L.zc[zc_packed(f, stride)])) {
+                        data[(size_t)(y + i) * w + x] = bit;
+                        dec_sign(L, f);
+                        set_significant_dec(f, stride);
+                    }
+                }
+                continue;
+            }
+            for (int yy = y; yy < y + 4 && yy < h; yy++) {
+                uint8_t *f = flags + (size_t)(yy + 1) * stride + T1D_XO + x;
+                const uint32_t fv = *f;
+                if (fv & T1Visit) { *f = (uint8_t)(fv & ~T1Visit); continue; }
+                if (fv & T1Sig) continue;
+                if (mq_decode(L.d, L.ent, L.mq, L.zc[zc_packed(f, stride)])) {
+                    data[(size_t)yy * w + x] = bit;
+                    dec_sign(L, f);
+                    set_significant_dec(f, stride);
+                }
+            }
+        }
+}
+__device__ __forceinline__ void t1_decode_passes(T1DecLane &L, int numBPS) {
     for (int bp = numBPS - 1; bp >= 0; bp--) {
         const int32_t bit = bp < 32 ? (int32_t)(1u << bp) : 0;
-        // SigProp and MagRef look at four samples per load and step from candidate to candidate with find-first-set; a
-        // sample that turns significant changes its right-hand neighbour's flags, so the group is read again after it
-        for (int y = 0; y < h; y++) {                                 // t1.go:1295-1319
-            uint8_t *const row = flags + (size_t)(y + 1) * stride + T1D_XO;
-            for (int x0 = 0; x0 < w; x0 += 4) {
-                const uint32_t inrow = x0 + 4 <= w ? 0x01010101u : (0x01010101u >> (8 * (x0 + 4 - w)));
-                uint32_t v = *reinterpret_cast<const uint32_t *>(row + x0);
-                uint32_t cand = (v >> 4) & ~v & inrow;               // bit 0 of a byte: has a significant neighbour, not significant
-                while (cand) {
-                    const int k = (__ffs((int)cand) - 1) >> 3, x = x0 + k;
-                    uint8_t *f = row + x;
-                    const bool sig = mq_decode(L.d, L.ent, L.mq, L.zc[zc_packed(f, stride)]) != 0;
-                    if (sig) {
-                        data[(size_t)y * w + x] = bit;
-                        dec_sign(L, f);
-                        set_significant_dec(f, stride);
-                    }
-                    *f |= T1Visit;
-                    const uint32_t later = k == 3 ? 0u : (0xFFFFFFFFu << (8 * (k + 1)));
-                    if (sig) {
-                        v = *reinterpret_cast<const uint32_t *>(row + x0);
-                        cand = (v >> 4) & ~v & inrow & later;
-                    } else cand &= later;
-                }
-            }
-        }
-        for (int y = 0; y < h; y++) {                                 // t1.go:1331-1347
-            uint8_t *const row = flags + (size_t)(y + 1) * stride + T1D_XO;
-            for (int x0 = 0; x0 < w; x0 += 4) {
-                const uint32_t inrow = x0 + 4 <= w ? 0x01010101u : (0x01010101u >> (8 * (x0 + 4 - w)));
-                const uint32_t v = *reinterpret_cast<const uint32_t *>(row + x0);
-                uint32_t memb = v & ~(v >> 1) & inrow;               // significant and not visited
-                while (memb) {
-                    const int k = (__ffs((int)memb) - 1) >> 3, x = x0 + k;
-                    memb &= memb - 1;
-                    const uint32_t fv = (v >> (8 * k)) & 0xFF;
-                    const int ctx = (fv & T1Refine) ? CtxMag2 : ((fv & T1HasNb) ? CtxMag1 : CtxMag0);
-                    if (mq_decode(L.d, L.ent, L.mq, ctx)) atomicOr(&data[(size_t)y * w + x], bit);
-                    row[x] = (uint8_t)(fv | T1Refine);
-                }
-            }
-        }
-        for (int y = 0; y < h; y += 4)                                // t1.go:1350-1410
-            for (int x = 0; x < w; x++) {
-                bool canRL = (y + 4 <= h);
-                if (canRL)
-                    for (int yy = y; yy < y + 4; yy++) {
-                        const uint8_t *f = flags + (size_t)(yy + 1) * stride + T1D_XO + x;
-                        if (*f & (T1Sig | T1Visit | T1HasNb)) { canRL = false; break; }
-                    }
-                if (canRL) {
-                    if (mq_decode(L.d, L.ent, L.mq, CtxRL) == 0) continue;
-                    int pos = mq_decode(L.d, L.ent, L.mq, CtxUni) << 1;
-                    pos |= mq_decode(L.d, L.ent, L.mq, CtxUni);
-                    {
-                        uint8_t *f = flags + (size_t)(y + pos + 1) * stride + T1D_XO + x;
-                        data[(size_t)(y + pos) * w + x] = bit;
-                        dec_sign(L, f);
-                        set_significant_dec(f, stride);
-                    }
-                    for (int i = pos + 1; i < 4 && y + i < h; i++) {
-                        uint8_t *f = flags + (size_t)(y + i + 1) * stride + T1D_XO + x;
-                        if (mq_decode(L.d, L.ent, L.mq, L.zc[zc_packed(f, stride)])) {
-                            data[(size_t)(y + i) * w + x] = bit;
-                            dec_sign(L, f);
-                            set_significant_dec(f, stride);
-                        }
-                    }
-                    continue;
-                }
-                for (int yy = y; yy < y + 4 && yy < h; yy++) {
-                    uint8_t *f = flags + (size_t)(yy + 1) * stride + T1D_XO + x;
-                    const uint32_t fv = *f;
-                    if (fv & T1Visit) { *f = (uint8_t)(fv & ~T1Visit); continue; }
-                    if (fv & T1Sig) continue;
-                    if (mq_decode(L.d, L.ent, L.mq, L.zc[zc_packed(f, stride)])) {
-                        data[(size_t)yy * w + x] = bit;
-                        dec_sign(L, f);
-                        set_significant_dec(f, stride);
-                    }
-                }
-            }
+        t1_dec_sigprop(L, bit);
+        t1_dec_magref(L, bit);
+        t1_dec_cleanup(L, bit);
     }
 }
 __device__ __forceinline__ void mq_dec_init(MqDec &d, const uint8_t *data, long len) {   // NewMQDecoder mqc.go:370-399
@@ -1043,6 +1061,7 @@ struct T1Dec64Shared {
     uint8_t zc[256];
     uint8_t sc[256];
     alignas(16) uint8_t flags[T1D64_FLAGS];      // doubles as the scratch the tables are built in
+    uint8_t mrctx[64];                           // MagRef: the contexts of one row's members, in coding order
 };
 static_assert(sizeof(T1Dec64Shared) <= 5632, "t1_decode64_kernel: LDS per block above 11 granules");
 __global__ __launch_bounds__(64) void t1_decode64_kernel(const BlockJob *__restrict__ jobs, int njobs, const uint8_t *__restrict__ stream,
@@ -1075,11 +1094,41 @@ __global__ __launch_bounds__(64) void t1_decode64_kernel(const BlockJob *__restr
     for (int i = lane; i < (stride * (h + 2) + 4 + 3) / 4; i += 64) reinterpret_cast<uint32_t *>(S.flags)[i] = 0;
     for (int i = lane; i < n; i += 64) out[i] = 0;
     __syncthreads();
-    if (lane == 0) {
-        T1DecLane L;
-        mq_dec_init(L.d, stream + offs[jid], (long)lens[jid]);
-        L.ent = S.ent; L.mq = S.mq; L.zc = S.zc; L.sc = S.sc; L.flags = S.flags; L.data = out; L.w = w; L.h = h; L.stride = stride;
-        t1_decode_passes(L, numbps[jid]);
+    // SigProp and Cleanup are lane 0's (every decision feeds the next context).  MagRef is not: its contexts depend only on
+    // flags that the pass does not change for OTHER samples, so per row all lanes (= columns) find the members and their
+    // contexts, lane 0 runs the MQ decoder over that short list, and all lanes apply the decisions.
+    T1DecLane L;
+    if (lane == 0) mq_dec_init(L.d, stream + offs[jid], (long)lens[jid]);
+    L.ent = S.ent; L.mq = S.mq; L.zc = S.zc; L.sc = S.sc; L.flags = S.flags; L.data = out; L.w = w; L.h = h; L.stride = stride;
+    const int numBPS = __shfl((int)numbps[jid], 0);
+    const uint64_t lt_lane = (1ull << lane) - 1;
+    for (int bp = numBPS - 1; bp >= 0; bp--) {
+        const int32_t bit = bp < 32 ? (int32_t)(1u << bp) : 0;
+        if (lane == 0) t1_dec_sigprop(L, bit);
+        __syncthreads();
+        for (int y = 0; y < h; y++) {                                 // t1.go:1331-1347
+            uint8_t *const f = S.flags + (y + 1) * stride + T1D_XO + lane;
+            const uint32_t fv = lane < w ? *f : 0u;
+            const bool member = (fv & T1Sig) && !(fv & T1Visit);
+            const uint64_t mask = __ballot(member);
+            if (mask == 0) continue;
+            const int pos = __popcll(mask & lt_lane);
+            if (member) S.mrctx[pos] = (uint8_t)((fv & T1Refine) ? CtxMag2 : ((fv & T1HasNb) ? CtxMag1 : CtxMag0));
+            __syncthreads();
+            uint64_t bits = 0;
+            if (lane == 0) {
+                const int nm = __popcll(mask);
+                for (int i = 0; i < nm; i++) bits |= (uint64_t)mq_decode(L.d, L.ent, L.mq, S.mrctx[i]) << i;
+            }
+            bits = (uint64_t)__shfl((int)(bits >> 32), 0) << 32 | (uint32_t)__shfl((int)bits, 0);
+            if (member) {
+                if ((bits >> pos) & 1) atomicOr(&out[y * w + lane], bit);
+                *f = (uint8_t)(fv | T1Refine);
+            }
+            __syncthreads();
+        }
+        if (lane == 0) t1_dec_cleanup(L, bit);
+        __syncthreads();
     }
     __syncthreads();                                                      // includes the wait for lane 0's stores and atomics
     for (int i = lane; i < n; i += 64) {                                  // t1.go:1281-1289
