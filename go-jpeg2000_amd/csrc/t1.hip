@@ -44,6 +44,7 @@ struct T1Tables {
     uint8_t sc[256];      // lutSignCtx | lutSignPred << 3 (t1_luts.go:153-230)
     uint8_t ctx[32];      // MQ context states (encoder)
     uint32_t ent[32];     // decoder: the table entry of each context's current state
+    uint8_t mrctx[64];    // decoder: the MagRef contexts of up to 64 samples of a row, in coding order
 };
 
 __device__ void build_tables(T1Tables &T, int band, int lane) {
@@ -922,28 +923,6 @@ __device__ __forceinline__ void t1_dec_sigprop(T1DecLane &L, int32_t bit) {
         }
     }
 }
-__device__ __forceinline__ void t1_dec_magref(T1DecLane &L, int32_t bit) {
-    const int w = L.w, h = L.h, stride = L.stride;
-    uint8_t *const flags = L.flags;
-    int32_t *const data = L.data;
-    (void)w; (void)h; (void)stride; (void)flags; (void)data;
-    for (int y = 0; y < h; y++) {                                 // t1.go:1331-1347
-        uint8_t *const row = flags + (size_t)(y + 1) * stride + T1D_XO;
-        for (int x0 = 0; x0 < w; x0 += 4) {
-            const uint32_t inrow = x0 + 4 <= w ? 0x01010101u : (0x01010101u >> (8 * (x0 + 4 - w)));
-            const uint32_t v = *reinterpret_cast<const uint32_t *>(row + x0);
-            uint32_t memb = v & ~(v >> 1) & inrow;               // significant and not visited
-            while (memb) {
-                const int k = (__ffs((int)memb) - 1) >> 3, x = x0 + k;
-                memb &= memb - 1;
-                const uint32_t fv = (v >> (8 * k)) & 0xFF;
-                const int ctx = (fv & T1Refine) ? CtxMag2 : ((fv & T1HasNb) ? CtxMag1 : CtxMag0);
-                if (mq_decode(L.d, L.ent, L.mq, ctx)) atomicOr(&data[(size_t)y * w + x], bit);
-                row[x] = (uint8_t)(fv | T1Refine);
-            }
-        }
-    }
-}
 __device__ __forceinline__ void t1_dec_cleanup(T1DecLane &L, int32_t bit) {
     const int w = L.w, h = L.h, stride = L.stride;
     uint8_t *const flags = L.flags;
@@ -990,12 +969,45 @@ __device__ __forceinline__ void t1_dec_cleanup(T1DecLane &L, int32_t bit) {
             }
         }
 }
-__device__ __forceinline__ void t1_decode_passes(T1DecLane &L, int numBPS) {
+// MagRef by the whole wavefront (t1.go:1331-1347).  Its contexts depend only on flags that the pass does not change for
+// OTHER samples, so it is not a serial pass: per row (64 columns at a time) all lanes find the members and their contexts,
+// lane 0 runs the MQ decoder over that short list, and all lanes apply the decisions.  L.d is lane 0's decoder.
+__device__ __forceinline__ void t1_dec_magref_wave(T1DecLane &L, int32_t bit, uint8_t *mrctx, int lane) {
+    const int w = L.w, h = L.h, stride = L.stride;
+    const uint64_t lt_lane = (1ull << lane) - 1;
+    for (int y = 0; y < h; y++)
+        for (int x0 = 0; x0 < w; x0 += 64) {
+            const int x = x0 + lane;
+            uint8_t *const f = L.flags + (size_t)(y + 1) * stride + T1D_XO + x;
+            const uint32_t fv = x < w ? *f : 0u;
+            const bool member = (fv & T1Sig) && !(fv & T1Visit);
+            const uint64_t mask = __ballot(member);
+            if (mask == 0) continue;
+            const int pos = __popcll(mask & lt_lane);
+            if (member) mrctx[pos] = (uint8_t)((fv & T1Refine) ? CtxMag2 : ((fv & T1HasNb) ? CtxMag1 : CtxMag0));
+            __syncthreads();
+            uint64_t bits = 0;
+            if (lane == 0) {
+                const int nm = __popcll(mask);
+                for (int i = 0; i < nm; i++) bits |= (uint64_t)mq_decode(L.d, L.ent, L.mq, mrctx[i]) << i;
+            }
+            bits = (uint64_t)__shfl((int)(bits >> 32), 0) << 32 | (uint32_t)__shfl((int)bits, 0);
+            if (member) {
+                if ((bits >> pos) & 1) atomicOr(&L.data[(size_t)y * w + x], bit);
+                *f = (uint8_t)(fv | T1Refine);
+            }
+            __syncthreads();
+        }
+}
+// One block, one wavefront: SigProp and Cleanup on lane 0, MagRef by all lanes.  All lanes call this.
+__device__ __forceinline__ void t1_decode_block_wave(T1DecLane &L, int numBPS, uint8_t *mrctx, int lane) {
     for (int bp = numBPS - 1; bp >= 0; bp--) {
         const int32_t bit = bp < 32 ? (int32_t)(1u << bp) : 0;
-        t1_dec_sigprop(L, bit);
-        t1_dec_magref(L, bit);
-        t1_dec_cleanup(L, bit);
+        if (lane == 0) t1_dec_sigprop(L, bit);
+        __syncthreads();
+        t1_dec_magref_wave(L, bit, mrctx, lane);
+        if (lane == 0) t1_dec_cleanup(L, bit);
+        __syncthreads();
     }
 }
 __device__ __forceinline__ void mq_dec_init(MqDec &d, const uint8_t *data, long len) {   // NewMQDecoder mqc.go:370-399
@@ -1033,13 +1045,13 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(const BlockJob *__restric
     __syncthreads();
     init_dec_contexts(T, lane);
     __syncthreads();
-    if (lane == 0) {
+    {
         T1DecLane L;
-        mq_dec_init(L.d, stream + offs[jid], (long)lens[jid]);
+        if (lane == 0) mq_dec_init(L.d, stream + offs[jid], (long)lens[jid]);
         L.ent = T.ent; L.mq = T.mq; L.zc = T.zc; L.sc = T.sc; L.flags = flags; L.data = out; L.w = w; L.h = h; L.stride = stride;
-        t1_decode_passes(L, numbps[jid]);
+        t1_decode_block_wave(L, __shfl((int)numbps[jid], 0), T.mrctx, lane);
     }
-    __syncthreads();                                                      // includes the wait for lane 0's stores and atomics
+    __syncthreads();                                                      // includes the wait for the stores and atomics above
     for (size_t i = lane; i < n; i += 64) {                               // t1.go:1281-1289
         if (!(flags[(i / w + 1) * stride + T1D_XO + (i % w)] & T1SignNeg)) continue;
         const int v = __hip_atomic_load(&out[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // L2, not this CU's L1
@@ -1094,41 +1106,11 @@ __global__ __launch_bounds__(64) void t1_decode64_kernel(const BlockJob *__restr
     for (int i = lane; i < (stride * (h + 2) + 4 + 3) / 4; i += 64) reinterpret_cast<uint32_t *>(S.flags)[i] = 0;
     for (int i = lane; i < n; i += 64) out[i] = 0;
     __syncthreads();
-    // SigProp and Cleanup are lane 0's (every decision feeds the next context).  MagRef is not: its contexts depend only on
-    // flags that the pass does not change for OTHER samples, so per row all lanes (= columns) find the members and their
-    // contexts, lane 0 runs the MQ decoder over that short list, and all lanes apply the decisions.
-    T1DecLane L;
-    if (lane == 0) mq_dec_init(L.d, stream + offs[jid], (long)lens[jid]);
-    L.ent = S.ent; L.mq = S.mq; L.zc = S.zc; L.sc = S.sc; L.flags = S.flags; L.data = out; L.w = w; L.h = h; L.stride = stride;
-    const int numBPS = __shfl((int)numbps[jid], 0);
-    const uint64_t lt_lane = (1ull << lane) - 1;
-    for (int bp = numBPS - 1; bp >= 0; bp--) {
-        const int32_t bit = bp < 32 ? (int32_t)(1u << bp) : 0;
-        if (lane == 0) t1_dec_sigprop(L, bit);
-        __syncthreads();
-        for (int y = 0; y < h; y++) {                                 // t1.go:1331-1347
-            uint8_t *const f = S.flags + (y + 1) * stride + T1D_XO + lane;
-            const uint32_t fv = lane < w ? *f : 0u;
-            const bool member = (fv & T1Sig) && !(fv & T1Visit);
-            const uint64_t mask = __ballot(member);
-            if (mask == 0) continue;
-            const int pos = __popcll(mask & lt_lane);
-            if (member) S.mrctx[pos] = (uint8_t)((fv & T1Refine) ? CtxMag2 : ((fv & T1HasNb) ? CtxMag1 : CtxMag0));
-            __syncthreads();
-            uint64_t bits = 0;
-            if (lane == 0) {
-                const int nm = __popcll(mask);
-                for (int i = 0; i < nm; i++) bits |= (uint64_t)mq_decode(L.d, L.ent, L.mq, S.mrctx[i]) << i;
-            }
-            bits = (uint64_t)__shfl((int)(bits >> 32), 0) << 32 | (uint32_t)__shfl((int)bits, 0);
-            if (member) {
-                if ((bits >> pos) & 1) atomicOr(&out[y * w + lane], bit);
-                *f = (uint8_t)(fv | T1Refine);
-            }
-            __syncthreads();
-        }
-        if (lane == 0) t1_dec_cleanup(L, bit);
-        __syncthreads();
+    {
+        T1DecLane L;                                              // SigProp and Cleanup on lane 0, MagRef by all lanes
+        if (lane == 0) mq_dec_init(L.d, stream + offs[jid], (long)lens[jid]);
+        L.ent = S.ent; L.mq = S.mq; L.zc = S.zc; L.sc = S.sc; L.flags = S.flags; L.data = out; L.w = w; L.h = h; L.stride = stride;
+        t1_decode_block_wave(L, __shfl((int)numbps[jid], 0), S.mrctx, lane);
     }
     __syncthreads();                                                      // includes the wait for lane 0's stores and atomics
     for (int i = lane; i < n; i += 64) {                                  // t1.go:1281-1289
