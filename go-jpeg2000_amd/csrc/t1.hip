@@ -891,84 +891,6 @@ __device__ __forceinline__ void dec_sign(T1DecLane &L, uint8_t *f) {   // t1.go:
     const uint32_t sc = L.sc[sc_index(f[-1], f[1], f[-L.stride], f[L.stride])];
     if (mq_decode(L.d, L.ent, L.mq, CtxSC0 + (sc & 7)) ^ (int)(sc >> 3)) *f |= T1SignNeg;
 }
-__device__ __forceinline__ void t1_dec_sigprop(T1DecLane &L, int32_t bit) {
-    const int w = L.w, h = L.h, stride = L.stride;
-    uint8_t *const flags = L.flags;
-    int32_t *const data = L.data;
-    (void)w; (void)h; (void)stride; (void)flags; (void)data;
-    // SigProp and MagRef look at four samples per load and step from candidate to candidate with find-first-set; a
-    // sample that turns significant changes its right-hand neighbour's flags, so the group is read again after it
-    for (int y = 0; y < h; y++) {                                 // t1.go:1295-1319
-        uint8_t *const row = flags + (size_t)(y + 1) * stride + T1D_XO;
-        for (int x0 = 0; x0 < w; x0 += 4) {
-            const uint32_t inrow = x0 + 4 <= w ? 0x01010101u : (0x01010101u >> (8 * (x0 + 4 - w)));
-            uint32_t v = *reinterpret_cast<const uint32_t *>(row + x0);
-            uint32_t cand = (v >> 4) & ~v & inrow;               // bit 0 of a byte: has a significant neighbour, not significant
-            while (cand) {
-                const int k = (__ffs((int)cand) - 1) >> 3, x = x0 + k;
-                uint8_t *f = row + x;
-                const bool sig = mq_decode(L.d, L.ent, L.mq, L.zc[zc_packed(f, stride)]) != 0;
-                if (sig) {
-                    data[(size_t)y * w + x] = bit;
-                    dec_sign(L, f);
-                    set_significant_dec(f, stride);
-                }
-                *f |= T1Visit;
-                const uint32_t later = k == 3 ? 0u : (0xFFFFFFFFu << (8 * (k + 1)));
-                if (sig) {
-                    v = *reinterpret_cast<const uint32_t *>(row + x0);
-                    cand = (v >> 4) & ~v & inrow & later;
-                } else cand &= later;
-            }
-        }
-    }
-}
-__device__ __forceinline__ void t1_dec_cleanup(T1DecLane &L, int32_t bit) {
-    const int w = L.w, h = L.h, stride = L.stride;
-    uint8_t *const flags = L.flags;
-    int32_t *const data = L.data;
-    (void)w; (void)h; (void)stride; (void)flags; (void)data;
-    for (int y = 0; y < h; y += 4)                                // t1.go:1350-1410
-        for (int x = 0; x < w; x++) {
-            bool canRL = (y + 4 <= h);
-            if (canRL)
-                for (int yy = y; yy < y + 4; yy++) {
-                    const uint8_t *f = flags + (size_t)(yy + 1) * stride + T1D_XO + x;
-                    if (*f & (T1Sig | T1Visit | T1HasNb)) { canRL = false; break; }
-                }
-            if (canRL) {
-                if (mq_decode(L.d, L.ent, L.mq, CtxRL) == 0) continue;
-                int pos = mq_decode(L.d, L.ent, L.mq, CtxUni) << 1;
-                pos |= mq_decode(L.d, L.ent, L.mq, CtxUni);
-                {
-                    uint8_t *f = flags + (size_t)(y + pos + 1) * stride + T1D_XO + x;
-                    data[(size_t)(y + pos) * w + x] = bit;
-                    dec_sign(L, f);
-                    set_significant_dec(f, stride);
-                }
-                for (int i = pos + 1; i < 4 && y + i < h; i++) {
-                    uint8_t *f = flags + (size_t)(y + i + 1) * stride + T1D_XO + x;
-                    if (mq_decode(L.d, L.ent, L.mq, L.zc[zc_packed(f, stride)])) {
-                        data[(size_t)(y + i) * w + x] = bit;
-                        dec_sign(L, f);
-                        set_significant_dec(f, stride);
-                    }
-                }
-                continue;
-            }
-            for (int yy = y; yy < y + 4 && yy < h; yy++) {
-                uint8_t *f = flags + (size_t)(yy + 1) * stride + T1D_XO + x;
-                const uint32_t fv = *f;
-                if (fv & T1Visit) { *f = (uint8_t)(fv & ~T1Visit); continue; }
-                if (fv & T1Sig) continue;
-                if (mq_decode(L.d, L.ent, L.mq, L.zc[zc_packed(f, stride)])) {
-                    data[(size_t)yy * w + x] = bit;
-                    dec_sign(L, f);
-                    set_significant_dec(f, stride);
-                }
-            }
-        }
-}
 // MagRef by the whole wavefront (t1.go:1331-1347).  Its contexts depend only on flags that the pass does not change for
 // OTHER samples, so it is not a serial pass: per row (64 columns at a time) all lanes find the members and their contexts,
 // lane 0 runs the MQ decoder over that short list, and all lanes apply the decisions.  L.d is lane 0's decoder.
@@ -999,15 +921,105 @@ __device__ __forceinline__ void t1_dec_magref_wave(T1DecLane &L, int32_t bit, ui
             __syncthreads();
         }
 }
-// One block, one wavefront: SigProp and Cleanup on lane 0, MagRef by all lanes.  All lanes call this.
+// SigProp (t1.go:1295-1319) with the scan done by all lanes: per row (64 columns at a time) a ballot gives the candidates
+// (not significant, a significant neighbour); lane 0 decodes them in order and, when a sample turns significant, adds its
+// right-hand neighbour to the set if that one is not significant (the row below is scanned later and sees it anyway).
+__device__ __forceinline__ void t1_dec_sigprop_wave(T1DecLane &L, int32_t bit, int lane) {
+    const int w = L.w, h = L.h, stride = L.stride;
+    for (int y = 0; y < h; y++)
+        for (int x0 = 0; x0 < w; x0 += 64) {
+            uint8_t *const row = L.flags + (size_t)(y + 1) * stride + T1D_XO + x0;
+            const uint32_t fv = x0 + lane < w ? row[lane] : (uint32_t)T1Sig;
+            uint64_t m = __ballot((fv & (T1Sig | T1HasNb)) == T1HasNb);
+            if (m == 0) continue;
+            if (lane == 0) {
+                while (m) {
+                    const int xi = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    uint8_t *f = row + xi;
+                    if (mq_decode(L.d, L.ent, L.mq, L.zc[zc_packed(f, stride)])) {
+                        L.data[(size_t)y * w + x0 + xi] = bit;
+                        dec_sign(L, f);
+                        set_significant_dec(f, stride);
+                        if (xi < 63 && x0 + xi + 1 < w && !(f[1] & T1Sig)) m |= 2ull << xi;
+                    }
+                    *f |= T1Visit;
+                }
+            }
+            __syncthreads();
+        }
+}
+// Cleanup (t1.go:1350-1410) with the classification done by all lanes: per 4-row stripe (64 columns at a time) every lane
+// looks at its column -- which rows are members (neither significant nor visited), is the column eligible for the
+// run-length symbol -- clears the visit flags and leaves one byte per column; lane 0 then walks only the columns that
+// have a member.  A column's run-length eligibility can be lost to a sample of the column before it that turns
+// significant in this very stripe: that one case is re-checked from the flags.
+__device__ __forceinline__ void t1_dec_cleanup_wave(T1DecLane &L, int32_t bit, uint8_t *colinfo, int lane) {
+    const int w = L.w, h = L.h, stride = L.stride;
+    int last_sig = -2;
+    for (int y = 0; y < h; y += 4)
+        for (int x0 = 0; x0 < w; x0 += 64) {
+            const int x = x0 + lane;
+            uint32_t m4 = 0, any = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (x < w && y + i < h) {
+                    uint8_t *f = L.flags + (size_t)(y + i + 1) * stride + T1D_XO + x;
+                    const uint32_t fv = *f;
+                    any |= fv;
+                    if (!(fv & (T1Sig | T1Visit))) m4 |= 1u << i;
+                    if (fv & T1Visit) *f = (uint8_t)(fv & ~T1Visit);
+                }
+            }
+            const bool clean = x < w && y + 4 <= h && !(any & (T1Sig | T1Visit | T1HasNb));
+            colinfo[lane] = (uint8_t)(m4 | (clean ? 16u : 0u));
+            uint64_t work = __ballot(m4 != 0);
+            if (work == 0) continue;
+            __syncthreads();
+            if (lane == 0) {
+                while (work) {
+                    const int xi = __ffsll((long long)work) - 1, xx = x0 + xi;
+                    work &= work - 1;
+                    const uint32_t info = colinfo[xi];
+                    const uint32_t mem = info & 15u;
+                    bool canRL = (info & 16u) != 0;
+                    if (canRL && last_sig == xx - 1)
+                        for (int i = 0; i < 4; i++)
+                            if (L.flags[(size_t)(y + i + 1) * stride + T1D_XO + xx] & T1HasNb) canRL = false;
+                    int first = 0;
+                    if (canRL) {
+                        if (mq_decode(L.d, L.ent, L.mq, CtxRL) == 0) continue;
+                        int pos = mq_decode(L.d, L.ent, L.mq, CtxUni) << 1;
+                        pos |= mq_decode(L.d, L.ent, L.mq, CtxUni);
+                        uint8_t *f = L.flags + (size_t)(y + pos + 1) * stride + T1D_XO + xx;
+                        L.data[(size_t)(y + pos) * w + xx] = bit;
+                        dec_sign(L, f);
+                        set_significant_dec(f, stride);
+                        last_sig = xx;
+                        first = pos + 1;
+                    }
+                    for (int i = first; i < 4; i++) {
+                        if (!((mem >> i) & 1)) continue;
+                        uint8_t *f = L.flags + (size_t)(y + i + 1) * stride + T1D_XO + xx;
+                        if (mq_decode(L.d, L.ent, L.mq, L.zc[zc_packed(f, stride)])) {
+                            L.data[(size_t)(y + i) * w + xx] = bit;
+                            dec_sign(L, f);
+                            set_significant_dec(f, stride);
+                            last_sig = xx;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+}
+// One block, one wavefront; all lanes call this.  Only the MQ decisions and what depends on them run on lane 0.
 __device__ __forceinline__ void t1_decode_block_wave(T1DecLane &L, int numBPS, uint8_t *mrctx, int lane) {
     for (int bp = numBPS - 1; bp >= 0; bp--) {
         const int32_t bit = bp < 32 ? (int32_t)(1u << bp) : 0;
-        if (lane == 0) t1_dec_sigprop(L, bit);
-        __syncthreads();
+        t1_dec_sigprop_wave(L, bit, lane);
         t1_dec_magref_wave(L, bit, mrctx, lane);
-        if (lane == 0) t1_dec_cleanup(L, bit);
-        __syncthreads();
+        t1_dec_cleanup_wave(L, bit, mrctx, lane);
     }
 }
 __device__ __forceinline__ void mq_dec_init(MqDec &d, const uint8_t *data, long len) {   // NewMQDecoder mqc.go:370-399
@@ -1107,7 +1119,7 @@ __global__ __launch_bounds__(64) void t1_decode64_kernel(const BlockJob *__restr
     for (int i = lane; i < n; i += 64) out[i] = 0;
     __syncthreads();
     {
-        T1DecLane L;                                              // SigProp and Cleanup on lane 0, MagRef by all lanes
+        T1DecLane L;                                              // L.d is lane 0's decoder
         if (lane == 0) mq_dec_init(L.d, stream + offs[jid], (long)lens[jid]);
         L.ent = S.ent; L.mq = S.mq; L.zc = S.zc; L.sc = S.sc; L.flags = S.flags; L.data = out; L.w = w; L.h = h; L.stride = stride;
         t1_decode_block_wave(L, __shfl((int)numbps[jid], 0), S.mrctx, lane);
