@@ -44,7 +44,7 @@ struct T1Tables {
     uint8_t sc[256];      // lutSignCtx | lutSignPred << 3 (t1_luts.go:153-230)
     uint8_t ctx[32];      // MQ context states (encoder)
     uint32_t ent[32];     // decoder: the table entry of each context's current state
-    uint8_t mrctx[64];    // decoder: the MagRef contexts of up to 64 samples of a row, in coding order
+    uint8_t mrctx[128];   // decoder: per-column context lists of the wave-level passes (two of 64 bytes)
 };
 
 __device__ void build_tables(T1Tables &T, int band, int lane) {
@@ -921,30 +921,63 @@ __device__ __forceinline__ void t1_dec_magref_wave(T1DecLane &L, int32_t bit, ui
             __syncthreads();
         }
 }
-// SigProp (t1.go:1295-1319) with the scan done by all lanes: per row (64 columns at a time) a ballot gives the candidates
-// (not significant, a significant neighbour); lane 0 decodes them in order and, when a sample turns significant, adds its
-// right-hand neighbour to the set if that one is not significant (the row below is scanned later and sees it anyway).
-__device__ __forceinline__ void t1_dec_sigprop_wave(T1DecLane &L, int32_t bit, int lane) {
+// SigProp (t1.go:1295-1319).  Per row (64 columns at a time) all lanes find the candidates (not significant, a significant
+// neighbour) with a ballot and compute, for every sample that is not significant yet, its ZC and sign context INDICES
+// from the flags.  Inside the row those can only be changed by the left-hand neighbour turning significant, which lane 0
+// knows: it walks the candidates touching no flag at all -- index from the list, patch the W bits, decode, keep the new
+// significances / signs / visits as three 64-bit masks -- and adds the right-hand neighbour of a sample that turns
+// significant to the candidates.  All lanes then write the row's flags, the neighbour bits of the rows above and below and
+// the magnitudes from the masks.
+__device__ __forceinline__ void t1_dec_sigprop_wave(T1DecLane &L, int32_t bit, uint8_t *zcl, uint8_t *scl, int lane) {
     const int w = L.w, h = L.h, stride = L.stride;
     for (int y = 0; y < h; y++)
         for (int x0 = 0; x0 < w; x0 += 64) {
             uint8_t *const row = L.flags + (size_t)(y + 1) * stride + T1D_XO + x0;
-            const uint32_t fv = x0 + lane < w ? row[lane] : (uint32_t)T1Sig;
+            uint8_t *const f = row + lane;
+            const bool inb = x0 + lane < w;
+            const uint32_t fv = inb ? *f : (uint32_t)T1Sig;
+            const uint64_t sigmask = __ballot((fv & T1Sig) != 0);
             uint64_t m = __ballot((fv & (T1Sig | T1HasNb)) == T1HasNb);
             if (m == 0) continue;
+            if (!(fv & T1Sig)) {
+                zcl[lane] = (uint8_t)zc_packed(f, stride);
+                scl[lane] = (uint8_t)sc_index(f[-1], f[1], f[-stride], f[stride]);
+            }
+            __syncthreads();
+            uint64_t newsig = 0, newneg = 0, vis = 0;
             if (lane == 0) {
                 while (m) {
                     const int xi = __ffsll((long long)m) - 1;
                     m &= m - 1;
-                    uint8_t *f = row + xi;
-                    if (mq_decode(L.d, L.ent, L.mq, L.zc[zc_packed(f, stride)])) {
-                        L.data[(size_t)y * w + x0 + xi] = bit;
-                        dec_sign(L, f);
-                        set_significant_dec(f, stride);
-                        if (xi < 63 && x0 + xi + 1 < w && !(f[1] & T1Sig)) m |= 2ull << xi;
+                    const uint64_t bx = 1ull << xi;
+                    const uint32_t wnew = xi > 0 ? (uint32_t)(newsig >> (xi - 1)) & 1u : 0u;   // (column x0 - 1: already in the flags)
+                    vis |= bx;
+                    if (mq_decode(L.d, L.ent, L.mq, L.zc[zcl[xi] | wnew])) {
+                        uint32_t sci = scl[xi];
+                        if (wnew) sci |= 1u | ((uint32_t)(newneg >> (xi - 1)) & 1u) << 1;
+                        const uint32_t sc = L.sc[sci];
+                        const uint64_t neg = (uint64_t)(mq_decode(L.d, L.ent, L.mq, CtxSC0 + (sc & 7)) ^ (int)(sc >> 3));
+                        newsig |= bx;
+                        newneg |= neg << xi;
+                        if (xi < 63 && x0 + xi + 1 < w && !((sigmask >> (xi + 1)) & 1)) m |= bx << 1;
                     }
-                    *f |= T1Visit;
                 }
+            }
+            newsig = (uint64_t)__shfl((int)(newsig >> 32), 0) << 32 | (uint32_t)__shfl((int)newsig, 0);
+            newneg = (uint64_t)__shfl((int)(newneg >> 32), 0) << 32 | (uint32_t)__shfl((int)newneg, 0);
+            vis = (uint64_t)__shfl((int)(vis >> 32), 0) << 32 | (uint32_t)__shfl((int)vis, 0);
+            if (inb) {
+                const uint32_t me = (uint32_t)(newsig >> lane) & 1u;
+                const uint64_t side = (newsig << 1) | (newsig >> 1);
+                uint32_t nf = fv | (((vis >> lane) & 1) ? T1Visit : 0u) | (me ? T1Sig : 0u) | (((newneg >> lane) & 1) ? T1SignNeg : 0u) |
+                              (((side >> lane) & 1) ? T1HasNb : 0u);
+                if (nf != fv) *f = (uint8_t)nf;
+                if (((side | newsig) >> lane) & 1) { f[-stride] |= T1HasNb; f[stride] |= T1HasNb; }
+                if (me) L.data[(size_t)y * w + x0 + lane] = bit;
+            }
+            if (lane == 0) {                         // the columns next to the chunk (border, or the neighbouring chunk)
+                if (newsig & 1) { row[-1] |= T1HasNb; row[-1 - stride] |= T1HasNb; row[-1 + stride] |= T1HasNb; }
+                if (newsig >> 63) { row[64] |= T1HasNb; row[64 - stride] |= T1HasNb; row[64 + stride] |= T1HasNb; }
             }
             __syncthreads();
         }
@@ -1017,7 +1050,7 @@ __device__ __forceinline__ void t1_dec_cleanup_wave(T1DecLane &L, int32_t bit, u
 __device__ __forceinline__ void t1_decode_block_wave(T1DecLane &L, int numBPS, uint8_t *mrctx, int lane) {
     for (int bp = numBPS - 1; bp >= 0; bp--) {
         const int32_t bit = bp < 32 ? (int32_t)(1u << bp) : 0;
-        t1_dec_sigprop_wave(L, bit, lane);
+        t1_dec_sigprop_wave(L, bit, mrctx, mrctx + 64, lane);
         t1_dec_magref_wave(L, bit, mrctx, lane);
         t1_dec_cleanup_wave(L, bit, mrctx, lane);
     }
@@ -1085,7 +1118,7 @@ struct T1Dec64Shared {
     uint8_t zc[256];
     uint8_t sc[256];
     alignas(16) uint8_t flags[T1D64_FLAGS];      // doubles as the scratch the tables are built in
-    uint8_t mrctx[64];                           // MagRef: the contexts of one row's members, in coding order
+    uint8_t mrctx[128];                          // per-column context lists of the wave-level passes (two of 64 bytes)
 };
 static_assert(sizeof(T1Dec64Shared) <= 5632, "t1_decode64_kernel: LDS per block above 11 granules");
 __global__ __launch_bounds__(64) void t1_decode64_kernel(const BlockJob *__restrict__ jobs, int njobs, const uint8_t *__restrict__ stream,
