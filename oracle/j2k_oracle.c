@@ -1605,3 +1605,99 @@ long orc_encode_tile_blocks(int32_t *const *planes, int ncomp, int w, int h,
     free(jobs);
     return status < 0 ? status : (long)total;
 }
+
+/* ======================================================================== */
+/* Pins: the oracle's internals exposed at the granularity the reference's   */
+/* OWN unit tests probe (internal/entropy/coverage_test.go, t1_test.go), so  */
+/* that every numeric vector those tests hold is reproduced by               */
+/* tests/test_oracle_reference_pins.py.  Test infrastructure only.           */
+/* ======================================================================== */
+
+/* mqByteOutLocal(buf, bp, c) -> (bp, c, ct)   t1_fast.go:11-34
+ * == mqByteOutCommon / mqByteOutRare          mq_inline.go:103-134 */
+void orc_pin_mq_byte_out(uint8_t *buf, size_t buflen, long bp, uint32_t c,
+                         long *bp_out, uint32_t *c_out, uint32_t *ct_out) {
+    mq_enc e;
+    e.A = 0x8000; e.C = c; e.CT = 0; e.buf = buf; e.cap = buflen + 1; e.bp = (size_t)bp; e.overflow = 0;
+    mq_byte_out(&e);
+    *bp_out = (long)e.bp; *c_out = e.C; *ct_out = e.CT;
+}
+/* mqNeedsSlowPath   mq_inline.go:96-98 */
+int orc_pin_mq_needs_slow_path(uint8_t buf_byte, uint32_t c) { return buf_byte == 0xFF || (c & 0x8000000u) != 0; }
+
+/* MQDecoder.byteIn on an explicit state   mqc.go:402-439 (endCounter counts the 0xFF00 feeds) */
+void orc_pin_mq_byte_in(const uint8_t *data, long len, long *bp, uint32_t *C, uint32_t *CT, int *end_counter) {
+    mq_dec d; memset(&d, 0, sizeof d);
+    d.data = data; d.len = len; d.bp = *bp; d.C = *C; d.CT = *CT; d.A = 0x8000;
+    const uint32_t c0 = d.C; const long bp0 = d.bp < 0 ? 0 : d.bp;
+    mq_byte_in(&d);
+    /* the two branches that feed 0xFF00 are the ones that bump endCounter (mqc.go:410-412, 425-428) */
+    if (d.bp == bp0 && d.C == c0 + 0xFF00u && d.CT == 8) (*end_counter)++;
+    *bp = d.bp; *C = d.C; *CT = d.CT;
+}
+
+/* getSignContextParams   mq_inline.go:26-65.  NOT on the hot path (lutSC is never read by the coders); restated
+ * only because coverage_test.go:961-1008 pins its values -- including its 10/11/12/14 constants, which are not
+ * CtxSC0..4 (= 9..13). */
+void orc_pin_sign_context_params(int hc, int vc, int *ctx, int *xorbit) {
+    int x = 0;
+    if (hc < 0) { x = 1; hc = -hc; }
+    if (hc == 0 && vc < 0) { x = 1; vc = -vc; }
+    if (hc > 1) hc = 1;
+    if (vc < 0) vc = -vc;
+    if (vc > 1) vc = 1;
+    if (hc == 1) *ctx = vc == 1 ? 14 : 12;
+    else if (hc == 0) *ctx = vc == 0 ? 10 : 11;
+    else *ctx = 10;
+    *xorbit = x;
+}
+/* getSignContrib / clampContrib   mq_inline.go:70-91 */
+int orc_pin_sign_contrib(int flag) { return (flag & T1Sig) == 0 ? 0 : ((flag & T1SignNeg) ? -1 : 1); }
+int orc_pin_clamp_contrib(int c) { return c < -2 ? -2 : (c > 2 ? 2 : c); }
+/* lutSCCtx[(hc+2)*5 + (vc+2)] = (ctx << 1) | pred   t1_luts.go:112-150 (getSCContextFast :240-258 clamps first) */
+int orc_pin_lut_sc_ctx(int hc, int vc) {
+    hc = orc_pin_clamp_contrib(hc); vc = orc_pin_clamp_contrib(vc);
+    int h = hc, v = vc, pred = 0, ctx = 0;
+    if (h < 0) { pred = 1; h = -h; }
+    if (h == 0 && v < 0) { pred = 1; v = -v; }
+    if (h == 1) ctx = v == 1 ? CtxSC0 + 4 : (v == 0 ? CtxSC0 + 2 : CtxSC0 + 1);
+    else if (h == 0) ctx = v == 1 ? CtxSC0 + 1 : (v == 0 ? CtxSC0 : 0);
+    else if (h == 2) ctx = CtxSC0 + 3;
+    return (ctx << 1) | pred;
+}
+
+/* Flag-array helpers on a caller-owned (w+2)*(h+2) array, as NewT1(w,h).flags (t1.go:94-122, flagIndex :307-309). */
+static uint8_t *pin_at(uint8_t *flags, int w, int x, int y) { return flags + (size_t)(y + 1) * (size_t)(w + 2) + x + 1; }
+/* updateNeighborFlags   t1.go:328-345 == setSignificant's neighbour part, t1_fast5.go:233-245 */
+void orc_pin_update_neighbor_flags(uint8_t *flags, int w, int h, int x, int y) {
+    t1_state t; t.w = w; t.h = h; t.stride = w + 2; t.band = 0; t.data = NULL; t.flags = flags;
+    uint8_t *f = pin_at(flags, w, x, y);
+    const uint8_t keep = *f;
+    set_significant(&t, f, x, y);
+    *f = keep;                        /* updateNeighborFlags does not touch the sample's own T1Sig */
+}
+int orc_pin_has_sig_neighbor(uint8_t *flags, int w, int h, int x, int y) {          /* t1.go:1087-1092 */
+    (void)h; return has_sig_neighbor(pin_at(flags, w, x, y), w + 2);
+}
+int orc_pin_mr_context(uint8_t *flags, int w, int h, int x, int y) {                /* t1.go:463-479 */
+    (void)h; return mr_context(pin_at(flags, w, x, y), w + 2);
+}
+int orc_pin_zc_context(uint8_t *flags, int w, int h, int x, int y, int band) {      /* t1.go:312-384 == LUT t1_luts.go:34-110 */
+    (void)h; init_tables(); return lutZCCtx[band * 256 + zc_packed(pin_at(flags, w, x, y), w + 2)];
+}
+void orc_pin_sc_context(uint8_t *flags, int w, int h, int x, int y, int *ctx, int *pred) { /* t1.go:387-460 */
+    (void)h; init_tables();
+    uint8_t *f = pin_at(flags, w, x, y);
+    const int s = w + 2, sci = sc_index(f[-1], f[1], f[-s], f[s]);
+    *ctx = lutSignCtx[sci] + CtxSC0; *pred = lutSignPred[sci];
+}
+/* canUseRunLength(x, y, bp)   t1.go:1195-1208 == canUseRunLengthInlined :774-813 == the test inside orc_t1_encode */
+int orc_pin_can_use_run_length(uint8_t *flags, int w, int h, int x, int y) {
+    if (y + 4 > h) return 0;
+    for (int yy = 0; yy < 4; yy++) {
+        uint8_t *f = pin_at(flags, w, x, y + yy);
+        if (*f & (T1Sig | T1Visit)) return 0;
+        if (has_sig_neighbor(f, w + 2)) return 0;
+    }
+    return 1;
+}

@@ -128,6 +128,23 @@ long orc_encode_tile_blocks(int32_t *const *planes, int ncomp, int w, int h,
                             int num_resolutions, int cb_w, int cb_h, int coder,
                             uint8_t *out, size_t cap, uint32_t *lens, uint8_t *numbps);
 
+/* ---- pins: internals at the granularity of the reference's own unit tests ------------
+ * (internal/entropy/coverage_test.go, t1_test.go; tests/test_oracle_reference_pins.py) */
+void orc_pin_mq_byte_out(uint8_t *buf, size_t buflen, long bp, uint32_t c,
+                         long *bp_out, uint32_t *c_out, uint32_t *ct_out);          /* t1_fast.go:11-34 */
+int orc_pin_mq_needs_slow_path(uint8_t buf_byte, uint32_t c);                        /* mq_inline.go:96-98 */
+void orc_pin_mq_byte_in(const uint8_t *data, long len, long *bp, uint32_t *C, uint32_t *CT, int *end_counter); /* mqc.go:402-439 */
+void orc_pin_sign_context_params(int hc, int vc, int *ctx, int *xorbit);             /* mq_inline.go:26-65 (dead code) */
+int orc_pin_sign_contrib(int flag);                                                  /* mq_inline.go:70-78 */
+int orc_pin_clamp_contrib(int c);                                                    /* mq_inline.go:83-91 */
+int orc_pin_lut_sc_ctx(int hc, int vc);                                              /* t1_luts.go:112-150, 240-258 */
+void orc_pin_update_neighbor_flags(uint8_t *flags, int w, int h, int x, int y);      /* t1.go:328-345 */
+int orc_pin_has_sig_neighbor(uint8_t *flags, int w, int h, int x, int y);            /* t1.go:1087-1092 */
+int orc_pin_mr_context(uint8_t *flags, int w, int h, int x, int y);                  /* t1.go:463-479 */
+int orc_pin_zc_context(uint8_t *flags, int w, int h, int x, int y, int band);        /* t1.go:312-384 */
+void orc_pin_sc_context(uint8_t *flags, int w, int h, int x, int y, int *ctx, int *pred); /* t1.go:387-460 */
+int orc_pin_can_use_run_length(uint8_t *flags, int w, int h, int x, int y);          /* t1.go:1195-1208 */
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,154 @@
+// l0_fwd_dev: stand-alone check + timing of the packed-RGBA8 level-0 forward kernel (go-jpeg2000_amd/csrc/dwt53_l0pix.inc)
+// on the C2 geometry (3840x2160, 512x512 tiles incl. the 256-wide / 112-high edge tiles).  Checks every output element against
+// a plain CPU restatement of DC shift + RCT + Forward2D53 (mct.go:28-38,96-101, dwt.go:73-118,356-407), then times each
+// instantiation per launch (dispatch-stamped events) at a cache-resident footprint (1 frame) and an HBM footprint (F frames).
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <string>
+#include <algorithm>
+#include "../../go-jpeg2000_amd/csrc/j2k_internal.h"
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+namespace j2k {
+typedef int v4i __attribute__((ext_vector_type(4)));
+#include "../../go-jpeg2000_amd/csrc/dwt53_l0pix.inc"
+}
+using namespace j2k;
+
+static void fwd53_1d(int *d, int n, int stride, std::vector<int> &tmp) {   // dwt.go:73-118 on a strided signal
+    if (n < 2) return;
+    tmp.resize(n);
+    for (int i = 0; i < n; i++) tmp[i] = d[(size_t)i * stride];
+    int *x = tmp.data();
+    for (int i = 1; i < n - 1; i += 2) x[i] -= (x[i - 1] + x[i + 1]) >> 1;
+    if (n % 2 == 0) x[n - 1] -= x[n - 2];
+    x[0] += (x[1] + x[1] + 2) >> 2;
+    for (int i = 2; i < n - 1; i += 2) x[i] += (x[i - 1] + x[i + 1] + 2) >> 2;
+    if (n % 2 == 1) x[n - 1] += (x[n - 2] + x[n - 2] + 2) >> 2;
+    const int half = (n + 1) / 2;
+    for (int i = 0; i < n; i++) d[(size_t)((i & 1) ? half + i / 2 : i / 2) * stride] = x[i];
+}
+
+int main(int argc, char **argv) {
+    const int W = 3840, H = 2160, T = 512, F = argc > 1 ? atoi(argv[1]) : 6;
+    const int TX = (W + T - 1) / T, TY = (H + T - 1) / T;
+    const size_t PX = (size_t)W * H;
+    // ---- planes: dense per-tile coefficient planes, prefix scratch ----
+    std::vector<DwtPlane> planes;
+    int64_t coef = 0, scr = 0;
+    for (int ty = 0; ty < TY; ty++)
+        for (int tx = 0; tx < TX; tx++) {
+            const int x0 = tx * T, y0 = ty * T, w = std::min(T, W - x0), h = std::min(T, H - y0);
+            DwtPlane D{};
+            for (int k = 0; k < 3; k++) {
+                D.src_off[k] = (int64_t)k * PX + (int64_t)y0 * W + x0;
+                D.out_off[k] = coef; coef += (int64_t)w * h;
+                D.nxt_off[k] = scr; scr += (int64_t)((w + 1) / 2) * ((h + 1) / 2);
+            }
+            D.src_stride = W; D.w = w; D.h = h; D.n_next = ((w + 1) / 2) * ((h + 1) / 2); D.out_stride = W;
+            planes.push_back(D);
+        }
+    printf("planes %zu coef %.1f MB scratch %.1f MB pix %.1f MB\n", planes.size(), coef * 4 / 1e6, scr * 4 / 1e6, PX * 4 / 1e6);
+    auto make_jobs = [&](int band, bool xcd) {
+        std::vector<DwtJob> jobs;
+        for (size_t i = 0; i < planes.size(); i++)
+            for (int pr = 0; pr < (planes[i].h + 1) / 2; pr += band) jobs.push_back(DwtJob{(int)i, 0, pr, band});
+        if (xcd) {   // workgroups b and b+8 share an XCD: keep a tile's workgroups on one XCD
+            std::vector<std::vector<DwtJob>> per(8);
+            for (const DwtJob &j : jobs) per[j.plane % 8].push_back(j);
+            size_t m = 0;
+            for (auto &v : per) m = std::max(m, v.size());
+            m = (m + 3) & ~size_t(3);
+            std::vector<DwtJob> perm(m * 8, DwtJob{-1, 0, 0, 0});
+            for (int x = 0; x < 8; x++)
+                for (size_t i = 0; i < per[x].size(); i++) perm[((i / 4) * 8 + x) * 4 + (i % 4)] = per[x][i];
+            jobs.swap(perm);
+        }
+        return jobs;
+    };
+    // ---- input + CPU reference ----
+    std::vector<uint32_t> hpix(PX);
+    uint32_t s = 12345;
+    for (size_t i = 0; i < PX; i++) {
+        s = s * 1664525u + 1013904223u;
+        const int x = (int)(i % W), y = (int)(i / W);
+        auto cl = [](int v) { return (uint32_t)std::min(255, std::max(0, v)); };
+        const int n0 = (int)((s >> 8) % 33) - 16, n1 = (int)((s >> 14) % 33) - 16, n2 = (int)((s >> 20) % 33) - 16;
+        hpix[i] = cl(x * 255 / W + n0) | cl(y * 255 / H + n1) << 8 | cl((x + y) * 127 / W + n2) << 16 | 0xFF000000u;
+    }
+    if (argc > 2) for (size_t i = 0; i < PX; i++) { s = s * 1664525u + 1013904223u; hpix[i] = s | 0xFF000000u; }   // full-range bytes
+    std::vector<int> want_out(coef), want_nxt(scr, 0);
+    {
+        std::vector<int> tmp, buf;
+        for (const DwtPlane &D : planes) {
+            const int w = D.w, h = D.h;
+            for (int k = 0; k < 3; k++) {
+                buf.assign((size_t)w * h, 0);
+                const int64_t o0 = D.src_off[0];
+                for (int y = 0; y < h; y++)
+                    for (int x = 0; x < w; x++) {
+                        const uint32_t p = hpix[o0 + (int64_t)y * W + x];
+                        const int r = (int)(p & 255) - 128, g = (int)((p >> 8) & 255) - 128, b = (int)((p >> 16) & 255) - 128;
+                        buf[(size_t)y * w + x] = k == 0 ? (r + 2 * g + b) >> 2 : (k == 1 ? b - g : r - g);
+                    }
+                for (int y = 0; y < h; y++) fwd53_1d(&buf[(size_t)y * w], w, 1, tmp);
+                for (int x = 0; x < w; x++) fwd53_1d(&buf[x], h, w, tmp);
+                for (int i = 0; i < w * h; i++) {
+                    if (i < D.n_next) want_nxt[D.nxt_off[k] + i] = buf[i];
+                    want_out[D.out_off[k] + i] = (i < D.n_next) ? 0x7fffffff : buf[i];
+                }
+            }
+        }
+    }
+    // ---- device ----
+    uint32_t *d_pix; int32_t *d_out, *d_nxt; DwtPlane *d_planes;
+    CK(hipMalloc(&d_pix, PX * 4 * F)); CK(hipMalloc(&d_out, (size_t)coef * 4 * F)); CK(hipMalloc(&d_nxt, (size_t)scr * 4 * F));
+    CK(hipMalloc(&d_planes, planes.size() * sizeof(DwtPlane)));
+    CK(hipMemcpy(d_planes, planes.data(), planes.size() * sizeof(DwtPlane), hipMemcpyHostToDevice));
+    for (int f = 0; f < F; f++) CK(hipMemcpy(d_pix + f * PX, hpix.data(), PX * 4, hipMemcpyHostToDevice));
+    hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    const int IT = 30;
+    std::vector<hipEvent_t> ea(IT), eb(IT);
+    for (int i = 0; i < IT; i++) { CK(hipEventCreate(&ea[i])); CK(hipEventCreate(&eb[i])); }
+    const double bytes = (double)PX * 16;
+    std::vector<int> got_out(coef), got_nxt(scr);
+    auto run = [&](const std::string &name, int band, bool xcd, auto kern) {
+        std::vector<DwtJob> jobs = make_jobs(band, xcd);
+        DwtJob *d_jobs; CK(hipMalloc(&d_jobs, jobs.size() * sizeof(DwtJob)));
+        CK(hipMemcpy(d_jobs, jobs.data(), jobs.size() * sizeof(DwtJob), hipMemcpyHostToDevice));
+        const int nj = (int)jobs.size(), grid = (nj + 3) / 4;
+        // check (frame 0)
+        CK(hipMemsetAsync(d_out, 0x7f, (size_t)coef * 4, st)); CK(hipMemsetAsync(d_nxt, 0x7f, (size_t)scr * 4, st));
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, nullptr, nullptr, 0, d_jobs, nj, d_planes, d_pix, d_out, d_nxt, 128, W);
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(got_out.data(), d_out, (size_t)coef * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(got_nxt.data(), d_nxt, (size_t)scr * 4, hipMemcpyDeviceToHost));
+        size_t bad = 0, first = 0;
+        for (size_t i = 0; i < (size_t)coef; i++) { const int wv = want_out[i] == 0x7fffffff ? 0x7f7f7f7f : want_out[i]; if (got_out[i] != wv && !bad++) first = i; }
+        for (size_t i = 0; i < (size_t)scr; i++) if (got_nxt[i] != want_nxt[i] && !bad++) first = i + (size_t)1e12;
+        for (int FF : {1, F}) {
+            for (int i = 0; i < 6; i++) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, nullptr, nullptr, 0, d_jobs, nj, d_planes, d_pix + (size_t)(i % FF) * PX, d_out + (size_t)(i % FF) * coef, d_nxt + (size_t)(i % FF) * scr, 128, W);
+            for (int i = 0; i < IT; i++) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, ea[i], eb[i], 0, d_jobs, nj, d_planes, d_pix + (size_t)(i % FF) * PX, d_out + (size_t)(i % FF) * coef, d_nxt + (size_t)(i % FF) * scr, 128, W);
+            CK(hipStreamSynchronize(st));
+            std::vector<float> us(IT);
+            for (int i = 0; i < IT; i++) { float ms; CK(hipEventElapsedTime(&ms, ea[i], eb[i])); us[i] = ms * 1e3f; }
+            std::sort(us.begin(), us.end());
+            double avg = 0; for (float u : us) avg += u; avg /= IT;
+            printf("%-34s jobs %5d F=%d  avg %6.2f us  med %6.2f  min %6.2f -> %5.0f GB/s  frac %.3f  %s\n", name.c_str(), nj, FF, avg, us[IT / 2], us[0], bytes / avg / 1e3, bytes / avg / 1e3 / 8000.0,
+                   bad ? "MISMATCH" : "ok");
+        }
+        if (bad) printf("   !! %zu mismatches, first at %zu\n", bad, first);
+        fflush(stdout);
+        CK(hipFree(d_jobs));
+    };
+#define RUN(PR, NT, WPE, XCD) run("PR=" #PR " nt=" #NT " wpe=" #WPE " xcd=" #XCD, PR, XCD, dwt53_fwd_rgba8_kernel<PR, NT, WPE>)
+    RUN(1, false, 4, false); RUN(1, true, 4, false); RUN(1, false, 4, true); RUN(1, true, 4, true);
+    RUN(2, false, 4, false); RUN(2, true, 4, false); RUN(2, false, 4, true); RUN(2, true, 4, true);
+    RUN(3, false, 4, false); RUN(3, true, 4, false); RUN(3, true, 4, true);
+    RUN(4, false, 4, false); RUN(4, true, 4, false); RUN(4, true, 4, true);
+    RUN(1, true, 3, false); RUN(2, true, 3, false); RUN(4, true, 3, false); RUN(4, true, 2, false); RUN(2, true, 2, false);
+    RUN(1, true, 5, false); RUN(2, true, 5, false); RUN(1, true, 6, false); RUN(2, true, 6, false); RUN(1, true, 8, false);
+    return 0;
+}
