@@ -645,9 +645,12 @@ __device__ __forceinline__ void inv_finish_row(int32_t *__restrict__ dst, const 
                           b_ = min(max(wadd(x[2][i], dc_shift), 0), 255);
                 px[i] = (uint32_t)r_ | (uint32_t)g_ << 8 | (uint32_t)b_ << 16 | 0xFF000000u;
             }
+            // reconstructed pixels are a pure output stream: non-temporal, so that they do not sit dirty in the Infinity
+            // Cache for the next kernel to write back (see st_decoded in ht.hip)
             uint32_t *p = reinterpret_cast<uint32_t *>(dst) + pix0 + (int64_t)ro * pix_stride + c;
-            *reinterpret_cast<uint4 *>(p) = make_uint4(px[0], px[1], px[2], px[3]);
-            *reinterpret_cast<uint4 *>(p + 4) = make_uint4(px[4], px[5], px[6], px[7]);
+            const v4i v0 = {(int)px[0], (int)px[1], (int)px[2], (int)px[3]}, v1 = {(int)px[4], (int)px[5], (int)px[6], (int)px[7]};
+            __builtin_nontemporal_store(v0, reinterpret_cast<v4i *>(p));
+            __builtin_nontemporal_store(v1, reinterpret_cast<v4i *>(p + 4));
             return;
         }
     }
@@ -1010,9 +1013,25 @@ hipError_t launch_dwt53_tail_inv(hipStream_t s, const TailPlane *planes, int npl
     return hipGetLastError();
 }
 
+#include "dwt53_l0pix.inc"
+
 // ================================================================================
 // launchers
 // ================================================================================
+template <int NW>
+static hipError_t fwd_wg_go(hipStream_t s, const LevelLaunch &L, const int32_t *src, int32_t *out, int32_t *nxt, int dc) {
+    const uint32_t *pix = reinterpret_cast<const uint32_t *>(src);
+#define J2K_WG(FL) hipExtLaunchKernelGGL((dwt53_fwd_rgba8_wg_kernel<NW, FL, 6>), dim3(L.njobs), dim3(NW * 64), 0, s, L.ev_start, L.ev_stop, 0, \
+                                         L.jobs, L.njobs, L.planes, pix, out, nxt, dc, L.pix_stride)
+    switch (L.wg_store) {
+        case 0: J2K_WG(0); break;
+        case 2: J2K_WG(2); break;
+        case 4: J2K_WG(4); break;
+        default: J2K_WG(1); break;
+    }
+#undef J2K_WG
+    return hipGetLastError();
+}
 template <int CPL, int NC, bool VEC>
 static hipError_t fwd_go(hipStream_t s, const LevelLaunch &L, const int32_t *src, int32_t *out, int32_t *nxt, int dc) {
     const int blocks = (L.njobs + 3) / 4;
@@ -1064,6 +1083,13 @@ static hipError_t inv_go(hipStream_t s, const LevelLaunch &L, const int32_t *coe
     } while (0)
 
 hipError_t launch_dwt53_fwd(hipStream_t s, const LevelLaunch &L, const int32_t *src, int32_t *out, int32_t *nxt, int dc_shift) {
+    if (L.wg_waves > 0) {      // packed RGBA8 level 0, workgroup form (dwt53_l0pix.inc); geometry checked by the plan
+        if (L.njobs <= 0) return hipSuccess;
+        if (L.pix_stride <= 0 || L.ncomp != 3) return hipErrorInvalidValue;
+        if (L.wg_waves == 4) return fwd_wg_go<4>(s, L, src, out, nxt, dc_shift);
+        if (L.wg_waves == 8) return fwd_wg_go<8>(s, L, src, out, nxt, dc_shift);
+        return hipErrorInvalidValue;
+    }
     J2K_DISPATCH(fwd_go, s, L, src, out, nxt, dc_shift);
 }
 hipError_t launch_dwt53_inv(hipStream_t s, const LevelLaunch &L, const int32_t *coef, const int32_t *prev, int32_t *dst,

@@ -1023,6 +1023,20 @@ __global__ __launch_bounds__(256) void ht_walk_kernel(const BlockJob *__restrict
 }
 
 #define HT_MAX_FF 64
+// Decoded blocks (115 MB per 4K frame, 3/4 of it zeros) are a pure output stream: nothing in the library reads them back,
+// so they are stored non-temporally.  Plain stores leave them dirty in the 256 MB Infinity Cache, and whatever kernel
+// runs next pays their write-back on top of its own traffic (measured with tools/probe/l0_fwd_dev.hip: the level-0
+// forward transform takes 31 us after a 300 MB plain-store copy, 27 us after the same copy with nt stores).
+#ifndef J2K_DECODED_NT
+#define J2K_DECODED_NT 1
+#endif
+__device__ __forceinline__ void st_decoded(int32_t *p, int a, int b, int c, int d) {
+    typedef int v4i_ __attribute__((ext_vector_type(4)));
+    const v4i_ v = {a, b, c, d};
+    if (J2K_DECODED_NT) __builtin_nontemporal_store(v, reinterpret_cast<v4i_ *>(p));
+    else *reinterpret_cast<v4i_ *>(p) = v;
+}
+
 struct HtDecShared {
     uint32_t mbuf[HT_DEC_MWORDS];
     uint32_t pair[HT_WALK_MAX_PAIRS];
@@ -1208,8 +1222,8 @@ __device__ bool ht_extract_fast(HtDecShared &S, const uint8_t *__restrict__ data
             const int xb = pi * 8;
             int32_t *orow = out + (size_t)(4 * r) * w + xb;
             if (xb + 8 <= w && (((uintptr_t)orow) & 15) == 0) {
-                reinterpret_cast<int4 *>(orow)[0] = make_int4(vals[0], vals[1], vals[2], vals[3]);
-                reinterpret_cast<int4 *>(orow)[1] = make_int4(vals[4], vals[5], vals[6], vals[7]);
+                st_decoded(orow, vals[0], vals[1], vals[2], vals[3]);
+                st_decoded(orow + 4, vals[4], vals[5], vals[6], vals[7]);
             } else {
 #pragma unroll
                 for (int i = 0; i < 8; i++)
@@ -1250,7 +1264,7 @@ __global__ __launch_bounds__(256) void ht_decode_kernel(const BlockJob *__restri
             const uint32_t dy = 64u / wq, dx = 64u % wq;
             uint32_t y = (uint32_t)lane / wq, x = (uint32_t)lane % wq;
             for (uint32_t i = lane; i < nq; i += 64) {
-                if (!skip_coded || (y & 3)) reinterpret_cast<int4 *>(out)[i] = make_int4(0, 0, 0, 0);
+                if (!skip_coded || (y & 3)) st_decoded(out + 4 * (size_t)i, 0, 0, 0, 0);
                 y += dy; x += dx;
                 if (x >= wq) { x -= wq; y++; }
             }

@@ -105,6 +105,8 @@ extern "C" int j2k_ctx_create(int device, j2k_ctx **out) {
         int v = atoi(e);
         if (v >= 1 && v <= 4096) ctx->band_prows = v;
     }
+    if (const char *e = getenv("J2K_L0_WG")) { int v = atoi(e); if (v == 0 || v == 4 || v == 8) ctx->l0_wg = v; }
+    if (const char *e = getenv("J2K_L0_STORE")) { int v = atoi(e); if (v == 0 || v == 1 || v == 2 || v == 4) ctx->l0_store = v; }
     if (const char *e = getenv("J2K_BAND_PROWS_PIX")) { int v = atoi(e); if (v >= 1 && v <= 4096) ctx->band_prows_pix = v; }
     if (const char *e = getenv("J2K_BAND_PROWS_97")) { int v = atoi(e); if (v >= 2 && v <= 4096) ctx->band_prows_97 = v; }
     if (const char *e = getenv("J2K_FORCE_NOVEC")) ctx->force_novec = atoi(e) != 0;
@@ -439,6 +441,21 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                     P->fwd_pix_njobs = (int)pj.size();
                     r = upload(ctx, &P->d_fwd_pix_jobs, pj);
                     if (r != J2K_OK) { j2k_plan_destroy(P); return r; }
+                    // workgroup form (dwt53_l0pix.inc): one job per workgroup of l0_wg waves = l0_wg - 1 pair-rows of one
+                    // plane; its geometry contract: one 512-column strip, whole 16-byte lanes, at least two rows
+                    bool wg_ok = ctx->l0_wg > 0;
+                    for (size_t i = 0; i < planes.size() && wg_ok; i++)
+                        if (pw[i] < 16 || pw[i] > 512 || (pw[i] % 8) || ph[i] < 2) wg_ok = false;
+                    if (wg_ok) {
+                        std::vector<DwtJob> wj;
+                        const int nr = ctx->l0_wg - 1;
+                        for (size_t i = 0; i < planes.size(); i++)
+                            for (int pr = 0; pr < (ph[i] + 1) / 2; pr += nr) wj.push_back(DwtJob{(int)i, 0, pr, nr});
+                        P->fwd_wg_njobs = (int)wj.size();
+                        P->fwd_wg_waves = ctx->l0_wg;
+                        r = upload(ctx, &P->d_fwd_wg_jobs, wj);
+                        if (r != J2K_OK) { j2k_plan_destroy(P); return r; }
+                    }
                 }
                 if (dir == 0) {
                     P->dwt_bytes += T.alg_bytes;
@@ -513,7 +530,7 @@ extern "C" void j2k_plan_destroy(j2k_plan *P) {
         for (auto &T : P->fwd[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); }
         for (auto &T : P->inv[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); }
     }
-    void *ptrs[] = {P->d_scrA, P->d_scrB, P->d_tail, P->d_bjobs, P->d_djobs, P->d_frame, P->d_coeff, P->d_slots, P->d_stream, P->d_lens, P->d_numbps, P->d_offs, P->d_status, P->d_fwd_pix_jobs, P->d_maglens, P->d_mels, P->d_toffs};
+    void *ptrs[] = {P->d_scrA, P->d_scrB, P->d_tail, P->d_bjobs, P->d_djobs, P->d_frame, P->d_coeff, P->d_slots, P->d_stream, P->d_lens, P->d_numbps, P->d_offs, P->d_status, P->d_fwd_pix_jobs, P->d_fwd_wg_jobs, P->d_maglens, P->d_mels, P->d_toffs};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete P;
 }
@@ -610,6 +627,9 @@ static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff, in
                 if (l == 0 && cls == pix_cls && pix_stride > 0) {         // packed frame (j2k_plan_forward_rgba8 / _pixels)
                     L.pix_stride = pix_stride;
                     if (cls == 1 && P->d_fwd_pix_jobs) { L.jobs = P->d_fwd_pix_jobs; L.njobs = P->fwd_pix_njobs; }
+                    if (cls == 1 && P->d_fwd_wg_jobs) {   // RGBA8: the workgroup form when every plane qualifies
+                        L.jobs = P->d_fwd_wg_jobs; L.njobs = P->fwd_wg_njobs; L.wg_waves = P->fwd_wg_waves; L.wg_store = ctx->l0_store;
+                    }
                 }
                 if (l == 0 && cls == 1 && ev1) { L.ev_start = ev0; L.ev_stop = ev1; }
                 HIPCHK(ctx, launch_dwt53_fwd(ctx->stream, L, (const int32_t *)in, (int32_t *)d_coeff, (int32_t *)nx, l == 0 ? S.dc_shift : 0));

@@ -59,6 +59,9 @@ struct LevelLaunch {
     int ncomp;            // 1 or 3 (3 = fused colour transform on level 0)
     int pf;               // forward 5-3: software-prefetch variant
     int pix_stride;       // level 0 of an RGB triple: > 0 = the frame is packed RGBA8 with this row stride in PIXELS
+    int wg_waves;         // > 0: `jobs` is the per-WORKGROUP table of dwt53_fwd_rgba8_wg_kernel (dwt53_l0pix.inc): wg_waves
+                          // wavefronts per workgroup, wg_waves - 1 pair-rows each; level 0 of an RGBA8 frame only
+    int wg_store;         // its final-coefficient store flavour (0 plain, 1 nt, ...)
     hipEvent_t ev_start, ev_stop;   // non-null: the dispatch itself stamps these (hipExtLaunchKernelGGL) -- the kernel's own
                                     // begin / end, without the launch gap an event pair around the launch would include
 };

@@ -14,6 +14,8 @@ struct j2k_ctx {
                                // Measured slower than the three kernels it replaces (61.7 vs 58.6 us: the prefix chain crosses XCDs)
     int fwd_link = 1;          // forward 5-3: bands of one workgroup exchange halo rows through LDS (J2K_FWD_LINK)
     int inv_link = 1;          // same for the inverse kernels (J2K_INV_LINK)
+    int l0_wg = 8;             // packed RGBA8 level-0 forward, workgroup form: wavefronts per workgroup (J2K_L0_WG: 0 off, 4, 8)
+    int l0_store = 1;          // its final-coefficient store flavour (J2K_L0_STORE: 0 plain, 1 nt, 2 sc1, 4 sc1 nt)
     int band_prows_pix = 3;    // packed-pixel level-0 forward (J2K_BAND_PROWS_PIX)
     int band_prows_97 = 8;     // 9-7 kernels: 7 halo rows per band, so taller bands (J2K_BAND_PROWS_97)
     int band_prows_inv = 0;    // 0: same as band_prows (J2K_BAND_PROWS_INV)
@@ -115,6 +117,8 @@ struct j2k_plan {
     // fused encode + compact (j2k_plan_encode_stream): look-back status words, tagged with the launch epoch
     j2k::DwtJob *d_fwd_pix_jobs = nullptr;  // level-0 forward job table of the packed-pixel path (shorter bands)
     int fwd_pix_njobs = 0;
+    j2k::DwtJob *d_fwd_wg_jobs = nullptr;   // the same as one job per WORKGROUP (dwt53_fwd_rgba8_wg_kernel), when every plane qualifies
+    int fwd_wg_njobs = 0, fwd_wg_waves = 0;
     uint32_t *d_maglens = nullptr;          // j2k_plan_encode_stream: end of each block's MagSgn bytes (the MEL hole starts there)
     uint32_t *d_mels = nullptr;      // per job: bytes of MEL zero run of an HT block (max(64, 2wh) / 4), built with d_maglens
     bool want_toffs = false, toffs_valid = false;   // pack_stream has been used on this plan / d_toffs belongs to the last encode_stream

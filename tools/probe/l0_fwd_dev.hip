@@ -18,6 +18,21 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 }
 using namespace j2k;
 
+__global__ __launch_bounds__(256) void thrash_copy(const v4i *__restrict__ a, v4i *__restrict__ b, size_t n) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, st = (size_t)gridDim.x * 256;
+    for (; i < n; i += st) b[i] = a[i] + 1;
+}
+__global__ __launch_bounds__(256) void thrash_copy_nt(const v4i *__restrict__ a, v4i *__restrict__ b, size_t n) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, st = (size_t)gridDim.x * 256;
+    for (; i < n; i += st) __builtin_nontemporal_store(a[i] + 1, &b[i]);
+}
+__global__ __launch_bounds__(256) void thrash_read(const v4i *__restrict__ a, int *__restrict__ sink, size_t n) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, st = (size_t)gridDim.x * 256;
+    v4i acc = {0, 0, 0, 0};
+    for (; i < n; i += st) acc += a[i];
+    if (acc.x + acc.y + acc.z + acc.w == 0x12345678) sink[0] = 1;
+}
+
 static void fwd53_1d(int *d, int n, int stride, std::vector<int> &tmp) {   // dwt.go:73-118 on a strided signal
     if (n < 2) return;
     tmp.resize(n);
@@ -110,27 +125,33 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(d_planes, planes.data(), planes.size() * sizeof(DwtPlane), hipMemcpyHostToDevice));
     for (int f = 0; f < F; f++) CK(hipMemcpy(d_pix + f * PX, hpix.data(), PX * 4, hipMemcpyHostToDevice));
     hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    // bench-like context: between two level-0 launches on the SAME buffers the rest of the pipeline moves ~600 MB through
+    // other buffers and finally re-reads the coefficient planes (the inverse transform)
+    const size_t TH = (size_t)300 << 20;
+    v4i *th_a, *th_b; int *sink;
+    CK(hipMalloc(&th_a, TH)); CK(hipMalloc(&th_b, TH)); CK(hipMalloc(&sink, 64)); CK(hipMemset(th_a, 1, TH)); CK(hipMemset(th_b, 1, TH));
     const int IT = 30;
     std::vector<hipEvent_t> ea(IT), eb(IT);
     for (int i = 0; i < IT; i++) { CK(hipEventCreate(&ea[i])); CK(hipEventCreate(&eb[i])); }
     const double bytes = (double)PX * 16;
     std::vector<int> got_out(coef), got_nxt(scr);
-    auto run = [&](const std::string &name, int band, bool xcd, auto kern) {
-        std::vector<DwtJob> jobs = make_jobs(band, xcd);
+    auto run = [&](const std::string &name, int band, bool xcd, auto kern, int nw = 0) {
+        std::vector<DwtJob> jobs = make_jobs(band, xcd && nw == 0);
         DwtJob *d_jobs; CK(hipMalloc(&d_jobs, jobs.size() * sizeof(DwtJob)));
         CK(hipMemcpy(d_jobs, jobs.data(), jobs.size() * sizeof(DwtJob), hipMemcpyHostToDevice));
-        const int nj = (int)jobs.size(), grid = (nj + 3) / 4;
+        const int nj = (int)jobs.size(), grid = nw ? nj : (nj + 3) / 4;
+        const int bs = nw ? nw * 64 : 256;
         // check (frame 0)
         CK(hipMemsetAsync(d_out, 0x7f, (size_t)coef * 4, st)); CK(hipMemsetAsync(d_nxt, 0x7f, (size_t)scr * 4, st));
-        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, nullptr, nullptr, 0, d_jobs, nj, d_planes, d_pix, d_out, d_nxt, 128, W);
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(bs), 0, st, nullptr, nullptr, 0, d_jobs, nj, d_planes, d_pix, d_out, d_nxt, 128, W);
         CK(hipStreamSynchronize(st));
         CK(hipMemcpy(got_out.data(), d_out, (size_t)coef * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(got_nxt.data(), d_nxt, (size_t)scr * 4, hipMemcpyDeviceToHost));
         size_t bad = 0, first = 0;
         for (size_t i = 0; i < (size_t)coef; i++) { const int wv = want_out[i] == 0x7fffffff ? 0x7f7f7f7f : want_out[i]; if (got_out[i] != wv && !bad++) first = i; }
         for (size_t i = 0; i < (size_t)scr; i++) if (got_nxt[i] != want_nxt[i] && !bad++) first = i + (size_t)1e12;
         for (int FF : {1, F}) {
-            for (int i = 0; i < 6; i++) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, nullptr, nullptr, 0, d_jobs, nj, d_planes, d_pix + (size_t)(i % FF) * PX, d_out + (size_t)(i % FF) * coef, d_nxt + (size_t)(i % FF) * scr, 128, W);
-            for (int i = 0; i < IT; i++) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, ea[i], eb[i], 0, d_jobs, nj, d_planes, d_pix + (size_t)(i % FF) * PX, d_out + (size_t)(i % FF) * coef, d_nxt + (size_t)(i % FF) * scr, 128, W);
+            for (int i = 0; i < 6; i++) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(bs), 0, st, nullptr, nullptr, 0, d_jobs, nj, d_planes, d_pix + (size_t)(i % FF) * PX, d_out + (size_t)(i % FF) * coef, d_nxt + (size_t)(i % FF) * scr, 128, W);
+            for (int i = 0; i < IT; i++) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(bs), 0, st, ea[i], eb[i], 0, d_jobs, nj, d_planes, d_pix + (size_t)(i % FF) * PX, d_out + (size_t)(i % FF) * coef, d_nxt + (size_t)(i % FF) * scr, 128, W);
             CK(hipStreamSynchronize(st));
             std::vector<float> us(IT);
             for (int i = 0; i < IT; i++) { float ms; CK(hipEventElapsedTime(&ms, ea[i], eb[i])); us[i] = ms * 1e3f; }
@@ -139,16 +160,26 @@ int main(int argc, char **argv) {
             printf("%-34s jobs %5d F=%d  avg %6.2f us  med %6.2f  min %6.2f -> %5.0f GB/s  frac %.3f  %s\n", name.c_str(), nj, FF, avg, us[IT / 2], us[0], bytes / avg / 1e3, bytes / avg / 1e3 / 8000.0,
                    bad ? "MISMATCH" : "ok");
         }
+        for (int mode : {1, 2, 3, 4, 5}) {   // 4: as 1 with nt stores in the copy; 5: as 2 with nt stores in the copy   // 1: thrash between launches; 2: thrash, then re-read the coefficient planes; 3: only re-read them
+            auto between = [&]() {
+                if (mode == 1 || mode == 2) hipLaunchKernelGGL(thrash_copy, dim3(4096), dim3(256), 0, st, th_a, th_b, TH / 16);
+                if (mode >= 4) hipLaunchKernelGGL(thrash_copy_nt, dim3(4096), dim3(256), 0, st, th_a, th_b, TH / 16);
+                if (mode == 2 || mode == 3 || mode == 5) hipLaunchKernelGGL(thrash_read, dim3(4096), dim3(256), 0, st, (const v4i *)d_out, sink, (size_t)coef / 4);
+            };
+            for (int i = 0; i < 3; i++) { between(); hipExtLaunchKernelGGL(kern, dim3(grid), dim3(bs), 0, st, nullptr, nullptr, 0, d_jobs, nj, d_planes, d_pix, d_out, d_nxt, 128, W); }
+            for (int i = 0; i < IT; i++) { between(); hipExtLaunchKernelGGL(kern, dim3(grid), dim3(bs), 0, st, ea[i], eb[i], 0, d_jobs, nj, d_planes, d_pix, d_out, d_nxt, 128, W); }
+            CK(hipStreamSynchronize(st));
+            std::vector<float> us(IT);
+            for (int i = 0; i < IT; i++) { float ms; CK(hipEventElapsedTime(&ms, ea[i], eb[i])); us[i] = ms * 1e3f; }
+            std::sort(us.begin(), us.end());
+            double avg = 0; for (float u : us) avg += u; avg /= IT;
+            printf("%-34s            mode %d avg %6.2f us  med %6.2f  min %6.2f -> %5.0f GB/s  frac %.3f\n", name.c_str(), mode, avg, us[IT / 2], us[0], bytes / avg / 1e3, bytes / avg / 1e3 / 8000.0);
+        }
         if (bad) printf("   !! %zu mismatches, first at %zu\n", bad, first);
         fflush(stdout);
         CK(hipFree(d_jobs));
     };
-#define RUN(PR, NT, WPE, XCD) run("PR=" #PR " nt=" #NT " wpe=" #WPE " xcd=" #XCD, PR, XCD, dwt53_fwd_rgba8_kernel<PR, NT, WPE>)
-    RUN(1, false, 4, false); RUN(1, true, 4, false); RUN(1, false, 4, true); RUN(1, true, 4, true);
-    RUN(2, false, 4, false); RUN(2, true, 4, false); RUN(2, false, 4, true); RUN(2, true, 4, true);
-    RUN(3, false, 4, false); RUN(3, true, 4, false); RUN(3, true, 4, true);
-    RUN(4, false, 4, false); RUN(4, true, 4, false); RUN(4, true, 4, true);
-    RUN(1, true, 3, false); RUN(2, true, 3, false); RUN(4, true, 3, false); RUN(4, true, 2, false); RUN(2, true, 2, false);
-    RUN(1, true, 5, false); RUN(2, true, 5, false); RUN(1, true, 6, false); RUN(2, true, 6, false); RUN(1, true, 8, false);
+#define RUNWG(NW, NT, WPE) run("WG NW=" #NW " nt=" #NT " wpe=" #WPE, NW - 1, false, dwt53_fwd_rgba8_wg_kernel<NW, NT, WPE>, NW)
+    RUNWG(8, 0, 6); RUNWG(8, 1, 6);
     return 0;
 }
