@@ -136,7 +136,7 @@ def main():
         def __init__(self):
             self.ctx = Context(local)
             self.plan = FramePlan(W, H, C, precision=PREC, lossless=True, num_resolutions=NRES, cb=(CB, CB), tile=(TILE, TILE),
-                                  coder=CODER_HT, ctx=self.ctx)
+                                  coder=CODER_HT, ctx=self.ctx, track_streams=False)   # buffers live for the whole run
             p, i = self.plan, self.plan.info
             self.n = int(i.blocks)
             self.frame = torch.from_numpy(frame_h).to(p.device)

@@ -191,6 +191,7 @@ __global__ void mel_table_kernel(const BlockJob *__restrict__ jobs, int n, uint3
 // copies in flight than seven).  fault: 4 = a pack does not belong to this plan / its pieces do not fit
 struct UnpackBatch {
     const uint8_t *pack[UNPACK_BATCH];
+    uint64_t pack_bytes[UNPACK_BATCH];     // bytes the caller really holds at pack[i] (>= the header: checked on the host)
     uint8_t *stream[UNPACK_BATCH];
     uint64_t *offs[UNPACK_BATCH];
     uint32_t *lens[UNPACK_BATCH];
@@ -204,7 +205,10 @@ __global__ __launch_bounds__(256) void unpack_kernel(const BlockJob *__restrict_
     uint32_t *__restrict__ lens = B.lens[blockIdx.y];
     uint8_t *__restrict__ numbps = B.numbps[blockIdx.y];
     const PackLayout L = pack_layout((size_t)n);
-    if (reinterpret_cast<const uint32_t *>(pack)[4] != (uint32_t)n) {
+    // header: the block count must be this plan's, and the payload size the pack claims must fit what the caller holds
+    const uint64_t avail = B.pack_bytes[blockIdx.y] - L.payload;          // host: pack_bytes >= L.payload
+    const uint64_t paylen = reinterpret_cast<const uint64_t *>(pack)[1];
+    if (reinterpret_cast<const uint32_t *>(pack)[4] != (uint32_t)n || paylen > avail) {
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(fault, 4);
         return;
     }
@@ -221,14 +225,16 @@ __global__ __launch_bounds__(256) void unpack_kernel(const BlockJob *__restrict_
     const uint32_t mag = reinterpret_cast<const uint32_t *>(pack + L.mag)[j];
     const uint32_t mel = has_mel ? mel_bytes(jobs[j]) : 0u;
     const uint64_t toff = reinterpret_cast<const uint64_t *>(pack + L.toffs)[j];
-    // a pack is foreign input: nothing is copied unless the block's pieces fit the pack and the stream
-    if (mag > len || mel > len - mag || toff + (len - mel) > reinterpret_cast<const uint64_t *>(pack)[1] ||
-        poffs[j] + len > poffs[n] || poffs[n] > stream_cap) {
+    // a pack is foreign input: nothing is copied unless the block's pieces fit the pack and the stream.  Every test is
+    // written so that no sum of untrusted 64-bit fields can wrap (an offset of 2^64 - k would pass `off + len > end`)
+    const uint64_t pj = poffs[j], pn = poffs[n];
+    if (mag > len || mel > len - mag || toff > paylen || (uint64_t)(len - mel) > paylen - toff ||
+        pn > stream_cap || pj > pn || (uint64_t)len > pn - pj) {
         if (lane == 0) atomicMax(fault, 4);
         return;
     }
     const uint8_t *src = pack + L.payload + toff;
-    uint8_t *dst = stream + poffs[j];
+    uint8_t *dst = stream + pj;
     copy_bytes(dst, src, mag, lane);
     zero_run(dst + mag, mel, lane);
     copy_bytes(dst + mag + mel, src + mag, len - mag - mel, lane);
@@ -249,13 +255,14 @@ hipError_t launch_mel_table(hipStream_t s, const BlockJob *jobs, int njobs, uint
     hipLaunchKernelGGL(mel_table_kernel, dim3((njobs + 255) / 256), dim3(256), 0, s, jobs, njobs, mels);
     return hipGetLastError();
 }
-hipError_t launch_unpack(hipStream_t s, const BlockJob *jobs, int njobs, int count, const uint8_t *const *packs, uint8_t *const *streams,
+hipError_t launch_unpack(hipStream_t s, const BlockJob *jobs, int njobs, int count, const uint8_t *const *packs, const size_t *pack_bytes,
+                         uint8_t *const *streams,
                          size_t stream_cap, uint64_t *const *offs, uint32_t *const *lens, uint8_t *const *numbps, int *fault) {
     for (int c0 = 0; c0 < count; c0 += UNPACK_BATCH) {
         UnpackBatch B{};
         const int m = count - c0 < UNPACK_BATCH ? count - c0 : UNPACK_BATCH;
         for (int i = 0; i < m; i++) {
-            B.pack[i] = packs[c0 + i]; B.stream[i] = streams[c0 + i]; B.offs[i] = offs[c0 + i]; B.lens[i] = lens[c0 + i];
+            B.pack[i] = packs[c0 + i]; B.pack_bytes[i] = (uint64_t)pack_bytes[c0 + i]; B.stream[i] = streams[c0 + i]; B.offs[i] = offs[c0 + i]; B.lens[i] = lens[c0 + i];
             B.numbps[i] = numbps[c0 + i];
         }
         hipLaunchKernelGGL(unpack_kernel, dim3((njobs + 1 + 3) / 4, m), dim3(256), 0, s, jobs, njobs, B, (uint64_t)stream_cap, fault);

@@ -1094,6 +1094,15 @@ hipError_t launch_dwt53_fwd(hipStream_t s, const LevelLaunch &L, const int32_t *
 }
 hipError_t launch_dwt53_inv(hipStream_t s, const LevelLaunch &L, const int32_t *coef, const int32_t *prev, int32_t *dst,
                             int dc_shift, int final_level) {
+    if (L.wg_waves > 0) {      // level 0 straight to a packed RGBA8 frame, workgroup form (dwt53_l0pix.inc)
+        if (L.njobs <= 0) return hipSuccess;
+        if (L.pix_stride <= 0 || L.ncomp != 3 || !final_level) return hipErrorInvalidValue;
+        uint32_t *pix = reinterpret_cast<uint32_t *>(dst);
+        if (L.wg_waves == 4) hipExtLaunchKernelGGL((dwt53_inv_rgba8_wg_kernel<4, 5>), dim3(L.njobs), dim3(256), 0, s, L.ev_start, L.ev_stop, 0, L.jobs, L.njobs, L.planes, coef, prev, pix, dc_shift, L.pix_stride);
+        else if (L.wg_waves == 8) hipExtLaunchKernelGGL((dwt53_inv_rgba8_wg_kernel<8, 5>), dim3(L.njobs), dim3(512), 0, s, L.ev_start, L.ev_stop, 0, L.jobs, L.njobs, L.planes, coef, prev, pix, dc_shift, L.pix_stride);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
     J2K_DISPATCH(inv_go, s, L, coef, prev, dst, dc_shift, final_level);
 }
 

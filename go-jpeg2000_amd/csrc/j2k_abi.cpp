@@ -47,8 +47,8 @@ hipError_t launch_scan(hipStream_t s, const uint32_t *lens, int njobs, uint64_t 
 size_t pack_header_bytes(size_t n);
 hipError_t launch_pack(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs, const uint64_t *toffs,
                        const uint32_t *lens, const uint8_t *numbps, const uint32_t *maglens, uint8_t *pack);
-hipError_t launch_unpack(hipStream_t s, const BlockJob *jobs, int njobs, int count, const uint8_t *const *packs, uint8_t *const *streams,
-                         size_t stream_cap, uint64_t *const *offs, uint32_t *const *lens, uint8_t *const *numbps, int *fault);
+hipError_t launch_unpack(hipStream_t s, const BlockJob *jobs, int njobs, int count, const uint8_t *const *packs, const size_t *pack_bytes,
+                         uint8_t *const *streams, size_t stream_cap, uint64_t *const *offs, uint32_t *const *lens, uint8_t *const *numbps, int *fault);
 }  // namespace j2k
 
 // ------------------------------------------------------------------------------
@@ -106,6 +106,8 @@ extern "C" int j2k_ctx_create(int device, j2k_ctx **out) {
         if (v >= 1 && v <= 4096) ctx->band_prows = v;
     }
     if (const char *e = getenv("J2K_L0_WG")) { int v = atoi(e); if (v == 0 || v == 4 || v == 8) ctx->l0_wg = v; }
+    if (const char *e = getenv("J2K_L0_XCD")) ctx->l0_xcd = atoi(e) != 0;
+    if (const char *e = getenv("J2K_L0_WG_INV")) ctx->l0_wg_inv = atoi(e) != 0;
     if (const char *e = getenv("J2K_L0_STORE")) { int v = atoi(e); if (v == 0 || v == 1 || v == 2 || v == 4) ctx->l0_store = v; }
     if (const char *e = getenv("J2K_BAND_PROWS_PIX")) { int v = atoi(e); if (v >= 1 && v <= 4096) ctx->band_prows_pix = v; }
     if (const char *e = getenv("J2K_BAND_PROWS_97")) { int v = atoi(e); if (v >= 2 && v <= 4096) ctx->band_prows_97 = v; }
@@ -216,7 +218,7 @@ static int stage_reserve(j2k_ctx *ctx, int slot, size_t bytes) {
 // ------------------------------------------------------------------------------
 bool PlanSpec::operator==(const PlanSpec &o) const {
     return W == o.W && H == o.H && C == o.C && tile_w == o.tile_w && tile_h == o.tile_h && levels == o.levels &&
-           wavelet == o.wavelet && precision == o.precision && dc_shift == o.dc_shift && mct == o.mct && quant == o.quant && quality == o.quality &&
+           wavelet == o.wavelet && precision == o.precision && dc_shift == o.dc_shift && dc_shift_inv == o.dc_shift_inv && mct == o.mct && quant == o.quant && quality == o.quality &&
            num_res_jobs == o.num_res_jobs && cb_w == o.cb_w && cb_h == o.cb_h && coder == o.coder &&
            tile_first == o.tile_first && tile_count == o.tile_count && frame_is_f64 == o.frame_is_f64;
 }
@@ -451,6 +453,18 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                         const int nr = ctx->l0_wg - 1;
                         for (size_t i = 0; i < planes.size(); i++)
                             for (int pr = 0; pr < (ph[i] + 1) / 2; pr += nr) wj.push_back(DwtJob{(int)i, 0, pr, nr});
+                        if (ctx->l0_xcd && wj.size() >= 64) {
+                            // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one), so
+                            // workgroup b takes job (b % 8) * chunk + b / 8: vertically adjacent bands -- which share three
+                            // halo rows -- run on one XCD at about the same time and the re-read is an L2 hit.  Speed only.
+                            const size_t chunk = (wj.size() + 7) / 8;
+                            std::vector<DwtJob> perm(chunk * 8, DwtJob{-1, 0, 0, 0});
+                            for (size_t b = 0; b < perm.size(); b++) {
+                                const size_t j = (b % 8) * chunk + b / 8;
+                                if (j < wj.size()) perm[b] = wj[j];
+                            }
+                            wj.swap(perm);
+                        }
                         P->fwd_wg_njobs = (int)wj.size();
                         P->fwd_wg_waves = ctx->l0_wg;
                         r = upload(ctx, &P->d_fwd_wg_jobs, wj);
@@ -544,8 +558,8 @@ static int spec_from_params(j2k_ctx *ctx, const j2k_params *p, PlanSpec &S) {
     if (S.levels <= 0) S.levels = 5;                                  // encoder.go:249-252
     S.wavelet = p->lossless ? W53 : W97;
     S.precision = p->precision;
-    S.dc_shift = (int)((uint32_t)1 << (p->precision - 1));            // mct.go:97
-    if (p->is_signed) S.dc_shift = 0;                                 // decoder.go:345 (decode side only skips it)
+    S.dc_shift = (int)((uint32_t)1 << (p->precision - 1));            // mct.go:97: encoder.preprocess ALWAYS shifts (encoder.go:218-220)
+    S.dc_shift_inv = p->is_signed ? 0 : S.dc_shift;                   // decoder.go:344-348: only the decode side skips it for signed components
     S.mct = p->ncomp >= 3;                                            // encoder.go:223
     S.quant = p->lossless ? Q_NONE : Q_ENCODER;
     S.quality = p->quality > 0 ? p->quality : 100;                    // encoder.go:265-268
@@ -663,13 +677,18 @@ static int plan_inverse_impl(j2k_plan *P, const void *d_coeff, void *d_frame, in
             if (S.wavelet == W53) {
                 LevelLaunch L = mk(T);
                 if (l == 0 && cls == pix_cls) L.pix_stride = pix_stride;  // packed frame (j2k_plan_inverse_rgba8 / _pixels)
+                if (l == 0 && cls == 1 && pix_cls == 1 && pix_stride > 0 && P->d_fwd_wg_jobs && ctx->l0_wg_inv) {
+                    // RGBA8: the workgroup form when every plane qualifies (same job table as the forward: the plane order
+                    // of the inverse level table is the forward one)
+                    L.jobs = P->d_fwd_wg_jobs; L.njobs = P->fwd_wg_njobs; L.wg_waves = P->fwd_wg_waves;
+                }
                 HIPCHK(ctx, launch_dwt53_inv(ctx->stream, L, (const int32_t *)d_coeff, (const int32_t *)prev, (int32_t *)dst,
-                                             l == 0 ? S.dc_shift : 0, l == 0));
+                                             l == 0 ? S.dc_shift_inv : 0, l == 0));
             } else {
                 // dst_mode: 0 = f64 scratch (l>0), 1 = f64 frame (unit calls), 2 = int32 frame via int32(v+0.5) (tcd.go:433-435)
                 const int dst_mode = (l > 0) ? 0 : (S.frame_is_f64 ? 1 : 2);
                 HIPCHK(ctx, launch_dwt97_inv(ctx->stream, mk(T), d_coeff, S.quant == Q_NONE ? 1 : 0, (const double *)prev, dst,
-                                             l == 0 ? S.dc_shift : 0, l == 0, dst_mode, (cls == 1) ? 1 : 0));
+                                             l == 0 ? S.dc_shift_inv : 0, l == 0, dst_mode, (cls == 1) ? 1 : 0));
             }
         }
     }
@@ -859,7 +878,7 @@ extern "C" int j2k_convert_colorspace(j2k_ctx *ctx, int cs, int32_t *const *plan
 // can the level-0 5-3 + RCT kernels read / write packed RGBA8 directly?
 static bool rgba8_fusable(const j2k_plan *P, const void *d_pix, size_t stride, bool inverse) {
     const PlanSpec &S = P->spec;
-    if (S.wavelet != W53 || !S.mct || S.C != 3 || S.levels < 1 || S.dc_shift != 128) return false;
+    if (S.wavelet != W53 || !S.mct || S.C != 3 || S.levels < 1 || (inverse ? S.dc_shift_inv : S.dc_shift) != 128) return false;
     const LevelTab &T = (inverse ? P->inv : P->fwd)[1][0];
     if (!T.njobs || !T.vec || T.cpl != 8 || (inverse ? P->inv : P->fwd)[0][0].njobs) return false;
     if (P->tail_l0 == 0) return false;
@@ -869,7 +888,7 @@ static bool rgba8_fusable(const j2k_plan *P, const void *d_pix, size_t stride, b
 // can the level-0 5-3 kernels of a one-component 16-bit plan read / write packed Gray16 (big-endian) directly?
 static bool gray16_fusable(const j2k_plan *P, const void *d_pix, size_t stride, bool inverse) {
     const PlanSpec &S = P->spec;
-    if (S.wavelet != W53 || S.C != 1 || S.levels < 1 || S.precision != 16 || S.dc_shift != 32768) return false;
+    if (S.wavelet != W53 || S.C != 1 || S.levels < 1 || S.precision != 16 || (inverse ? S.dc_shift_inv : S.dc_shift) != 32768) return false;
     const LevelTab &T = (inverse ? P->inv : P->fwd)[0][0];
     if (!T.njobs || !T.vec || T.cpl != 8 || (inverse ? P->inv : P->fwd)[1][0].njobs) return false;
     if (P->tail_l0 == 0) return false;
@@ -895,7 +914,7 @@ extern "C" int j2k_plan_inverse_rgba8(j2k_plan *P, const int32_t *d_coeff, void 
     j2k_ctx *ctx = P->ctx;
     const PlanSpec &S = P->spec;
     if (S.C != 3) return fail(ctx, J2K_ERR_INVALID_ARG, "j2k_plan_inverse_rgba8 needs a 3-component plan");
-    if (S.dc_shift != 128) return fail(ctx, J2K_ERR_UNSUPPORTED, "j2k_plan_inverse_rgba8 needs an unsigned 8-bit plan");
+    if (S.dc_shift_inv != 128) return fail(ctx, J2K_ERR_UNSUPPORTED, "j2k_plan_inverse_rgba8 needs an unsigned 8-bit plan");
     if (stride < (size_t)S.W * 4 || (((uintptr_t)d_pix | stride) & 3)) return fail(ctx, J2K_ERR_INVALID_ARG, "bad RGBA8 stride / alignment");
     if (rgba8_fusable(P, d_pix, stride, true)) return plan_inverse_impl(P, d_coeff, d_pix, (int)(stride / 4));
     int r = stage_reserve(ctx, 0, (size_t)S.W * S.H * 3 * 4 + 64);
@@ -925,7 +944,7 @@ extern "C" int j2k_plan_inverse_pixels(j2k_plan *P, const int32_t *d_coeff, void
     if (!P || !d_pix || !d_coeff) return J2K_ERR_INVALID_ARG;
     j2k_ctx *ctx = P->ctx;
     const PlanSpec &S = P->spec;
-    if (S.C == 3 && S.precision == 8 && S.dc_shift == 128) return j2k_plan_inverse_rgba8(P, d_coeff, d_pix, stride);
+    if (S.C == 3 && S.precision == 8 && S.dc_shift_inv == 128) return j2k_plan_inverse_rgba8(P, d_coeff, d_pix, stride);
     if (stride >= (size_t)S.W * 2 && gray16_fusable(P, d_pix, stride, true)) return plan_inverse_impl(P, d_coeff, d_pix, (int)(stride / 2), 0);
     int r = stage_reserve(ctx, 0, (size_t)S.W * S.H * S.C * 4 + 64);
     if (r != J2K_OK) return r;
@@ -1036,6 +1055,7 @@ extern "C" int j2k_plan_encode_stream(j2k_plan *P, const int32_t *d_coeff, uint8
         HIPCHK(ctx, launch_compact(ctx->stream, P->d_bjobs, n, (const uint8_t *)P->d_slots, d_lens, d_offs, d_stream, P->d_maglens,
                                    P->want_toffs ? P->d_mels : nullptr, P->want_toffs ? P->d_toffs : nullptr));
         P->toffs_valid = P->want_toffs;
+        P->last_stream = d_stream; P->last_lens = d_lens;
         return J2K_OK;
     }
     int r = j2k_plan_encode_blocks(P, d_coeff, (uint8_t *)P->d_slots, d_lens, d_numbps);
@@ -1056,6 +1076,10 @@ extern "C" int j2k_plan_pack_stream(j2k_plan *P, const uint8_t *d_stream, const 
     const int n = (int)P->blocks.size();
     const bool ht = P->spec.coder == J2K_CODER_HT;
     if (ht && !P->d_maglens) return fail(ctx, J2K_ERR_UNSUPPORTED, "pack_stream: no j2k_plan_encode_stream (three-kernel path) ran on this plan");
+    // the MagSgn lengths / transport offsets the pack needs are plan state left by the LAST encode_stream: refuse any other
+    // stream (e.g. an older buffer of a rotating set) instead of silently mixing two frames' arrays
+    if (ht && (P->last_stream != d_stream || P->last_lens != d_lens))
+        return fail(ctx, J2K_ERR_INVALID_ARG, "pack_stream: d_stream / d_lens are not the outputs of the last j2k_plan_encode_stream on this plan");
     if (ht && !P->toffs_valid) {      // first pack on this plan: scan the transport lengths now, and with every encode from here on
         int r = stage_reserve(ctx, 1, ((size_t)n + 1) * 8 + 4096);
         if (r != J2K_OK) return r;
@@ -1068,26 +1092,29 @@ extern "C" int j2k_plan_pack_stream(j2k_plan *P, const uint8_t *d_stream, const 
     return J2K_OK;
 }
 
-extern "C" int j2k_plan_unpack_streams(j2k_plan *P, int count, const uint8_t *const *d_packs, uint8_t *const *d_streams,
-                                       uint64_t *const *d_offs, uint32_t *const *d_lens, uint8_t *const *d_numbps) {
-    if (!P || count < 0 || (count && (!d_packs || !d_streams || !d_offs || !d_lens || !d_numbps))) return J2K_ERR_INVALID_ARG;
+extern "C" int j2k_plan_unpack_streams(j2k_plan *P, int count, const uint8_t *const *d_packs, const size_t *pack_bytes,
+                                       uint8_t *const *d_streams, uint64_t *const *d_offs, uint32_t *const *d_lens, uint8_t *const *d_numbps) {
+    if (!P || count < 0 || (count && (!d_packs || !pack_bytes || !d_streams || !d_offs || !d_lens || !d_numbps))) return J2K_ERR_INVALID_ARG;
     for (int i = 0; i < count; i++)
         if (!d_packs[i] || !d_streams[i] || !d_offs[i] || !d_lens[i] || !d_numbps[i]) return J2K_ERR_INVALID_ARG;
     j2k_ctx *ctx = P->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (!count) return J2K_OK;
     const int n = (int)P->blocks.size();
+    // a pack is foreign input: its header and per-block sections must lie inside the bytes the caller really has
+    for (int i = 0; i < count; i++)
+        if (pack_bytes[i] < pack_header_bytes((size_t)n)) return fail(ctx, J2K_ERR_INVALID_ARG, "unpack_stream: the pack is shorter than its own header");
     int r = stage_reserve(ctx, 3, 256);
     if (r != J2K_OK) return r;
     ctx->fault_armed = true;
-    HIPCHK(ctx, launch_unpack(ctx->stream, P->d_bjobs, n, count, d_packs, d_streams, (size_t)P->bytes_cap, d_offs, d_lens, d_numbps,
+    HIPCHK(ctx, launch_unpack(ctx->stream, P->d_bjobs, n, count, d_packs, pack_bytes, d_streams, (size_t)P->bytes_cap, d_offs, d_lens, d_numbps,
                               (int *)ctx->stage[3]));
     return J2K_OK;
 }
 
-extern "C" int j2k_plan_unpack_stream(j2k_plan *P, const uint8_t *d_pack, uint8_t *d_stream, uint64_t *d_offs, uint32_t *d_lens,
-                                      uint8_t *d_numbps) {
-    return j2k_plan_unpack_streams(P, 1, &d_pack, &d_stream, &d_offs, &d_lens, &d_numbps);
+extern "C" int j2k_plan_unpack_stream(j2k_plan *P, const uint8_t *d_pack, size_t pack_bytes, uint8_t *d_stream, uint64_t *d_offs,
+                                      uint32_t *d_lens, uint8_t *d_numbps) {
+    return j2k_plan_unpack_streams(P, 1, &d_pack, &pack_bytes, &d_stream, &d_offs, &d_lens, &d_numbps);
 }
 
 extern "C" int j2k_plan_compact(j2k_plan *P, const uint8_t *d_slots, const uint32_t *d_lens, uint64_t *d_offs, uint8_t *d_stream) {
@@ -1148,7 +1175,7 @@ static int host_dwt(j2k_ctx *ctx, void *data, int w, int h, int levels, int wave
     if (!data) return fail(ctx, J2K_ERR_INVALID_ARG, "data == NULL");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     PlanSpec S;
-    S.W = w; S.H = h; S.C = 1; S.levels = levels; S.wavelet = wavelet; S.dc_shift = 0; S.mct = 0;
+    S.W = w; S.H = h; S.C = 1; S.levels = levels; S.wavelet = wavelet; S.dc_shift = 0; S.dc_shift_inv = 0; S.mct = 0;
     S.quant = quant; S.frame_is_f64 = frame_f64; S.num_res_jobs = 1; S.cb_w = 1 << 20; S.cb_h = 1 << 20;
     j2k_plan *P = nullptr;
     int r = cached_plan(ctx, S, &P);

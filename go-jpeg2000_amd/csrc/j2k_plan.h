@@ -14,7 +14,9 @@ struct j2k_ctx {
                                // Measured slower than the three kernels it replaces (61.7 vs 58.6 us: the prefix chain crosses XCDs)
     int fwd_link = 1;          // forward 5-3: bands of one workgroup exchange halo rows through LDS (J2K_FWD_LINK)
     int inv_link = 1;          // same for the inverse kernels (J2K_INV_LINK)
-    int l0_wg = 8;             // packed RGBA8 level-0 forward, workgroup form: wavefronts per workgroup (J2K_L0_WG: 0 off, 4, 8)
+    int l0_wg = 4;             // packed RGBA8 level-0 forward, workgroup form: wavefronts per workgroup (J2K_L0_WG: 0 off, 4, 8)
+    bool l0_xcd = true;        // XCD-aware order of the workgroup jobs (J2K_L0_XCD=0: plane-major order)
+    bool l0_wg_inv = true;     // the inverse level 0 to RGBA8 in workgroup form too (J2K_L0_WG_INV=0: the general kernel)
     int l0_store = 1;          // its final-coefficient store flavour (J2K_L0_STORE: 0 plain, 1 nt, 2 sc1, 4 sc1 nt)
     int band_prows_pix = 3;    // packed-pixel level-0 forward (J2K_BAND_PROWS_PIX)
     int band_prows_97 = 8;     // 9-7 kernels: 7 halo rows per band, so taller bands (J2K_BAND_PROWS_97)
@@ -57,7 +59,8 @@ struct PlanSpec {
     int levels = 1;            // DWT levels actually run
     int wavelet = W53;
     int precision = 8;         // component precision of the plan (pixel pack / unpack)
-    int dc_shift = 0;          // value subtracted on the way in / added on the way out
+    int dc_shift = 0;          // value subtracted on the way in (encoder.go:218-220)
+    int dc_shift_inv = 0;      // value added on the way out: 0 for signed components (decoder.go:344-348), else dc_shift
     int mct = 0;               // fused RCT (W53) / ICT (W97) on comps 0-2 when C>=3
     int quant = Q_NONE;
     int quality = 100;
@@ -121,6 +124,7 @@ struct j2k_plan {
     int fwd_wg_njobs = 0, fwd_wg_waves = 0;
     uint32_t *d_maglens = nullptr;          // j2k_plan_encode_stream: end of each block's MagSgn bytes (the MEL hole starts there)
     uint32_t *d_mels = nullptr;      // per job: bytes of MEL zero run of an HT block (max(64, 2wh) / 4), built with d_maglens
+    const void *last_stream = nullptr, *last_lens = nullptr;   // outputs of the last j2k_plan_encode_stream: what d_maglens / d_toffs describe
     bool want_toffs = false, toffs_valid = false;   // pack_stream has been used on this plan / d_toffs belongs to the last encode_stream
     uint64_t *d_toffs = nullptr;     // n + 1: exclusive scan of the transport lengths of the last j2k_plan_encode_stream (pack_stream)
     uint64_t *d_status = nullptr;

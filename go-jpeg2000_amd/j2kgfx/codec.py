@@ -4,9 +4,16 @@ tcd.TileDecoder.DecodeCodeBlock / ApplyInverseDWT (tcd.go:393-437) and the tail 
 decoder.decodeTiles (decoder.go:321-348).
 
 torch is used only to own device memory (tensors on `cuda:<ctx.device>`); all kernels are
-launched by libj2kgfx on the context's own HIP stream.  Callers that produce inputs with
-torch ops must torch.cuda.synchronize() first (bench.py and the tests do).
+launched by libj2kgfx on the context's own (non-blocking) HIP stream, which torch's caching allocator
+knows nothing about.  With `track_streams=True` (the default) every stage call therefore
+  * makes the library stream wait for what torch has queued on its current stream (inputs written by torch ops), and
+  * records the library stream on every tensor handed over (`Tensor.record_stream`), so that a temporary dropped
+    before `ctx.sync()` -- `plan.decode_blocks(*plan.encode_stream(plan.forward(x)))` -- is not given to another
+    tensor while kernels still use it.
+Results are read after `ctx.sync()` (or after ordering torch's stream behind `torch.cuda.ExternalStream(ctx.stream)`).
+bench.py passes `track_streams=False`: its buffers live for the whole run and the launching thread has no slack.
 """
+import functools
 import ctypes as C
 
 import numpy as np
@@ -22,11 +29,24 @@ def _torch():
     return torch
 
 
+def _stage(fn):
+    """A stage call: order the library stream behind torch's current stream first (see the module docstring)."""
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        if self.track_streams:
+            t = _torch()
+            self._ext().wait_stream(t.cuda.current_stream(self.device))
+        return fn(self, *a, **k)
+    return wrapped
+
+
 class FramePlan:
     def __init__(self, width, height, ncomp, precision=8, lossless=True, quality=0, num_resolutions=6,
                  cb=(64, 64), tile=(0, 0), coder=_lib.CODER_MQ, is_signed=False, tile_first=0, tile_count=0,
-                 ctx=None):
+                 ctx=None, track_streams=True):
         self.ctx = ctx or default_context()
+        self.track_streams = bool(track_streams)
+        self._ext_stream = None
         L = self.ctx.L
         self.params = _lib.Params(width=width, height=height, ncomp=ncomp, precision=precision,
                                   is_signed=int(bool(is_signed)), lossless=int(bool(lossless)), quality=quality,
@@ -85,14 +105,18 @@ class FramePlan:
         t = _torch()
         return t.empty((self.ncomp, self.height, self.width), dtype=t.int32, device=self.device)
 
-    @staticmethod
-    def _p(t):
+    def _ext(self):
+        if self._ext_stream is None:
+            self._ext_stream = _torch().cuda.ExternalStream(self.ctx.stream, device=self.device)
+        return self._ext_stream
+
+    def _p(self, t):
+        if self.track_streams:
+            t.record_stream(self._ext())     # the allocator may not recycle t's block before the library stream passes this point
         return C.c_void_p(t.data_ptr())
 
     # ---- stages (asynchronous on the ctx stream) ------------------------------------
-    # The calls return before the kernels have run, and they run on the LIBRARY's stream, which torch's caching
-    # allocator knows nothing about: keep every tensor passed in alive (do not pass temporaries) until ctx.sync(), or
-    # order the streams yourself (torch.cuda.ExternalStream(ctx.stream).wait_stream / record_stream).
+    @_stage
     def forward(self, frame, coeff=None):
         """encoder.preprocess for every tile-component: frame int32 [C,H,W] -> coefficient buffer."""
         coeff = coeff if coeff is not None else self.alloc_coeff()
@@ -100,11 +124,13 @@ class FramePlan:
         self.ctx.check(self.ctx.L.j2k_plan_forward(self.h, self._p(frame), self._p(coeff)))
         return coeff
 
+    @_stage
     def inverse(self, coeff, frame=None):
         frame = frame if frame is not None else self.alloc_frame()
         self.ctx.check(self.ctx.L.j2k_plan_inverse(self.h, self._p(coeff), self._p(frame)))
         return frame
 
+    @_stage
     def forward_rgba8(self, pix, coeff=None):
         """extractImageData + preprocess fused: pix = device uint8 [H, stride] packed RGBA (image.RGBA.Pix)."""
         coeff = coeff if coeff is not None else self.alloc_coeff()
@@ -112,6 +138,7 @@ class FramePlan:
         self.ctx.check(self.ctx.L.j2k_plan_forward_rgba8(self.h, self._p(pix), C.c_size_t(int(pix.shape[1])), self._p(coeff)))
         return coeff
 
+    @_stage
     def inverse_rgba8(self, coeff, pix=None):
         """inverse path + createImage (3 components, 8 bit) fused: returns device uint8 [H, W*4] packed RGBA."""
         t = _torch()
@@ -120,6 +147,7 @@ class FramePlan:
         self.ctx.check(self.ctx.L.j2k_plan_inverse_rgba8(self.h, self._p(coeff), self._p(pix), C.c_size_t(int(pix.shape[1]))))
         return pix
 
+    @_stage
     def encode_blocks(self, coeff, slots=None, lens=None, numbps=None):
         t = _torch()
         n = int(self.info.blocks)
@@ -130,6 +158,7 @@ class FramePlan:
                                                          self._p(numbps)))
         return slots, lens, numbps
 
+    @_stage
     def forward_pixels(self, fmt, pix, coeff=None):
         """extractImageData (+ rescale to the plan's precision) + preprocess: pix = device uint8 [H, stride] in a Go Pix layout."""
         coeff = coeff if coeff is not None else self.alloc_coeff()
@@ -137,11 +166,13 @@ class FramePlan:
         self.ctx.check(self.ctx.L.j2k_plan_forward_pixels(self.h, int(fmt), self._p(pix), C.c_size_t(int(pix.shape[1])), self._p(coeff)))
         return coeff
 
+    @_stage
     def inverse_pixels(self, coeff, pix):
         """inverse path + createImage for the plan's component count and precision into pix (device uint8 [H, stride])."""
         self.ctx.check(self.ctx.L.j2k_plan_inverse_pixels(self.h, self._p(coeff), self._p(pix), C.c_size_t(int(pix.shape[1]))))
         return pix
 
+    @_stage
     def encode_stream(self, coeff, stream=None, offs=None, lens=None, numbps=None):
         """encode_blocks + compact in one call (one kernel for HT blocks up to 64x64): returns (stream, offs, lens, numbps)."""
         t = _torch()
@@ -157,6 +188,7 @@ class FramePlan:
     def pack_bound(self):
         return int(self.ctx.L.j2k_plan_pack_bound(self.h))
 
+    @_stage
     def pack_stream(self, stream, offs, lens, numbps, pack=None):
         """Transport form (blocks without the reference's MEL zero runs + the per-block arrays) of the stream the LAST
         encode_stream call on this plan produced; the first int64 of the pack is its length in bytes."""
@@ -166,6 +198,7 @@ class FramePlan:
                                                        self._p(pack)))
         return pack
 
+    @_stage
     def unpack_stream(self, pack, stream=None, offs=None, lens=None, numbps=None):
         """Root side of the gather: pack -> (stream, offs, lens, numbps), byte for byte what encode_stream produced."""
         t = _torch()
@@ -174,21 +207,25 @@ class FramePlan:
         offs = offs if offs is not None else self.empty(n + 1, t.int64)
         lens = lens if lens is not None else self.empty(n, t.int32)
         numbps = numbps if numbps is not None else self.empty(n, t.uint8)
-        self.ctx.check(self.ctx.L.j2k_plan_unpack_stream(self.h, self._p(pack), self._p(stream), self._p(offs), self._p(lens),
-                                                         self._p(numbps)))
+        self.ctx.check(self.ctx.L.j2k_plan_unpack_stream(self.h, self._p(pack), C.c_size_t(int(pack.numel())), self._p(stream), self._p(offs),
+                                                         self._p(lens), self._p(numbps)))
         return stream, offs, lens, numbps
 
+    @_stage
     def unpack_streams(self, packs, outs):
         """unpack_stream for several packs of this geometry in ONE launch: packs = list of uint8 tensors, outs = list of
-        (stream, offs, lens, numbps) tuples to fill."""
+        (stream, offs, lens, numbps) tuples to fill.  A pack is foreign input: its tensor length is passed along and
+        nothing outside it is read."""
         k = len(packs)
         assert k == len(outs)
         VP = C.c_void_p * k
         cols = list(zip(*outs)) if k else [(), (), (), ()]
-        arrs = [VP(*[int(t_.data_ptr()) for t_ in col]) for col in ([*packs],) + tuple(cols)]
-        self.ctx.check(self.ctx.L.j2k_plan_unpack_streams(self.h, C.c_int(k), *arrs))
+        arrs = [VP(*[self._p(t_).value for t_ in col]) for col in ([*packs],) + tuple(cols)]
+        sizes = (C.c_size_t * k)(*[int(p_.numel()) for p_ in packs])
+        self.ctx.check(self.ctx.L.j2k_plan_unpack_streams(self.h, C.c_int(k), arrs[0], sizes, *arrs[1:]))
         return outs
 
+    @_stage
     def compact(self, slots, lens, offs=None, stream=None):
         t = _torch()
         n = int(self.info.blocks)
@@ -198,6 +235,7 @@ class FramePlan:
                                                    self._p(stream)))
         return offs, stream
 
+    @_stage
     def decode_blocks(self, stream, offs, lens, numbps, decoded=None):
         t = _torch()
         decoded = decoded if decoded is not None else self.empty(self.info.decoded_elems, t.int32)

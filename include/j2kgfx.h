@@ -197,17 +197,22 @@ int j2k_plan_encode_stream(j2k_plan *plan, const int32_t *d_coeff, uint8_t *d_st
  * (j2k_plan_pack_bound bytes at most; the first u64 of the pack is its length) and the root rebuilds the dense stream,
  * d_offs (n + 1), d_lens and d_numbps byte for byte with j2k_plan_unpack_stream on a plan of the same geometry (any
  * other pack is reported as J2K_ERR_INVALID_ARG at the next sync).  j2k_plan_pack_stream packs the stream made by the
- * LAST j2k_plan_encode_stream call on this plan (the plan remembers where each block's MagSgn bytes end); MQ streams
- * have no zero runs and are packed as they are. */
+ * LAST j2k_plan_encode_stream call on this plan (the plan remembers where each block's MagSgn bytes end) and returns
+ * J2K_ERR_INVALID_ARG when d_stream / d_lens are not that call's outputs; MQ streams have no zero runs and are packed as
+ * they are. */
 size_t j2k_plan_pack_bound(const j2k_plan *plan);
 int j2k_plan_pack_stream(j2k_plan *plan, const uint8_t *d_stream, const uint64_t *d_offs, const uint32_t *d_lens,
                          const uint8_t *d_numbps, uint8_t *d_pack);
-int j2k_plan_unpack_stream(j2k_plan *plan, const uint8_t *d_pack, uint8_t *d_stream, uint64_t *d_offs,
+/* pack_bytes = the bytes the caller really holds at d_pack (what it received): a pack is foreign input, and nothing
+ * outside [d_pack, d_pack + pack_bytes) is read -- a pack shorter than its header is J2K_ERR_INVALID_ARG at once, one whose
+ * fields point outside it or outside the stream is J2K_ERR_INVALID_ARG at the next sync and copies nothing for the
+ * offending block (every bound is tested without forming a sum of untrusted 64-bit fields). */
+int j2k_plan_unpack_stream(j2k_plan *plan, const uint8_t *d_pack, size_t pack_bytes, uint8_t *d_stream, uint64_t *d_offs,
                            uint32_t *d_lens, uint8_t *d_numbps);
-/* the same for `count` packs of this geometry in one launch (host arrays of device pointers): the root of an N-GPU
- * gather rebuilds the N-1 peers' streams of a frame slot at once */
-int j2k_plan_unpack_streams(j2k_plan *plan, int count, const uint8_t *const *d_packs, uint8_t *const *d_streams,
-                            uint64_t *const *d_offs, uint32_t *const *d_lens, uint8_t *const *d_numbps);
+/* the same for `count` packs of this geometry in one launch (host arrays of device pointers / of byte counts): the root
+ * of an N-GPU gather rebuilds the N-1 peers' streams of a frame slot at once */
+int j2k_plan_unpack_streams(j2k_plan *plan, int count, const uint8_t *const *d_packs, const size_t *pack_bytes,
+                            uint8_t *const *d_streams, uint64_t *const *d_offs, uint32_t *const *d_lens, uint8_t *const *d_numbps);
 /* tcd.TileDecoder.DecodeCodeBlock (tcd.go:393-413) for every job: dense stream + offsets
  * + lens + numbps -> d_decoded (decoded_elems int32, block j dense at its job offset). */
 int j2k_plan_decode_blocks(j2k_plan *plan, const uint8_t *d_stream, const uint64_t *d_offs,

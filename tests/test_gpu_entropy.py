@@ -362,9 +362,8 @@ def test_pack_unpack_stream_round_trip(W, H, tile, cb, coder):
     tot = int(offs[n].item())
     pbytes = int(pack[:8].view(torch.int64)[0].item())
     assert 0 < pbytes <= plan.pack_bound()
-    sent = pack[:pbytes].clone()                                   # what would travel
-    torch.cuda.synchronize()                                       # (the copy ran on torch's stream, the plans have their own)
-    s2, o2, l2, n2 = root.unpack_stream(sent)
+    sent = pack[:pbytes].clone()                                   # what would travel (a torch op on torch's stream: the
+    s2, o2, l2, n2 = root.unpack_stream(sent)                      #  wrapper orders the library stream behind it)
     root.ctx.sync()
     assert torch.equal(o2[:n + 1], offs[:n + 1]) and torch.equal(l2[:n], lens[:n]) and torch.equal(n2[:n], nb[:n])
     assert torch.equal(s2[:tot], stream[:tot])
@@ -377,15 +376,77 @@ def test_pack_unpack_stream_round_trip(W, H, tile, cb, coder):
     outs = [(root.empty(root.info.bytes_cap, torch.uint8), root.empty(n + 1, torch.int64), root.empty(n, torch.int32),
              root.empty(n, torch.uint8)) for _ in range(3)]
     sent2 = sent.clone()
-    torch.cuda.synchronize()
     root.unpack_streams([sent, sent2, sent], outs)
     root.ctx.sync()
     for s3, o3, l3, n3 in outs:
         assert torch.equal(o3[:n + 1], offs[:n + 1]) and torch.equal(l3[:n], lens[:n]) and torch.equal(n3[:n], nb[:n])
         assert torch.equal(s3[:tot], stream[:tot])
     other = FramePlan(W + 64, H, 3, ctx=Context(0), **kw)
-    kept = other.unpack_stream(sent)                               # (outputs kept alive until the sync: the call is asynchronous)
+    other.unpack_stream(sent)                                      # temporaries: record_stream keeps them alive until the kernel ran
     with pytest.raises(J2KError):
         other.ctx.sync()
-    del kept
-    torch.cuda.synchronize()
+    # ---- a pack is foreign input: truncated packs and wrapping offsets are refused, nothing is written ----
+    with pytest.raises(J2KError):                                  # shorter than its own header: refused at the call
+        root.unpack_stream(sent[:64].clone())
+    cut = sent[:pbytes - 1024].clone() if pbytes > 4096 else None  # header intact, payload cut: the claimed size does not fit
+    if cut is not None:
+        root.unpack_stream(cut)
+        with pytest.raises(J2KError):
+            root.ctx.sync()
+    # per-block offset of the first non-empty block set to 2^64 - 8: `off + len > end` would wrap and pass
+    lens_h = lens.cpu().numpy()[:n]
+    j = int(np.flatnonzero(lens_h)[0])
+    # section layout (compact.hip pack_layout): 64-byte header | lens u32[n] | maglens u32[n] | numbps u8[n] | offs u64[n+1] |
+    # toffs u64[n+1] | payload, every section 16-byte aligned
+    a16 = lambda x: (x + 15) & ~15
+    offs_o = a16(a16(a16(64 + 4 * n) + 4 * n) + n)
+    toffs_o = a16(offs_o + 8 * (n + 1))
+    assert a16(toffs_o + 8 * (n + 1)) + int(pack[8:16].view(torch.int64)[0].item()) <= pbytes
+    evil = sent.clone()
+    offs_sec = evil[offs_o:offs_o + 8 * (n + 1)].view(torch.int64)
+    offs_sec[j] = -8
+    guard = torch.full((root.info.bytes_cap + 4096,), 0x5A, dtype=torch.uint8, device=root.device)
+    out_stream = guard[2048:2048 + root.info.bytes_cap]            # poisoned on both sides: a write before / after the stream shows
+    o4, l4, n4 = root.empty(n + 1, torch.int64), root.empty(n, torch.int32), root.empty(n, torch.uint8)
+    root.unpack_stream(evil, out_stream, o4, l4, n4)
+    with pytest.raises(J2KError):
+        root.ctx.sync()
+    assert bool((guard[:2048] == 0x5A).all()) and bool((guard[2048 + root.info.bytes_cap:] == 0x5A).all())
+    evil = sent.clone()
+    toffs_sec = evil[toffs_o:toffs_o + 8 * (n + 1)].view(torch.int64)
+    toffs_sec[j] = -8                                              # transport offset wraps: would read before the payload
+    root.unpack_stream(evil, out_stream, o4, l4, n4)
+    with pytest.raises(J2KError):
+        root.ctx.sync()
+    # ---- pack_stream only packs the outputs of the LAST encode_stream on the plan ----
+    if coder == 1:
+        stream_b, offs_b, lens_b, nb_b = plan.encode_stream(coeff)
+        with pytest.raises(J2KError):
+            plan.pack_stream(stream, offs, lens, nb)               # the older buffers: refused instead of mixing two frames' arrays
+        plan.pack_stream(stream_b, offs_b, lens_b, nb_b)
+        plan.ctx.sync()
+
+
+def test_stage_calls_with_temporaries():
+    """every stage runs on the library's own stream; the wrappers record that stream on the tensors they are
+    given and order it behind torch's, so chained calls on temporaries need no synchronisation in between."""
+    import torch
+    from j2kgfx import Context
+    from j2kgfx.codec import FramePlan
+    rng = np.random.default_rng(5)
+    W, H = 1024, 512
+    plan = FramePlan(W, H, 3, precision=8, lossless=True, num_resolutions=6, cb=(64, 64), tile=(512, 512), coder=1, ctx=Context(0))
+    frame = torch.from_numpy(rng.integers(0, 256, size=(3, H, W)).astype(np.int32)).to(plan.device)
+    coeff = plan.forward(frame)
+    stream, offs, lens, nb = plan.encode_stream(coeff)
+    want = plan.decode_blocks(stream, offs, lens, nb)
+    plan.ctx.sync()
+    want = want.clone()
+    for _ in range(8):
+        # producers on torch's stream (frame * 1), every intermediate a temporary, allocations in between that would reuse
+        # a freed block at once if the library stream were not recorded on it
+        got = plan.decode_blocks(*plan.encode_stream(plan.forward(frame * 1)))
+        junk = [torch.full((plan.info.coeff_elems,), 7, dtype=torch.int32, device=plan.device) for _ in range(3)]
+        plan.ctx.sync()
+        assert torch.equal(got, want)
+        del junk
