@@ -23,9 +23,15 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "go-jpeg2000_amd"))
 
+sys.path.insert(0, ROOT)
+import bench_extra  # noqa: E402  (workload definitions, CPU baseline, the C3 / C5 runner, the tile-sharded mode)
+
 W, H, C, TILE, NRES, CB, PREC = 3840, 2160, 3, 512, 6, 64, 8
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 SEED = 0x4A324B30              # "J2K0" 
+# sha256 of the int32 `decoded` buffer (every code-block of frame 0 as HTDecoder.Decode returns it, job order) -- what the
+# block decoder must have produced in the timed region; tests/test_bench_digest.py recomputes it with the oracle on CPU
+DECODED_SHA256 = "76eab55b1f63e2eb3644d138c6d655d4b16975c46310378f3f9f1bc509de7d5e"
 # HBM traffic of one level-0 launch from the rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KiB -> bytes);
 # cannot be collected from inside this process, so it is the committed measurement (see profiles/)
 TRAFFIC = {   # frame_io -> (bytes per level-0 forward launch, source)
@@ -42,38 +48,12 @@ def synth_frame(np, index):
     return np.clip(base + rng.integers(-16, 17, size=(C, H, W)), 0, 255).astype(np.int32)
 
 
-def cpu_baseline(np, frame, budget_s=12.0):
-    """The C oracle (restatement of the Go algorithm, sequential code-block semantics) on one host
-    thread: same per-tile pipeline as the GPU step, on a bounded sample of tiles."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle as orc
-    orc.lib()
-    tiles = [(x0, y0) for y0 in range(0, H, TILE) for x0 in range(0, W, TILE)]
-    done_px, t0, ntiles = 0, time.perf_counter(), 0
-    import itertools
-    for (x0, y0) in itertools.cycle(tiles):
-        w, h = min(TILE, W - x0), min(TILE, H - y0)
-        crop = [np.ascontiguousarray(frame[c, y0:y0 + h, x0:x0 + w]) for c in range(C)]
-        coeff = orc.preprocess(crop, w, h, PREC, True, NRES)
-        data, lens, _ = orc.encode_tile_blocks(coeff, w, h, NRES, CB, CB, 1)
-        pos = 0
-        for b, ln in zip(orc.enumerate_blocks(C, w, h, NRES, CB, CB), lens):
-            orc.ht_decode(data[pos:pos + int(ln)], int(b["w"]), int(b["h"]))
-            pos += int(ln)
-        back = [orc.reconstruct53(cf, w, h, NRES - 1) for cf in coeff]
-        back = orc.postprocess(back, PREC, True)
-        assert all(np.array_equal(back[c], crop[c]) for c in range(C))
-        done_px += w * h
-        ntiles += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": round(done_px / dt / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": "port",
-            "sample": "%d tiles (%.2f passes over the %d tiles of the same frame, %d px), encode+decode, C oracle -O2, "
-                      "1 thread, %.1f s" % (ntiles, ntiles / len(tiles), len(tiles), done_px, dt)}
+def cpu_baseline(budget_s=10.0):
+    """The C oracle on one host thread and on all host cores, same per-tile pipeline as the GPU step (bench_extra)."""
+    return bench_extra.cpu_baseline("c2", index=0, budget_s=budget_s)
 
 
-def main():
+def run(state):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -85,9 +65,28 @@ def main():
                          "int32 component planes (e.componentData, the boundary of SURVEY 8a-e)")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("J2K_BENCH_INFLIGHT", "3")),
                     help="independent frames coded concurrently per step, each on its own context/stream")
+    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c2",
+                    help="BASELINE.json configuration: c2 (default, the headline: 4K RGB8 5-3 + HT), c3 (4K RGB 12-bit, 9-7 lossy + MQ), "
+                         "c5 (2048x2048 gray16 frames, 5-3 + HT); c4 only with --shard tiles")
+    ap.add_argument("--shard", choices=["frames", "tiles"], default="frames",
+                    help="N > 1: every rank codes its own frames (weak scaling, the default) or ONE frame's tiles are sharded over "
+                         "the ranks, gathered and assembled into tile-parts on rank 0 (strong scaling, C4 geometry)")
     args = ap.parse_args()
     import faulthandler
-    faulthandler.enable()           # a native crash in a rank prints its Python stack
+    faulthandler.enable(all_threads=True)   # a native crash in a rank prints every thread's Python stack
+    if args.shard == "tiles":
+        if args.config == "c2" and "--config" not in sys.argv:
+            args.config = "c4"
+        args.inflight = 1
+        return bench_extra.run_shard_tiles(args)
+    if args.config != "c2":
+        if "--inflight" not in " ".join(sys.argv):
+            args.inflight = 0           # the configuration's own default
+        return bench_extra.run_config(args, args.config)
+    # CPU baseline first (N = 1 only): nothing has touched the GPU yet, so the worker processes are plain forks / spawns
+    cpu_base = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline:
+        cpu_base = cpu_baseline()
 
     import numpy as np
     import torch
@@ -152,7 +151,7 @@ def main():
             self.numbpss = [p.empty(self.n, torch.uint8) for _ in range(nb)]
             self.offss = [p.empty(self.n + 1, torch.int64) for _ in range(nb)]
             self.stream, self.lens, self.numbps, self.offs = self.streams[0], self.lenss[0], self.numbpss[0], self.offss[0]
-            self.decoded = p.empty(i.decoded_elems, torch.int32)
+            self.decoded = torch.zeros(max(int(i.decoded_elems), 4), dtype=torch.int32, device=p.device)   # (padding between blocks stays 0: digest)
             self.back = p.alloc_frame()
             self.gather_bufs = [None] * nb
             # N > 1: what travels is the transport form of the stream (j2k_plan_pack_stream: the blocks without the
@@ -193,6 +192,7 @@ def main():
             self.decode_side()
 
     lanes = [Lane() for _ in range(F)]
+    state["lanes"], state["multi"] = lanes, multi
     # Rank 0 also rebuilds the streams of the other N - 1 ranks (F per rank and step).  From five GPUs on that is more work
     # than coding a frame (measured with J2K_BENCH_ROOT_REHEARSAL: rank 0 at 75 % of the others' rate at N = 8), so rank 0
     # then codes F - 1 frames per step and keeps its last slot for receiving only; `value` counts the frames actually coded.
@@ -305,7 +305,8 @@ def main():
             finally:
                 xdone[b].set()
 
-    xthread = threading.Thread(target=helper, daemon=True)
+    xthread = threading.Thread(target=helper, daemon=False)   # joined by the teardown, also on the error path
+    state["helper"], state["stop_helper"] = xthread, (lambda: xq.put(None))
     if multi:
         xthread.start()
 
@@ -418,6 +419,13 @@ def main():
         else:
             assert torch.equal(ln.back, ln.frame), "lossless round trip failed"
     total_bytes = int(lanes[0].offs[n].item())
+    # the block decoder's output of the timed region (it is not what the inverse transform consumed, see config.workload)
+    decoded_sha = None
+    if rank == 0 and world == 1 and lanes[0].codes:
+        import hashlib
+        decoded_sha = hashlib.sha256(lanes[0].decoded[:int(info.decoded_elems)].cpu().numpy().tobytes()).hexdigest()
+        if DECODED_SHA256 and not DECODED_SHA256.startswith("%"):
+            assert decoded_sha == DECODED_SHA256, "decoded blocks differ from the committed digest (tests/test_bench_digest.py)"
     if pr_mode == "5":                                   # the packs came back through RCCL and were rebuilt: same bytes
         ln = lanes[0]
         a_s, a_o, a_l, a_n = ln.assembled[0]
@@ -452,14 +460,19 @@ def main():
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "3840x2160 sRGB 8-bit, 512x512 tiles, 5-3 lossless + HT block coder, 64x64 code-blocks, "
                                    "6 resolutions (BASELINE configs[1]); frames_in_flight independent frames per rank per step, "
-                                   "each on its own HIP stream; N>1 gathers the compressed streams to rank 0 over RCCL (sent without "
+                                   "each on its own HIP stream; a step = forward transform + HT block coding + stream compaction, then HT "
+                                   "block decode of that stream (checked against a committed sha256) + inverse transform of the ENCODER's "
+                                   "coefficients back to pixels (checked equal to the input): two halves, not a round trip through the "
+                                   "decoded blocks -- the reference's HT coder codes one row in four (SURVEY fact 3) and its decoder has no "
+                                   "packet->plane placement to mirror; N>1 gathers the compressed streams to rank 0 over RCCL (sent without "
                                    "the reference's MEL zero runs, rebuilt byte for byte at rank 0 inside the timed region)",
+                       "decoded_sha256": decoded_sha,
                        "tiles": int(info.tiles), "code_blocks": n, "compressed_bytes_per_frame": total_bytes,
                        "frames_in_flight": F, "frames_in_flight_rank0": F - root_idle_all, "frame_io": args.io,
                        "parallelism": "frames/rank" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm",
-                         "kernel": "dwt53_fwd_kernel<8,3,true,false,%s> (level 0: %sDC shift + RCT + 5-3 lifting, fused)"
-                                   % (("true", "RGBA8 unpack + ") if args.io == "rgba8" else ("false", "")),
+                         "kernel": ("dwt53_fwd_rgba8_wg_kernel (level 0: RGBA8 unpack + DC shift + RCT + 5-3 lifting, fused)" if args.io == "rgba8"
+                                    else "dwt53_fwd_kernel<8,3,true,false,false> (level 0: DC shift + RCT + 5-3 lifting, fused)"),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": TRAFFIC[args.io][0],
                          "algorithmic_bytes_per_launch": alg_bytes,
@@ -472,14 +485,21 @@ def main():
                          "copy_gbs_measured": round(copy_gbs, 1) if copy_gbs else None,
                          "frac_of_measured_copy": round(achieved / copy_gbs, 4) if copy_gbs else None},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(np, frame_h)
+        if cpu_base is not None:
+            out["cpu_baseline"] = cpu_base
         print(json.dumps(out))
-    if multi:
-        xq.put(None)
-        xthread.join()
-        dist.barrier()
-        dist.destroy_process_group()
+
+
+def main():
+    """Explicit teardown whatever happens in the step loop: the exchange helper is stopped and joined,
+    every library stream drained, plans then contexts destroyed, and only then the process group -- see bench_extra.teardown."""
+    state = {}
+    ok = False
+    try:
+        run(state)
+        ok = True
+    finally:
+        bench_extra.teardown(state.get("lanes", []), state.get("multi", False), state.get("helper"), state.get("stop_helper"), ok=ok)
 
 
 if __name__ == "__main__":

@@ -19,6 +19,7 @@
 // constants, the same operand association; the symmetric-extension edge terms are computed as
 // c*(x+x), which is bitwise equal to the reference's (2*c)*x (scaling by two is exact).
 #include "j2k_internal.h"
+#include <hip/hip_ext.h>
 
 namespace j2k {
 
@@ -484,11 +485,11 @@ hipError_t launch_dwt97_fwd(hipStream_t s, const LevelLaunch &L, const void *src
     if (L.njobs <= 0) return hipSuccess;
     const int blocks = (L.njobs + 3) / 4;
     if (L.ncomp == 3) {
-        hipLaunchKernelGGL((dwt97_fwd_kernel<2, 3>), dim3(blocks), dim3(256), 0, s, L.jobs, L.njobs, L.planes, src, src_is_f64, out_i32, out_f64, nxt, dc_shift, quant, step, mct);
+        hipExtLaunchKernelGGL((dwt97_fwd_kernel<2, 3>), dim3(blocks), dim3(256), 0, s, L.ev_start, L.ev_stop, 0, L.jobs, L.njobs, L.planes, src, src_is_f64, out_i32, out_f64, nxt, dc_shift, quant, step, mct);
     } else if (L.cpl == 4) {
-        hipLaunchKernelGGL((dwt97_fwd_kernel<4, 1>), dim3(blocks), dim3(256), 0, s, L.jobs, L.njobs, L.planes, src, src_is_f64, out_i32, out_f64, nxt, dc_shift, quant, step, mct);
+        hipExtLaunchKernelGGL((dwt97_fwd_kernel<4, 1>), dim3(blocks), dim3(256), 0, s, L.ev_start, L.ev_stop, 0, L.jobs, L.njobs, L.planes, src, src_is_f64, out_i32, out_f64, nxt, dc_shift, quant, step, mct);
     } else {
-        hipLaunchKernelGGL((dwt97_fwd_kernel<2, 1>), dim3(blocks), dim3(256), 0, s, L.jobs, L.njobs, L.planes, src, src_is_f64, out_i32, out_f64, nxt, dc_shift, quant, step, mct);
+        hipExtLaunchKernelGGL((dwt97_fwd_kernel<2, 1>), dim3(blocks), dim3(256), 0, s, L.ev_start, L.ev_stop, 0, L.jobs, L.njobs, L.planes, src, src_is_f64, out_i32, out_f64, nxt, dc_shift, quant, step, mct);
     }
     return hipGetLastError();
 }

@@ -631,7 +631,9 @@ static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff, in
         void *in = (l == 0) ? const_cast<void *>(d_frame) : ((l & 1) ? P->d_scrA : P->d_scrB);
         void *nx = (l & 1) ? P->d_scrB : P->d_scrA;
         // profiling (bench.py's roofline line): the level-0 dispatch of the RGB triples stamps its own begin / end
-        hipEvent_t ev0 = (l == 0 && S.wavelet == W53 && P->fwd[1][0].njobs) ? profile_event(ctx) : nullptr;
+        // (the RGB triples' launch when the plan has any, else the single-component one; 5-3 and 9-7 alike)
+        const int prof_cls = P->fwd[1][0].njobs ? 1 : 0;
+        hipEvent_t ev0 = (l == 0 && P->fwd[prof_cls][0].njobs) ? profile_event(ctx) : nullptr;
         hipEvent_t ev1 = ev0 ? profile_event(ctx) : nullptr;
         for (int cls = 0; cls < 2; cls++) {
             const LevelTab &T = P->fwd[cls][l];
@@ -645,11 +647,13 @@ static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff, in
                         L.jobs = P->d_fwd_wg_jobs; L.njobs = P->fwd_wg_njobs; L.wg_waves = P->fwd_wg_waves; L.wg_store = ctx->l0_store;
                     }
                 }
-                if (l == 0 && cls == 1 && ev1) { L.ev_start = ev0; L.ev_stop = ev1; }
+                if (l == 0 && cls == prof_cls && ev1) { L.ev_start = ev0; L.ev_stop = ev1; }
                 HIPCHK(ctx, launch_dwt53_fwd(ctx->stream, L, (const int32_t *)in, (int32_t *)d_coeff, (int32_t *)nx, l == 0 ? S.dc_shift : 0));
             } else {
                 const int src_f64 = (l > 0) || S.frame_is_f64;
-                HIPCHK(ctx, launch_dwt97_fwd(ctx->stream, mk(T), in, src_f64, (int32_t *)d_coeff, (double *)d_coeff, (double *)nx,
+                LevelLaunch L97 = mk(T);
+                if (l == 0 && cls == prof_cls && ev1) { L97.ev_start = ev0; L97.ev_stop = ev1; }
+                HIPCHK(ctx, launch_dwt97_fwd(ctx->stream, L97, in, src_f64, (int32_t *)d_coeff, (double *)d_coeff, (double *)nx,
                                              l == 0 ? S.dc_shift : 0, S.quant, step, (cls == 1) ? 1 : 0));
             }
         }

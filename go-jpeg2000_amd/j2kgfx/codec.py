@@ -7,9 +7,10 @@ torch is used only to own device memory (tensors on `cuda:<ctx.device>`); all ke
 launched by libj2kgfx on the context's own (non-blocking) HIP stream, which torch's caching allocator
 knows nothing about.  With `track_streams=True` (the default) every stage call therefore
   * makes the library stream wait for what torch has queued on its current stream (inputs written by torch ops), and
-  * records the library stream on every tensor handed over (`Tensor.record_stream`), so that a temporary dropped
-    before `ctx.sync()` -- `plan.decode_blocks(*plan.encode_stream(plan.forward(x)))` -- is not given to another
-    tensor while kernels still use it.
+  * keeps a reference to every tensor handed over until the next `ctx.sync()` (or `ctx.close()`), so that a temporary
+    dropped before then -- `plan.decode_blocks(*plan.encode_stream(plan.forward(x)))` -- is not given to another tensor
+    while kernels still use it.  (Not `Tensor.record_stream`: the allocator would record an event on the library stream
+    when such a tensor is finally freed, possibly after its context -- and the stream -- are gone: a crash at teardown.)
 Results are read after `ctx.sync()` (or after ordering torch's stream behind `torch.cuda.ExternalStream(ctx.stream)`).
 bench.py passes `track_streams=False`: its buffers live for the whole run and the launching thread has no slack.
 """
@@ -112,7 +113,7 @@ class FramePlan:
 
     def _p(self, t):
         if self.track_streams:
-            t.record_stream(self._ext())     # the allocator may not recycle t's block before the library stream passes this point
+            self.ctx.hold(t)                 # alive until the library stream has been synchronised
         return C.c_void_p(t.data_ptr())
 
     # ---- stages (asynchronous on the ctx stream) ------------------------------------

@@ -14,14 +14,24 @@ class Context:
         self.h = h
         self.device = int(device)
         self.L = L
+        self._held = []          # tensors in use by work queued on this context's stream (FramePlan stage calls)
 
     def check(self, st):
         if st != _lib.OK:
             raise _lib.J2KError(st, "%s: %s" % (self.L.j2k_status_string(st).decode(),
                                                  self.L.j2k_ctx_last_error(self.h).decode()))
 
+    def hold(self, t):
+        """Keep `t` alive until the next sync(): kernels queued on the library stream may still read or write it."""
+        self._held.append(t)
+        if len(self._held) > 8192:           # a caller that never synchronises: do it for them rather than grow for ever
+            self.sync()
+
     def sync(self):
-        self.check(self.L.j2k_ctx_sync(self.h))
+        try:
+            self.check(self.L.j2k_ctx_sync(self.h))
+        finally:
+            self._held.clear()
 
     def profile_enable(self, on=True):
         self.check(self.L.j2k_ctx_profile_enable(self.h, int(bool(on))))
@@ -38,8 +48,12 @@ class Context:
 
     def close(self):
         if self.h:
-            self.L.j2k_ctx_destroy(self.h)
-            self.h = None
+            try:
+                self.L.j2k_ctx_sync(self.h)      # drain the stream before its buffers and the stream itself go away
+            finally:
+                self._held.clear()
+                self.L.j2k_ctx_destroy(self.h)
+                self.h = None
 
     def __del__(self):
         try:

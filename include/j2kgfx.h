@@ -299,6 +299,34 @@ int j2k_convert_colorspace_device(j2k_ctx *ctx, int colorspace, int32_t *d_plane
 int j2k_encode_frame(j2k_plan *plan, int32_t *const *planes, int32_t *coeff, uint8_t *out, size_t cap,
                      size_t *out_len, uint64_t *tile_offs, uint32_t *lens, uint8_t *numbps);
 
+/* ---- multi-tile codestream assembly: host calls, no device needed ------------------------------
+ * j2k_create_tile_header = encoder.createTileHeader(tileIdx, tileData) (encoder.go:746-760): SOT (0xFF90) Lsot = 10,
+ * Isot = uint16(tileIdx), Psot = uint32(14 + len), TPsot = 0, TNsot = 1, SOD (0xFF93), then the tile data -- 14 + len bytes.
+ * j2k_assemble_tiles applies it to every tile of a (gathered) stream, tile t = stream[tile_offs[t], tile_offs[t+1]) with
+ * index tile_first + t, tile-parts laid end to end: what rank 0 hands to the Go side between the main header and EOC
+ * (the reference's generateTiles, encoder.go:568-579, emits tile 0 only). */
+size_t j2k_tile_part_bound(const uint64_t *tile_offs, int ntiles);
+int j2k_create_tile_header(int tile_idx, const uint8_t *tile_data, size_t len, uint8_t *out, size_t cap, size_t *out_len);
+int j2k_assemble_tiles(const uint8_t *stream, const uint64_t *tile_offs, int tile_first, int ntiles, uint8_t *out, size_t cap,
+                       size_t *out_len);
+/* codestream.Parser.ReadTilePartHeader (internal/codestream/parser.go:894-983): the SOT fields of the tile-part whose SOT
+ * marker is at cs[pos], its in-header marker segments skipped by length (parser.go:180-190; their contents stay with the
+ * Go-side parser: header_off / header_markers say where they are), and where its data lies (Psot = 0: to the end).
+ * Errors as the parser's: Lsot != 10, a segment length < 2, truncated input -> J2K_ERR_INVALID_ARG. */
+typedef struct j2k_tile_part {
+    uint16_t tile_index;          /* Isot  */
+    uint8_t tile_part_index;      /* TPsot */
+    uint8_t num_tile_parts;       /* TNsot */
+    uint32_t tile_part_length;    /* Psot  */
+    uint32_t header_markers;      /* marker segments between the SOT segment and SOD */
+    uint32_t pad_;
+    uint64_t header_off;          /* offset of the first of them (== data_off - 2 when there are none) */
+    uint64_t data_off, data_len;  /* the tile-part's data */
+} j2k_tile_part;
+int j2k_read_tile_part_header(const uint8_t *cs, size_t len, size_t pos, j2k_tile_part *tp);
+/* every tile-part of a run of tile-parts (up to EOC or the end); *nparts = how many there are (J2K_ERR_CAPACITY if > cap) */
+int j2k_parse_tile_parts(const uint8_t *cs, size_t len, j2k_tile_part *parts, size_t cap, size_t *nparts);
+
 #ifdef __cplusplus
 }
 #endif

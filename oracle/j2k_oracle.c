@@ -1701,3 +1701,20 @@ int orc_pin_can_use_run_length(uint8_t *flags, int w, int h, int x, int y) {
     }
     return 1;
 }
+
+/* ======================================================================== */
+/* encoder.createTileHeader (encoder.go:746-760) -- SURVEY 8f rank 1          */
+/* ======================================================================== */
+size_t orc_create_tile_header(int tile_idx, const uint8_t *tile_data, size_t len, uint8_t *out) {
+    const uint32_t psot = (uint32_t)(14 + len);             /* uint32(14 + len(tileData)) */
+    const uint16_t isot = (uint16_t)tile_idx;               /* uint16(tileIdx) */
+    out[0] = 0xFF; out[1] = 0x90;                           /* codestream.SOT, markers.go:9 */
+    out[2] = 0; out[3] = 10;                                /* sotLength */
+    out[4] = (uint8_t)(isot >> 8); out[5] = (uint8_t)isot;
+    out[6] = (uint8_t)(psot >> 24); out[7] = (uint8_t)(psot >> 16); out[8] = (uint8_t)(psot >> 8); out[9] = (uint8_t)psot;
+    out[10] = 0;                                            /* tile-part index */
+    out[11] = 1;                                            /* number of tile-parts */
+    out[12] = 0xFF; out[13] = 0x93;                         /* codestream.SOD, markers.go:10 */
+    for (size_t i = 0; i < len; i++) out[14 + i] = tile_data[i];
+    return 14 + len;
+}

@@ -128,6 +128,9 @@ long orc_encode_tile_blocks(int32_t *const *planes, int ncomp, int w, int h,
                             int num_resolutions, int cb_w, int cb_h, int coder,
                             uint8_t *out, size_t cap, uint32_t *lens, uint8_t *numbps);
 
+/* encoder.createTileHeader(tileIdx, tileData) (encoder.go:746-760): writes 14 + len bytes to out, returns that count */
+size_t orc_create_tile_header(int tile_idx, const uint8_t *tile_data, size_t len, uint8_t *out);
+
 /* ---- pins: internals at the granularity of the reference's own unit tests ------------
  * (internal/entropy/coverage_test.go, t1_test.go; tests/test_oracle_reference_pins.py) */
 void orc_pin_mq_byte_out(uint8_t *buf, size_t buflen, long bp, uint32_t c,

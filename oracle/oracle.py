@@ -300,3 +300,12 @@ def encode_tile_blocks(planes, w, h, num_resolutions, cb_w, cb_h, coder):
     if n < 0:
         raise ValueError("orc_encode_tile_blocks status %d" % n)
     return out[:n].copy(), lens[:nj].copy(), nbps[:nj].copy()
+
+
+def create_tile_header(tile_idx, tile_data):
+    """encoder.createTileHeader (encoder.go:746-760)"""
+    d = np.frombuffer(bytes(tile_data), dtype=np.uint8)
+    out = np.zeros(14 + d.size, np.uint8)
+    lib().orc_create_tile_header.restype = C.c_size_t
+    n = lib().orc_create_tile_header(int(tile_idx), _u8(d) if d.size else None, C.c_size_t(d.size), _u8(out))
+    return out[:n].tobytes()

@@ -162,6 +162,36 @@ def test_bench_two_rank_control_flow_rehearsal():
     assert d["n_gpus"] == 2 and d["config"]["frames_in_flight"] == 2 and d["value"] > 0
 
 
+def _bench_two_ranks(extra):
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, J2K_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"] + extra
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_bench_tile_sharded_two_rank_rehearsal():
+    """bench.py --shard tiles with two ranks sharing this box's GPU over gloo: rank r codes its contiguous range of one frame's
+    tiles, rank 0 rebuilds rank 1's pack and assembles every tile into a tile-part; bench.py itself asserts that the tile-parts
+    name tiles 0..n-1 in order and carry, byte for byte, the stream of an unsharded plan."""
+    d = _bench_two_ranks(["--shard", "tiles", "--config", "c2"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["tiles"] == 40 and d["value"] > 0
+
+
+def test_bench_frames_per_rank_c5_two_rank_rehearsal():
+    """bench.py --config c5 (frames sharded over the ranks, no exchange) with two ranks over gloo."""
+    d = _bench_two_ranks(["--config", "c5", "--inflight", "2"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+
+
 def test_bench_rccl_self_loop_rehearsal():
     """The transfer calls of bench.py's N > 1 step on this box's one GPU: a one-rank RCCL group, the rank sends its packs
     to itself (batched isend / irecv issued from the helper thread), rebuilds them and bench.py asserts the rebuilt
