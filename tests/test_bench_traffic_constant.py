@@ -1,0 +1,26 @@
+"""CPU: bench.py's `roofline.traffic` constant is the committed PMC measurement it cites (the number
+must not go stale silently when the kernel or its profile changes)."""
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_traffic_constant_matches_committed_pmc_summary():
+    import bench
+    nbytes, src = bench.TRAFFIC["rgba8"]
+    path = os.path.join(ROOT, src.split(":")[0])
+    assert os.path.exists(path), path
+    vals = {}
+    for ln in open(path):
+        m = re.match(r"\s*(\S.*?)\s+(FETCH_SIZE|WRITE_SIZE) n=\d+ avg=([0-9.]+)", ln)
+        if m and m.group(1).startswith("dwt53_fwd_rgba8_wg_kernel"):
+            vals[m.group(2)] = float(m.group(3))
+    assert set(vals) == {"FETCH_SIZE", "WRITE_SIZE"}
+    # gfx950: FETCH_SIZE reads half the bytes of a wide coalesced stream (MI355X_MICROARCH.md, HBM); both in KiB
+    measured = (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024
+    assert abs(measured - nbytes) <= 0.001 * nbytes, (measured, nbytes)
+    alg = 3840 * 2160 * 16                                  # one RGBA8 dword in, three int32 out per pixel
+    assert 1.0 <= nbytes / alg < 1.03                       # halo re-reads are L2 hits: traffic ~= algorithmic bytes
