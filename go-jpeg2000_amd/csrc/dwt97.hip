@@ -477,12 +477,39 @@ __global__ __launch_bounds__(256) void dwt97_inv_kernel(const DwtJob *__restrict
     }
 }
 
+typedef int v4i __attribute__((ext_vector_type(4)));
+#include "dwt97_l0wg.inc"
+
 // ================================================================================
 // launchers
 // ================================================================================
+template <int NW>
+static hipError_t fwd97_wg_go(hipStream_t s, const LevelLaunch &L, const void *src, int32_t *out_i32, double *out_f64, double *nxt,
+                              int dc_shift, int quant, double step) {
+    const int32_t *p = reinterpret_cast<const int32_t *>(src);
+    const double rstep = 1.0 / step;          // RN(1 / step): the reciprocal of the Markstein division (dwt97_l0wg.inc)
+#define J2K_WG97(Q) hipExtLaunchKernelGGL((dwt97_fwd_rgb_wg_kernel<NW, Q, 7>), dim3(L.njobs), dim3(NW * 64), 0, s, L.ev_start, L.ev_stop, 0, \
+                                           L.jobs, L.njobs, L.planes, p, out_i32, out_f64, nxt, dc_shift, step, rstep)
+    if (quant == Q_ENCODER_) J2K_WG97(Q_ENCODER_);
+    else if (quant == Q_TCD_) J2K_WG97(Q_TCD_);
+    else J2K_WG97(Q_NONE_);
+#undef J2K_WG97
+    return hipGetLastError();
+}
+
 hipError_t launch_dwt97_fwd(hipStream_t s, const LevelLaunch &L, const void *src, int src_is_f64, int32_t *out_i32, double *out_f64,
                             double *nxt, int dc_shift, int quant, double step, int mct) {
     if (L.njobs <= 0) return hipSuccess;
+    if (L.wg_waves > 0) {      // level 0 of an int32 RGB triple with ICT, workgroup form (dwt97_l0wg.inc); geometry checked by the plan
+        if (L.ncomp != 3 || src_is_f64 || !mct) return hipErrorInvalidValue;
+        if (L.wg_waves == 6) return fwd97_wg_go<6>(s, L, src, out_i32, out_f64, nxt, dc_shift, quant, step);
+        if (L.wg_waves == 8) return fwd97_wg_go<8>(s, L, src, out_i32, out_f64, nxt, dc_shift, quant, step);
+        if (L.wg_waves == 10) return fwd97_wg_go<10>(s, L, src, out_i32, out_f64, nxt, dc_shift, quant, step);
+        if (L.wg_waves == 12) return fwd97_wg_go<12>(s, L, src, out_i32, out_f64, nxt, dc_shift, quant, step);
+        if (L.wg_waves == 14) return fwd97_wg_go<14>(s, L, src, out_i32, out_f64, nxt, dc_shift, quant, step);
+        if (L.wg_waves == 16) return fwd97_wg_go<16>(s, L, src, out_i32, out_f64, nxt, dc_shift, quant, step);
+        return hipErrorInvalidValue;
+    }
     const int blocks = (L.njobs + 3) / 4;
     if (L.ncomp == 3) {
         hipExtLaunchKernelGGL((dwt97_fwd_kernel<2, 3>), dim3(blocks), dim3(256), 0, s, L.ev_start, L.ev_stop, 0, L.jobs, L.njobs, L.planes, src, src_is_f64, out_i32, out_f64, nxt, dc_shift, quant, step, mct);

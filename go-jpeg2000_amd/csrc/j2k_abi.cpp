@@ -106,6 +106,7 @@ extern "C" int j2k_ctx_create(int device, j2k_ctx **out) {
         if (v >= 1 && v <= 4096) ctx->band_prows = v;
     }
     if (const char *e = getenv("J2K_L0_WG")) { int v = atoi(e); if (v == 0 || v == 4 || v == 8) ctx->l0_wg = v; }
+    if (const char *e = getenv("J2K_L0_WG97")) { int v = atoi(e); if (v == 0 || (v >= 6 && v <= 16 && v % 2 == 0)) ctx->l0_wg97 = v; }
     if (const char *e = getenv("J2K_L0_XCD")) ctx->l0_xcd = atoi(e) != 0;
     if (const char *e = getenv("J2K_L0_WG_INV")) ctx->l0_wg_inv = atoi(e) != 0;
     if (const char *e = getenv("J2K_L0_STORE")) { int v = atoi(e); if (v == 0 || v == 1 || v == 2 || v == 4) ctx->l0_store = v; }
@@ -471,6 +472,39 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                         if (r != J2K_OK) { j2k_plan_destroy(P); return r; }
                     }
                 }
+                if (dir == 0 && l == 0 && cls == 1 && S.wavelet == W97 && S.mct && !S.frame_is_f64 && ctx->l0_wg97 > 0) {
+                    // workgroup form of the lossy level 0 (dwt97_l0wg.inc): one job per (plane, band of NW - 3 pair-rows,
+                    // component); the three components of a band are neighbours in the table and the whole table is dealt
+                    // XCD-aware like the 5-3 one, so the rows they share are L2 hits
+                    // (precision <= 16 and Quality < 8192 keep every value the kernel converts inside int32: round_half_away_inrange)
+                    bool ok97 = S.precision <= 16 && S.quality > 0 && S.quality < 8192;
+                    for (size_t i = 0; i < planes.size() && ok97; i++) {
+                        const DwtPlane &D = planes[i];
+                        if (pw[i] < 16 || pw[i] > 512 || (pw[i] % 8) || ph[i] < 2 || (S.W % 4)) ok97 = false;
+                        for (int k = 0; k < 3; k++)
+                            if ((D.src_off[k] % 4) || (D.out_off[k] % 4) || (D.nxt_off[k] % 4)) ok97 = false;
+                    }
+                    if (ok97) {
+                        std::vector<DwtJob> wj;
+                        const int nr = ctx->l0_wg97 - 3;
+                        for (size_t i = 0; i < planes.size(); i++)
+                            for (int pr = 0; pr < (ph[i] + 1) / 2; pr += nr)
+                                for (int k = 0; k < 3; k++) wj.push_back(DwtJob{(int)i, k, pr, nr});
+                        if (ctx->l0_xcd && wj.size() >= 64) {
+                            const size_t chunk = (wj.size() + 7) / 8;
+                            std::vector<DwtJob> perm(chunk * 8, DwtJob{-1, 0, 0, 0});
+                            for (size_t b = 0; b < perm.size(); b++) {
+                                const size_t j = (b % 8) * chunk + b / 8;
+                                if (j < wj.size()) perm[b] = wj[j];
+                            }
+                            wj.swap(perm);
+                        }
+                        P->fwd97_wg_njobs = (int)wj.size();
+                        P->fwd97_wg_waves = ctx->l0_wg97;
+                        r = upload(ctx, &P->d_fwd97_wg_jobs, wj);
+                        if (r != J2K_OK) { j2k_plan_destroy(P); return r; }
+                    }
+                }
                 if (dir == 0) {
                     P->dwt_bytes += T.alg_bytes;
                     if (l == 0) P->dwt_level0_bytes += T.alg_bytes;
@@ -544,7 +578,7 @@ extern "C" void j2k_plan_destroy(j2k_plan *P) {
         for (auto &T : P->fwd[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); }
         for (auto &T : P->inv[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); }
     }
-    void *ptrs[] = {P->d_scrA, P->d_scrB, P->d_tail, P->d_bjobs, P->d_djobs, P->d_frame, P->d_coeff, P->d_slots, P->d_stream, P->d_lens, P->d_numbps, P->d_offs, P->d_status, P->d_fwd_pix_jobs, P->d_fwd_wg_jobs, P->d_maglens, P->d_mels, P->d_toffs};
+    void *ptrs[] = {P->d_scrA, P->d_scrB, P->d_tail, P->d_bjobs, P->d_djobs, P->d_frame, P->d_coeff, P->d_slots, P->d_stream, P->d_lens, P->d_numbps, P->d_offs, P->d_status, P->d_fwd_pix_jobs, P->d_fwd_wg_jobs, P->d_fwd97_wg_jobs, P->d_maglens, P->d_mels, P->d_toffs};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete P;
 }
@@ -653,6 +687,9 @@ static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff, in
                 const int src_f64 = (l > 0) || S.frame_is_f64;
                 LevelLaunch L97 = mk(T);
                 if (l == 0 && cls == prof_cls && ev1) { L97.ev_start = ev0; L97.ev_stop = ev1; }
+                if (l == 0 && cls == 1 && !src_f64 && P->d_fwd97_wg_jobs) {      // the workgroup form when every plane qualifies
+                    L97.jobs = P->d_fwd97_wg_jobs; L97.njobs = P->fwd97_wg_njobs; L97.wg_waves = P->fwd97_wg_waves;
+                }
                 HIPCHK(ctx, launch_dwt97_fwd(ctx->stream, L97, in, src_f64, (int32_t *)d_coeff, (double *)d_coeff, (double *)nx,
                                              l == 0 ? S.dc_shift : 0, S.quant, step, (cls == 1) ? 1 : 0));
             }
