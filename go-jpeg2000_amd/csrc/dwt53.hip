@@ -1098,9 +1098,13 @@ hipError_t launch_dwt53_inv(hipStream_t s, const LevelLaunch &L, const int32_t *
         if (L.njobs <= 0) return hipSuccess;
         if (L.pix_stride <= 0 || L.ncomp != 3 || !final_level) return hipErrorInvalidValue;
         uint32_t *pix = reinterpret_cast<uint32_t *>(dst);
-        if (L.wg_waves == 4) hipExtLaunchKernelGGL((dwt53_inv_rgba8_wg_kernel<4, 5>), dim3(L.njobs), dim3(256), 0, s, L.ev_start, L.ev_stop, 0, L.jobs, L.njobs, L.planes, coef, prev, pix, dc_shift, L.pix_stride);
-        else if (L.wg_waves == 8) hipExtLaunchKernelGGL((dwt53_inv_rgba8_wg_kernel<8, 5>), dim3(L.njobs), dim3(512), 0, s, L.ev_start, L.ev_stop, 0, L.jobs, L.njobs, L.planes, coef, prev, pix, dc_shift, L.pix_stride);
+#define J2K_INVWG(NW, WPE) hipExtLaunchKernelGGL((dwt53_inv_rgba8_wg_kernel<NW, WPE>), dim3(L.njobs), dim3(NW * 64), 0, s, L.ev_start, L.ev_stop, 0, \
+                                             L.jobs, L.njobs, L.planes, coef, prev, pix, dc_shift, L.pix_stride)
+        const int wpe = L.wg_store;    // (inverse: occupancy variant, J2K_L0_INV_WPE: 5 = everything in registers, 6 / 7 = odd row parked in LDS)
+        if (L.wg_waves == 4) { if (wpe == 5) J2K_INVWG(4, 5); else if (wpe == 7) J2K_INVWG(4, 7); else J2K_INVWG(4, 6); }
+        else if (L.wg_waves == 8) { if (wpe == 5) J2K_INVWG(8, 5); else if (wpe == 7) J2K_INVWG(8, 7); else J2K_INVWG(8, 6); }
         else return hipErrorInvalidValue;
+#undef J2K_INVWG
         return hipGetLastError();
     }
     J2K_DISPATCH(inv_go, s, L, coef, prev, dst, dc_shift, final_level);

@@ -357,16 +357,31 @@ __device__ bool ht_encode_fast(const BlockJob &J, const int32_t *__restrict__ sr
     return ht_emit<true>(J, out, lane, vbuf, mbuf, TM, TV, magLenOut, vlcLenOut);
 }
 
+// ujobs / alias_next (j2k_plan_encode_stream only): the block coder addresses every band's blocks from the TOP-LEFT of the plane
+// (encoder.go:763-795), so the three bands of a resolution read the same windows, and this coder ignores the band
+// (ht.go:942): jobs with the same window are byte-identical.  The plan lists one job per distinct window (ujobs), chains
+// the others to it (alias_next) and points their slot at the coded one's; the kernel codes each distinct window once and
+// reports its length / bit-plane count / MagSgn length for every job of the chain.
+__device__ __forceinline__ void ht_publish(int jid, const int *__restrict__ alias_next, uint32_t *__restrict__ lens, uint8_t *__restrict__ numbps,
+                                           uint32_t *__restrict__ maglens, uint32_t len, uint32_t nb, bool has_mag, uint32_t mag) {
+    for (int j = jid; j >= 0; j = alias_next ? alias_next[j] : -1) {
+        lens[j] = len;
+        numbps[j] = (uint8_t)nb;
+        if (maglens && has_mag) maglens[j] = mag;
+    }
+}
+
 __global__ __launch_bounds__(64) void ht_encode_kernel(const BlockJob *__restrict__ jobs, int njobs,
                                                        const int32_t *__restrict__ coef, uint8_t *__restrict__ slots,
                                                        uint32_t *__restrict__ lens, uint8_t *__restrict__ numbps,
-                                                       int *__restrict__ fault, uint32_t *__restrict__ maglens) {
+                                                       int *__restrict__ fault, uint32_t *__restrict__ maglens,
+                                                       const int *__restrict__ ujobs, const int *__restrict__ alias_next) {
     // maglens != NULL (j2k_plan_encode_stream): also report where the MagSgn bytes end, and do NOT write the MEL
     // segment's zero bytes into the slot -- the gather puts zeros straight into the stream instead of copying them
     __shared__ uint32_t s_vbuf[HT_VLC_WORDS];
     __shared__ uint32_t s_mbuf[HT_MS_WORDS];
-    const int jid = blockIdx.x;
-    if (jid >= njobs) return;
+    if ((int)blockIdx.x >= njobs) return;          // njobs = entries of ujobs when given
+    const int jid = ujobs ? ujobs[blockIdx.x] : (int)blockIdx.x;
     const int lane = threadIdx.x;
     const BlockJob J = jobs[jid];
     const int w = J.w, h = J.h, stride = J.stride;
@@ -380,13 +395,26 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(const BlockJob *__restric
         const int wq = w >> 2, nq = wq * h;
         const int dy = 64 / wq, dx = 64 - dy * wq;
         int y = lane / wq, xq = lane - y * wq;
-        for (int e = lane; e < nq; e += 64) {
-            const int4 q = *reinterpret_cast<const int4 *>(src + (size_t)y * stride + 4 * xq);
-            const int a0 = q.x < 0 ? (int)(0u - (uint32_t)q.x) : q.x, a1 = q.y < 0 ? (int)(0u - (uint32_t)q.y) : q.y;
-            const int a2 = q.z < 0 ? (int)(0u - (uint32_t)q.z) : q.z, a3 = q.w < 0 ? (int)(0u - (uint32_t)q.w) : q.w;
-            maxMag = max(max(maxMag, max(a0, a1)), max(a2, a3));
-            y += dy; xq += dx;
-            if (xq >= wq) { xq -= wq; y++; }
+        // eight loads in flight per step (clamped, unconditional addresses): one load per iteration made a 64x64 block sixteen
+        // SERIAL memory round trips -- the wave's whole life (~30 us under load) and the reason this kernel did not speed up
+        // when two thirds of its blocks went away
+        for (int e0 = lane; e0 < nq; e0 += 64 * 8) {
+            int4 qv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const bool ok = e0 + 64 * u < nq;
+                const int4 t = *reinterpret_cast<const int4 *>(ok ? src + (size_t)y * stride + 4 * xq : src);
+                qv[u] = ok ? t : make_int4(0, 0, 0, 0);
+                y += dy; xq += dx;
+                if (xq >= wq) { xq -= wq; y++; }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int4 q = qv[u];
+                const int a0 = q.x < 0 ? (int)(0u - (uint32_t)q.x) : q.x, a1 = q.y < 0 ? (int)(0u - (uint32_t)q.y) : q.y;
+                const int a2 = q.z < 0 ? (int)(0u - (uint32_t)q.z) : q.z, a3 = q.w < 0 ? (int)(0u - (uint32_t)q.w) : q.w;
+                maxMag = max(max(maxMag, max(a0, a1)), max(a2, a3));
+            }
         }
     } else {
         for (int y = 0; y < h; y++)
@@ -398,7 +426,7 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(const BlockJob *__restric
     }
     for (int o = 32; o > 0; o >>= 1) maxMag = max(maxMag, __shfl_xor(maxMag, o));
     if (maxMag == 0) {
-        if (lane == 0) { lens[jid] = 0; numbps[jid] = 0; }
+        if (lane == 0) ht_publish(jid, alias_next, lens, numbps, maglens, 0, 0, false, 0);
         return;
     }
     if ((size_t)((h + 3) / 4) * (size_t)w <= HT_FAST_MAX_SAMPLES) {
@@ -407,18 +435,16 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(const BlockJob *__restric
         const size_t maxSize_ = nsamp_ * 2 < 64 ? 64 : nsamp_ * 2;
         const size_t melLen_ = maxSize_ / 4;
         if (!ht_encode_fast(J, src, out, lane, s_vbuf, s_mbuf, mLen, vLen)) {
-            if (lane == 0) { atomicMax(fault, 1); lens[jid] = 0; numbps[jid] = 0; }
+            if (lane == 0) { atomicMax(fault, 1); ht_publish(jid, alias_next, lens, numbps, maglens, 0, 0, false, 0); }
             return;
         }
         if (!maglens) zero_bytes(out + mLen, melLen_, lane);
         if (lane == 0) {
-            if (maglens) maglens[jid] = (uint32_t)mLen;
             const size_t scup = melLen_ + (size_t)vLen + 2;
             const size_t total = (size_t)mLen + scup;
             out[total - 2] = (uint8_t)(scup >> 8);
             out[total - 1] = (uint8_t)(scup & 0xFF);
-            lens[jid] = (uint32_t)total;
-            numbps[jid] = (uint8_t)(32 - __clz((uint32_t)maxMag));
+            ht_publish(jid, alias_next, lens, numbps, maglens, (uint32_t)total, 32 - __clz((uint32_t)maxMag), true, (uint32_t)mLen);
         }
         return;
     }
@@ -485,7 +511,7 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(const BlockJob *__restric
     }
     magLen = __shfl(magLen, 0); vlcLen = __shfl(vlcLen, 0); bad = __shfl(bad, 0);
     if (bad) {
-        if (lane == 0) { atomicMax(fault, 1); lens[jid] = 0; numbps[jid] = 0; }
+        if (lane == 0) { atomicMax(fault, 1); ht_publish(jid, alias_next, lens, numbps, maglens, 0, 0, false, 0); }
         return;
     }
     // ---- assemble: MagSgn | MEL zeros | VLC | SCUP (ht.go:1017-1042) ----
@@ -505,9 +531,7 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(const BlockJob *__restric
         const size_t total = (size_t)magLen + scup;
         out[total - 2] = (uint8_t)(scup >> 8);
         out[total - 1] = (uint8_t)(scup & 0xFF);
-        lens[jid] = (uint32_t)total;
-        numbps[jid] = (uint8_t)(32 - __clz((uint32_t)maxMag));
-        if (maglens) maglens[jid] = (uint32_t)magLen;
+        ht_publish(jid, alias_next, lens, numbps, maglens, (uint32_t)total, 32 - __clz((uint32_t)maxMag), true, (uint32_t)magLen);
     }
 }
 
@@ -1413,11 +1437,13 @@ static hipError_t ht_tables_ready(hipStream_t s) {
 }
 
 hipError_t launch_ht_encode(hipStream_t s, const BlockJob *jobs, int njobs, const int32_t *coef, uint8_t *slots,
-                            uint32_t *lens, uint8_t *numbps, int *fault, uint32_t *maglens) {
+                            uint32_t *lens, uint8_t *numbps, int *fault, uint32_t *maglens, const int *ujobs, int nunique,
+                            const int *alias_next) {
     if (njobs <= 0) return hipSuccess;
     hipError_t e;
     if ((e = ht_tables_ready(s)) != hipSuccess) return e;
-    hipLaunchKernelGGL(ht_encode_kernel, dim3(njobs), dim3(64), 0, s, jobs, njobs, coef, slots, lens, numbps, fault, maglens);
+    const int n = ujobs ? nunique : njobs;
+    hipLaunchKernelGGL(ht_encode_kernel, dim3(n), dim3(64), 0, s, jobs, n, coef, slots, lens, numbps, fault, maglens, ujobs, alias_next);
     return hipGetLastError();
 }
 

@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <tuple>
 
 #include "j2k_plan.h"
 
@@ -20,7 +22,8 @@ hipError_t launch_dwt97_fwd(hipStream_t s, const LevelLaunch &L, const void *src
 hipError_t launch_dwt97_inv(hipStream_t s, const LevelLaunch &L, const void *coef, int coef_is_f64, const double *prev,
                             void *dst, int dc_shift, int final_level, int dst_mode, int mct);
 hipError_t launch_ht_encode(hipStream_t s, const BlockJob *jobs, int njobs, const int32_t *coef, uint8_t *slots,
-                            uint32_t *lens, uint8_t *numbps, int *fault, uint32_t *maglens = nullptr);
+                            uint32_t *lens, uint8_t *numbps, int *fault, uint32_t *maglens = nullptr, const int *ujobs = nullptr, int nunique = 0,
+                            const int *alias_next = nullptr);
 hipError_t launch_ht_decode(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs,
                             const uint32_t *lens, int32_t *decoded, uint32_t *scratch);
 size_t ht_decode_scratch_words(int njobs);
@@ -108,6 +111,8 @@ extern "C" int j2k_ctx_create(int device, j2k_ctx **out) {
     if (const char *e = getenv("J2K_L0_WG")) { int v = atoi(e); if (v == 0 || v == 4 || v == 8) ctx->l0_wg = v; }
     if (const char *e = getenv("J2K_L0_WG97")) { int v = atoi(e); if (v == 0 || (v >= 6 && v <= 16 && v % 2 == 0)) ctx->l0_wg97 = v; }
     if (const char *e = getenv("J2K_L0_XCD")) ctx->l0_xcd = atoi(e) != 0;
+    if (const char *e = getenv("J2K_HT_ALIAS")) ctx->ht_alias = atoi(e) != 0;
+    if (const char *e = getenv("J2K_L0_INV_WPE")) { int v = atoi(e); if (v >= 5 && v <= 7) ctx->l0_inv_wpe = v; }
     if (const char *e = getenv("J2K_L0_WG_INV")) ctx->l0_wg_inv = atoi(e) != 0;
     if (const char *e = getenv("J2K_L0_STORE")) { int v = atoi(e); if (v == 0 || v == 1 || v == 2 || v == 4) ctx->l0_store = v; }
     if (const char *e = getenv("J2K_BAND_PROWS_PIX")) { int v = atoi(e); if (v >= 1 && v <= 4096) ctx->band_prows_pix = v; }
@@ -563,6 +568,26 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
         }
         P->bytes_cap = slot; P->decoded_elems = dec;
         int r = upload(ctx, &P->d_bjobs, bj);
+        if (r == J2K_OK && S.coder == J2K_CODER_HT && ctx->ht_alias) {
+            // Jobs with the same window are byte-identical for the HT coder (top-left addressing + a coder that ignores the
+            // band: see ht_encode_kernel): one coded job per distinct window, the others chained to it and gathering from its
+            // slot.  Only j2k_plan_encode_stream uses these tables (its slot buffer is private); the per-slot API does not.
+            std::map<std::tuple<int64_t, int32_t, int32_t, int32_t>, int> first;
+            std::vector<int> ujobs, next(bj.size(), -1), last(bj.size(), -1);
+            std::vector<BlockJob> aj = bj;
+            for (size_t i = 0; i < bj.size(); i++) {
+                auto key = std::make_tuple(bj[i].src_off, bj[i].stride, bj[i].w, bj[i].h);
+                auto it = first.find(key);
+                if (it == first.end()) { first[key] = (int)i; ujobs.push_back((int)i); last[i] = (int)i; }
+                else { const int c = it->second; next[last[c]] = (int)i; last[c] = (int)i; aj[i].out_off = bj[c].out_off; }
+            }
+            if (ujobs.size() < bj.size()) {
+                P->ht_nunique = (int)ujobs.size();
+                r = upload(ctx, &P->d_ht_ujobs, ujobs);
+                if (r == J2K_OK) r = upload(ctx, &P->d_ht_alias_next, next);
+                if (r == J2K_OK) r = upload(ctx, &P->d_bjobs_alias, aj);
+            }
+        }
         for (size_t i = 0; i < bj.size(); i++) bj[i].out_off = (int64_t)P->dec_off[i];   // decode table: dense decoded blocks
         if (r == J2K_OK) r = upload(ctx, &P->d_djobs, bj);
         if (r != J2K_OK) { j2k_plan_destroy(P); return r; }
@@ -578,7 +603,7 @@ extern "C" void j2k_plan_destroy(j2k_plan *P) {
         for (auto &T : P->fwd[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); }
         for (auto &T : P->inv[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); }
     }
-    void *ptrs[] = {P->d_scrA, P->d_scrB, P->d_tail, P->d_bjobs, P->d_djobs, P->d_frame, P->d_coeff, P->d_slots, P->d_stream, P->d_lens, P->d_numbps, P->d_offs, P->d_status, P->d_fwd_pix_jobs, P->d_fwd_wg_jobs, P->d_fwd97_wg_jobs, P->d_maglens, P->d_mels, P->d_toffs};
+    void *ptrs[] = {P->d_scrA, P->d_scrB, P->d_tail, P->d_bjobs, P->d_djobs, P->d_frame, P->d_coeff, P->d_slots, P->d_stream, P->d_lens, P->d_numbps, P->d_offs, P->d_status, P->d_fwd_pix_jobs, P->d_fwd_wg_jobs, P->d_fwd97_wg_jobs, P->d_ht_ujobs, P->d_ht_alias_next, P->d_bjobs_alias, P->d_maglens, P->d_mels, P->d_toffs};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete P;
 }
@@ -721,7 +746,7 @@ static int plan_inverse_impl(j2k_plan *P, const void *d_coeff, void *d_frame, in
                 if (l == 0 && cls == 1 && pix_cls == 1 && pix_stride > 0 && P->d_fwd_wg_jobs && ctx->l0_wg_inv) {
                     // RGBA8: the workgroup form when every plane qualifies (same job table as the forward: the plane order
                     // of the inverse level table is the forward one)
-                    L.jobs = P->d_fwd_wg_jobs; L.njobs = P->fwd_wg_njobs; L.wg_waves = P->fwd_wg_waves;
+                    L.jobs = P->d_fwd_wg_jobs; L.njobs = P->fwd_wg_njobs; L.wg_waves = P->fwd_wg_waves; L.wg_store = ctx->l0_inv_wpe;
                 }
                 HIPCHK(ctx, launch_dwt53_inv(ctx->stream, L, (const int32_t *)d_coeff, (const int32_t *)prev, (int32_t *)dst,
                                              l == 0 ? S.dc_shift_inv : 0, l == 0));
@@ -1091,9 +1116,9 @@ extern "C" int j2k_plan_encode_stream(j2k_plan *P, const int32_t *d_coeff, uint8
         if (r != J2K_OK) return r;
         ctx->fault_armed = true;
         HIPCHK(ctx, launch_ht_encode(ctx->stream, P->d_bjobs, n, d_coeff, (uint8_t *)P->d_slots, d_lens, d_numbps, (int *)ctx->stage[3],
-                                     P->d_maglens));
+                                     P->d_maglens, P->d_ht_ujobs, P->ht_nunique, P->d_ht_alias_next));
         // the transport offsets (a second running sum in the scan, +4 us) only once j2k_plan_pack_stream has asked for them
-        HIPCHK(ctx, launch_compact(ctx->stream, P->d_bjobs, n, (const uint8_t *)P->d_slots, d_lens, d_offs, d_stream, P->d_maglens,
+        HIPCHK(ctx, launch_compact(ctx->stream, P->d_bjobs_alias ? P->d_bjobs_alias : P->d_bjobs, n, (const uint8_t *)P->d_slots, d_lens, d_offs, d_stream, P->d_maglens,
                                    P->want_toffs ? P->d_mels : nullptr, P->want_toffs ? P->d_toffs : nullptr));
         P->toffs_valid = P->want_toffs;
         P->last_stream = d_stream; P->last_lens = d_lens;

@@ -17,6 +17,8 @@ struct j2k_ctx {
     int l0_wg = 4;             // packed RGBA8 level-0 forward, workgroup form: wavefronts per workgroup (J2K_L0_WG: 0 off, 4, 8)
     int l0_wg97 = 8;           // lossy level-0 forward of an RGB triple, workgroup form: waves per workgroup (J2K_L0_WG97: 0 off, 6..16 even; measured 4K: 8 -> 78 us, 16 -> 88 us, general kernel 160 us)
     bool l0_xcd = true;        // XCD-aware order of the workgroup jobs (J2K_L0_XCD=0: plane-major order)
+    bool ht_alias = true;      // j2k_plan_encode_stream (HT): code each distinct block window once (J2K_HT_ALIAS=0: every job)
+    int l0_inv_wpe = 5;        // its occupancy variant (J2K_L0_INV_WPE: 5 = all in registers, 26.4 us; 6 = odd row parked in LDS for 6 waves per SIMD, measured slower: 33.6 us)
     bool l0_wg_inv = true;     // the inverse level 0 to RGBA8 in workgroup form too (J2K_L0_WG_INV=0: the general kernel)
     int l0_store = 1;          // its final-coefficient store flavour (J2K_L0_STORE: 0 plain, 1 nt, 2 sc1, 4 sc1 nt)
     int band_prows_pix = 3;    // packed-pixel level-0 forward (J2K_BAND_PROWS_PIX)
@@ -121,6 +123,9 @@ struct j2k_plan {
     // fused encode + compact (j2k_plan_encode_stream): look-back status words, tagged with the launch epoch
     j2k::DwtJob *d_fwd_pix_jobs = nullptr;  // level-0 forward job table of the packed-pixel path (shorter bands)
     int fwd_pix_njobs = 0;
+    int *d_ht_ujobs = nullptr, *d_ht_alias_next = nullptr;   // HT: jobs with distinct windows / chain of the jobs sharing a window
+    j2k::BlockJob *d_bjobs_alias = nullptr;                  // d_bjobs with every job's slot = the slot of its window's coded job
+    int ht_nunique = 0;
     j2k::DwtJob *d_fwd97_wg_jobs = nullptr; // 9-7: one job per workgroup = (plane, component, band) of dwt97_fwd_rgb_wg_kernel
     int fwd97_wg_njobs = 0, fwd97_wg_waves = 0;
     j2k::DwtJob *d_fwd_wg_jobs = nullptr;   // the same as one job per WORKGROUP (dwt53_fwd_rgba8_wg_kernel), when every plane qualifies
