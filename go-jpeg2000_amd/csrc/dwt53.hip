@@ -1023,6 +1023,20 @@ static hipError_t fwd_wg_go(hipStream_t s, const LevelLaunch &L, const int32_t *
     const uint32_t *pix = reinterpret_cast<const uint32_t *>(src);
 #define J2K_WG(FL) hipExtLaunchKernelGGL((dwt53_fwd_rgba8_wg_kernel<NW, FL, 6>), dim3(L.njobs), dim3(NW * 64), 0, s, L.ev_start, L.ev_stop, 0, \
                                          L.jobs, L.njobs, L.planes, pix, out, nxt, dc, L.pix_stride)
+    // with a fused part the event pair brackets both launches (start on the first, stop on the second)
+    const hipEvent_t ev_a = L.ev_start, ev_b = L.ev_stop;
+    if (L.njobs2 > 0) {
+#define J2K_WG2(W, FL) hipExtLaunchKernelGGL((dwt53_fwd_rgba8_wg2_kernel<W, FL, 5>), dim3(L.njobs2), dim3(W * 64), 0, s, ev_a, L.njobs > 0 ? nullptr : ev_b, 0, \
+                                             L.jobs2, L.njobs2, L.planes, L.planes1, pix, out, L.nxt1, dc, L.pix_stride)
+        if (L.wg2_waves == 16) { if (L.wg_store == 0) J2K_WG2(16, 0); else J2K_WG2(16, 1); }
+        else { if (L.wg_store == 0) J2K_WG2(8, 0); else J2K_WG2(8, 1); }
+#undef J2K_WG2
+        if (L.njobs <= 0) return hipGetLastError();
+    }
+    const hipEvent_t ev_s = L.njobs2 > 0 ? nullptr : ev_a;
+#undef J2K_WG
+#define J2K_WG(FL) hipExtLaunchKernelGGL((dwt53_fwd_rgba8_wg_kernel<NW, FL, 6>), dim3(L.njobs), dim3(NW * 64), 0, s, ev_s, ev_b, 0, \
+                                         L.jobs, L.njobs, L.planes, pix, out, nxt, dc, L.pix_stride)
     switch (L.wg_store) {
         case 0: J2K_WG(0); break;
         case 2: J2K_WG(2); break;
@@ -1084,7 +1098,7 @@ static hipError_t inv_go(hipStream_t s, const LevelLaunch &L, const int32_t *coe
 
 hipError_t launch_dwt53_fwd(hipStream_t s, const LevelLaunch &L, const int32_t *src, int32_t *out, int32_t *nxt, int dc_shift) {
     if (L.wg_waves > 0) {      // packed RGBA8 level 0, workgroup form (dwt53_l0pix.inc); geometry checked by the plan
-        if (L.njobs <= 0) return hipSuccess;
+        if (L.njobs <= 0 && L.njobs2 <= 0) return hipSuccess;
         if (L.pix_stride <= 0 || L.ncomp != 3) return hipErrorInvalidValue;
         if (L.wg_waves == 4) return fwd_wg_go<4>(s, L, src, out, nxt, dc_shift);
         if (L.wg_waves == 8) return fwd_wg_go<8>(s, L, src, out, nxt, dc_shift);

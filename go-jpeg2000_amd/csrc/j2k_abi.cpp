@@ -108,6 +108,7 @@ extern "C" int j2k_ctx_create(int device, j2k_ctx **out) {
         int v = atoi(e);
         if (v >= 1 && v <= 4096) ctx->band_prows = v;
     }
+    if (const char *e = getenv("J2K_L0_FUSE")) { int v = atoi(e); if (v == 0 || v == 8 || v == 16) ctx->l0_fuse = v; }
     if (const char *e = getenv("J2K_L0_WG")) { int v = atoi(e); if (v == 0 || v == 4 || v == 8) ctx->l0_wg = v; }
     if (const char *e = getenv("J2K_L0_WG97")) { int v = atoi(e); if (v == 0 || (v >= 6 && v <= 16 && v % 2 == 0)) ctx->l0_wg97 = v; }
     if (const char *e = getenv("J2K_L0_XCD")) ctx->l0_xcd = atoi(e) != 0;
@@ -475,6 +476,33 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                         P->fwd_wg_waves = ctx->l0_wg;
                         r = upload(ctx, &P->d_fwd_wg_jobs, wj);
                         if (r != J2K_OK) { j2k_plan_destroy(P); return r; }
+                        // levels 0 + 1 in one launch (dwt53_fwd_rgba8_wg2_kernel): needs a level 1 (levels >= 2), only RGB
+                        // triples in the frame (the level-1 plane table is then three planes per level-0 plane, same order)
+                        if (ctx->l0_fuse > 0 && L >= 2 && S.C == 3 && (P->tail_l0 < 0 || P->tail_l0 >= 2)) {
+                            auto xcd = [&](std::vector<DwtJob> &v) {
+                                if (!ctx->l0_xcd || v.size() < 64) return;
+                                const size_t chunk = (v.size() + 7) / 8;
+                                std::vector<DwtJob> perm(chunk * 8, DwtJob{-1, 0, 0, 0});
+                                for (size_t b = 0; b < perm.size(); b++) {
+                                    const size_t j = (b % 8) * chunk + b / 8;
+                                    if (j < v.size()) perm[b] = v[j];
+                                }
+                                v.swap(perm);
+                            };
+                            std::vector<DwtJob> fj, rj;
+                            const int nr2 = ctx->l0_fuse - 3, nr = ctx->l0_wg - 1;
+                            for (size_t i = 0; i < planes.size(); i++) {
+                                const int halfH = (ph[i] + 1) / 2, halfH1 = (halfH + 1) / 2;
+                                int pr = 0;
+                                for (; pr < halfH1; pr += nr2) fj.push_back(DwtJob{(int)i, 0, pr, nr2});
+                                for (; pr < halfH; pr += nr) rj.push_back(DwtJob{(int)i, 0, pr, nr});
+                            }
+                            xcd(fj); xcd(rj);
+                            P->fwd_wg2_njobs = (int)fj.size(); P->fwd_wg2_waves = ctx->l0_fuse; P->fwd_wg_rest_njobs = (int)rj.size();
+                            r = upload(ctx, &P->d_fwd_wg2_jobs, fj);
+                            if (r == J2K_OK && !rj.empty()) r = upload(ctx, &P->d_fwd_wg_rest_jobs, rj);
+                            if (r != J2K_OK) { j2k_plan_destroy(P); return r; }
+                        }
                     }
                 }
                 if (dir == 0 && l == 0 && cls == 1 && S.wavelet == W97 && S.mct && !S.frame_is_f64 && ctx->l0_wg97 > 0) {
@@ -603,7 +631,7 @@ extern "C" void j2k_plan_destroy(j2k_plan *P) {
         for (auto &T : P->fwd[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); }
         for (auto &T : P->inv[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); }
     }
-    void *ptrs[] = {P->d_scrA, P->d_scrB, P->d_tail, P->d_bjobs, P->d_djobs, P->d_frame, P->d_coeff, P->d_slots, P->d_stream, P->d_lens, P->d_numbps, P->d_offs, P->d_status, P->d_fwd_pix_jobs, P->d_fwd_wg_jobs, P->d_fwd97_wg_jobs, P->d_ht_ujobs, P->d_ht_alias_next, P->d_bjobs_alias, P->d_maglens, P->d_mels, P->d_toffs};
+    void *ptrs[] = {P->d_scrA, P->d_scrB, P->d_tail, P->d_bjobs, P->d_djobs, P->d_frame, P->d_coeff, P->d_slots, P->d_stream, P->d_lens, P->d_numbps, P->d_offs, P->d_status, P->d_fwd_pix_jobs, P->d_fwd_wg2_jobs, P->d_fwd_wg_rest_jobs, P->d_fwd_wg_jobs, P->d_fwd97_wg_jobs, P->d_ht_ujobs, P->d_ht_alias_next, P->d_bjobs_alias, P->d_maglens, P->d_mels, P->d_toffs};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete P;
 }
@@ -686,7 +714,9 @@ static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff, in
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const double step = 1.0 / (double)S.quality;   // encoder.go:269
     const int nlevel_launches = (P->tail_l0 >= 0) ? P->tail_l0 : S.levels;
+    bool fused_l1 = false;             // level 1 ran inside the level-0 launch (packed RGBA8 frames, dwt53_fwd_rgba8_wg2_kernel)
     for (int l = 0; l < nlevel_launches; l++) {
+        if (l == 1 && fused_l1) continue;
         void *in = (l == 0) ? const_cast<void *>(d_frame) : ((l & 1) ? P->d_scrA : P->d_scrB);
         void *nx = (l & 1) ? P->d_scrB : P->d_scrA;
         // profiling (bench.py's roofline line): the level-0 dispatch of the RGB triples stamps its own begin / end
@@ -704,6 +734,12 @@ static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff, in
                     if (cls == 1 && P->d_fwd_pix_jobs) { L.jobs = P->d_fwd_pix_jobs; L.njobs = P->fwd_pix_njobs; }
                     if (cls == 1 && P->d_fwd_wg_jobs) {   // RGBA8: the workgroup form when every plane qualifies
                         L.jobs = P->d_fwd_wg_jobs; L.njobs = P->fwd_wg_njobs; L.wg_waves = P->fwd_wg_waves; L.wg_store = ctx->l0_store;
+                        if (P->d_fwd_wg2_jobs) {           // ... with level 1 fused into the bands of the top half of every plane
+                            L.jobs2 = P->d_fwd_wg2_jobs; L.njobs2 = P->fwd_wg2_njobs; L.wg2_waves = P->fwd_wg2_waves;
+                            L.jobs = P->d_fwd_wg_rest_jobs; L.njobs = P->fwd_wg_rest_njobs;
+                            L.planes1 = P->fwd[0][1].d_planes; L.nxt1 = (int32_t *)P->d_scrB;
+                            fused_l1 = true;
+                        }
                     }
                 }
                 if (l == 0 && cls == prof_cls && ev1) { L.ev_start = ev0; L.ev_stop = ev1; }

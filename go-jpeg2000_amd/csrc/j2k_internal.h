@@ -62,6 +62,13 @@ struct LevelLaunch {
     int wg_waves;         // > 0: `jobs` is the per-WORKGROUP table of dwt53_fwd_rgba8_wg_kernel (dwt53_l0pix.inc): wg_waves
                           // wavefronts per workgroup, wg_waves - 1 pair-rows each; level 0 of an RGBA8 frame only
     int wg_store;         // its final-coefficient store flavour (0 plain, 1 nt, ...)
+    // levels 0 + 1 in one launch (dwt53_fwd_rgba8_wg2_kernel): jobs2 = the bands of the top half of every plane (wg2_waves waves
+    // each), planes1 = the level-1 plane table (three per level-0 plane), nxt1 = the scratch that feeds level 2; `jobs` then
+    // holds only the remaining bands
+    const DwtJob *jobs2;
+    int njobs2, wg2_waves;
+    const DwtPlane *planes1;
+    int32_t *nxt1;
     hipEvent_t ev_start, ev_stop;   // non-null: the dispatch itself stamps these (hipExtLaunchKernelGGL) -- the kernel's own
                                     // begin / end, without the launch gap an event pair around the launch would include
 };

@@ -14,6 +14,7 @@ struct j2k_ctx {
                                // Measured slower than the three kernels it replaces (61.7 vs 58.6 us: the prefix chain crosses XCDs)
     int fwd_link = 1;          // forward 5-3: bands of one workgroup exchange halo rows through LDS (J2K_FWD_LINK)
     int inv_link = 1;          // same for the inverse kernels (J2K_INV_LINK)
+    int l0_fuse = 0;           // forward levels 0 + 1 of RGBA8 frames in one launch: waves per workgroup of the fused bands (J2K_L0_FUSE: 0 off, 8, 16)
     int l0_wg = 4;             // packed RGBA8 level-0 forward, workgroup form: wavefronts per workgroup (J2K_L0_WG: 0 off, 4, 8)
     int l0_wg97 = 8;           // lossy level-0 forward of an RGB triple, workgroup form: waves per workgroup (J2K_L0_WG97: 0 off, 6..16 even; measured 4K: 8 -> 78 us, 16 -> 88 us, general kernel 160 us)
     bool l0_xcd = true;        // XCD-aware order of the workgroup jobs (J2K_L0_XCD=0: plane-major order)
@@ -128,6 +129,8 @@ struct j2k_plan {
     int ht_nunique = 0;
     j2k::DwtJob *d_fwd97_wg_jobs = nullptr; // 9-7: one job per workgroup = (plane, component, band) of dwt97_fwd_rgb_wg_kernel
     int fwd97_wg_njobs = 0, fwd97_wg_waves = 0;
+    j2k::DwtJob *d_fwd_wg2_jobs = nullptr, *d_fwd_wg_rest_jobs = nullptr;   // fused levels 0+1: top-half bands / the remaining bands
+    int fwd_wg2_njobs = 0, fwd_wg2_waves = 0, fwd_wg_rest_njobs = 0;
     j2k::DwtJob *d_fwd_wg_jobs = nullptr;   // the same as one job per WORKGROUP (dwt53_fwd_rgba8_wg_kernel), when every plane qualifies
     int fwd_wg_njobs = 0, fwd_wg_waves = 0;
     uint32_t *d_maglens = nullptr;          // j2k_plan_encode_stream: end of each block's MagSgn bytes (the MEL hole starts there)

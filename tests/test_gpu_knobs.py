@@ -1,0 +1,72 @@
+"""GPU: the non-default settings of the round-2 A/B knobs produce the same bits as the default ones ("none of them
+changes results").  The knobs are read when a context is created, so each case builds its own Context under a patched
+environment and compares with the default context on the same frame."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(env):
+    from j2kgfx import Context
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return Context(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("env", [{"J2K_L0_FUSE": 8}, {"J2K_L0_FUSE": 16}, {"J2K_L0_WG": 0}, {"J2K_L0_WG": 8}, {"J2K_L0_WG": 4, "J2K_L0_XCD": 0}, {"J2K_L0_STORE": 0}, {"J2K_L0_STORE": 4},
+                                 {"J2K_L0_WG_INV": 0}, {"J2K_L0_INV_WPE": 6}, {"J2K_HT_ALIAS": 0}])
+def test_rgba8_pipeline_knobs(env):
+    """packed RGBA8 frame (tiles of 512, 256-wide and short edge tiles): coefficients, HT stream + arrays and reconstructed
+    pixels are identical whatever level-0 kernel / store flavour / job order / alias setting produced them"""
+    import torch
+    from j2kgfx import Context
+    from j2kgfx.codec import FramePlan
+    W, H = 1280, 624
+    rng = np.random.default_rng(11)
+    pix_h = rng.integers(0, 256, size=(H, W * 4), dtype=np.uint8)
+    pix_h.reshape(H, W, 4)[:, :, 3] = 255
+    kw = dict(precision=8, lossless=True, num_resolutions=6, cb=(64, 64), tile=(512, 512), coder=1)
+    out = []
+    for ctx in (Context(0), _ctx(env)):
+        plan = FramePlan(W, H, 3, ctx=ctx, **kw)
+        pix = torch.from_numpy(pix_h).to(plan.device)
+        coeff = plan.forward_rgba8(pix)
+        stream, offs, lens, nb = plan.encode_stream(coeff)
+        back = plan.inverse_rgba8(coeff)
+        ctx.sync()
+        n = int(plan.info.blocks)
+        tot = int(offs[n].item())
+        out.append((coeff.cpu(), stream[:tot].cpu(), offs[:n + 1].cpu(), lens[:n].cpu(), nb[:n].cpu(), back.cpu()))
+        assert torch.equal(out[-1][5], torch.from_numpy(pix_h))
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("wg", [0, 6, 12, 16])
+def test_lossy_level0_knobs(wg):
+    """lossy RGB frame: the quantised coefficients of the general 9-7 kernel and of the workgroup form (any waves per
+    workgroup) are identical -- including the Markstein division against the IEEE division of the general kernel"""
+    import torch
+    from j2kgfx import Context
+    from j2kgfx.codec import FramePlan
+    W, H = 1024, 600
+    rng = np.random.default_rng(12)
+    frame_h = rng.integers(0, 4096, size=(3, H, W)).astype(np.int32)
+    kw = dict(precision=12, lossless=False, quality=75, num_resolutions=6, cb=(64, 64), tile=(512, 512), coder=0)
+    res = []
+    for ctx in (Context(0), _ctx({"J2K_L0_WG97": wg})):
+        plan = FramePlan(W, H, 3, ctx=ctx, **kw)
+        coeff = plan.forward(torch.from_numpy(frame_h).to(plan.device))
+        ctx.sync()
+        res.append(coeff.cpu())
+    assert torch.equal(res[0], res[1])

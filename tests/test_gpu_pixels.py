@@ -82,6 +82,51 @@ def test_plan_forward_inverse_rgba8(oracle, W, H, tile, pad):
     assert np.array_equal(bpix.cpu().numpy().reshape(H, W, 4)[..., :3], pix[:, :W * 4].reshape(H, W, 4)[..., :3])   # lossless
 
 
+def _ctx_with(env):
+    import os
+    from j2kgfx import Context
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return Context(0)                       # the knobs are read when a context is created
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("fuse", [0, 8, 16])
+@pytest.mark.parametrize("nres", [2, 3, 4, 6])
+@pytest.mark.parametrize("W,H,tile", [(512, 512, 0), (512, 112, 0), (256, 110, 0), (64, 114, 0), (16, 6, 0), (24, 2, 0), (512, 4, 0), (128, 10, 0),
+                                      (512, 258, 0), (496, 200, 0), (40, 37, 0), (512, 511, 0), (1280, 624, 512), (768, 300, 256), (1024, 1024, 512), (3840, 2160, 512)])
+def test_rgba8_workgroup_kernels_shapes(W, H, tile, nres, fuse):
+    """The workgroup level-0 kernels (and, J2K_L0_FUSE = 8 / 16, level 1 fused into the forward one) against the general planar kernels of the same
+    plan on every boundary shape: odd and tiny heights, odd level-1 heights (h = 110, 114, 37), bands that end exactly at /
+    one row before the prefix, narrow planes (16, 24, 40 columns), 1 to 5 decomposition levels (levels = 1: nothing to fuse;
+    levels = 2: level 1 is the last level, nothing of it goes to scratch)."""
+    import torch
+    from j2kgfx.codec import FramePlan
+    rng = np.random.default_rng(W * 7 + H + nres)
+    pix = rng.integers(0, 256, (H, W * 4)).astype(np.uint8)
+    plan = FramePlan(W, H, 3, precision=8, lossless=True, num_resolutions=nres, cb=(64, 64), tile=(tile, tile), coder=1,
+                     ctx=_ctx_with({"J2K_L0_FUSE": fuse}))
+    dpix = torch.from_numpy(pix).to(plan.device)
+    planes = np.stack([pix.reshape(H, W, 4)[..., c].astype(np.int32) for c in range(3)])
+    frame = torch.from_numpy(planes).to(plan.device)
+    want = plan.forward(frame)
+    got = plan.forward_rgba8(dpix)
+    plan.ctx.sync()
+    assert torch.equal(got, want)
+    got = plan.forward_rgba8(dpix)               # once more on an idle device: a different issue timing (this caught a
+    plan.ctx.sync()                              # store-data hazard behind an inline-asm store that the first, queued run hid)
+    assert torch.equal(got, want)
+    bpix = plan.inverse_rgba8(got)
+    plan.ctx.sync()
+    assert np.array_equal(bpix.cpu().numpy().reshape(H, W, 4)[..., :3], pix.reshape(H, W, 4)[..., :3])
+
+
 @pytest.mark.parametrize("W,H,tile,pad", [(2048, 2048, 0, 0), (1024, 256, 512, 32), (512, 64, 0, 16), (200, 96, 0, 0), (100, 75, 64, 6)])
 def test_plan_forward_inverse_gray16(oracle, W, H, tile, pad):
     """BASELINE C5's input format: image.Gray16 at 16 bit.  The level-0 kernels read / write the big-endian pixels
