@@ -171,16 +171,18 @@ __device__ __forceinline__ uint32_t get_bits8(const uint32_t *buf, uint32_t bitp
 
 // Part 1: every quad pair's code words and MagSgn fields deposited into the two LDS bit strings.  Returns false on the
 // reference's panic domain (MinInt32).  TM / TV = bits in the MagSgn / VLC strings.
-__device__ bool ht_form(const BlockJob &J, const int32_t *__restrict__ src, int lane, uint32_t *vbuf, uint32_t *mbuf,
-                        uint32_t &TMout, uint32_t &TVout) {
-    const int w = J.w, h = J.h, stride = J.stride;
+// LROWS: the coded rows (y % 4 == 0) were staged in LDS by the caller's max scan (row r at lrows + r * w): no second trip to memory.
+template <bool LROWS>
+__device__ __forceinline__ bool ht_form(const BlockJob &J, const int32_t *__restrict__ src, int lane, uint32_t *vbuf, uint32_t *mbuf,
+                        uint32_t &TMout, uint32_t &TVout, const int32_t *lrows, const uint16_t *enc) {
+    const int w = J.w, h = J.h, stride = LROWS ? J.w : J.stride;
     const int quadCols = (w + 3) / 4, P = (quadCols + 1) / 2, R = (h + 3) / 4, N = R * P;
     for (int i = lane; i < HT_VLC_WORDS; i += 64) vbuf[i] = 0;
     for (int i = lane; i < HT_MS_WORDS; i += 64) mbuf[i] = 0;
     __syncthreads();
     uint32_t vbase = 0, mbase = 0;   // running bit totals
     int bad = 0;
-    const bool vec_ok = ((stride & 3) == 0) && ((J.src_off & 3) == 0);
+    const bool vec_ok = ((J.stride & 3) == 0) && ((J.src_off & 3) == 0);
     for (int i0 = 0; i0 < N; i0 += 64) {
         const int it = i0 + lane;
         uint64_t vv = 0; uint32_t vl = 0, ml = 0;
@@ -190,10 +192,10 @@ __device__ bool ht_form(const BlockJob &J, const int32_t *__restrict__ src, int 
         if (it < N) {
             const int r = it / P, pi = it - r * P;
             const int initial = (r == 0);
-            const int32_t *row = src + (size_t)(4 * r) * stride;
+            const int32_t *row = LROWS ? lrows + r * w : src + (size_t)(4 * r) * stride;
             const int xb = pi * 8;
             int v[8];
-            if (vec_ok && xb + 8 <= w) {
+            if ((LROWS || vec_ok) && xb + 8 <= w) {
                 const int4 a = *reinterpret_cast<const int4 *>(row + xb), b = *reinterpret_cast<const int4 *>(row + xb + 4);
                 v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
             } else {
@@ -209,8 +211,8 @@ __device__ bool ht_form(const BlockJob &J, const int32_t *__restrict__ src, int 
                 if (v[i] != 0) rho |= 1u << i;
                 if (v[4 + i] != 0) rho2 |= 1u << i;
             }
-            const uint32_t e1 = g_vlc_enc[(initial << 6) | rho];
-            const uint32_t e2 = g_vlc_enc[(initial << 6) | ((rho >> 2) << 4) | rho2];
+            const uint32_t e1 = enc[(initial << 6) | rho];
+            const uint32_t e2 = enc[(initial << 6) | ((rho >> 2) << 4) | rho2];
             vv = (uint64_t)(e1 >> 4);
             vl = e1 & 0xF;
             vv |= (uint64_t)(e2 >> 4) << vl;
@@ -254,9 +256,22 @@ __device__ bool ht_form(const BlockJob &J, const int32_t *__restrict__ src, int 
         uint32_t vpos = vbase + vs - vl, mpos = mbase + ms - ml;
         if (it < N) {
             or_bits(vbuf, vpos, vv);
+            if (ml <= 64) {
+                // the item's fields concatenated in registers, one deposit: an eighth of the LDS atomics, and blocks of small
+                // magnitudes (1-bit fields, 32 to a word) no longer serialise on one word
+                uint64_t acc = 0;
+                uint32_t sh = 0;
 #pragma unroll
-            for (int i = 0; i < 8; i++)
-                if (mlen[i]) { or_bits(mbuf, mpos, (uint64_t)mval[i]); mpos += mlen[i]; }
+                for (int i = 0; i < 8; i++) {
+                    acc |= shl64((uint64_t)mval[i], sh);       // mval < 2^mlen; an absent field is 0 bits of 0
+                    sh += mlen[i];
+                }
+                if (acc) or_bits(mbuf, mpos, acc);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                    if (mlen[i]) { or_bits(mbuf, mpos, (uint64_t)mval[i]); mpos += mlen[i]; }
+            }
         }
         vbase += vtot; mbase += mtot;
     }
@@ -267,150 +282,274 @@ __device__ bool ht_form(const BlockJob &J, const int32_t *__restrict__ src, int 
     return true;
 }
 
+// Where the 0xFF bytes of the MagSgn segment fall.  The stuffing rule (after a 0xFF byte the next byte takes 7 bits,
+// ht.go:1303-1327) makes byte boundaries depend on every 0xFF before them, but a 0xFF byte is eight consecutive one bits
+// of the unstuffed string starting at a byte boundary, and such places are rare: all lanes look for 8-runs of ones in
+// their words, and only those candidates are visited in order (a wave-uniform loop, a dozen scalar instructions each):
+// a candidate at p is a 0xFF byte iff p is a byte boundary of the current alignment; the byte after it starts at p + 8
+// and is 7 bits wide (never 0xFF), the next 8-bit byte starts at p + 15.  flist[i] = start bit of the i-th 0xFF byte.
+#define HT_MS_FF_CAP 2176                      /* > 31 * HT_FAST_MAX_SAMPLES / 15 */
+__device__ __forceinline__ int ht_ms_find_ff(const uint32_t *mbuf, uint32_t TM, int lane, uint16_t *flist, uint32_t &myF) {
+    int nF = 0;
+    uint32_t base = 0;                         // byte boundaries: the positions >= base congruent to base mod 8
+    myF = 0;                                   // lane i also keeps flist[i] (i < 64) in a register
+    const uint32_t nwords = (TM + 31) >> 5;
+    for (uint32_t w0 = 0; w0 < nwords; w0 += 64) {
+        const uint32_t wi = w0 + lane;
+        uint64_t x = 0;
+        if (wi < nwords) x = (uint64_t)mbuf[wi] | ((uint64_t)mbuf[wi + 1] << 32);   // (the string is followed by zero words)
+        uint64_t y = x & (x >> 1);
+        y &= y >> 2;
+        y &= y >> 4;                           // bit p: bits p .. p+7 of x are all ones
+        const uint32_t m = (uint32_t)y;        // runs that start inside my word
+        // One vector step per 0xFF byte: every lane masks its candidates down to those on the current byte grid at or behind
+        // `base`; the lowest one in the wave is the next 0xFF byte and moves the grid.  (A scalar walk over the candidate
+        // words cost ~200 cycles per word, branches mostly; blocks of small magnitudes have dozens of them and few real 0xFF.)
+        const uint32_t p0 = 32u * wi;
+        for (;;) {
+            const uint32_t lo = base > p0 ? base - p0 : 0u;
+            const uint32_t cand = lo >= 32 ? 0u : (m & (0xFFFFFFFFu << lo) & (0x01010101u << (base & 7)));   // p0 is a multiple of 8
+            const unsigned long long who = __ballot(cand != 0);
+            if (!who) break;
+            const int L = __ffsll((long long)who) - 1;
+            const uint32_t cL = (uint32_t)__builtin_amdgcn_readlane((int)cand, L);
+            const uint32_t p = 32u * (w0 + (uint32_t)L) + (uint32_t)__ffs((int)cL) - 1;
+            if (lane == 0) flist[nF] = (uint16_t)p;
+            if (lane == nF) myF = p;
+            nF++;
+            base = p + 15;
+        }
+    }
+    return nF;
+}
+
 // Part 2: the bytes.  WRITE = false only counts them (the fused encode + compact kernel needs the length of a block
-// before it knows where the block goes).
+// before it knows where the block goes).  flist: HT_MS_FF_CAP halfwords of LDS.
 template <bool WRITE>
 __device__ bool ht_emit(const BlockJob &J, uint8_t *__restrict__ out, int lane, const uint32_t *vbuf, const uint32_t *mbuf,
-                        uint32_t mbase, uint32_t vbase, long &magLenOut, long &vlcLenOut) {
+                        uint32_t mbase, uint32_t vbase, long &magLenOut, long &vlcLenOut, uint16_t *flist) {
     const size_t nsamp = (size_t)J.w * J.h;
     const size_t maxSize = nsamp * 2 < 64 ? 64 : nsamp * 2;
     const long msCap = (long)(maxSize / 2), vlcCap = (long)(maxSize / 2);
     const size_t melLen = maxSize / 4;
-    // ---- MagSgn emission with 0xFF stuffing (ht.go:1303-1341) ----
+    // ---- MagSgn emission with 0xFF stuffing (ht.go:1303-1341), all bytes in parallel ----
+    // With the 0xFF bytes known (ht_ms_find_ff; byte index of the i-th: kF(i) = (flist[i] + i) / 8), byte k starts at bit
+    // 8k - #{i : kF(i) <= k - 2} and is 7 bits wide iff byte k - 1 is one of them.  The write loop of the reference emits a
+    // byte while at least 8 bits are left (also for a 7-bit byte), the flush one more byte if any bit is left, unmasked.
     const uint32_t TM = mbase;
-    uint32_t pos = 0, last = 0;
-    long outpos = 0;
-    while (TM - pos >= 8) {
-        if (last == 0xFF) {                         // wave-uniform: one 7-bit byte
-            const uint32_t b = get_bits8(mbuf, pos) & 0x7F;
-            if (outpos >= msCap) return false;
-            if (WRITE && lane == 0) out[outpos] = (uint8_t)b;
-            outpos++; pos += 7; last = b;
-            continue;
+#ifdef J2K_ENC_STAMP
+    const long long e0 = wall_clock64();
+#endif
+    uint32_t myF;
+    const int nF = ht_ms_find_ff(mbuf, TM, lane, flist, myF);
+    __syncthreads();
+#ifdef J2K_ENC_STAMP
+    const long long e05 = wall_clock64();
+#endif
+    auto kF = [&](int i) { return (long)(((uint32_t)flist[i] + (uint32_t)i) >> 3); };
+    long K = 0;                                    // bytes out of the write loop
+    uint32_t posK = 0;                             // bits consumed by them
+    if (TM >= 8) {
+        K = (long)((TM - 8 + (uint32_t)nF) >> 3) + 1;          // right when byte K - 1 lies behind the last 0xFF's 7-bit successor
+        posK = (uint32_t)(8 * K) - (uint32_t)nF;
+        if (nF) {
+            const uint32_t Fl = flist[nF - 1];
+            const long kl = kF(nF - 1);
+            if (K - 1 < kl + 2) {
+                if (Fl + 16 <= TM) { K = kl + 2; posK = Fl + 15; }   // the 7-bit byte is the last one
+                else { K = kl + 1; posK = Fl + 8; }                   // the 0xFF byte is
+            }
         }
-        // four bytes per lane, up to 256 per step; the step ends at the first 0xFF (the byte after it is 7 bits wide)
-        const uint32_t nbytes = min((TM - pos) >> 3, 256u);
-        const uint32_t mine = 4u * lane < nbytes ? min(nbytes - 4u * lane, 4u) : 0u;
-        const uint32_t dw = mine ? ms_bits32(mbuf, pos + 32 * lane) : 0u;
-        uint32_t ffj = 4;
+    }
+    const bool tail = TM > posK;                   // magSgnFlush: the remaining < 8 bits, no stuffing rule
+    const long magLen = K + (tail ? 1 : 0);
+    if (magLen > msCap) return false;
+    if (WRITE) {
+        // up to 64 0xFF bytes (practically always): their byte indices live in registers, counted with ballots and fetched
+        // with v_readlane; more than that: the same from the LDS list
+        const bool inreg = nF <= 64;
+        const long myK = (lane < nF) ? (long)((myF + (uint32_t)lane) >> 3) : (long)0x7FFFFFFF;
+        int fi = 0;                                // 0xFF bytes that shift every byte of the chunk: kF <= kb - 2
+        for (long kb = 0; kb < K; kb += 256) {
+            int fe;                                // .. that shift some of them: kF <= kb + 254
+            if (inreg) {
+                fi = __popcll(__ballot(myK <= kb - 2));
+                fe = __popcll(__ballot(myK <= kb + 254));
+            } else {
+                while (fi < nF && kF(fi) <= kb - 2) fi++;
+                fe = fi;
+                while (fe < nF && kF(fe) <= kb + 254) fe++;
+            }
+            const long k0 = kb + 4 * lane;
+            uint32_t dw = 0;
+            if (fe == fi) {
+                if (k0 < K) dw = ms_bits32(mbuf, (uint32_t)(8 * k0) - (uint32_t)fi);
+            } else {
+                uint32_t n[4] = {(uint32_t)fi, (uint32_t)fi, (uint32_t)fi, (uint32_t)fi}, narrow = 0;
+                for (int i = fi; i < fe; i++) {
+                    const long kk = inreg ? (long)__builtin_amdgcn_readlane((int)myK, i) : kF(i);
 #pragma unroll
-        for (int j = 3; j >= 0; j--)
-            if ((uint32_t)j < mine && ((dw >> (8 * j)) & 0xFF) == 0xFF) ffj = j;
-        const unsigned long long fmask = __ballot(ffj < 4);
-        int first = 256;
-        if (fmask) {
-            const int fl = __ffsll((long long)fmask) - 1;
-            first = 4 * fl + (int)__shfl(ffj, fl);
-        }
-        const int count = min((int)nbytes, first + 1);
-        if (outpos + count > msCap) return false;
-        if (WRITE) {
-            const int my0 = 4 * lane;
-            uint8_t *q = out + outpos + my0;
-            if (my0 + 4 <= count) __builtin_memcpy(q, &dw, 4);          // unaligned 4-byte store
+                    for (int j = 0; j < 4; j++) {
+                        if (kk <= k0 + j - 2) n[j]++;
+                        if (kk == k0 + j - 1) narrow |= 1u << j;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (k0 + j >= K) break;
+                    const uint32_t bj = get_bits8(mbuf, (uint32_t)(8 * (k0 + j)) - n[j]) & (((narrow >> j) & 1) ? 0x7Fu : 0xFFu);
+                    dw |= bj << (8 * j);
+                }
+            }
+            if (k0 >= K) continue;
+            uint8_t *q = out + k0;
+            if (k0 + 4 <= K) __builtin_memcpy(q, &dw, 4);               // unaligned 4-byte store
             else {
 #pragma unroll
                 for (int j = 0; j < 3; j++)
-                    if (my0 + j < count) q[j] = (uint8_t)(dw >> (8 * j));
+                    if (k0 + j < K) q[j] = (uint8_t)(dw >> (8 * j));
             }
         }
-        last = (first < (int)nbytes) ? 0xFFu : ((__shfl(dw, (count - 1) >> 2) >> (8 * ((count - 1) & 3))) & 0xFF);
-        outpos += count; pos += 8 * count;
+        if (tail && lane == 0) out[K] = (uint8_t)get_bits8(mbuf, posK);
     }
-    if (TM > pos) {                                 // magSgnFlush: the remaining < 8 bits, no stuffing rule
-        if (outpos >= msCap) return false;
-        if (WRITE && lane == 0) out[outpos] = (uint8_t)get_bits8(mbuf, pos);
-        outpos++;
-    }
-    const long magLen = outpos;
+#ifdef J2K_ENC_STAMP
+    const long long e1 = wall_clock64();
+#endif
     // ---- VLC bytes: position-preserving stuffing (ht.go:1271-1300) ----
     const uint32_t TV = vbase;
     const long nfull = TV >> 3, vlcLen = (TV + 7) >> 3;
     if (vlcLen > vlcCap) return false;
     uint8_t *vout = out + magLen + melLen;
-    for (long i = lane; WRITE && i < vlcLen; i += 64) {
-        uint32_t b = get_bits8(vbuf, (uint32_t)(8 * i));
-        if (i < nfull && (b & 0x7F) == 0x7F && i > 0) {
-            // final value of the previous byte: walk back over the run of bytes whose low 7 bits are all ones
-            long j = i - 1;
-            while (j > 0 && (get_bits8(vbuf, (uint32_t)(8 * j)) & 0x7F) == 0x7F) j--;
-            uint32_t prev = (j == 0 && (get_bits8(vbuf, 0) & 0x7F) == 0x7F) ? get_bits8(vbuf, 0)      // byte 0: lastByte starts at 0, never masked
-                                                                             : get_bits8(vbuf, (uint32_t)(8 * j));
-            for (long k = j + 1; k < i; k++) {
-                uint32_t rb = get_bits8(vbuf, (uint32_t)(8 * k));
-                if (prev > 0x8F && (rb & 0x7F) == 0x7F) rb &= 0x7F;
-                prev = rb;
+    for (long i0 = 4 * lane; WRITE && i0 < vlcLen; i0 += 256) {               // four bytes per lane
+        uint32_t dw = ms_bits32(vbuf, (uint32_t)(8 * i0));
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+            const long i = i0 + jj;
+            uint32_t b = (dw >> (8 * jj)) & 0xFF;
+            if (i < nfull && (b & 0x7F) == 0x7F && i > 0) {
+                // final value of the previous byte: walk back over the run of bytes whose low 7 bits are all ones
+                long j = i - 1;
+                while (j > 0 && (get_bits8(vbuf, (uint32_t)(8 * j)) & 0x7F) == 0x7F) j--;
+                uint32_t prev = (j == 0 && (get_bits8(vbuf, 0) & 0x7F) == 0x7F) ? get_bits8(vbuf, 0)      // byte 0: lastByte starts at 0, never masked
+                                                                                 : get_bits8(vbuf, (uint32_t)(8 * j));
+                for (long k = j + 1; k < i; k++) {
+                    uint32_t rb = get_bits8(vbuf, (uint32_t)(8 * k));
+                    if (prev > 0x8F && (rb & 0x7F) == 0x7F) rb &= 0x7F;
+                    prev = rb;
+                }
+                if (prev > 0x8F) dw &= ~(0x80u << (8 * jj));
             }
-            if (prev > 0x8F) b &= 0x7F;
         }
-        vout[i] = (uint8_t)b;
+        uint8_t *q = vout + i0;
+        if (i0 + 4 <= vlcLen) __builtin_memcpy(q, &dw, 4);
+        else {
+#pragma unroll
+            for (int jj = 0; jj < 3; jj++)
+                if (i0 + jj < vlcLen) q[jj] = (uint8_t)(dw >> (8 * jj));
+        }
     }
     magLenOut = magLen; vlcLenOut = vlcLen;
+#ifdef J2K_ENC_STAMP
+    if (((blockIdx.x % 200) == 7) && lane == 0) printf("   wg %d find_ff %lld (nF %d) ms emit %lld vlc emit %lld\n", (int)blockIdx.x, e05 - e0, nF, e1 - e05, wall_clock64() - e1);
+#endif
     return true;
 }
 
 
-__device__ bool ht_encode_fast(const BlockJob &J, const int32_t *__restrict__ src, uint8_t *__restrict__ out, int lane,
-                               uint32_t *vbuf, uint32_t *mbuf, long &magLenOut, long &vlcLenOut) {
+template <bool LROWS>
+__device__ __forceinline__ bool ht_encode_fast(const BlockJob &J, const int32_t *__restrict__ src, uint8_t *__restrict__ out, int lane,
+                               uint32_t *vbuf, uint32_t *mbuf, long &magLenOut, long &vlcLenOut, const int32_t *lrows, const uint16_t *enc,
+                               uint16_t *flist) {
     uint32_t TM, TV;
-    if (!ht_form(J, src, lane, vbuf, mbuf, TM, TV)) return false;
-    return ht_emit<true>(J, out, lane, vbuf, mbuf, TM, TV, magLenOut, vlcLenOut);
+#ifdef J2K_ENC_STAMP
+    const long long f0 = wall_clock64(), c0 = clock64();
+#endif
+    if (!ht_form<LROWS>(J, src, lane, vbuf, mbuf, TM, TV, lrows, enc)) return false;
+#ifdef J2K_ENC_STAMP
+    if (0) printf("   wg %d form %lld wall ticks, %lld shader clocks\n", (int)blockIdx.x, wall_clock64() - f0, clock64() - c0);
+#endif
+    return ht_emit<true>(J, out, lane, vbuf, mbuf, TM, TV, magLenOut, vlcLenOut, flist);
 }
 
-// ujobs / alias_next (j2k_plan_encode_stream only): the block coder addresses every band's blocks from the TOP-LEFT of the plane
+// utab / alias_ids (j2k_plan_encode_stream only): the block coder addresses every band's blocks from the TOP-LEFT of the plane
 // (encoder.go:763-795), so the three bands of a resolution read the same windows, and this coder ignores the band
-// (ht.go:942): jobs with the same window are byte-identical.  The plan lists one job per distinct window (ujobs), chains
-// the others to it (alias_next) and points their slot at the coded one's; the kernel codes each distinct window once and
-// reports its length / bit-plane count / MagSgn length for every job of the chain.
-__device__ __forceinline__ void ht_publish(int jid, const int *__restrict__ alias_next, uint32_t *__restrict__ lens, uint8_t *__restrict__ numbps,
-                                           uint32_t *__restrict__ maglens, uint32_t len, uint32_t nb, bool has_mag, uint32_t mag) {
-    for (int j = jid; j >= 0; j = alias_next ? alias_next[j] : -1) {
-        lens[j] = len;
-        numbps[j] = (uint8_t)nb;
-        if (maglens && has_mag) maglens[j] = mag;
-    }
-}
-
+// (ht.go:942): jobs with the same window are byte-identical.  The plan lists one entry per distinct window (utab: the job
+// itself + where its list of job ids -- its own first -- sits in alias_ids); the kernel codes each distinct window once and
+// reports its length / bit-plane count / MagSgn length for every job of the list, one lane per job.
+//
+// A wavefront's life here is a chain of memory round trips, not work (1851 wavefronts per 4K frame on 1024 SIMDs), so the
+// kernel is organised to make as few as possible: ONE for the table entry, then the alias ids, the code-word table and all
+// sixteen 16-byte loads of a 64x64 block's max scan go out together; the coded rows (y % 4 == 0) are parked in LDS by the
+// scan, so forming the code words does not go back to memory.  (Before: job id -> job -> two rounds of scan loads -> two
+// rounds of row loads, each followed by table look-ups in global memory -> the alias chain, link by link: 33 us.)
 __global__ __launch_bounds__(64) void ht_encode_kernel(const BlockJob *__restrict__ jobs, int njobs,
                                                        const int32_t *__restrict__ coef, uint8_t *__restrict__ slots,
                                                        uint32_t *__restrict__ lens, uint8_t *__restrict__ numbps,
                                                        int *__restrict__ fault, uint32_t *__restrict__ maglens,
-                                                       const int *__restrict__ ujobs, const int *__restrict__ alias_next) {
+                                                       const HtUJob *__restrict__ utab, const int *__restrict__ alias_ids) {
     // maglens != NULL (j2k_plan_encode_stream): also report where the MagSgn bytes end, and do NOT write the MEL
     // segment's zero bytes into the slot -- the gather puts zeros straight into the stream instead of copying them
     __shared__ uint32_t s_vbuf[HT_VLC_WORDS];
     __shared__ uint32_t s_mbuf[HT_MS_WORDS];
-    if ((int)blockIdx.x >= njobs) return;          // njobs = entries of ujobs when given
-    const int jid = ujobs ? ujobs[blockIdx.x] : (int)blockIdx.x;
+    __shared__ __align__(16) int32_t s_rows[HT_FAST_MAX_SAMPLES];
+    __shared__ uint32_t s_enc[64];
+    __shared__ uint16_t s_ff[HT_MS_FF_CAP];
+    if ((int)blockIdx.x >= njobs) return;          // njobs = entries of utab when given
     const int lane = threadIdx.x;
-    const BlockJob J = jobs[jid];
+#ifdef J2K_ENC_STAMP
+    const long long st0 = wall_clock64();
+#endif
+    BlockJob J;
+    int jid = (int)blockIdx.x, nalias = 1, aoff = 0;
+    if (utab) {
+        const HtUJob U = utab[blockIdx.x];
+        J = U.J; jid = U.jid; nalias = U.nalias; aoff = U.alias_off;
+    } else {
+        J = jobs[jid];
+    }
+    int myalias = jid;
+    if (utab && lane < nalias) myalias = alias_ids[aoff + lane];
+    s_enc[lane] = reinterpret_cast<const uint32_t *>(g_vlc_enc)[lane];
     const int w = J.w, h = J.h, stride = J.stride;
     const int32_t *src = coef + J.src_off;
     uint8_t *out = slots + J.out_off;
+    auto publish = [&](uint32_t len, uint32_t nb, bool has_mag, uint32_t mag) {
+        for (int k = lane; k < nalias; k += 64) {
+            const int j = k < 64 ? myalias : alias_ids[aoff + k];
+            lens[j] = len;
+            numbps[j] = (uint8_t)nb;
+            if (maglens && has_mag) maglens[j] = mag;
+        }
+    };
+    const bool fast = (size_t)((h + 3) / 4) * (size_t)w <= HT_FAST_MAX_SAMPLES;
 
     // ---- max |x| over the WHOLE block: nil decision (ht.go:947-960) and numbps ----
     int maxMag = 0;  // Go compares int32: -MinInt32 stays negative and never wins
-    if ((w & 3) == 0 && (stride & 3) == 0 && (J.src_off & 3) == 0) {
+    const bool quads = (w & 3) == 0 && (stride & 3) == 0 && (J.src_off & 3) == 0;
+    const bool lrows = quads && fast;              // the scan parks the coded rows in s_rows
+    if (quads) {
         // (row, quad) kept incrementally: a division by the block width per load was a third of this loop's instructions
         const int wq = w >> 2, nq = wq * h;
         const int dy = 64 / wq, dx = 64 - dy * wq;
         int y = lane / wq, xq = lane - y * wq;
-        // eight loads in flight per step (clamped, unconditional addresses): one load per iteration made a 64x64 block sixteen
-        // SERIAL memory round trips -- the wave's whole life (~30 us under load) and the reason this kernel did not speed up
-        // when two thirds of its blocks went away
-        for (int e0 = lane; e0 < nq; e0 += 64 * 8) {
-            int4 qv[8];
+        // sixteen loads in flight per step (clamped, unconditional addresses): a whole 64x64 block in one round trip
+        for (int e0 = lane; e0 < nq; e0 += 64 * 16) {
+            int4 qv[16];
+            int ys[16];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < 16; u++) {
                 const bool ok = e0 + 64 * u < nq;
                 const int4 t = *reinterpret_cast<const int4 *>(ok ? src + (size_t)y * stride + 4 * xq : src);
                 qv[u] = ok ? t : make_int4(0, 0, 0, 0);
+                ys[u] = ok ? (y << 8 | xq) : -1;
                 y += dy; xq += dx;
                 if (xq >= wq) { xq -= wq; y++; }
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < 16; u++) {
                 const int4 q = qv[u];
+                if (lrows && ys[u] >= 0 && ((ys[u] >> 8) & 3) == 0)
+                    *reinterpret_cast<int4 *>(&s_rows[(ys[u] >> 10) * w + 4 * (ys[u] & 0xFF)]) = q;
                 const int a0 = q.x < 0 ? (int)(0u - (uint32_t)q.x) : q.x, a1 = q.y < 0 ? (int)(0u - (uint32_t)q.y) : q.y;
                 const int a2 = q.z < 0 ? (int)(0u - (uint32_t)q.z) : q.z, a3 = q.w < 0 ? (int)(0u - (uint32_t)q.w) : q.w;
                 maxMag = max(max(maxMag, max(a0, a1)), max(a2, a3));
@@ -425,27 +564,39 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(const BlockJob *__restric
             }
     }
     for (int o = 32; o > 0; o >>= 1) maxMag = max(maxMag, __shfl_xor(maxMag, o));
+#ifdef J2K_ENC_STAMP
+    const long long st1 = wall_clock64();
+#endif
     if (maxMag == 0) {
-        if (lane == 0) ht_publish(jid, alias_next, lens, numbps, maglens, 0, 0, false, 0);
+        publish(0, 0, false, 0);
         return;
     }
-    if ((size_t)((h + 3) / 4) * (size_t)w <= HT_FAST_MAX_SAMPLES) {
+    if (fast) {
         long mLen = 0, vLen = 0;
         const size_t nsamp_ = (size_t)w * h;
         const size_t maxSize_ = nsamp_ * 2 < 64 ? 64 : nsamp_ * 2;
         const size_t melLen_ = maxSize_ / 4;
-        if (!ht_encode_fast(J, src, out, lane, s_vbuf, s_mbuf, mLen, vLen)) {
-            if (lane == 0) { atomicMax(fault, 1); ht_publish(jid, alias_next, lens, numbps, maglens, 0, 0, false, 0); }
+        const uint16_t *enc = reinterpret_cast<const uint16_t *>(s_enc);
+        const bool ok = lrows ? ht_encode_fast<true>(J, src, out, lane, s_vbuf, s_mbuf, mLen, vLen, s_rows, enc, s_ff)
+                              : ht_encode_fast<false>(J, src, out, lane, s_vbuf, s_mbuf, mLen, vLen, nullptr, enc, s_ff);
+        if (!ok) {
+            if (lane == 0) atomicMax(fault, 1);
+            publish(0, 0, false, 0);
             return;
         }
         if (!maglens) zero_bytes(out + mLen, melLen_, lane);
+        const size_t scup = melLen_ + (size_t)vLen + 2;
+        const size_t total = (size_t)mLen + scup;
         if (lane == 0) {
-            const size_t scup = melLen_ + (size_t)vLen + 2;
-            const size_t total = (size_t)mLen + scup;
             out[total - 2] = (uint8_t)(scup >> 8);
             out[total - 1] = (uint8_t)(scup & 0xFF);
-            ht_publish(jid, alias_next, lens, numbps, maglens, (uint32_t)total, 32 - __clz((uint32_t)maxMag), true, (uint32_t)mLen);
         }
+        publish((uint32_t)total, 32 - __clz((uint32_t)maxMag), true, (uint32_t)mLen);
+#ifdef J2K_ENC_STAMP
+        const long long st2 = wall_clock64();
+        if (((blockIdx.x % 200) == 7 || blockIdx.x >= njobs - 3) && lane == 0)
+            printf("enc wg %d: start %lld end %lld scan %lld  form+emit %lld (x10 ns)  mLen %ld vLen %ld\n", (int)blockIdx.x, st0 % 100000, st2 % 100000, st1 - st0, st2 - st1, mLen, vLen);
+#endif
         return;
     }
     // ---- generic path for large blocks: bit-serial packing on lane 0 ----
@@ -511,7 +662,8 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(const BlockJob *__restric
     }
     magLen = __shfl(magLen, 0); vlcLen = __shfl(vlcLen, 0); bad = __shfl(bad, 0);
     if (bad) {
-        if (lane == 0) { atomicMax(fault, 1); ht_publish(jid, alias_next, lens, numbps, maglens, 0, 0, false, 0); }
+        if (lane == 0) atomicMax(fault, 1);
+        publish(0, 0, false, 0);
         return;
     }
     // ---- assemble: MagSgn | MEL zeros | VLC | SCUP (ht.go:1017-1042) ----
@@ -526,12 +678,14 @@ __global__ __launch_bounds__(64) void ht_encode_kernel(const BlockJob *__restric
         if (i < vlcLen) out[D + i] = b;
         __syncthreads();
     }
-    if (lane == 0) {
+    {
         const size_t scup = melLen + (size_t)vlcLen + 2;
         const size_t total = (size_t)magLen + scup;
-        out[total - 2] = (uint8_t)(scup >> 8);
-        out[total - 1] = (uint8_t)(scup & 0xFF);
-        ht_publish(jid, alias_next, lens, numbps, maglens, (uint32_t)total, 32 - __clz((uint32_t)maxMag), true, (uint32_t)magLen);
+        if (lane == 0) {
+            out[total - 2] = (uint8_t)(scup >> 8);
+            out[total - 1] = (uint8_t)(scup & 0xFF);
+        }
+        publish((uint32_t)total, 32 - __clz((uint32_t)maxMag), true, (uint32_t)magLen);
     }
 }
 
@@ -557,6 +711,7 @@ __global__ __launch_bounds__(64) void ht_encode_stream_kernel(const BlockJob *__
                                                               uint32_t epoch, int *__restrict__ fault) {
     __shared__ uint32_t s_vbuf[HT_VLC_WORDS];
     __shared__ uint32_t s_mbuf[HT_MS_WORDS];
+    __shared__ uint16_t s_ff[HT_MS_FF_CAP];
     const int jid = blockIdx.x;
     if (jid >= njobs) return;
     const int lane = threadIdx.x;
@@ -593,8 +748,8 @@ __global__ __launch_bounds__(64) void ht_encode_stream_kernel(const BlockJob *__
     long mLen = 0, vLen = 0;
     unsigned long long total = 0;
     if (maxMag != 0) {
-        bool ok = ht_form(J, src, lane, s_vbuf, s_mbuf, TM, TV);
-        if (ok) ok = ht_emit<false>(J, nullptr, lane, s_vbuf, s_mbuf, TM, TV, mLen, vLen);
+        bool ok = ht_form<false>(J, src, lane, s_vbuf, s_mbuf, TM, TV, nullptr, g_vlc_enc);
+        if (ok) ok = ht_emit<false>(J, nullptr, lane, s_vbuf, s_mbuf, TM, TV, mLen, vLen, s_ff);
         if (ok) total = (unsigned long long)mLen + melLen + (unsigned long long)vLen + 2;
         else if (lane == 0) atomicMax(fault, 1);                      // the reference panics on this input
     }
@@ -633,7 +788,7 @@ __global__ __launch_bounds__(64) void ht_encode_stream_kernel(const BlockJob *__
     if (!total) return;
     // ---- the bytes, straight into their final place ----
     uint8_t *out = stream + excl;
-    ht_emit<true>(J, out, lane, s_vbuf, s_mbuf, TM, TV, mLen, vLen);
+    ht_emit<true>(J, out, lane, s_vbuf, s_mbuf, TM, TV, mLen, vLen, s_ff);
     zero_bytes(out + mLen, melLen, lane);
     if (lane == 0) {
         const size_t scup = melLen + (size_t)vLen + 2;
@@ -1437,13 +1592,13 @@ static hipError_t ht_tables_ready(hipStream_t s) {
 }
 
 hipError_t launch_ht_encode(hipStream_t s, const BlockJob *jobs, int njobs, const int32_t *coef, uint8_t *slots,
-                            uint32_t *lens, uint8_t *numbps, int *fault, uint32_t *maglens, const int *ujobs, int nunique,
-                            const int *alias_next) {
+                            uint32_t *lens, uint8_t *numbps, int *fault, uint32_t *maglens, const HtUJob *utab, int nunique,
+                            const int *alias_ids) {
     if (njobs <= 0) return hipSuccess;
     hipError_t e;
     if ((e = ht_tables_ready(s)) != hipSuccess) return e;
-    const int n = ujobs ? nunique : njobs;
-    hipLaunchKernelGGL(ht_encode_kernel, dim3(n), dim3(64), 0, s, jobs, n, coef, slots, lens, numbps, fault, maglens, ujobs, alias_next);
+    const int n = utab ? nunique : njobs;
+    hipLaunchKernelGGL(ht_encode_kernel, dim3(n), dim3(64), 0, s, jobs, n, coef, slots, lens, numbps, fault, maglens, utab, alias_ids);
     return hipGetLastError();
 }
 
@@ -1469,10 +1624,13 @@ hipError_t launch_ht_decode(hipStream_t s, const BlockJob *jobs, int njobs, cons
     hipError_t e;
     if ((e = ht_tables_ready(s)) != hipSuccess) return e;
     uint32_t *pairs = scratch, *vbits = scratch + (size_t)njobs * HT_WALK_REC;
+    if (!(g_dev_skip & 32))
     hipLaunchKernelGGL(ht_vlcprep_kernel, dim3((njobs + 3) / 4), dim3(256), 0, s, jobs, njobs, stream, offs, lens, vbits, pairs);
     if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (!(g_dev_skip & 64))
     hipLaunchKernelGGL(ht_walk_kernel, dim3((njobs + HT_WALK_BLOCKS - 1) / HT_WALK_BLOCKS), dim3(256), sizeof(HtWalkShared), s, jobs, njobs, vbits, pairs);
     if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (!(g_dev_skip & 128))
     hipLaunchKernelGGL(ht_decode_kernel, dim3((njobs + 3) / 4), dim3(256), 0, s, jobs, njobs, stream, offs, lens, decoded, pairs);
     return hipGetLastError();
 }

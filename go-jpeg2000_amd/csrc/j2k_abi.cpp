@@ -14,6 +14,7 @@
 using namespace j2k;
 
 namespace j2k {
+int g_dev_skip = 0;
 hipError_t launch_add_const(hipStream_t s, int32_t *d, size_t n, int delta);
 hipError_t launch_rct(hipStream_t s, int32_t *a, int32_t *b, int32_t *c, size_t n, int inverse);
 hipError_t launch_ict(hipStream_t s, double *a, double *b, double *c, size_t n, int inverse);
@@ -22,8 +23,8 @@ hipError_t launch_dwt97_fwd(hipStream_t s, const LevelLaunch &L, const void *src
 hipError_t launch_dwt97_inv(hipStream_t s, const LevelLaunch &L, const void *coef, int coef_is_f64, const double *prev,
                             void *dst, int dc_shift, int final_level, int dst_mode, int mct);
 hipError_t launch_ht_encode(hipStream_t s, const BlockJob *jobs, int njobs, const int32_t *coef, uint8_t *slots,
-                            uint32_t *lens, uint8_t *numbps, int *fault, uint32_t *maglens = nullptr, const int *ujobs = nullptr, int nunique = 0,
-                            const int *alias_next = nullptr);
+                            uint32_t *lens, uint8_t *numbps, int *fault, uint32_t *maglens = nullptr, const HtUJob *utab = nullptr, int nunique = 0,
+                            const int *alias_ids = nullptr);
 hipError_t launch_ht_decode(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs,
                             const uint32_t *lens, int32_t *decoded, uint32_t *scratch);
 size_t ht_decode_scratch_words(int njobs);
@@ -108,6 +109,7 @@ extern "C" int j2k_ctx_create(int device, j2k_ctx **out) {
         int v = atoi(e);
         if (v >= 1 && v <= 4096) ctx->band_prows = v;
     }
+    if (const char *e = getenv("J2K_DEV_SKIP")) j2k::g_dev_skip = (int)strtol(e, nullptr, 0);
     if (const char *e = getenv("J2K_L0_FUSE")) { int v = atoi(e); if (v == 0 || v == 8 || v == 16) ctx->l0_fuse = v; }
     if (const char *e = getenv("J2K_L0_WG")) { int v = atoi(e); if (v == 0 || v == 4 || v == 8) ctx->l0_wg = v; }
     if (const char *e = getenv("J2K_L0_WG97")) { int v = atoi(e); if (v == 0 || (v >= 6 && v <= 16 && v % 2 == 0)) ctx->l0_wg97 = v; }
@@ -601,18 +603,25 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
             // band: see ht_encode_kernel): one coded job per distinct window, the others chained to it and gathering from its
             // slot.  Only j2k_plan_encode_stream uses these tables (its slot buffer is private); the per-slot API does not.
             std::map<std::tuple<int64_t, int32_t, int32_t, int32_t>, int> first;
-            std::vector<int> ujobs, next(bj.size(), -1), last(bj.size(), -1);
+            std::vector<int> ujobs;
+            std::vector<std::vector<int>> lists;
             std::vector<BlockJob> aj = bj;
             for (size_t i = 0; i < bj.size(); i++) {
                 auto key = std::make_tuple(bj[i].src_off, bj[i].stride, bj[i].w, bj[i].h);
                 auto it = first.find(key);
-                if (it == first.end()) { first[key] = (int)i; ujobs.push_back((int)i); last[i] = (int)i; }
-                else { const int c = it->second; next[last[c]] = (int)i; last[c] = (int)i; aj[i].out_off = bj[c].out_off; }
+                if (it == first.end()) { first[key] = (int)ujobs.size(); ujobs.push_back((int)i); lists.push_back({(int)i}); }
+                else { lists[it->second].push_back((int)i); aj[i].out_off = bj[ujobs[it->second]].out_off; }
             }
             if (ujobs.size() < bj.size()) {
+                std::vector<HtUJob> utab;
+                std::vector<int> ids;
+                for (size_t u = 0; u < ujobs.size(); u++) {
+                    utab.push_back(HtUJob{bj[ujobs[u]], ujobs[u], (int)ids.size(), (int)lists[u].size(), 0});
+                    ids.insert(ids.end(), lists[u].begin(), lists[u].end());
+                }
                 P->ht_nunique = (int)ujobs.size();
-                r = upload(ctx, &P->d_ht_ujobs, ujobs);
-                if (r == J2K_OK) r = upload(ctx, &P->d_ht_alias_next, next);
+                r = upload(ctx, &P->d_ht_ujobs, utab);
+                if (r == J2K_OK) r = upload(ctx, &P->d_ht_alias_next, ids);
                 if (r == J2K_OK) r = upload(ctx, &P->d_bjobs_alias, aj);
             }
         }
@@ -717,6 +726,7 @@ static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff, in
     bool fused_l1 = false;             // level 1 ran inside the level-0 launch (packed RGBA8 frames, dwt53_fwd_rgba8_wg2_kernel)
     for (int l = 0; l < nlevel_launches; l++) {
         if (l == 1 && fused_l1) continue;
+        if (g_dev_skip & (l == 0 ? 1 : (l == 1 ? 2 : 4))) continue;
         void *in = (l == 0) ? const_cast<void *>(d_frame) : ((l & 1) ? P->d_scrA : P->d_scrB);
         void *nx = (l & 1) ? P->d_scrB : P->d_scrA;
         // profiling (bench.py's roofline line): the level-0 dispatch of the RGB triples stamps its own begin / end
@@ -756,7 +766,7 @@ static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff, in
             }
         }
     }
-    if (P->tail_l0 >= 0)
+    if (P->tail_l0 >= 0 && !(g_dev_skip & 4))
         HIPCHK(ctx, launch_dwt53_tail_fwd(ctx->stream, P->d_tail, P->ntail, P->tail_lds_fwd,
                                           (const int32_t *)((P->tail_l0 & 1) ? P->d_scrA : P->d_scrB), (int32_t *)d_coeff));
     return J2K_OK;
@@ -767,12 +777,13 @@ static int plan_inverse_impl(j2k_plan *P, const void *d_coeff, void *d_frame, in
     const PlanSpec &S = P->spec;
     if (((uintptr_t)d_frame & 15) || ((uintptr_t)d_coeff & 15)) return fail(ctx, J2K_ERR_INVALID_ARG, "device pointers must be 16-byte aligned");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (P->tail_l0 >= 0)
+    if (P->tail_l0 >= 0 && !(g_dev_skip & 0x100))
         HIPCHK(ctx, launch_dwt53_tail_inv(ctx->stream, P->d_tail, P->ntail, P->tail_lds_inv, (const int32_t *)d_coeff,
                                           (int32_t *)((P->tail_l0 & 1) ? P->d_scrA : P->d_scrB)));
     for (int l = ((P->tail_l0 >= 0) ? P->tail_l0 : S.levels) - 1; l >= 0; l--) {
         void *prev = (l & 1) ? P->d_scrB : P->d_scrA;                     // X_{l+1}
         void *dst = (l == 0) ? d_frame : ((l & 1) ? P->d_scrA : P->d_scrB);  // X_l
+        if (g_dev_skip & (l == 0 ? 0x400 : (l == 1 ? 0x200 : 0x100))) continue;
         for (int cls = 0; cls < 2; cls++) {
             const LevelTab &T = P->inv[cls][l];
             if (!T.njobs) continue;
@@ -1151,8 +1162,10 @@ extern "C" int j2k_plan_encode_stream(j2k_plan *P, const int32_t *d_coeff, uint8
         int r = stage_reserve(ctx, 3, 256);
         if (r != J2K_OK) return r;
         ctx->fault_armed = true;
+        if (!(g_dev_skip & 8))
         HIPCHK(ctx, launch_ht_encode(ctx->stream, P->d_bjobs, n, d_coeff, (uint8_t *)P->d_slots, d_lens, d_numbps, (int *)ctx->stage[3],
                                      P->d_maglens, P->d_ht_ujobs, P->ht_nunique, P->d_ht_alias_next));
+        if (!(g_dev_skip & 16))
         // the transport offsets (a second running sum in the scan, +4 us) only once j2k_plan_pack_stream has asked for them
         HIPCHK(ctx, launch_compact(ctx->stream, P->d_bjobs_alias ? P->d_bjobs_alias : P->d_bjobs, n, (const uint8_t *)P->d_slots, d_lens, d_offs, d_stream, P->d_maglens,
                                    P->want_toffs ? P->d_mels : nullptr, P->want_toffs ? P->d_toffs : nullptr));

@@ -40,6 +40,15 @@ struct BlockJob {
     int32_t band;
 };
 
+// One distinct block window of the HT encoder (j2k_plan_encode_stream): the job + the jobs that read the same window
+struct HtUJob {
+    BlockJob J;
+    int32_t jid;          // the job that is coded (first of its list)
+    int32_t alias_off;    // its list of job ids in the plan's alias_ids table (its own id first)
+    int32_t nalias;
+    int32_t pad_;
+};
+
 // One tile-component for the fused "tail" kernels: decomposition levels l0..l0+nlev-1 run inside LDS.
 struct TailPlane {
     int64_t scr_off;      // forward: level-l0 input prefix in scratch; inverse: where X_{l0} is written
@@ -87,4 +96,7 @@ hipError_t launch_unpack_pixels(hipStream_t s, const uint8_t *pix, size_t stride
 hipError_t launch_colorspace(hipStream_t s, int cs, int32_t *planes, int ncomp, size_t n, int precision);
 hipError_t launch_pack_pixels(hipStream_t s, const int32_t *planes, int ncomp, int precision, int w, int h, uint8_t *pix, size_t stride);
 
+// DEV ONLY (J2K_DEV_SKIP, bit mask): launches left out to measure what each kernel costs with several frames in flight.
+// Results are wrong with any bit set; nothing in the product sets it.
+extern int g_dev_skip;
 }  // namespace j2k

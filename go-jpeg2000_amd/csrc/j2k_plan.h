@@ -124,7 +124,7 @@ struct j2k_plan {
     // fused encode + compact (j2k_plan_encode_stream): look-back status words, tagged with the launch epoch
     j2k::DwtJob *d_fwd_pix_jobs = nullptr;  // level-0 forward job table of the packed-pixel path (shorter bands)
     int fwd_pix_njobs = 0;
-    int *d_ht_ujobs = nullptr, *d_ht_alias_next = nullptr;   // HT: jobs with distinct windows / chain of the jobs sharing a window
+    j2k::HtUJob *d_ht_ujobs = nullptr; int *d_ht_alias_next = nullptr;   // HT: one entry per distinct window / the job ids sharing each window
     j2k::BlockJob *d_bjobs_alias = nullptr;                  // d_bjobs with every job's slot = the slot of its window's coded job
     int ht_nunique = 0;
     j2k::DwtJob *d_fwd97_wg_jobs = nullptr; // 9-7: one job per workgroup = (plane, component, band) of dwt97_fwd_rgb_wg_kernel

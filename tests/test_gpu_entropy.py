@@ -162,6 +162,33 @@ def test_ht_encode_decode_bytes(ent, oracle, w, h):
         assert np.array_equal(dec.reshape(h, w), oracle.ht_decode(want, w, h))
 
 
+@pytest.mark.parametrize("w,h", [(64, 64), (64, 61), (60, 64), (32, 32), (16, 9), (8, 8), (8, 1), (4, 4), (3, 5), (1, 1), (12, 3), (24, 24), (40, 17)])
+def test_ht_encode_magsgn_stuffing(ent, oracle, w, h):
+    """MagSgn segments full of 0xFF bytes (negative values of the form -(2^n - 1) are all-one fields): the encoder places every
+    byte in parallel from the list of 0xFF positions -- runs of ones of every length and alignment, 0xFF as the last byte, as
+    the byte before the last, segments shorter than a byte, and ordinary data in between (ht.go:1303-1341)"""
+    rng = np.random.default_rng(w * 131 + h)
+    cases = [np.full((h, w), -1), np.full((h, w), -3), np.full((h, w), -127), np.full((h, w), -(2 ** 20 - 1)), np.full((h, w), 1)]
+    for p_neg in (0.5, 0.9, 0.99):
+        for vals in ((-1, 1), (-1, -3, 2), (-1, -7, -15, 5, 0), (-255, -1, 0)):
+            x = rng.choice(vals, size=(h, w))
+            x[rng.random((h, w)) > p_neg] = rng.integers(-9, 10)
+            cases.append(x)
+    for run in (7, 8, 9, 15, 16, 17, 23, 30, 31, 64):                  # one run of `run` ones at every offset mod 16, zeros elsewhere is not
+        for off in range(0, 16, 3):                                    # expressible (a field starts with its sign) -- use -1 / +1 fields
+            x = np.ones((h, w), np.int64)
+            flat = x[::4].reshape(-1)                                  # the coded rows, in coding order only for w % 8 == 0; good enough
+            flat[off:off + run] = -1
+            x[::4] = flat.reshape(x[::4].shape)
+            cases.append(x)
+    for x in cases:
+        x = np.ascontiguousarray(x, dtype=np.int32)
+        want = oracle.ht_encode(x, w, h)
+        enc = ent.NewHTEncoder(w, h); enc.SetData(x)
+        got = enc.Encode(0)
+        assert (got is None and want.size == 0) or got == bytes(want)
+
+
 def test_ht_decoder_edge_inputs(ent, oracle):
     """ht_test.go:126-147: nil, 1-byte and 2-byte inputs; plus bad SCUP and random payloads"""
     rng = np.random.default_rng(4)
