@@ -69,6 +69,21 @@ __device__ __forceinline__ uint64_t shl64(uint64_t x, uint32_t n) { return n >= 
 __device__ __forceinline__ uint64_t shr64(uint64_t x, uint32_t n) { return n >= 64 ? 0ull : x >> n; }
 __device__ __forceinline__ uint32_t uabs(int v) { return v < 0 ? 0u - (uint32_t)v : (uint32_t)v; }
 
+// Inclusive prefix sum over the 64 lanes on the DPP cross-lane network (row_shr 1 / 2 / 4 / 8 inside the rows of 16, then
+// row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3): six VALU instructions and no LDS round trip -- the
+// __shfl_up ladder it replaces is six dependent ds_bpermute_b32 (~100 cycles each), and these scans sit on the one
+// wavefront's critical path in the encoder's and decoder's bit-position bookkeeping.
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_last(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
+
 // ---------------------------------------------------------------------------------
 // encoder
 // ---------------------------------------------------------------------------------
@@ -246,13 +261,8 @@ __device__ __forceinline__ bool ht_form(const BlockJob &J, const int32_t *__rest
             }
         }
         // exclusive prefix sums over the 64 items of this round
-        uint32_t vs = vl, ms = ml;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t a = __shfl_up(vs, o), b = __shfl_up(ms, o);
-            if (lane >= o) { vs += a; ms += b; }
-        }
-        const uint32_t vtot = __shfl(vs, 63), mtot = __shfl(ms, 63);
+        const uint32_t vs = wave_incl_scan(vl), ms = wave_incl_scan(ml);
+        const uint32_t vtot = wave_last(vs), mtot = wave_last(ms);
         uint32_t vpos = vbase + vs - vl, mpos = mbase + ms - ml;
         if (it < N) {
             or_bits(vbuf, vpos, vv);
@@ -1068,11 +1078,9 @@ __global__ __launch_bounds__(256) void ht_vlcprep_kernel(const BlockJob *__restr
             wsum += wj;
             prev = bj;
         }
-        uint32_t ws = wsum;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t a2 = __shfl_up(ws, o); if (lane >= o) ws += a2; }
+        const uint32_t ws = wave_incl_scan(wsum);
         if (merged) or_bits(vb, off + ws - wsum, merged);
-        off += __shfl(ws, 63);
+        off += wave_last(ws);
     }
     wave_sync();
     uint32_t *dst = vbits + (size_t)jid * HT_VBITS_WORDS;
@@ -1216,7 +1224,14 @@ __device__ __forceinline__ void st_decoded(int32_t *p, int a, int b, int c, int 
     else *reinterpret_cast<v4i_ *>(p) = v;
 }
 
+#ifdef J2K_DEC_STAMP
+static __device__ long long g_dbg_unstuff_dummy;
+#define g_dbg_unstuff S.dbg_t
+#endif
 struct HtDecShared {
+#ifdef J2K_DEC_STAMP
+    long long dbg_t;
+#endif
     uint32_t mbuf[HT_DEC_MWORDS];
     uint32_t pair[HT_WALK_MAX_PAIRS];
     uint32_t ffpos[HT_MAX_FF];      // indices of 0xFF bytes in the MagSgn segment (only needed when a u exceeds 32)
@@ -1241,11 +1256,20 @@ __device__ uint32_t ht_loaded_bits(const HtDecShared &S, uint32_t nff, long segL
 }
 
 // returns false when the block needs the bit-serial decoder (never on encoder output)
+// mpos2[t] = bit position of pair lane + 64 t in the MagSgn bit string, total_bits = the bits all pairs consume (both from the
+// caller, which has the records in registers): the LDS string is prepared only as far as it will be read.
 __device__ bool ht_extract_fast(HtDecShared &S, const uint8_t *__restrict__ data, long len, long scup, int w, int h,
-                                int32_t *__restrict__ out, int lane, bool bigu) {
+                                int32_t *__restrict__ out, int lane, bool bigu, const uint32_t (&mpos2)[2], uint32_t total_bits,
+                                const uint32_t (&raw0)[4]) {
     const int quadCols = (w + 3) / 4, P = (quadCols + 1) / 2, R = (h + 3) / 4, N = R * P;
     const long lcup = len;
-    for (int i = lane; i < HT_DEC_MWORDS; i += 64) S.mbuf[i] = 0;
+    {
+        const long segLen0 = lcup - scup;
+        const long cap0 = (long)HT_DEC_MWORDS * 4 - 16;
+        const uint32_t zw = bigu ? (uint32_t)HT_DEC_MWORDS
+                                 : min((uint32_t)HT_DEC_MWORDS, (uint32_t)(((segLen0 < cap0 ? segLen0 : cap0) * 8) >> 5) + 3u);
+        for (uint32_t i = lane; i < zw; i += 64) S.mbuf[i] = 0;       // deposits reach 8 x (bytes staged) bits
+    }
     if (lane == 0) S.nff = 0;
     wave_sync();
     constexpr int PF = 4;   // prefetch 4 x 256 bytes (one aligned dword per lane each) before processing
@@ -1263,7 +1287,8 @@ __device__ bool ht_extract_fast(HtDecShared &S, const uint8_t *__restrict__ data
 #pragma unroll
             for (int c = 0; c < PF; c++) {
                 const long j = j0 + 64 * c + lane;
-                raw[c] = wsrc[j < ndw ? j : ndw - 1];               // clamped: unconditional, issued back to back
+                if (j0 == 0) raw[c] = raw0[c];                      // the first 1 KB was fetched by the caller, ahead of its zero fill
+                else raw[c] = wsrc[j < ndw ? j : ndw - 1];          // clamped: unconditional, issued back to back
             }
 #pragma unroll
             for (int c = 0; c < PF; c++) {
@@ -1289,9 +1314,7 @@ __device__ bool ht_extract_fast(HtDecShared &S, const uint8_t *__restrict__ data
                         if (idx < HT_MAX_FF) S.ffpos[idx] = (uint32_t)k;
                     }
                 }
-                uint32_t ws = tot;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) { const uint32_t a = __shfl_up(ws, o); if (lane >= o) ws += a; }
+                const uint32_t ws = wave_incl_scan(tot);
                 uint32_t pos = off + ws - tot;
                 if (plain) {
                     if (dw) or_bits(S.mbuf, pos, (uint64_t)dw);      // four 8-bit bytes: one deposit
@@ -1303,18 +1326,22 @@ __device__ bool ht_extract_fast(HtDecShared &S, const uint8_t *__restrict__ data
                         pos += wd[t];
                     }
                 }
-                off += __shfl(ws, 63);
+                off += wave_last(ws);
             }
         }
         wave_sync();
         if (bigu && (nb != segLen || S.nff > HT_MAX_FF)) return false;
         if (nb == segLen) {   // everything past the segment reads as ones (ht.go:407, 447-449, 462-464)
             const uint32_t wd0 = off >> 5;
-            for (uint32_t i = wd0 + lane; i < HT_DEC_MWORDS; i += 64)
+            const uint32_t wend = bigu ? (uint32_t)HT_DEC_MWORDS : min((uint32_t)HT_DEC_MWORDS, (total_bits >> 5) + 3u);   // .. as far as it is read
+            for (uint32_t i = wd0 + lane; i < wend; i += 64)
                 S.mbuf[i] = (i == wd0) ? (S.mbuf[i] | (0xFFFFFFFFu << (off & 31))) : 0xFFFFFFFFu;
         }
     }
     wave_sync();
+#ifdef J2K_DEC_STAMP
+    g_dbg_unstuff = wall_clock64();
+#endif
     // ---- u > 32: the reference's uint32 bit counter wraps when it advances by more bits than it has loaded
     //      (ht.go:515-519); from then on the reader never refills and everything reads as zero.  Equivalent:
     //      the bit string is cut to zeros at L = "bits loaded when the first such advance happens".  Find L. ----
@@ -1335,11 +1362,9 @@ __device__ bool ht_extract_fast(HtDecShared &S, const uint8_t *__restrict__ data
                 rho &= m1; rho2 &= m2;
                 nbits = __popc(rho) * (u0 + 1) + __popc(rho2) * (u1 + 1);
             }
-            uint32_t ns = nbits;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const uint32_t a = __shfl_up(ns, o); if (lane >= o) ns += a; }
+            const uint32_t ns = wave_incl_scan(nbits);
             uint32_t mpos = mb + ns - nbits;
-            mb += __shfl(ns, 63);
+            mb += wave_last(ns);
             if (it < N) {
                 for (int i = 0; i < 8; i++) {
                     const uint32_t rr = (i < 4) ? rho : rho2, emb = (i < 4) ? u0 : u1;
@@ -1361,10 +1386,11 @@ __device__ bool ht_extract_fast(HtDecShared &S, const uint8_t *__restrict__ data
         const unsigned long long who = __ballot(best_key == k && k != 0xFFFFFFFFu);
         if (who) Lcut = __shfl(best_L, __ffsll((long long)who) - 1);
     }
-    uint32_t mbase = 0;
-    for (int i0 = 0; i0 < N; i0 += 64) {
-        const int it = i0 + lane;
-        uint32_t nbits = 0, rho = 0, rho2 = 0, u0 = 1, u1 = 1;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        if (64 * t >= N) break;
+        const int it = 64 * t + lane;
+        uint32_t rho = 0, rho2 = 0, u0 = 1, u1 = 1;
         int r = 0, pi = 0;
         if (it < N) {
             const uint32_t info = S.pair[it];
@@ -1375,29 +1401,51 @@ __device__ bool ht_extract_fast(HtDecShared &S, const uint8_t *__restrict__ data
             const uint32_t m1 = (xb + 4 <= w) ? 0xFu : ((xb < w) ? ((1u << (w - xb)) - 1) : 0u);
             const uint32_t m2 = (xb + 8 <= w) ? 0xFu : ((xb + 4 < w) ? ((1u << (w - xb - 4)) - 1) : 0u);
             rho &= m1; rho2 &= m2;
-            nbits = __popc(rho) * (u0 + 1) + __popc(rho2) * (u1 + 1);
         }
-        uint32_t ns = nbits;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t a = __shfl_up(ns, o); if (lane >= o) ns += a; }
-        uint32_t mpos = mbase + ns - nbits;
-        mbase += __shfl(ns, 63);
+        uint32_t mpos = mpos2[t];
+        int vals[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (it < N) {
-            int vals[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const uint32_t rr = (i < 4) ? rho : rho2, emb = (i < 4) ? u0 : u1;
-                vals[i] = 0;
                 if (!((rr >> (i & 3)) & 1)) continue;
-                const uint32_t magVal = bigu ? get_bits32_cut(S.mbuf, mpos, Lcut) : get_bits32(S.mbuf, mpos);
+                uint32_t magVal, sign;
+                if (bigu) {
+                    magVal = get_bits32_cut(S.mbuf, mpos, Lcut);
+                    sign = get_bits32_cut(S.mbuf, mpos + emb, Lcut) & 1;
+                } else {
+                    // one 64-bit window holds the magnitude bits and the sign behind them (emb <= 32 here, offset <= 31)
+                    const uint32_t wd = mpos >> 5, sh = mpos & 31;
+                    const uint64_t two = ((uint64_t)S.mbuf[wd] | ((uint64_t)S.mbuf[wd + 1] << 32)) >> sh;
+                    magVal = (uint32_t)two;
+                    sign = (uint32_t)(two >> emb) & 1;
+                }
                 const uint32_t mag = (magVal & (shl32(1, emb) - 1)) + shl32(1, emb - 1);
-                mpos += emb;
-                const uint32_t sign = (bigu ? get_bits32_cut(S.mbuf, mpos, Lcut) : get_bits32(S.mbuf, mpos)) & 1;
-                mpos += 1;
+                mpos += emb + 1;
                 vals[i] = sign ? (int32_t)(0u - mag) : (int32_t)mag;
             }
-            // the pair's 8 columns of the coded row are written exactly once (zeros included): the zero fill
-            // of the kernel skips coded rows, so no store ever has to be ordered behind another
+        }
+        // the pair's 8 columns of the coded row are written exactly once (zeros included): the zero fill
+        // of the kernel skips coded rows, so no store ever has to be ordered behind another
+        if (w == 64 && (((uintptr_t)out) & 15) == 0) {
+            // 64-wide blocks: lane = (row of this round, pair) holds 32 bytes of a 256-byte row, and storing them as they lie
+            // makes every store instruction write 16-byte pieces 32 bytes apart -- half-written 128-byte lines, which the
+            // memory system turns into partial writes (measured: the kernel's 102 MB left at 3.2 TB/s against 5.4 TB/s for
+            // the zero rows alone).  One cross-lane move later each instruction writes four whole rows.
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const int drow = half * 4 + (lane >> 4), q = lane & 15;     // the row of this round / 16-byte piece I store
+                const int src = drow * 8 + (q >> 1);                        // the lane that decoded it
+                int o[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int a = __shfl(vals[i], src), b = __shfl(vals[4 + i], src);
+                    o[i] = (q & 1) ? b : a;
+                }
+                const int rg = 8 * t + drow;                                // coded row index in the block
+                if (rg < R) st_decoded(out + (size_t)(4 * rg) * 64 + 4 * q, o[0], o[1], o[2], o[3]);
+            }
+        } else if (it < N) {
             const int xb = pi * 8;
             int32_t *orow = out + (size_t)(4 * r) * w + xb;
             if (xb + 8 <= w && (((uintptr_t)orow) & 15) == 0) {
@@ -1414,7 +1462,7 @@ __device__ bool ht_extract_fast(HtDecShared &S, const uint8_t *__restrict__ data
 }
 
 // four independent wavefronts per workgroup, one block each (no workgroup barrier anywhere on the fast path)
-__global__ __launch_bounds__(256) void ht_decode_kernel(const BlockJob *__restrict__ jobs, int njobs,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void ht_decode_kernel(const BlockJob *__restrict__ jobs, int njobs,
                                                         const uint8_t *__restrict__ stream, const uint64_t *__restrict__ offs,
                                                         const uint32_t *__restrict__ lens, int32_t *__restrict__ decoded,
                                                         const uint32_t *__restrict__ pairs) {
@@ -1423,6 +1471,9 @@ __global__ __launch_bounds__(256) void ht_decode_kernel(const BlockJob *__restri
     const int jid = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (jid >= njobs) return;
     const int lane = threadIdx.x & 63;
+#ifdef J2K_DEC_STAMP
+    const long long d0 = wall_clock64();
+#endif
     const BlockJob J = jobs[jid];
     const int w = J.w, h = J.h;
     int32_t *out = decoded + J.out_off;
@@ -1430,6 +1481,8 @@ __global__ __launch_bounds__(256) void ht_decode_kernel(const BlockJob *__restri
     // records first (their latency hides behind the zero fill)
     const uint32_t *rec = pairs + (size_t)jid * HT_WALK_REC;
     const uint32_t r0 = rec[lane], r1 = rec[64 + lane];
+    const uint64_t my_off = offs[jid];                         // (issued with the records: one round trip for all of them)
+    const uint32_t my_len = lens[jid], my_scup = rec[HT_WALK_MAX_PAIRS];
     const uint32_t tag = __shfl(r0, 0);
     const bool fast = (tag != HT_PAIR_ZERO) && (tag != HT_PAIR_SERIAL);
     // fresh NewHTDecoder: zeroed data.  On the fast path the coded rows (y % 4 == 0) are written in full by the
@@ -1438,7 +1491,14 @@ __global__ __launch_bounds__(256) void ht_decode_kernel(const BlockJob *__restri
     // (row index kept incrementally: a 64-bit i / wq per iteration costs ~150 VALU instructions and made this
     //  loop the most expensive part of the kernel)
     auto zero_fill = [&](bool skip_coded) {
-        if ((w & 3) == 0 && (J.out_off & 3) == 0) {
+        if (w == 64 && (J.out_off & 3) == 0) {
+            // 16 quads per row: the 64 lanes cover four rows per step, lanes 0..15 always the coded one
+            if (skip_coded && lane < 16) return;
+            int32_t *q = out + 4 * (size_t)lane;
+            for (int i = 0; i < h / 4; i++) st_decoded(q + 256 * (size_t)i, 0, 0, 0, 0);
+            const int rem = h & 3;                               // last, partial stripe
+            if (lane < 16 * rem) st_decoded(q + 256 * (size_t)(h / 4), 0, 0, 0, 0);
+        } else if ((w & 3) == 0 && (J.out_off & 3) == 0) {
             const uint32_t wq = (uint32_t)w >> 2, nq = (uint32_t)(n >> 2);
             const uint32_t dy = 64u / wq, dx = 64u % wq;
             uint32_t y = (uint32_t)lane / wq, x = (uint32_t)lane % wq;
@@ -1459,8 +1519,42 @@ __global__ __launch_bounds__(256) void ht_decode_kernel(const BlockJob *__restri
         }
     };
     if (!fast) zero_fill(false);
-    // finish the walk's records: u0/u1 from the 16 stream bits kept at the u-VLC (ht.go:716-864) -> rho | rho2 << 4 | u0 << 8 | u1 << 14
+    // Fast path: the first 1 KB of the MagSgn segment is requested NOW and the zero fill of the rows that carry no coded
+    // sample goes out right behind it -- 12 of a block's 16 KB, fire and forget, so the memory system writes while the
+    // wavefront unstuffs and extracts.  (Stores first and loads behind them would make the loads wait for every store:
+    // vmcnt retires in order.  Stores last -- the round-1 order -- left HBM idle for the first half of the kernel and
+    // then had all 7005 wavefronts store at once: the kernel ran at half the write bandwidth.)
+    uint32_t raw0[4] = {0, 0, 0, 0};
+#ifdef J2K_DEC_STAMP
+    const long long d_a = wall_clock64();
+#endif
+    if (fast) {
+        const uint8_t *fdata = stream + my_off;
+        const long segLen = (long)my_len - (long)my_scup;
+        const long maxbytes = (long)HT_DEC_MWORDS * 4 - 16;
+        const long nb = segLen < maxbytes ? segLen : maxbytes;
+        const long d = (long)((uintptr_t)fdata & 3);
+        const uint32_t *wsrc = reinterpret_cast<const uint32_t *>(fdata - d);
+        const long ndw = (d + nb + 3) >> 2;
+        if (ndw > 0) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const long j = 64 * c + lane;
+                raw0[c] = wsrc[j < ndw ? j : ndw - 1];
+            }
+        }
+        zero_fill(true);
+#ifdef J2K_DEC_ONLY_ZERO
+        return;                                    // DEV experiment: the store stream alone
+#endif
+    }
+#ifdef J2K_DEC_STAMP
+    const long long d_b = wall_clock64();
+#endif
+    // finish the walk's records: u0/u1 from the 16 stream bits kept at the u-VLC (ht.go:716-864) -> rho | rho2 << 4 | u0 << 8 | u1 << 14,
+    // and every pair's position in the MagSgn bit string: the prefix sum of popcount(rho) * (u + 1) (ht.go:661-710)
     bool bigu = false;
+    uint32_t mpos2[2] = {0, 0}, total_bits = 0;
     {
         const int quadCols = (w + 3) / 4, P = (quadCols + 1) / 2, N = ((h + 3) / 4) * P;
         uint32_t rr[2] = {r0, r1};
@@ -1468,23 +1562,42 @@ __global__ __launch_bounds__(256) void ht_decode_kernel(const BlockJob *__restri
         for (int t = 0; t < 2; t++) {
             const int it = lane + 64 * t;
             const uint32_t r = rr[t], mode = (r >> 8) & 3, vw = r >> 16;
-            uint32_t u[2], u0, u1;
-            decode_uvlc(vw, mode, u, 1);
+            uint32_t u0, u1;
             decode_uvlc_later(vw, mode >> 1, mode & 1, u0, u1);
-            if (it < P) { u0 = u[0]; u1 = u[1]; }
+            if (it < P) {                                         // first row: the other u-VLC rule (a few lanes of round 0)
+                uint32_t u[2];
+                decode_uvlc(vw, mode, u, 1);
+                u0 = u[0]; u1 = u[1];
+            }
             if (it < N && (u0 > 32 || u1 > 32)) bigu = true;
             S.pair[it] = (r & 0xFF) | (u0 & 0x3F) << 8 | (u1 & 0x3F) << 14;
+            uint32_t nbits = 0;
+            if (it < N) {
+                const int pi = it % P, xb = pi * 8;
+                // samples beyond the block width are skipped even when their rho bit is set (ht.go:661, 689)
+                const uint32_t m1 = (xb + 4 <= w) ? 0xFu : ((xb < w) ? ((1u << (w - xb)) - 1) : 0u);
+                const uint32_t m2 = (xb + 8 <= w) ? 0xFu : ((xb + 4 < w) ? ((1u << (w - xb - 4)) - 1) : 0u);
+                nbits = __popc(r & 0xF & m1) * ((u0 & 0x3F) + 1) + __popc((r >> 4) & 0xF & m2) * ((u1 & 0x3F) + 1);
+            }
+            const uint32_t ns = wave_incl_scan(nbits);
+            mpos2[t] = total_bits + ns - nbits;
+            total_bits += wave_last(ns);
         }
         bigu = __any(bigu);
     }
     wave_sync();
+#ifdef J2K_DEC_STAMP
+    const long long d_c = wall_clock64();
+#endif
     if (tag == HT_PAIR_ZERO) return;
     if (tag != HT_PAIR_SERIAL) {
-        const uint8_t *fdata = stream + offs[jid];
-        const long flen = (long)lens[jid];
-        const long fscup = (long)__shfl(rec[HT_WALK_MAX_PAIRS], 0);   // validated by ht_vlcprep_kernel
-        if (ht_extract_fast(S, fdata, flen, fscup, w, h, out, lane, bigu)) {
-            zero_fill(true);
+        const uint8_t *fdata = stream + my_off;
+        const long flen = (long)my_len;
+        const long fscup = (long)my_scup;                              // validated by ht_vlcprep_kernel
+        if (ht_extract_fast(S, fdata, flen, fscup, w, h, out, lane, bigu, mpos2, total_bits, raw0)) {
+#ifdef J2K_DEC_STAMP
+            if ((jid % 700) == 13 && lane == 0) printf("dec job %d: start %lld | job+records %lld | prefetch+zero issue %lld | uvlc+pos %lld | unstuff %lld | extract %lld | end %lld (x10 ns)\n", jid, d0 % 100000, d_a - d0, d_b - d_a, d_c - d_b, g_dbg_unstuff - d_c, wall_clock64() - g_dbg_unstuff, wall_clock64() % 100000);
+#endif
             return;
         }
         zero_fill(false);       // exotic input (more than HT_MAX_FF 0xFF bytes together with u > 32): serial decoder
