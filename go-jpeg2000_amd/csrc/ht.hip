@@ -1110,7 +1110,7 @@ __device__ __forceinline__ uint32_t uvlc_used_later(uint32_t vlc, uint32_t uOff1
 // most 128 quad pairs long, so the kernel time is 128 x the latency of one pair: everything that is not needed to find
 // the NEXT pair's bit position is left to ht_decode_kernel.  Per pair: fetch 64 bits at the current position
 // (three LDS words + two v_alignbit), ONE LDS lookup that resolves both quads (g_vlc_pair1), the u-VLC's LENGTH, one
-// record store:  rho | rho2 << 4 | (uOff1 << 1 | uOff2) << 8 | (the 16 stream bits at the u-VLC) << 16.
+// record store:  rho | rho2 << 4 | (uOff1 << 1 | uOff2) << 13 | (the 16 stream bits at the u-VLC) << 16  (bits 8..12: scratch).
 // The first row (other table, other u-VLC rule) and code words with a length nibble above 7 use two lookups.
 // A pair consumes at most 46 bits and HT_VBITS_WORDS covers 128 of them plus the read-ahead, so no clamping.
 __global__ __launch_bounds__(256) void ht_walk_kernel(const BlockJob *__restrict__ jobs, int njobs,
@@ -1184,22 +1184,41 @@ __global__ __launch_bounds__(256) void ht_walk_kernel(const BlockJob *__restrict
         uint32_t u[2];
         const uint32_t used = decode_uvlc(vw, mode, u, 1);
         pos += len + used;
-        rec[pi] = rho | rho2 << 4 | mode << 8 | vw << 16;
+        rec[pi] = rho | rho2 << 4 | mode << 13 | vw << 16;           // (the later rows' layout; bits 8..12 are not read)
     }
     // ---- later rows ----
-    for (int it = P; it < R * P; it++) {
-        HT_FETCH(w0, w1)
-        uint32_t e = S.pair1[w0 & 0x3FFF];
-        if (e & 0x8000) {                                            // rare: length nibble > 7
-            const uint32_t qinf = S.tbl1[w0 & 0x7F];
-            const uint32_t rho = (qinf >> 4) & 0xF, len1 = qinf & 0xF;
-            const uint32_t qinf2 = S.tbl1[((rho >> 2) << 7) | ((w0 >> len1) & 0x7F)];
-            e = rho | (qinf2 & 0xF0) | (len1 + (qinf2 & 0xF)) << 8 | ((qinf2 >> 3) & 1) << 13 | ((qinf >> 3) & 1) << 14;
+    // A lone wavefront retires about one instruction per 8-9 cycles whatever their dependencies (measured here and on the MQ
+    // coder), so what a step costs is its instruction COUNT plus the one LDS round trip of the table look-up: the loop is
+    // kept to the instructions the next position needs.  The u-VLC's length comes from two nibble tables in 32-bit
+    // constants (prefix lengths 3,1,2,1,3,1,2,1 and totals 8,1,2,1,4,1,2,1 for the three prefix bits), the record is the
+    // table entry as it is (rho | rho2 << 4 | len << 8 | uOff2 << 13 | uOff1 << 14) with the 16 stream bits at the u-VLC on
+    // top, and the trip count is the wavefront's maximum (scalar loop control): a lane whose block has fewer pairs walks on
+    // through its zero-padded row and writes records nobody reads (every block owns HT_WALK_MAX_PAIRS record words).
+    // (Tried: the stream words prefetched a step ahead into registers -- the selects cost what the round trip saves.)
+    {
+        int nsteps = R * P;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nsteps = max(nsteps, __shfl_xor(nsteps, o));
+        nsteps = min(__builtin_amdgcn_readfirstlane(nsteps), HT_WALK_MAX_PAIRS);   // (lanes that left early contribute nothing)
+        for (int it = P; it < nsteps; it++) {
+            HT_FETCH(w0, w1)
+            uint32_t e = S.pair1[w0 & 0x3FFF];
+            if (e & 0x8000) {                                            // rare: length nibble > 7
+                const uint32_t qinf = S.tbl1[w0 & 0x7F];
+                const uint32_t rho = (qinf >> 4) & 0xF, len1 = qinf & 0xF;
+                const uint32_t qinf2 = S.tbl1[((rho >> 2) << 7) | ((w0 >> len1) & 0x7F)];
+                e = rho | (qinf2 & 0xF0) | (len1 + (qinf2 & 0xF)) << 8 | ((qinf2 >> 3) & 1) << 13 | ((qinf >> 3) & 1) << 14;
+            }
+            const uint32_t len = (e >> 8) & 0x1F;
+            const uint32_t vw = __builtin_amdgcn_alignbit(w1, w0, len);
+            // u-VLC length (see decode_uvlc_later): the first prefix is read iff uOff2 (bit 13), the second iff uOff1 (bit 14)
+            const uint32_t m1 = (uint32_t)((int32_t)(e << 18) >> 31), m2 = (uint32_t)((int32_t)(e << 17) >> 31);
+            const uint32_t pl1 = (0x12131213u >> ((vw & 7) << 2)) & 3 & m1;
+            const uint32_t t1 = (0x12141218u >> ((vw & 7) << 2)) & 0xF & m1;
+            const uint32_t t2 = (0x12141218u >> (((vw >> pl1) & 7) << 2)) & 0xF & m2;
+            pos += len + t1 + t2;
+            rec[it] = (e & 0x7FFF) | vw << 16;
         }
-        const uint32_t len = (e >> 8) & 0x1F;
-        const uint32_t vw = __builtin_amdgcn_alignbit(w1, w0, len);
-        pos += len + uvlc_used_later(vw, (e >> 14) & 1, (e >> 13) & 1);
-        rec[it] = (e & 0xFF) | ((e >> 5) & 0x300) | vw << 16;
     }
 #undef HT_FETCH
 #ifdef J2K_WALK_STAMP
@@ -1561,7 +1580,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
 #pragma unroll
         for (int t = 0; t < 2; t++) {
             const int it = lane + 64 * t;
-            const uint32_t r = rr[t], mode = (r >> 8) & 3, vw = r >> 16;
+            const uint32_t r = rr[t], mode = (r >> 13) & 3, vw = r >> 16;
             uint32_t u0, u1;
             decode_uvlc_later(vw, mode >> 1, mode & 1, u0, u1);
             if (it < P) {                                         // first row: the other u-VLC rule (a few lanes of round 0)
