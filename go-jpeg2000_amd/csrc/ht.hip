@@ -1361,6 +1361,9 @@ __device__ bool ht_extract_fast(HtDecShared &S, const uint8_t *__restrict__ data
 #ifdef J2K_DEC_STAMP
     g_dbg_unstuff = wall_clock64();
 #endif
+#ifdef J2K_DEC_STOP_B
+    if (total_bits != 0x7fffffff) return true;      // DEV experiment: .. + the MagSgn unstuffing
+#endif
     // ---- u > 32: the reference's uint32 bit counter wraps when it advances by more bits than it has loaded
     //      (ht.go:515-519); from then on the reader never refills and everything reads as zero.  Equivalent:
     //      the bit string is cut to zeros at L = "bits loaded when the first such advance happens".  Find L. ----
@@ -1423,22 +1426,28 @@ __device__ bool ht_extract_fast(HtDecShared &S, const uint8_t *__restrict__ data
         }
         uint32_t mpos = mpos2[t];
         int vals[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (it < N) {
+        if (it < N && !bigu) {
+            // every u is at most 31 here (bigu starts at 32): one 32-bit window holds a sample's magnitude bits and the sign
+            // behind them.  Branch-free: an absent sample reads the window at the current position and advances by nothing.
+            const uint32_t half0 = 1u << (u0 - 1), half1 = 1u << (u1 - 1);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint32_t rr = (i < 4) ? rho : rho2, emb = (i < 4) ? u0 : u1;
+                const bool on = (rr >> (i & 3)) & 1;
+                const uint32_t wd = mpos >> 5;
+                const uint32_t win = __builtin_amdgcn_alignbit(S.mbuf[wd + 1], S.mbuf[wd], mpos & 31);
+                const uint32_t mag = __builtin_amdgcn_ubfe(win, 0, emb) + ((i < 4) ? half0 : half1);
+                const uint32_t sg = 0u - ((win >> emb) & 1);
+                vals[i] = on ? (int32_t)((mag ^ sg) - sg) : 0;
+                mpos += on ? emb + 1 : 0u;
+            }
+        } else if (it < N) {
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const uint32_t rr = (i < 4) ? rho : rho2, emb = (i < 4) ? u0 : u1;
                 if (!((rr >> (i & 3)) & 1)) continue;
-                uint32_t magVal, sign;
-                if (bigu) {
-                    magVal = get_bits32_cut(S.mbuf, mpos, Lcut);
-                    sign = get_bits32_cut(S.mbuf, mpos + emb, Lcut) & 1;
-                } else {
-                    // one 64-bit window holds the magnitude bits and the sign behind them (emb <= 32 here, offset <= 31)
-                    const uint32_t wd = mpos >> 5, sh = mpos & 31;
-                    const uint64_t two = ((uint64_t)S.mbuf[wd] | ((uint64_t)S.mbuf[wd + 1] << 32)) >> sh;
-                    magVal = (uint32_t)two;
-                    sign = (uint32_t)(two >> emb) & 1;
-                }
+                const uint32_t magVal = get_bits32_cut(S.mbuf, mpos, Lcut);
+                const uint32_t sign = get_bits32_cut(S.mbuf, mpos + emb, Lcut) & 1;
                 const uint32_t mag = (magVal & (shl32(1, emb) - 1)) + shl32(1, emb - 1);
                 mpos += emb + 1;
                 vals[i] = sign ? (int32_t)(0u - mag) : (int32_t)mag;
@@ -1462,6 +1471,9 @@ __device__ bool ht_extract_fast(HtDecShared &S, const uint8_t *__restrict__ data
                     o[i] = (q & 1) ? b : a;
                 }
                 const int rg = 8 * t + drow;                                // coded row index in the block
+#ifdef J2K_DEC_NO_CODED_STORES
+                if (o[0] == 0x7fffffff)            // DEV experiment: everything but the coded rows' stores
+#endif
                 if (rg < R) st_decoded(out + (size_t)(4 * rg) * 64 + 4 * q, o[0], o[1], o[2], o[3]);
             }
         } else if (it < N) {
@@ -1588,7 +1600,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
                 decode_uvlc(vw, mode, u, 1);
                 u0 = u[0]; u1 = u[1];
             }
-            if (it < N && (u0 > 32 || u1 > 32)) bigu = true;
+            if (it < N && (u0 > 31 || u1 > 31)) bigu = true;   // 32 itself only because the fast extraction reads a sample's u + 1 bits from one 32-bit window
             S.pair[it] = (r & 0xFF) | (u0 & 0x3F) << 8 | (u1 & 0x3F) << 14;
             uint32_t nbits = 0;
             if (it < N) {
@@ -1607,6 +1619,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     wave_sync();
 #ifdef J2K_DEC_STAMP
     const long long d_c = wall_clock64();
+#endif
+#ifdef J2K_DEC_STOP_A
+    if (total_bits != 0x7fffffff) return;           // DEV experiment: loads, zero rows, u-VLC + positions only
 #endif
     if (tag == HT_PAIR_ZERO) return;
     if (tag != HT_PAIR_SERIAL) {
