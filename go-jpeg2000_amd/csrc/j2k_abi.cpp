@@ -14,7 +14,9 @@
 using namespace j2k;
 
 namespace j2k {
+#ifdef J2K_DEV
 int g_dev_skip = 0;
+#endif
 hipError_t launch_add_const(hipStream_t s, int32_t *d, size_t n, int delta);
 hipError_t launch_rct(hipStream_t s, int32_t *a, int32_t *b, int32_t *c, size_t n, int inverse);
 hipError_t launch_ict(hipStream_t s, double *a, double *b, double *c, size_t n, int inverse);
@@ -109,7 +111,9 @@ extern "C" int j2k_ctx_create(int device, j2k_ctx **out) {
         int v = atoi(e);
         if (v >= 1 && v <= 4096) ctx->band_prows = v;
     }
+#ifdef J2K_DEV
     if (const char *e = getenv("J2K_DEV_SKIP")) j2k::g_dev_skip = (int)strtol(e, nullptr, 0);
+#endif
     if (const char *e = getenv("J2K_L0_FUSE")) { int v = atoi(e); if (v == 0 || v == 8 || v == 16) ctx->l0_fuse = v; }
     if (const char *e = getenv("J2K_L0_WG")) { int v = atoi(e); if (v == 0 || v == 4 || v == 8) ctx->l0_wg = v; }
     if (const char *e = getenv("J2K_L0_WG97")) { int v = atoi(e); if (v == 0 || (v >= 6 && v <= 16 && v % 2 == 0)) ctx->l0_wg97 = v; }

@@ -96,7 +96,12 @@ hipError_t launch_unpack_pixels(hipStream_t s, const uint8_t *pix, size_t stride
 hipError_t launch_colorspace(hipStream_t s, int cs, int32_t *planes, int ncomp, size_t n, int precision);
 hipError_t launch_pack_pixels(hipStream_t s, const int32_t *planes, int ncomp, int precision, int w, int h, uint8_t *pix, size_t stride);
 
-// DEV ONLY (J2K_DEV_SKIP, bit mask): launches left out to measure what each kernel costs with several frames in flight.
-// Results are wrong with any bit set; nothing in the product sets it.
+// DEV BUILDS ONLY (make CXXFLAGS+=-DJ2K_DEV; env J2K_DEV_SKIP = bit mask): launches left out to measure what each kernel
+// costs with several frames in flight (tools/ab_skip.sh).  Results are wrong with any bit set, so the shipped library
+// does not have the switch at all: g_dev_skip is the constant 0 and every test of it folds away.
+#ifdef J2K_DEV
 extern int g_dev_skip;
+#else
+constexpr int g_dev_skip = 0;
+#endif
 }  // namespace j2k

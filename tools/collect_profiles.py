@@ -1,0 +1,24 @@
+"""After `gpurun -- bash tools/round_profiles.sh`: copy what is judged from gpurun_out/round/ into profiles/ (tracked).
+python tools/collect_profiles.py <tag>   e.g. r02b -> profiles/<tag>_bench_default_3inflight_kernel_stats.csv, ..._inflight1_...,
+..._inflight1_pmc_summary.txt (+ the per-dispatch rows of the transform kernels), <tag>_c3_kernel_stats.csv"""
+import csv, glob, os, shutil, subprocess, sys
+tag = sys.argv[1]
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+O = os.path.join(R, "gpurun_out", "round"); P = os.path.join(R, "profiles")
+def newest(pat):
+    return sorted(glob.glob(os.path.join(O, pat)), key=os.path.getmtime)[-1]
+shutil.copy(newest("stats_default/*/*kernel_stats.csv"), os.path.join(P, tag + "_bench_default_3inflight_kernel_stats.csv"))
+shutil.copy(newest("stats_inflight1/*/*kernel_stats.csv"), os.path.join(P, tag + "_bench_inflight1_kernel_stats.csv"))
+shutil.copy(newest("stats_c3/*/*kernel_stats.csv"), os.path.join(P, tag + "_c3_kernel_stats.csv"))
+lines = ["# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), python bench.py --steps 10 --warmup 3 --no-cpu-baseline --inflight 1; per-kernel average, KiB",
+         "# (gfx950: FETCH_SIZE counts 64 B per 128-B request of a wide coalesced read -> double it; WRITE_SIZE is exact)"]
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    out = subprocess.run([sys.executable, os.path.join(R, "tools", "pmc_sum.py"), os.path.join(O, "pmc_" + c)], capture_output=True, text=True).stdout
+    lines += [l for l in out.splitlines() if l.strip()]
+    src = newest("pmc_%s/*/*counter_collection.csv" % c)
+    rows = list(csv.reader(open(src)))
+    keep = [rows[0]] + [r for r in rows[1:] if "dwt" in ",".join(r)]
+    with open(os.path.join(P, "%s_bench_inflight1_pmc_%s_dwt.csv" % (tag, c)), "w", newline="") as f:
+        csv.writer(f).writerows(keep)
+open(os.path.join(P, tag + "_bench_inflight1_pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
+print(open(os.path.join(P, tag + "_bench_inflight1_pmc_summary.txt")).read())
