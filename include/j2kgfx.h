@@ -327,6 +327,72 @@ int j2k_read_tile_part_header(const uint8_t *cs, size_t len, size_t pos, j2k_til
 /* every tile-part of a run of tile-parts (up to EOC or the end); *nparts = how many there are (J2K_ERR_CAPACITY if > cap) */
 int j2k_parse_tile_parts(const uint8_t *cs, size_t len, j2k_tile_part *parts, size_t cap, size_t *nparts);
 
+/* ---- Tier-2 packet coding and tile geometry: host calls, no device needed -------------------------
+ * The reference's internal/tcd/t2.go and the geometry of tcd.go, reproduced as they are written -- the "tag tree" values
+ * are unary (t2.go:368-377), the length-of-length field is 3 bits and wraps for blocks of 128 bytes or more
+ * (t2.go:408-437), PCRL runs every component / resolution to the LARGEST precinct count (t2.go:86-114), the packet
+ * decoder's Position() moves over markers and bodies only (t2.go:463-503) -- because parity with the reference is the
+ * contract; none of this is a conformant Part-1 packet stream (SURVEY 8f calls a conformant mode "explicitly outside
+ * reference parity").  In the reference only tests call t2.go; decoder.go:312,373 calls the geometry.
+ *
+ * j2k_t2_packet_sequence = NewPacketIterator + Next() until exhausted (t2.go:41-238), progression order
+ * 0..4 = LRCP, RLCP, RPCL, PCRL, CPRL (codestream/markers.go:177-188; any other order yields no packet, t2.go:86-100).
+ * precincts [][][]int is passed flat: prec_ncomp = len(precincts), prec_nres[c] = len(precincts[c]),
+ * prec_counts = precincts[c][r][0] for c, r in order (a (c, r) the table does not cover counts as one precinct).
+ * *count = packets in the sequence; J2K_ERR_CAPACITY (with *count set) when cap is smaller. */
+typedef struct j2k_packet { int32_t layer, resolution, component, precinct; } j2k_packet;
+int j2k_t2_packet_sequence(int ncomp, int nres, int nlayers, const int32_t *prec_counts, const int32_t *prec_nres, int prec_ncomp,
+                           int order, j2k_packet *out, size_t cap, size_t *count);
+
+/* A precinct as the packet coder sees it (tcd.go:86-128): nbands lists of code-blocks (band_ncb[b] each, flat in cbs) and
+ * the widths of its two tag trees (only used as divisors: a width of 0 is the Go divide panic, J2K_ERR_GO_PANIC).
+ * Code-block fields: IncludedInLayers, ZeroBitPlanes, len(Passes), Data (data_len bytes at data; data_cap = room the
+ * decoder may fill). */
+typedef struct j2k_t2_cb {
+    int32_t included_in_layers, zero_bit_planes, num_passes;
+    uint32_t data_len, data_cap, pad_;
+    uint8_t *data;
+} j2k_t2_cb;
+typedef struct j2k_t2_precinct {
+    int32_t nbands, incl_tree_w, imsb_tree_w, pad_;
+    const int32_t *band_ncb;
+    j2k_t2_cb *cbs;
+} j2k_t2_precinct;
+/* PacketEncoder.EncodePacket (t2.go:250-290): [SOP FF91 0004 uint16(layer)] header bits through the byte-stuffing
+ * writer (bio.go:157-226: after a 0xFF byte the next byte holds 7 bits), flushed; [EPH FF92]; the bodies of the
+ * code-blocks with IncludedInLayers <= layer and data.  *bio_delay carries the writer's "last byte was 0xFF" flag from
+ * one packet of an encoder to the next (0 for a new encoder).  j2k_t2_packet_bound: an upper bound of *len. */
+size_t j2k_t2_packet_bound(const j2k_t2_precinct *p);
+int j2k_t2_encode_packet(const j2k_t2_precinct *p, int layer, int sop, int eph, uint8_t *bio_delay, uint8_t *out, size_t cap, size_t *len);
+/* PacketDecoder.DecodePacket (t2.go:463-503) on data[0, len): the decoder object's state is the caller's -- pos
+ * (Position(): markers and bodies), and the header bit reader's own position / byte / bit count / "saw 0xFF"
+ * (a zeroed struct is NewPacketDecoder).  Fills the code-blocks' fields; a block's data is zeroed to its decoded length
+ * (J2K_ERR_CAPACITY if data_cap is smaller) and then filled from the body.  Running out of header bits or body bytes is
+ * the reference's error return: J2K_ERR_INVALID_ARG. */
+typedef struct j2k_t2_dec_state { uint64_t pos, rpos; uint8_t buf, cnt, saw_ff, pad_[5]; } j2k_t2_dec_state;
+int j2k_t2_decode_packet(const uint8_t *data, size_t len, j2k_t2_dec_state *st, j2k_t2_precinct *p, int layer, int sop, int eph);
+/* NewTagTree(width, height) (tcd.go:168-197): number of levels and nodes per level (the coder never walks the tree) */
+int j2k_tagtree_shape(int width, int height, int32_t *levels, int64_t *level_sizes, size_t cap);
+
+/* TileDecoder.InitTile (tcd.go:240-390; TileEncoder.InitTile :459-500 computes the same tile and component bounds):
+ * tile bounds, component bounds after subsampling (ceilDiv), per resolution r its bounds at scale 2^(NumDecompositions - r)
+ * and its bands -- LL for r = 0, else HL, LH, HH with the rectangles initBand writes (HL = upper half, LH = left half,
+ * HH = lower right quadrant of the RESOLUTION's rectangle, tcd.go:343-361) -- and every band's code-block grid
+ * (2^(exp + 2) squares from the band's origin, clipped).  Flat outputs: comps[ncomp], ress[ncomp * (nd + 1)],
+ * bands (component-major, resolution, band order), cbs (band by band, row-major); J2K_ERR_CAPACITY with the counts set
+ * when a table is too small.  Field ranges: NumDecompositions <= 32, code-block exponents <= 28, subsampling >= 1
+ * (beyond them the reference divides by zero: J2K_ERR_GO_PANIC). */
+typedef struct j2k_tcd_header {
+    uint32_t image_w, image_h, image_x0, image_y0, tile_w, tile_h, tile_x0, tile_y0, num_tiles_x;
+    int32_t ncomp;
+    const uint8_t *subsampling;          /* SubsamplingX, SubsamplingY per component */
+    uint8_t num_decompositions, cb_w_exp, cb_h_exp, pad_[5];
+} j2k_tcd_header;
+typedef struct j2k_tcd_rect { int32_t x0, y0, x1, y1; } j2k_tcd_rect;
+typedef struct j2k_tcd_band { int32_t comp, res, type, cbx, cby, pad_; j2k_tcd_rect r; uint64_t cb0; } j2k_tcd_band;
+int j2k_tcd_init_tile(const j2k_tcd_header *h, int tile_index, j2k_tcd_rect *tile, j2k_tcd_rect *comps, j2k_tcd_rect *ress,
+                      j2k_tcd_band *bands, size_t band_cap, size_t *nbands, j2k_tcd_rect *cbs, size_t cb_cap, size_t *ncbs);
+
 #ifdef __cplusplus
 }
 #endif
