@@ -1029,6 +1029,7 @@ static hipError_t fwd_wg_go(hipStream_t s, const LevelLaunch &L, const int32_t *
 #define J2K_WG2(W, FL) hipExtLaunchKernelGGL((dwt53_fwd_rgba8_wg2_kernel<W, FL, 5>), dim3(L.njobs2), dim3(W * 64), 0, s, ev_a, L.njobs > 0 ? nullptr : ev_b, 0, \
                                              L.jobs2, L.njobs2, L.planes, L.planes1, pix, out, L.nxt1, dc, L.pix_stride)
         if (L.wg2_waves == 16) { if (L.wg_store == 0) J2K_WG2(16, 0); else J2K_WG2(16, 1); }
+        else if (L.wg2_waves == 10) { if (L.wg_store == 0) J2K_WG2(10, 0); else J2K_WG2(10, 1); }
         else { if (L.wg_store == 0) J2K_WG2(8, 0); else J2K_WG2(8, 1); }
 #undef J2K_WG2
         if (L.njobs <= 0) return hipGetLastError();

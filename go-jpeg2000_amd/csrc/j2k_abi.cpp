@@ -114,7 +114,7 @@ extern "C" int j2k_ctx_create(int device, j2k_ctx **out) {
 #ifdef J2K_DEV
     if (const char *e = getenv("J2K_DEV_SKIP")) j2k::g_dev_skip = (int)strtol(e, nullptr, 0);
 #endif
-    if (const char *e = getenv("J2K_L0_FUSE")) { int v = atoi(e); if (v == 0 || v == 8 || v == 16) ctx->l0_fuse = v; }
+    if (const char *e = getenv("J2K_L0_FUSE")) { int v = atoi(e); if (v == 0 || v == 8 || v == 10 || v == 16) ctx->l0_fuse = v; }
     if (const char *e = getenv("J2K_L0_WG")) { int v = atoi(e); if (v == 0 || v == 4 || v == 8) ctx->l0_wg = v; }
     if (const char *e = getenv("J2K_L0_WG97")) { int v = atoi(e); if (v == 0 || (v >= 6 && v <= 16 && v % 2 == 0)) ctx->l0_wg97 = v; }
     if (const char *e = getenv("J2K_L0_XCD")) ctx->l0_xcd = atoi(e) != 0;

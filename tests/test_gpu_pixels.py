@@ -97,7 +97,7 @@ def _ctx_with(env):
                 os.environ[k] = v
 
 
-@pytest.mark.parametrize("fuse", [0, 8, 16])
+@pytest.mark.parametrize("fuse", [0, 8, 10, 16])
 @pytest.mark.parametrize("nres", [2, 3, 4, 6])
 @pytest.mark.parametrize("W,H,tile", [(512, 512, 0), (512, 112, 0), (256, 110, 0), (64, 114, 0), (16, 6, 0), (24, 2, 0), (512, 4, 0), (128, 10, 0),
                                       (512, 258, 0), (496, 200, 0), (40, 37, 0), (512, 511, 0), (1280, 624, 512), (768, 300, 256), (1024, 1024, 512), (3840, 2160, 512)])
