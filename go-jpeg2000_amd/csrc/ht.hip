@@ -1771,13 +1771,13 @@ hipError_t launch_ht_decode(hipStream_t s, const BlockJob *jobs, int njobs, cons
     hipError_t e;
     if ((e = ht_tables_ready(s)) != hipSuccess) return e;
     uint32_t *pairs = scratch, *vbits = scratch + (size_t)njobs * HT_WALK_REC;
-    if (!(g_dev_skip & 32))
+    for (int rep_ = 0; rep_ < dev_reps(32); rep_++)
     hipLaunchKernelGGL(ht_vlcprep_kernel, dim3((njobs + 3) / 4), dim3(256), 0, s, jobs, njobs, stream, offs, lens, vbits, pairs);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    if (!(g_dev_skip & 64))
+    for (int rep_ = 0; rep_ < dev_reps(64); rep_++)
     hipLaunchKernelGGL(ht_walk_kernel, dim3((njobs + HT_WALK_BLOCKS - 1) / HT_WALK_BLOCKS), dim3(256), sizeof(HtWalkShared), s, jobs, njobs, vbits, pairs);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    if (!(g_dev_skip & 128))
+    for (int rep_ = 0; rep_ < dev_reps(128); rep_++)
     hipLaunchKernelGGL(ht_decode_kernel, dim3((njobs + 3) / 4), dim3(256), 0, s, jobs, njobs, stream, offs, lens, decoded, pairs);
     return hipGetLastError();
 }

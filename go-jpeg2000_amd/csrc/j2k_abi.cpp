@@ -15,7 +15,7 @@ using namespace j2k;
 
 namespace j2k {
 #ifdef J2K_DEV
-int g_dev_skip = 0;
+int g_dev_skip = 0, g_dev_dup = 0;
 #endif
 hipError_t launch_add_const(hipStream_t s, int32_t *d, size_t n, int delta);
 hipError_t launch_rct(hipStream_t s, int32_t *a, int32_t *b, int32_t *c, size_t n, int inverse);
@@ -113,6 +113,7 @@ extern "C" int j2k_ctx_create(int device, j2k_ctx **out) {
     }
 #ifdef J2K_DEV
     if (const char *e = getenv("J2K_DEV_SKIP")) j2k::g_dev_skip = (int)strtol(e, nullptr, 0);
+    if (const char *e = getenv("J2K_DEV_DUP")) j2k::g_dev_dup = (int)strtol(e, nullptr, 0);
 #endif
     if (const char *e = getenv("J2K_L0_FUSE")) { int v = atoi(e); if (v == 0 || v == 8 || v == 10 || v == 16) ctx->l0_fuse = v; }
     if (const char *e = getenv("J2K_L0_WG")) { int v = atoi(e); if (v == 0 || v == 4 || v == 8) ctx->l0_wg = v; }
@@ -728,9 +729,9 @@ static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff, in
     const double step = 1.0 / (double)S.quality;   // encoder.go:269
     const int nlevel_launches = (P->tail_l0 >= 0) ? P->tail_l0 : S.levels;
     bool fused_l1 = false;             // level 1 ran inside the level-0 launch (packed RGBA8 frames, dwt53_fwd_rgba8_wg2_kernel)
-    for (int l = 0; l < nlevel_launches; l++) {
+    for (int l = 0; l < nlevel_launches; l++)
+    for (int rep_ = 0; rep_ < dev_reps(l == 0 ? 1 : (l == 1 ? 2 : 4)); rep_++) {      // (always once outside dev builds)
         if (l == 1 && fused_l1) continue;
-        if (g_dev_skip & (l == 0 ? 1 : (l == 1 ? 2 : 4))) continue;
         void *in = (l == 0) ? const_cast<void *>(d_frame) : ((l & 1) ? P->d_scrA : P->d_scrB);
         void *nx = (l & 1) ? P->d_scrB : P->d_scrA;
         // profiling (bench.py's roofline line): the level-0 dispatch of the RGB triples stamps its own begin / end
@@ -770,7 +771,7 @@ static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff, in
             }
         }
     }
-    if (P->tail_l0 >= 0 && !(g_dev_skip & 4))
+    for (int rep_ = 0; P->tail_l0 >= 0 && rep_ < dev_reps(4); rep_++)
         HIPCHK(ctx, launch_dwt53_tail_fwd(ctx->stream, P->d_tail, P->ntail, P->tail_lds_fwd,
                                           (const int32_t *)((P->tail_l0 & 1) ? P->d_scrA : P->d_scrB), (int32_t *)d_coeff));
     return J2K_OK;
@@ -781,13 +782,13 @@ static int plan_inverse_impl(j2k_plan *P, const void *d_coeff, void *d_frame, in
     const PlanSpec &S = P->spec;
     if (((uintptr_t)d_frame & 15) || ((uintptr_t)d_coeff & 15)) return fail(ctx, J2K_ERR_INVALID_ARG, "device pointers must be 16-byte aligned");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (P->tail_l0 >= 0 && !(g_dev_skip & 0x100))
+    for (int rep_ = 0; P->tail_l0 >= 0 && rep_ < dev_reps(0x100); rep_++)
         HIPCHK(ctx, launch_dwt53_tail_inv(ctx->stream, P->d_tail, P->ntail, P->tail_lds_inv, (const int32_t *)d_coeff,
                                           (int32_t *)((P->tail_l0 & 1) ? P->d_scrA : P->d_scrB)));
-    for (int l = ((P->tail_l0 >= 0) ? P->tail_l0 : S.levels) - 1; l >= 0; l--) {
+    for (int l = ((P->tail_l0 >= 0) ? P->tail_l0 : S.levels) - 1; l >= 0; l--)
+    for (int rep_ = 0; rep_ < dev_reps(l == 0 ? 0x400 : (l == 1 ? 0x200 : 0x100)); rep_++) {
         void *prev = (l & 1) ? P->d_scrB : P->d_scrA;                     // X_{l+1}
         void *dst = (l == 0) ? d_frame : ((l & 1) ? P->d_scrA : P->d_scrB);  // X_l
-        if (g_dev_skip & (l == 0 ? 0x400 : (l == 1 ? 0x200 : 0x100))) continue;
         for (int cls = 0; cls < 2; cls++) {
             const LevelTab &T = P->inv[cls][l];
             if (!T.njobs) continue;
@@ -1166,10 +1167,10 @@ extern "C" int j2k_plan_encode_stream(j2k_plan *P, const int32_t *d_coeff, uint8
         int r = stage_reserve(ctx, 3, 256);
         if (r != J2K_OK) return r;
         ctx->fault_armed = true;
-        if (!(g_dev_skip & 8))
+        for (int rep_ = 0; rep_ < dev_reps(8); rep_++)
         HIPCHK(ctx, launch_ht_encode(ctx->stream, P->d_bjobs, n, d_coeff, (uint8_t *)P->d_slots, d_lens, d_numbps, (int *)ctx->stage[3],
                                      P->d_maglens, P->d_ht_ujobs, P->ht_nunique, P->d_ht_alias_next));
-        if (!(g_dev_skip & 16))
+        for (int rep_ = 0; rep_ < dev_reps(16); rep_++)
         // the transport offsets (a second running sum in the scan, +4 us) only once j2k_plan_pack_stream has asked for them
         HIPCHK(ctx, launch_compact(ctx->stream, P->d_bjobs_alias ? P->d_bjobs_alias : P->d_bjobs, n, (const uint8_t *)P->d_slots, d_lens, d_offs, d_stream, P->d_maglens,
                                    P->want_toffs ? P->d_mels : nullptr, P->want_toffs ? P->d_toffs : nullptr));

@@ -100,8 +100,10 @@ hipError_t launch_pack_pixels(hipStream_t s, const int32_t *planes, int ncomp, i
 // costs with several frames in flight (tools/ab_skip.sh).  Results are wrong with any bit set, so the shipped library
 // does not have the switch at all: g_dev_skip is the constant 0 and every test of it folds away.
 #ifdef J2K_DEV
-extern int g_dev_skip;
+extern int g_dev_skip, g_dev_dup;      // J2K_DEV_DUP: the same bits, launches issued TWICE (every one is idempotent: results stay valid)
+inline int dev_reps(int bit) { return (g_dev_skip & bit) ? 0 : ((g_dev_dup & bit) ? 2 : 1); }
 #else
 constexpr int g_dev_skip = 0;
+constexpr int dev_reps(int) { return 1; }
 #endif
 }  // namespace j2k
