@@ -1014,6 +1014,7 @@ hipError_t launch_dwt53_tail_inv(hipStream_t s, const TailPlane *planes, int npl
 }
 
 #include "dwt53_l0pix.inc"
+#include "dwt53_plane_wg.inc"
 
 // ================================================================================
 // launchers
@@ -1104,6 +1105,16 @@ hipError_t launch_dwt53_fwd(hipStream_t s, const LevelLaunch &L, const int32_t *
         if (L.wg_waves == 4) return fwd_wg_go<4>(s, L, src, out, nxt, dc_shift);
         if (L.wg_waves == 8) return fwd_wg_go<8>(s, L, src, out, nxt, dc_shift);
         return hipErrorInvalidValue;
+    }
+    if (L.pwaves > 0 && L.ncomp == 1 && L.pnjobs > 0) {     // single-component planes, workgroup form (dwt53_plane_wg.inc)
+#define J2K_PWG(NW, SRC, MULTI) hipExtLaunchKernelGGL((dwt53_fwd_plane_wg_kernel<NW, SRC, MULTI, 8>), dim3(L.pnjobs), dim3(NW * 64), 0, s, L.ev_start, L.ev_stop, 0, \
+                                                 L.pjobs, L.pnjobs, L.planes, (const void *)src, out, nxt, dc_shift, L.pix_stride)
+#define J2K_PWG2(NW) do { if (L.pix_stride > 0) { if (L.pmulti) J2K_PWG(NW, 1, true); else J2K_PWG(NW, 1, false); } \
+                          else { if (L.pmulti) J2K_PWG(NW, 0, true); else J2K_PWG(NW, 0, false); } } while (0)
+        if (L.pwaves == 8) J2K_PWG2(8); else J2K_PWG2(4);
+#undef J2K_PWG2
+#undef J2K_PWG
+        return hipGetLastError();
     }
     J2K_DISPATCH(fwd_go, s, L, src, out, nxt, dc_shift);
 }

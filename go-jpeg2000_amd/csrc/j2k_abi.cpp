@@ -115,6 +115,7 @@ extern "C" int j2k_ctx_create(int device, j2k_ctx **out) {
     if (const char *e = getenv("J2K_DEV_SKIP")) j2k::g_dev_skip = (int)strtol(e, nullptr, 0);
     if (const char *e = getenv("J2K_DEV_DUP")) j2k::g_dev_dup = (int)strtol(e, nullptr, 0);
 #endif
+    if (const char *e = getenv("J2K_PLANE_WG")) { int v = atoi(e); if (v == 0 || v == 4 || v == 8) ctx->plane_wg = v; }
     if (const char *e = getenv("J2K_L0_FUSE")) { int v = atoi(e); if (v == 0 || v == 8 || v == 10 || v == 16) ctx->l0_fuse = v; }
     if (const char *e = getenv("J2K_L0_WG")) { int v = atoi(e); if (v == 0 || v == 4 || v == 8) ctx->l0_wg = v; }
     if (const char *e = getenv("J2K_L0_WG97")) { int v = atoi(e); if (v == 0 || (v >= 6 && v <= 16 && v % 2 == 0)) ctx->l0_wg97 = v; }
@@ -450,6 +451,35 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                 int r = upload(ctx, &T.d_planes, planes);
                 if (r == J2K_OK) r = upload(ctx, &T.d_jobs, jobs);
                 if (r != J2K_OK) { j2k_plan_destroy(P); return r; }
+                if (dir == 0 && cls == 0 && S.wavelet == W53 && vec_ok && ctx->plane_wg > 0) {
+                    // workgroup form for single-component planes (dwt53_plane_wg.inc): whole 16-byte lanes, at least two rows
+                    bool ok = true;
+                    int multi = 0;
+                    for (size_t i = 0; i < planes.size() && ok; i++) {
+                        if (pw[i] < 16 || (pw[i] % 8) || ph[i] < 2) ok = false;
+                        if (l == 0 && (S.W % 8)) ok = false;                  // packed Gray16 rows: 16-byte lanes of the frame
+                        if (pw[i] > 512) multi = 1;
+                    }
+                    if (ok) {
+                        std::vector<DwtJob> pj;
+                        const int nr = ctx->plane_wg - 1;
+                        for (size_t i = 0; i < planes.size(); i++)
+                            for (int c0 = 0; c0 < pw[i]; c0 += 512)
+                                for (int pr = 0; pr < (ph[i] + 1) / 2; pr += nr) pj.push_back(DwtJob{(int)i, c0, pr, nr});
+                        if (ctx->l0_xcd && pj.size() >= 64) {                 // XCD-aware order, as for the RGBA8 kernels
+                            const size_t chunk = (pj.size() + 7) / 8;
+                            std::vector<DwtJob> perm(chunk * 8, DwtJob{-1, 0, 0, 0});
+                            for (size_t b = 0; b < perm.size(); b++) {
+                                const size_t j = (b % 8) * chunk + b / 8;
+                                if (j < pj.size()) perm[b] = pj[j];
+                            }
+                            pj.swap(perm);
+                        }
+                        T.pnjobs = (int)pj.size(); T.pwaves = ctx->plane_wg; T.pmulti = multi;
+                        r = upload(ctx, &T.d_pjobs, pj);
+                        if (r != J2K_OK) { j2k_plan_destroy(P); return r; }
+                    }
+                }
                 if (dir == 0 && l == 0 && cls == 1 && S.wavelet == W53 && vec_ok && cpl == 8) {
                     // the packed-pixel forward (j2k_plan_forward_rgba8) moves a third of the bytes per row on the read side
                     // and likes shorter bands: its own job table (measured: 3 pair-rows 29.6 us, 5 pair-rows 31.9 us)
@@ -642,8 +672,8 @@ extern "C" void j2k_plan_destroy(j2k_plan *P) {
     if (!P) return;
     if (P->ctx) { (void)hipSetDevice(P->ctx->device); (void)hipStreamSynchronize(P->ctx->stream); }
     for (int cls = 0; cls < 2; cls++) {
-        for (auto &T : P->fwd[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); }
-        for (auto &T : P->inv[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); }
+        for (auto &T : P->fwd[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); if (T.d_pjobs) (void)hipFree(T.d_pjobs); }
+        for (auto &T : P->inv[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); if (T.d_pjobs) (void)hipFree(T.d_pjobs); }
     }
     void *ptrs[] = {P->d_scrA, P->d_scrB, P->d_tail, P->d_bjobs, P->d_djobs, P->d_frame, P->d_coeff, P->d_slots, P->d_stream, P->d_lens, P->d_numbps, P->d_offs, P->d_status, P->d_fwd_pix_jobs, P->d_fwd_wg2_jobs, P->d_fwd_wg_rest_jobs, P->d_fwd_wg_jobs, P->d_fwd97_wg_jobs, P->d_ht_ujobs, P->d_ht_alias_next, P->d_bjobs_alias, P->d_maglens, P->d_mels, P->d_toffs};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -718,7 +748,11 @@ extern "C" int j2k_plan_get_decoded_offsets(const j2k_plan *P, uint64_t *offs, s
 // ------------------------------------------------------------------------------
 // transform stages on device buffers
 // ------------------------------------------------------------------------------
-static LevelLaunch mk(const LevelTab &T, int pf = 0) { return LevelLaunch{T.d_jobs, T.njobs, T.d_planes, T.cpl, T.vec, T.ncomp, pf}; }
+static LevelLaunch mk(const LevelTab &T, int pf = 0) {
+    LevelLaunch L{T.d_jobs, T.njobs, T.d_planes, T.cpl, T.vec, T.ncomp, pf};
+    L.pjobs = T.d_pjobs; L.pnjobs = T.pnjobs; L.pwaves = T.pwaves; L.pmulti = T.pmulti;
+    return L;
+}
 
 // pix_stride > 0: d_frame is a packed-pixel frame read by the level-0 kernels of class pix_cls (1: RGBA8 triples, 0: Gray16 planes)
 static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff, int pix_stride = 0, int pix_cls = 1) {

@@ -78,6 +78,8 @@ struct LevelLaunch {
     int njobs2, wg2_waves;
     const DwtPlane *planes1;
     int32_t *nxt1;
+    const DwtJob *pjobs;  // single-component planes in workgroup form (dwt53_plane_wg.inc): per-workgroup table, pwaves waves each
+    int pnjobs, pwaves, pmulti;
     hipEvent_t ev_start, ev_stop;   // non-null: the dispatch itself stamps these (hipExtLaunchKernelGGL) -- the kernel's own
                                     // begin / end, without the launch gap an event pair around the launch would include
 };

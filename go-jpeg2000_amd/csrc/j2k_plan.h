@@ -14,6 +14,7 @@ struct j2k_ctx {
                                // Measured slower than the three kernels it replaces (61.7 vs 58.6 us: the prefix chain crosses XCDs)
     int fwd_link = 1;          // forward 5-3: bands of one workgroup exchange halo rows through LDS (J2K_FWD_LINK)
     int inv_link = 1;          // same for the inverse kernels (J2K_INV_LINK)
+    int plane_wg = 4;          // single-component planes (every level > 0, gray level 0) in workgroup form: waves per workgroup (J2K_PLANE_WG: 0 off, 4, 8)
     int l0_fuse = 0;           // forward levels 0 + 1 of RGBA8 frames in one launch: waves per workgroup of the fused bands (J2K_L0_FUSE: 0 off, 8, 16)
     int l0_wg = 4;             // packed RGBA8 level-0 forward, workgroup form: wavefronts per workgroup (J2K_L0_WG: 0 off, 4, 8)
     int l0_wg97 = 8;           // lossy level-0 forward of an RGB triple, workgroup form: waves per workgroup (J2K_L0_WG97: 0 off, 6..16 even; measured 4K: 8 -> 78 us, 16 -> 88 us, general kernel 160 us)
@@ -90,6 +91,10 @@ struct LevelTab {
     int njobs = 0, nplanes = 0;
     int cpl = 2, vec = 0, ncomp = 1;
     int64_t alg_bytes = 0;
+    // single-component planes in workgroup form (dwt53_plane_wg.inc): one entry per (plane, 512-column strip, band of
+    // pwaves - 1 pair-rows); empty when a plane of the level breaks the geometry contract
+    DwtJob *d_pjobs = nullptr;
+    int pnjobs = 0, pwaves = 0, pmulti = 0;
 };
 
 }  // namespace j2k
