@@ -264,7 +264,7 @@ def run_config(args, cfgname):
             k_s = (iso_ms / max(iso_n, 1)) * 1e-3
             ach = alg / k_s / 1e9 if iso_n else 0.0
             kern = {"c3": "dwt97_fwd_kernel (level 0: DC shift + ICT + rounding + 9-7 lifting + quantisation, fused)",
-                    "c5": "dwt53_fwd_kernel<8,1,...,PIX> (level 0: Gray16 unpack + DC shift + 5-3 lifting, fused)"}.get(cfgname, "level-0 forward kernel")
+                    "c5": "dwt53_fwd_plane_wg_kernel<4,1,true,8> (level 0: Gray16 unpack + DC shift + 5-3 lifting, fused; four 512-column strips)"}.get(cfgname, "level-0 forward kernel")
             out = {"metric": cfg["metric"], "value": round(world * F * W * H / (dt / args.steps) / 1e6, 1), "unit": "Mpixels/s", "n_gpus": world,
                    "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
                    "scaling": "weak", "vs_baseline": None, "dtype": "int32" if cfg["lossless"] else "f64", "data": "synthetic",

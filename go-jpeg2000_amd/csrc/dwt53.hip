@@ -1133,6 +1133,17 @@ hipError_t launch_dwt53_inv(hipStream_t s, const LevelLaunch &L, const int32_t *
 #undef J2K_INVWG
         return hipGetLastError();
     }
+    if (L.pwaves > 0 && L.ncomp == 1 && L.pnjobs > 0) {     // single-component planes, workgroup form (dwt53_plane_wg.inc)
+        if (L.pix_stride > 0 && !final_level) return hipErrorInvalidValue;
+#define J2K_PWG(NW, DST, MULTI) hipLaunchKernelGGL((dwt53_inv_plane_wg_kernel<NW, DST, MULTI, 8>), dim3(L.pnjobs), dim3(NW * 64), 0, s, \
+                                                 L.pjobs, L.pnjobs, L.planes, coef, prev, (void *)dst, dc_shift, final_level, L.pix_stride)
+#define J2K_PWG2(NW) do { if (L.pix_stride > 0) { if (L.pmulti) J2K_PWG(NW, 1, true); else J2K_PWG(NW, 1, false); } \
+                          else { if (L.pmulti) J2K_PWG(NW, 0, true); else J2K_PWG(NW, 0, false); } } while (0)
+        if (L.pwaves == 8) J2K_PWG2(8); else J2K_PWG2(4);
+#undef J2K_PWG2
+#undef J2K_PWG
+        return hipGetLastError();
+    }
     J2K_DISPATCH(inv_go, s, L, coef, prev, dst, dc_shift, final_level);
 }
 

@@ -451,7 +451,7 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                 int r = upload(ctx, &T.d_planes, planes);
                 if (r == J2K_OK) r = upload(ctx, &T.d_jobs, jobs);
                 if (r != J2K_OK) { j2k_plan_destroy(P); return r; }
-                if (dir == 0 && cls == 0 && S.wavelet == W53 && vec_ok && ctx->plane_wg > 0) {
+                if (cls == 0 && S.wavelet == W53 && vec_ok && ctx->plane_wg > 0) {           // both directions
                     // workgroup form for single-component planes (dwt53_plane_wg.inc): whole 16-byte lanes, at least two rows
                     bool ok = true;
                     int multi = 0;
