@@ -1106,11 +1106,12 @@ hipError_t launch_dwt53_fwd(hipStream_t s, const LevelLaunch &L, const int32_t *
         if (L.wg_waves == 8) return fwd_wg_go<8>(s, L, src, out, nxt, dc_shift);
         return hipErrorInvalidValue;
     }
-    if (L.pwaves > 0 && L.ncomp == 1 && L.pnjobs > 0) {     // single-component planes, workgroup form (dwt53_plane_wg.inc)
-#define J2K_PWG(NW, SRC, MULTI) hipExtLaunchKernelGGL((dwt53_fwd_plane_wg_kernel<NW, SRC, MULTI, 8>), dim3(L.pnjobs), dim3(NW * 64), 0, s, L.ev_start, L.ev_stop, 0, \
+    if (L.pwaves > 0 && L.pnjobs > 0 && (L.ncomp == 1 || L.pix_stride <= 0)) {     // planes in workgroup form (dwt53_plane_wg.inc)
+#define J2K_PWG(NW, NC, SRC, MULTI, WPE) hipExtLaunchKernelGGL((dwt53_fwd_plane_wg_kernel<NW, NC, SRC, MULTI, WPE>), dim3(L.pnjobs), dim3(NW * 64), 0, s, L.ev_start, L.ev_stop, 0, \
                                                  L.pjobs, L.pnjobs, L.planes, (const void *)src, out, nxt, dc_shift, L.pix_stride)
-#define J2K_PWG2(NW) do { if (L.pix_stride > 0) { if (L.pmulti) J2K_PWG(NW, 1, true); else J2K_PWG(NW, 1, false); } \
-                          else { if (L.pmulti) J2K_PWG(NW, 0, true); else J2K_PWG(NW, 0, false); } } while (0)
+#define J2K_PWG2(NW) do { if (L.ncomp == 3) { if (L.pmulti) J2K_PWG(NW, 3, 0, true, 4); else J2K_PWG(NW, 3, 0, false, 5); } \
+                          else if (L.pix_stride > 0) { if (L.pmulti) J2K_PWG(NW, 1, 1, true, 8); else J2K_PWG(NW, 1, 1, false, 8); } \
+                          else { if (L.pmulti) J2K_PWG(NW, 1, 0, true, 8); else J2K_PWG(NW, 1, 0, false, 8); } } while (0)
         if (L.pwaves == 8) J2K_PWG2(8); else J2K_PWG2(4);
 #undef J2K_PWG2
 #undef J2K_PWG
@@ -1133,12 +1134,13 @@ hipError_t launch_dwt53_inv(hipStream_t s, const LevelLaunch &L, const int32_t *
 #undef J2K_INVWG
         return hipGetLastError();
     }
-    if (L.pwaves > 0 && L.ncomp == 1 && L.pnjobs > 0) {     // single-component planes, workgroup form (dwt53_plane_wg.inc)
+    if (L.pwaves > 0 && L.pnjobs > 0 && (L.ncomp == 1 || L.pix_stride <= 0)) {     // planes in workgroup form (dwt53_plane_wg.inc)
         if (L.pix_stride > 0 && !final_level) return hipErrorInvalidValue;
-#define J2K_PWG(NW, DST, MULTI) hipLaunchKernelGGL((dwt53_inv_plane_wg_kernel<NW, DST, MULTI, 8>), dim3(L.pnjobs), dim3(NW * 64), 0, s, \
+#define J2K_PWG(NW, NC, DST, MULTI, WPE) hipLaunchKernelGGL((dwt53_inv_plane_wg_kernel<NW, NC, DST, MULTI, WPE>), dim3(L.pnjobs), dim3(NW * 64), 0, s, \
                                                  L.pjobs, L.pnjobs, L.planes, coef, prev, (void *)dst, dc_shift, final_level, L.pix_stride)
-#define J2K_PWG2(NW) do { if (L.pix_stride > 0) { if (L.pmulti) J2K_PWG(NW, 1, true); else J2K_PWG(NW, 1, false); } \
-                          else { if (L.pmulti) J2K_PWG(NW, 0, true); else J2K_PWG(NW, 0, false); } } while (0)
+#define J2K_PWG2(NW) do { if (L.ncomp == 3) { if (L.pmulti) J2K_PWG(NW, 3, 0, true, 3); else J2K_PWG(NW, 3, 0, false, 5); } \
+                          else if (L.pix_stride > 0) { if (L.pmulti) J2K_PWG(NW, 1, 1, true, 8); else J2K_PWG(NW, 1, 1, false, 8); } \
+                          else { if (L.pmulti) J2K_PWG(NW, 1, 0, true, 8); else J2K_PWG(NW, 1, 0, false, 8); } } while (0)
         if (L.pwaves == 8) J2K_PWG2(8); else J2K_PWG2(4);
 #undef J2K_PWG2
 #undef J2K_PWG

@@ -115,6 +115,7 @@ extern "C" int j2k_ctx_create(int device, j2k_ctx **out) {
     if (const char *e = getenv("J2K_DEV_SKIP")) j2k::g_dev_skip = (int)strtol(e, nullptr, 0);
     if (const char *e = getenv("J2K_DEV_DUP")) j2k::g_dev_dup = (int)strtol(e, nullptr, 0);
 #endif
+    if (const char *e = getenv("J2K_PLANE_WG3")) ctx->plane_wg3 = atoi(e) != 0;
     if (const char *e = getenv("J2K_PLANE_WG")) { int v = atoi(e); if (v == 0 || v == 4 || v == 8) ctx->plane_wg = v; }
     if (const char *e = getenv("J2K_L0_FUSE")) { int v = atoi(e); if (v == 0 || v == 8 || v == 10 || v == 16) ctx->l0_fuse = v; }
     if (const char *e = getenv("J2K_L0_WG")) { int v = atoi(e); if (v == 0 || v == 4 || v == 8) ctx->l0_wg = v; }
@@ -451,7 +452,7 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                 int r = upload(ctx, &T.d_planes, planes);
                 if (r == J2K_OK) r = upload(ctx, &T.d_jobs, jobs);
                 if (r != J2K_OK) { j2k_plan_destroy(P); return r; }
-                if (cls == 0 && S.wavelet == W53 && vec_ok && ctx->plane_wg > 0) {           // both directions
+                if (S.wavelet == W53 && vec_ok && ctx->plane_wg > 0 && (cls == 0 || ctx->plane_wg3)) {   // both directions; cls 1 = level 0 of RGB triples of int32 planes
                     // workgroup form for single-component planes (dwt53_plane_wg.inc): whole 16-byte lanes, at least two rows
                     bool ok = true;
                     int multi = 0;

@@ -79,13 +79,39 @@ def test_levels_above_zero_of_rgb_frames(W, H, tile):
     rng = np.random.default_rng(W + H)
     frame_h = rng.integers(0, 256, (3, H, W)).astype(np.int32)
     got = []
-    for wg in (0, 4, 8):
+    for wg in (0, 4, 8, 12):                   # 12: 4 waves + the triple variant of level 0 (J2K_PLANE_WG3)
         plan = FramePlan(W, H, 3, precision=8, lossless=True, num_resolutions=6, cb=(64, 64), tile=(tile, tile), coder=1,
-                         ctx=_ctx(J2K_PLANE_WG=wg))
+                         ctx=_ctx(J2K_PLANE_WG=wg & 7 if wg == 12 else wg, J2K_PLANE_WG3=int(wg == 12)))
         frame = torch.from_numpy(frame_h).to(plan.device)
         coeff = plan.forward(frame)
         back = plan.inverse(coeff)
         plan.ctx.sync()
         got.append(coeff.cpu().numpy())
         assert np.array_equal(back.cpu().numpy().reshape(3, H, W), frame_h)
-    assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2])
+    assert all(np.array_equal(got[0], g) for g in got[1:])
+
+
+@pytest.mark.parametrize("W,H,tile,prec", [(1280, 624, 512, 8), (3840, 64, 0, 12), (520, 33, 0, 31), (16, 2, 0, 16)])
+def test_rgb_triple_level0_variant(oracle, W, H, tile, prec):
+    """J2K_PLANE_WG3: level 0 of an RGB triple of int32 planes (DC shift + RCT + lifting, any precision: wraparound) in
+    workgroup form, strips included -- against the general kernel and the oracle"""
+    import torch
+    from j2kgfx.codec import FramePlan
+    rng = np.random.default_rng(W + H + prec)
+    frame_h = rng.integers(0, 2 ** prec, (3, H, W), dtype=np.int64).astype(np.int32)
+    got = []
+    for wg3 in (0, 1):
+        plan = FramePlan(W, H, 3, precision=prec, lossless=True, num_resolutions=4, cb=(64, 64), tile=(tile, tile), coder=1,
+                         ctx=_ctx(J2K_PLANE_WG=4, J2K_PLANE_WG3=wg3))
+        frame = torch.from_numpy(frame_h).to(plan.device)
+        coeff = plan.forward(frame)
+        back = plan.inverse(coeff)
+        plan.ctx.sync()
+        got.append((coeff.cpu().numpy(), back.cpu().numpy()))
+        if prec <= 16:             # (at 31 bits the RCT's (R + 2G + B) >> 2 wraps: the reference does not round-trip either)
+            assert np.array_equal(got[-1][1].reshape(3, H, W), frame_h)
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+    got = [g[0] for g in got]
+    if tile == 0 and W * H <= 1 << 18:
+        want = oracle.preprocess([frame_h[c] for c in range(3)], W, H, prec, True, 4)
+        assert np.array_equal(got[1].reshape(3, H, W), np.stack(want))
