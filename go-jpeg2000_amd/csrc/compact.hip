@@ -2,6 +2,7 @@
 // builds with `tileData = append(tileData, encoded...)` (encoder.go:684): exclusive scan of the
 // job lengths, then one wave per job gathers its bytes.
 #include "j2k_internal.h"
+#include <algorithm>
 
 namespace j2k {
 
@@ -317,6 +318,52 @@ hipError_t launch_unpack(hipStream_t s, const BlockJob *jobs, int njobs, int cou
         }
         hipLaunchKernelGGL(unpack_kernel, dim3((njobs + 1 + 3) / 4, m), dim3(256), 0, s, jobs, njobs, B, (uint64_t)stream_cap, fault);
     }
+    return hipGetLastError();
+}
+
+// ---- tile-parts on the device (multi-tile codestream assembly) ----
+// encoder.createTileHeader (encoder.go:746-760) for every tile of a dense stream at once: tile t of the plan (index tile_first
+// + t) is the bytes of its jobs, offs[job0[t]] .. offs[job0[t+1]]; its tile-part is SOT (FF90, Lsot = 10, Isot = uint16(index),
+// Psot = uint32(14 + len), TPsot = 0, TNsot = 1), SOD (FF93), then the data -- laid end to end, tile t at 14 t + its
+// stream offset.  One workgroup per (tile, 64 KiB chunk); the first chunk's first lanes write the header.  out_len[0] =
+// total bytes.  (The host call j2k_assemble_tiles does the same from host memory; this one saves the host pass and lets one
+// D2H copy carry the finished tile-parts.)
+__global__ __launch_bounds__(256) void assemble_tiles_kernel(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ offs,
+                                                              const int *__restrict__ job0, int ntiles, int tile_first,
+                                                              uint8_t *__restrict__ out, uint64_t *__restrict__ out_len) {
+    const int t = blockIdx.x;
+    const uint64_t base = offs[job0[0]], o0 = offs[job0[t]], o1 = offs[job0[t + 1]];
+    const uint64_t len = o1 - o0;
+    uint8_t *dst = out + (o0 - base) + 14ull * (uint64_t)t;
+    if (blockIdx.y == 0 && threadIdx.x < 14) {
+        const uint32_t idx = (uint32_t)(tile_first + t) & 0xFFFFu, psot = (uint32_t)(14 + len);
+        const uint8_t hdr[14] = {0xFF, 0x90, 0x00, 0x0A, (uint8_t)(idx >> 8), (uint8_t)idx, (uint8_t)(psot >> 24), (uint8_t)(psot >> 16),
+                                 (uint8_t)(psot >> 8), (uint8_t)psot, 0x00, 0x01, 0xFF, 0x93};
+        dst[threadIdx.x] = hdr[threadIdx.x];
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *out_len = (offs[job0[ntiles]] - base) + 14ull * (uint64_t)ntiles;
+    const uint64_t c0 = (uint64_t)blockIdx.y << 16;
+    if (c0 >= len) return;
+    const uint32_t n = (uint32_t)(len - c0 < 65536 ? len - c0 : 65536);
+    const uint8_t *src = stream + o0 + c0;
+    uint8_t *d = dst + 14 + c0;
+    // bytes up to the destination's next 16-byte boundary, aligned 16-byte stores of (unaligned) 16-byte loads, tail bytes
+    const uint32_t head = min(n, (uint32_t)((16 - ((uintptr_t)d & 15)) & 15));
+    if (threadIdx.x < head) d[threadIdx.x] = src[threadIdx.x];
+    const uint32_t nv = (n - head) >> 4;
+    for (uint32_t i = threadIdx.x; i < nv; i += 256) {
+        uint4 v;
+        __builtin_memcpy(&v, src + head + 16 * (size_t)i, 16);
+        *reinterpret_cast<uint4 *>(d + head + 16 * (size_t)i) = v;
+    }
+    const uint32_t done = head + (nv << 4);
+    if (done + threadIdx.x < n) d[done + threadIdx.x] = src[done + threadIdx.x];
+}
+hipError_t launch_assemble_tiles(hipStream_t s, const uint8_t *stream, const uint64_t *offs, const int *job0, int ntiles, int tile_first,
+                                 uint64_t max_tile_bytes, uint8_t *out, uint64_t *out_len) {
+    if (ntiles <= 0) return hipSuccess;
+    const unsigned chunks = (unsigned)std::max<uint64_t>(1, (max_tile_bytes + 65535) >> 16);
+    hipLaunchKernelGGL(assemble_tiles_kernel, dim3(ntiles, chunks), dim3(256), 0, s, stream, offs, job0, ntiles, tile_first, out, out_len);
     return hipGetLastError();
 }
 

@@ -49,6 +49,8 @@ size_t t1_flag_bytes(int w, int h);
 hipError_t launch_compact(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *slots, const uint32_t *lens,
                           uint64_t *offs, uint8_t *stream, const uint32_t *maglens, const uint32_t *mels = nullptr, uint64_t *toffs = nullptr);
 hipError_t launch_mel_table(hipStream_t s, const BlockJob *jobs, int njobs, uint32_t *mels);
+hipError_t launch_assemble_tiles(hipStream_t s, const uint8_t *stream, const uint64_t *offs, const int *job0, int ntiles, int tile_first,
+                                 uint64_t max_tile_bytes, uint8_t *out, uint64_t *out_len);
 hipError_t launch_scan(hipStream_t s, const uint32_t *lens, int njobs, uint64_t *offs, const uint32_t *mels, uint64_t *toffs);
 size_t pack_header_bytes(size_t n);
 hipError_t launch_pack(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs, const uint64_t *toffs,
@@ -633,6 +635,16 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                 }
         }
         P->bytes_cap = slot; P->decoded_elems = dec;
+        {   // first job of every tile of the shard (jobs are enumerated tile by tile) and the largest tile's slot bytes
+            std::vector<int> job0;
+            std::vector<uint64_t> tstart;
+            for (size_t i = 0; i < bj.size(); i++)
+                if (i == 0 || P->block_tile[i] != P->block_tile[i - 1]) { job0.push_back((int)i); tstart.push_back(P->slot_off[i]); }
+            job0.push_back((int)bj.size()); tstart.push_back((uint64_t)slot);
+            for (size_t t = 0; t + 1 < tstart.size(); t++) P->max_tile_bytes = std::max(P->max_tile_bytes, tstart[t + 1] - tstart[t]);
+            int r0 = upload(ctx, &P->d_tile_job0, job0);
+            if (r0 != J2K_OK) { j2k_plan_destroy(P); return r0; }
+        }
         int r = upload(ctx, &P->d_bjobs, bj);
         if (r == J2K_OK && S.coder == J2K_CODER_HT && ctx->ht_alias) {
             // Jobs with the same window are byte-identical for the HT coder (top-left addressing + a coder that ignores the
@@ -676,7 +688,7 @@ extern "C" void j2k_plan_destroy(j2k_plan *P) {
         for (auto &T : P->fwd[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); if (T.d_pjobs) (void)hipFree(T.d_pjobs); }
         for (auto &T : P->inv[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); if (T.d_pjobs) (void)hipFree(T.d_pjobs); }
     }
-    void *ptrs[] = {P->d_scrA, P->d_scrB, P->d_tail, P->d_bjobs, P->d_djobs, P->d_frame, P->d_coeff, P->d_slots, P->d_stream, P->d_lens, P->d_numbps, P->d_offs, P->d_status, P->d_fwd_pix_jobs, P->d_fwd_wg2_jobs, P->d_fwd_wg_rest_jobs, P->d_fwd_wg_jobs, P->d_fwd97_wg_jobs, P->d_ht_ujobs, P->d_ht_alias_next, P->d_bjobs_alias, P->d_maglens, P->d_mels, P->d_toffs};
+    void *ptrs[] = {P->d_tile_job0, P->d_scrA, P->d_scrB, P->d_tail, P->d_bjobs, P->d_djobs, P->d_frame, P->d_coeff, P->d_slots, P->d_stream, P->d_lens, P->d_numbps, P->d_offs, P->d_status, P->d_fwd_pix_jobs, P->d_fwd_wg2_jobs, P->d_fwd_wg_rest_jobs, P->d_fwd_wg_jobs, P->d_fwd97_wg_jobs, P->d_ht_ujobs, P->d_ht_alias_next, P->d_bjobs_alias, P->d_maglens, P->d_mels, P->d_toffs};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete P;
 }
@@ -1221,6 +1233,20 @@ extern "C" int j2k_plan_encode_stream(j2k_plan *P, const int32_t *d_coeff, uint8
 extern "C" size_t j2k_plan_pack_bound(const j2k_plan *P) {
     if (!P) return 0;
     return pack_header_bytes(P->blocks.size()) + (size_t)P->bytes_cap + 64;
+}
+
+extern "C" size_t j2k_plan_tile_parts_bound(const j2k_plan *P) {
+    return P ? (size_t)P->bytes_cap + 14 * (size_t)P->tile_count : 0;
+}
+extern "C" int j2k_plan_assemble_tiles_device(j2k_plan *P, const uint8_t *d_stream, const uint64_t *d_offs, uint8_t *d_out,
+                                              uint64_t *d_out_len) {
+    if (!P) return J2K_ERR_INVALID_ARG;
+    j2k_ctx *ctx = P->ctx;
+    if (!d_stream || !d_offs || !d_out || !d_out_len) return fail(ctx, J2K_ERR_INVALID_ARG, "null device pointer");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, launch_assemble_tiles(ctx->stream, d_stream, d_offs, P->d_tile_job0, P->tile_count, P->tile_first,
+                                      P->max_tile_bytes, d_out, d_out_len));
+    return J2K_OK;
 }
 
 extern "C" int j2k_plan_pack_stream(j2k_plan *P, const uint8_t *d_stream, const uint64_t *d_offs, const uint32_t *d_lens,

@@ -118,6 +118,8 @@ struct j2k_plan {
     // code-block jobs
     std::vector<j2k_block> blocks;          // plane = shard-local tile-component index
     std::vector<int32_t> block_tile;        // tile of each job
+    int *d_tile_job0 = nullptr;             // first job of each tile of the shard (+ the job count): j2k_plan_assemble_tiles_device
+    uint64_t max_tile_bytes = 0;            // slot bytes of the largest tile (an upper bound of its stream bytes)
     std::vector<uint64_t> slot_off;         // byte offset of each job's worst-case slot
     std::vector<uint64_t> dec_off;          // element offset of each job's decoded block
     j2k::BlockJob *d_bjobs = nullptr;       // out_off = slot byte offset (encode)

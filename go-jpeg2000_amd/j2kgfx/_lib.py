@@ -58,6 +58,7 @@ SYMBOLS = [
     "j2k_unpack_pixels", "j2k_pack_pixels", "j2k_plan_forward_rgba8", "j2k_plan_inverse_rgba8",
     "j2k_plan_forward_pixels", "j2k_plan_inverse_pixels",
     "j2k_tile_part_bound", "j2k_create_tile_header", "j2k_assemble_tiles", "j2k_read_tile_part_header", "j2k_parse_tile_parts",
+    "j2k_plan_tile_parts_bound", "j2k_plan_assemble_tiles_device",
     "j2k_t2_packet_sequence", "j2k_t2_packet_bound", "j2k_t2_encode_packet", "j2k_t2_decode_packet", "j2k_tagtree_shape", "j2k_tcd_init_tile",
     "j2k_plan_pack_bound", "j2k_plan_pack_stream", "j2k_plan_unpack_stream", "j2k_plan_unpack_streams",
 ]

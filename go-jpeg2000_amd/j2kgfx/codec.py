@@ -16,6 +16,7 @@ bench.py passes `track_streams=False`: its buffers live for the whole run and th
 """
 import functools
 import ctypes as C
+import sys
 
 import numpy as np
 
@@ -61,13 +62,18 @@ class FramePlan:
         self.info = info
         self.width, self.height, self.ncomp = width, height, ncomp
         self.device = "cuda:%d" % self.ctx.device
+        from .context import register_plan
+        register_plan(self)                     # closed by the package's atexit hook if the caller never does
 
     def close(self):
         if getattr(self, "h", None):
-            self.ctx.L.j2k_plan_destroy(self.h)
+            if getattr(self.ctx, "h", None):    # (a plan whose context is gone was destroyed with it)
+                self.ctx.L.j2k_plan_destroy(self.h)
             self.h = None
 
     def __del__(self):
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -198,6 +204,18 @@ class FramePlan:
         self.ctx.check(self.ctx.L.j2k_plan_pack_stream(self.h, self._p(stream), self._p(offs), self._p(lens), self._p(numbps),
                                                        self._p(pack)))
         return pack
+
+    @_stage
+    def assemble_tiles(self, stream, offs, out=None, out_len=None):
+        """encoder.createTileHeader for every tile of this plan's shard, on the device (j2k_plan_assemble_tiles_device):
+        (out uint8, out_len int64[1]); out[:out_len] = SOT ... SOD data of tile tile_first, tile_first + 1, ... end to end."""
+        t = _torch()
+        L = self.ctx.L
+        L.j2k_plan_tile_parts_bound.restype = C.c_size_t
+        out = out if out is not None else self.empty(int(L.j2k_plan_tile_parts_bound(self.h)), t.uint8)
+        out_len = out_len if out_len is not None else self.empty(1, t.int64)
+        self.ctx.check(L.j2k_plan_assemble_tiles_device(self.h, self._p(stream), self._p(offs), self._p(out), self._p(out_len)))
+        return out, out_len
 
     @_stage
     def unpack_stream(self, pack, stream=None, offs=None, lens=None, numbps=None):

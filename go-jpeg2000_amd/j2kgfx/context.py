@@ -1,7 +1,36 @@
 """j2k_ctx wrapper."""
+import atexit
 import ctypes as C
+import sys
+import weakref
 
 from . import _lib
+
+# Live contexts and plans.  They are closed by an atexit hook -- plans first, then contexts -- i.e. while the interpreter, torch
+# and the HIP runtime are all still up.  Left to the garbage collector at interpreter shutdown the order is arbitrary: a
+# context destroyed after the HIP runtime's own teardown aborts the process from a destructor ("terminate called after
+# throwing an instance of 'std::bad_variant_access'", seen whenever a failing test kept a plan alive in its traceback), so
+# __del__ does nothing once the interpreter is finalizing.
+_live_contexts = weakref.WeakSet()
+_live_plans = weakref.WeakSet()
+
+
+def register_plan(plan):
+    _live_plans.add(plan)
+
+
+@atexit.register
+def _close_all():
+    for p in list(_live_plans):
+        try:
+            p.close()
+        except Exception:
+            pass
+    for c in list(_live_contexts):
+        try:
+            c.close()
+        except Exception:
+            pass
 
 
 class Context:
@@ -15,6 +44,7 @@ class Context:
         self.device = int(device)
         self.L = L
         self._held = []          # tensors in use by work queued on this context's stream (FramePlan stage calls)
+        _live_contexts.add(self)
 
     def check(self, st):
         if st != _lib.OK:
@@ -56,6 +86,8 @@ class Context:
                 self.h = None
 
     def __del__(self):
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:

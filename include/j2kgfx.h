@@ -309,6 +309,12 @@ size_t j2k_tile_part_bound(const uint64_t *tile_offs, int ntiles);
 int j2k_create_tile_header(int tile_idx, const uint8_t *tile_data, size_t len, uint8_t *out, size_t cap, size_t *out_len);
 int j2k_assemble_tiles(const uint8_t *stream, const uint64_t *tile_offs, int tile_first, int ntiles, uint8_t *out, size_t cap,
                        size_t *out_len);
+/* The same on device buffers, for a plan's shard: every tile of d_stream / d_offs (as j2k_plan_encode_stream or
+ * j2k_plan_unpack_stream made them) becomes a tile-part with index tile_first + t, laid end to end in d_out
+ * (j2k_plan_tile_parts_bound bytes at most); *d_out_len (device) = the bytes written.  Asynchronous on the context's
+ * stream: one D2H copy then carries finished tile-parts instead of a stream the host still has to cut up. */
+size_t j2k_plan_tile_parts_bound(const j2k_plan *plan);
+int j2k_plan_assemble_tiles_device(j2k_plan *plan, const uint8_t *d_stream, const uint64_t *d_offs, uint8_t *d_out, uint64_t *d_out_len);
 /* codestream.Parser.ReadTilePartHeader (internal/codestream/parser.go:894-983): the SOT fields of the tile-part whose SOT
  * marker is at cs[pos], its in-header marker segments skipped by length (parser.go:180-190; their contents stay with the
  * Go-side parser: header_off / header_markers say where they are), and where its data lies (Psot = 0: to the end).

@@ -232,3 +232,31 @@ def test_c5_full_size_frame_matches_oracle():
     yy, xx = np.mgrid[0:2048, 0:2048]
     frame = np.clip((xx * 65535 // 2048 + yy * 65535 // 2048) // 2 + rng.integers(-2000, 2001, (2048, 2048)), 0, 65535).astype(np.int32)[None]
     _sample_tile_parity(2048, 2048, 0, 16, True, 0, 1, [0], frame, ncomp=1)
+
+
+@pytest.mark.parametrize("W,H,tile,first,count", [(1280, 624, 512, 0, 0), (1280, 624, 512, 2, 3), (200, 96, 64, 1, 4), (512, 512, 0, 0, 0), (3840, 2160, 512, 17, 9)])
+def test_device_tile_part_assembly_equals_host(W, H, tile, first, count):
+    """j2k_plan_assemble_tiles_device: the tile-parts of a shard built on the device are byte for byte what the host call
+    (j2k_assemble_tiles = encoder.createTileHeader per tile, checked against the oracle in test_codestream_tiles.py) builds
+    from the same stream, and the reference's tile-part parser reads them back"""
+    import torch
+    from j2kgfx import codestream
+    from j2kgfx.codec import FramePlan
+    rng = np.random.default_rng(W + first)
+    frame_h = rng.integers(0, 256, (3, H, W)).astype(np.int32)
+    plan = FramePlan(W, H, 3, precision=8, lossless=True, num_resolutions=4, cb=(32, 32), tile=(tile, tile), coder=1,
+                     tile_first=first, tile_count=count)
+    frame = torch.from_numpy(frame_h).to(plan.device)
+    stream, offs, lens, nb = plan.encode_stream(plan.forward(frame))
+    out, out_len = plan.assemble_tiles(stream, offs)
+    plan.ctx.sync()
+    n = int(plan.info.blocks)
+    o_h = offs.cpu().numpy()
+    tiles_of = plan.planes()[:, 0][plan.blocks()["plane"]]
+    starts = np.flatnonzero(np.diff(np.concatenate([[-1], tiles_of]))).tolist() + [n]
+    t_offs = np.array([int(o_h[j]) for j in starts], dtype=np.uint64)
+    want = codestream.assemble_tiles(stream[:int(o_h[n])].cpu().numpy(), t_offs, tile_first=first)
+    got = out[:int(out_len[0].item())].cpu().numpy().tobytes()
+    assert got == want
+    parts = codestream.parse_tile_parts(got)
+    assert [p.TileIndex for p, _ in parts] == list(range(first, first + len(starts) - 1))

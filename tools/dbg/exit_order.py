@@ -1,0 +1,8 @@
+import sys, numpy as np, torch
+sys.path.insert(0, "go-jpeg2000_amd")
+from j2kgfx.codec import FramePlan
+plans = [FramePlan(512, 512, 3, precision=8, lossless=True, num_resolutions=4, cb=(64, 64), tile=(0, 0), coder=1) for _ in range(3)]
+x = torch.zeros((3, 512, 512), dtype=torch.int32, device=plans[0].device)
+c = plans[0].forward(x)
+keep = (plans, c)          # alive at interpreter shutdown, never closed, work possibly still queued
+raise SystemExit(3)
