@@ -463,6 +463,15 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                         if (l == 0 && (S.W % 8)) ok = false;                  // packed Gray16 rows: 16-byte lanes of the frame
                         if (pw[i] > 512) multi = 1;
                     }
+                    // Where it pays: a lane takes eight columns, so planes narrower than 512 leave lanes idle -- fine while the
+                    // level is latency-bound (few waves: the deeper levels of one big plane), a loss against the general
+                    // kernels' four-columns-per-lane variant when there are many such planes (C2's level 1: 120 planes of
+                    // 256 x 256, measured 13.1 us against 10.4 us in the inverse)
+                    if (ok && maxw < 512) {
+                        int64_t prows = 0;
+                        for (size_t i = 0; i < planes.size(); i++) prows += (ph[i] + 1) / 2;
+                        if (prows > 4096 && !getenv("J2K_PLANE_WG_ALWAYS")) ok = false;
+                    }
                     if (ok) {
                         std::vector<DwtJob> pj;
                         const int nr = ctx->plane_wg - 1;
