@@ -134,7 +134,8 @@ def test_t1_batch_both_decoder_kernels(ent, oracle, general, monkeypatch):
         assert np.array_equal(got[j], wants[j]), (j, blocks[j], general)
 
 
-HT_SHAPES = [(4, 4), (8, 8), (16, 16), (64, 64), (32, 32), (8, 5), (13, 9), (7, 4), (5, 8), (12, 16), (64, 7), (3, 16), (128, 128)]
+HT_SHAPES = [(4, 4), (8, 8), (16, 16), (64, 64), (32, 32), (8, 5), (13, 9), (7, 4), (5, 8), (12, 16), (64, 7), (3, 16), (128, 128),
+             (128, 32), (256, 16), (1024, 4), (512, 8), (128, 31), (252, 16), (1020, 3)]
 
 
 @pytest.mark.parametrize("w,h", HT_SHAPES)
