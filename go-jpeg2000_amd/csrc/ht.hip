@@ -1159,9 +1159,17 @@ __global__ __launch_bounds__(256) void ht_walk_kernel(const BlockJob *__restrict
 #ifdef J2K_WALK_STAMP
     const long long st1 = __builtin_amdgcn_s_memtime();
 #endif
-    if (tid >= 64 || !have) return;
-    if (tag == HT_PAIR_SERIAL || tag == HT_PAIR_ZERO) return;
+    if (tid >= 64) return;
     const int quadCols = (w + 3) / 4, P = (quadCols + 1) / 2, R = (h + 3) / 4;
+    // the walking wavefront's trip count: the largest pair count among its blocks -- reduced while all 64 lanes are still
+    // active (a butterfly over a wave with holes leaves different partial maxima in different lanes: taken after the early
+    // returns below it cut some blocks' walks short, found by tools/fuzz_gpu.py on a frame of mixed block sizes)
+    const bool walks = have && tag != HT_PAIR_SERIAL && tag != HT_PAIR_ZERO;
+    int nsteps = walks ? R * P : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nsteps = max(nsteps, __shfl_xor(nsteps, o));
+    nsteps = min(__builtin_amdgcn_readfirstlane(nsteps), HT_WALK_MAX_PAIRS);
+    if (!walks) return;
     const uint32_t *row = &S.vb[lane][0];
     uint32_t pos = 0;
 #define HT_FETCH(w0, w1)                                                          \
@@ -1196,10 +1204,6 @@ __global__ __launch_bounds__(256) void ht_walk_kernel(const BlockJob *__restrict
     // through its zero-padded row and writes records nobody reads (every block owns HT_WALK_MAX_PAIRS record words).
     // (Tried: the stream words prefetched a step ahead into registers -- the selects cost what the round trip saves.)
     {
-        int nsteps = R * P;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) nsteps = max(nsteps, __shfl_xor(nsteps, o));
-        nsteps = min(__builtin_amdgcn_readfirstlane(nsteps), HT_WALK_MAX_PAIRS);   // (lanes that left early contribute nothing)
         for (int it = P; it < nsteps; it++) {
             HT_FETCH(w0, w1)
             uint32_t e = S.pair1[w0 & 0x3FFF];

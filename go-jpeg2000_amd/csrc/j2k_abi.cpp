@@ -171,7 +171,8 @@ static int check_fault(j2k_ctx *ctx) {
     HIPCHK(ctx, hipMemsetAsync(ctx->stage[3], 0, sizeof(int), ctx->stream));   // ordered with the next launches on this stream
     if (f == 1) return fail(ctx, J2K_ERR_GO_PANIC, "block coder: input on which the reference panics (stream buffer overrun / MinInt32)");
     if (f == 4) return fail(ctx, J2K_ERR_INVALID_ARG, "unpack_stream: the pack was not made by a plan of this geometry");
-    return fail(ctx, J2K_ERR_CAPACITY, "block coder: slot overflow");
+    // the MQ coder ran past the reference's own mqBuf size (j2k_block_bound): the Go code indexes out of range there
+    return fail(ctx, J2K_ERR_GO_PANIC, "block coder: the block needs more bytes than the reference's own buffer holds (t1_fast5.go:47-56: index out of range)");
 }
 
 extern "C" int j2k_ctx_sync(j2k_ctx *ctx) {
@@ -250,7 +251,11 @@ extern "C" size_t j2k_block_bound(int coder, int w, int h) {
         size_t maxSize = std::max<size_t>(n * 2, 64);
         return maxSize / 2 + maxSize / 4 + maxSize / 2 + 2;
     }
-    return n * 2 + 1024;                       // t1_fast5.go:47 (the reference's own bound)
+    // t1_fast5.go:47-56: mqBuf has width*height*2 + 1024 bytes but never fewer than 16384 (a fresh T1; a pooled one may have
+    // more left over from a larger block, which is history, not geometry).  A block that needs more than this is an index
+    // panic in the reference; one that fits must be coded: the 16384 floor matters for deep 64x64 blocks (16-bit noise
+    // after five lifting levels is ~9.3 KB against 2wh + 1024 = 9216; found by tools/fuzz_gpu.py).
+    return std::max<size_t>(n * 2 + 1024, 16384);
 }
 
 template <typename T>

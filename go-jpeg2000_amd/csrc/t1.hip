@@ -179,6 +179,9 @@ size_t t1_work_bytes(int w, int h) {
     return flags + (size_t)w * h * 4;
 }
 
+// bytes of the reference's mqBuf for a block of n samples (t1_fast5.go:47-56: 2n + 1024, never fewer than 16384) = the slot
+// size j2k_block_bound gives the block; running past it is the Go index panic
+__host__ __device__ inline size_t t1_mqbuf_bytes(size_t n) { return n * 2 + 1024 < 16384 ? (size_t)16384 : n * 2 + 1024; }
 #define T1_LDS_LIMIT (60 * 1024)
 
 // LDSW: the flag / magnitude workspace is in LDS (every block fits) or in `work`; a template parameter so that the
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(64) void t1_encode_kernel(const BlockJob *__restric
     if (lane != 0) return;
     const int numBPS = 32 - __clz((uint32_t)maxVal);
     uint8_t *out = slots + J.out_off;
-    MqEnc e{0x8000, 0, 12, 0, 0, out, (long)(n * 2 + 1024), 0};
+    MqEnc e{0x8000, 0, 12, 0, 0, out, (long)t1_mqbuf_bytes(n), 0};
 
     for (int bp = numBPS - 1; bp >= 0; bp--) {
         const int32_t bit = (int32_t)(1u << bp);
@@ -507,7 +510,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
     const uint64_t lt = (1ull << lane) - 1;         // columns before this lane's column
     uint64_t S = 0, REF = 0;
     uint8_t *out = slots + J.out_off;
-    MqEnc e{0x8000, 0, 12, 0, 0, out, (long)(n * 2 + 1024), 0};
+    MqEnc e{0x8000, 0, 12, 0, 0, out, (long)t1_mqbuf_bytes(n), 0};
     const int x = lane;
     uint32_t nsym = 0;
 #define T1F_DRAIN()                                           \
@@ -733,7 +736,7 @@ __global__ __launch_bounds__(64) void t1_mq_lanes_kernel(const BlockJob *__restr
     const BlockJob J = jobs[live ? jid : 0];
     const uint8_t *src = gsym + (size_t)(live ? jid : 0) * sym_stride;
     uint8_t *const out = slots + J.out_off;
-    const uint32_t cap = (uint32_t)J.w * J.h * 2 + 1024;
+    const uint32_t cap = (uint32_t)t1_mqbuf_bytes((size_t)J.w * J.h);
     uint32_t A = 0x8000, C = 0, CT = 12;
     uint32_t curb = 0, bp = 0, ovf = 0;            // pending byte buf[bp]; byte k >= 1 goes to out[k - 1] (t1_fast.go:11-34)
     // One byte leaves C (mqc.go:270-299 as t1_fast.go restates it), select-only: the pending byte takes the carry unless it

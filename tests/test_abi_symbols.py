@@ -58,3 +58,14 @@ def test_fails_loudly_without_gpu(lib):
     from j2kgfx import Context, J2KError
     with pytest.raises(J2KError):
         Context(0)
+
+
+def test_block_bound_is_the_references_buffer_size():
+    """host-only: j2k_block_bound = the reference's own output buffer of a block -- T1: max(16384, 2wh + 1024)
+    (t1_fast5.go:47-56), HT: MagSgn + MEL + VLC buffers + SCUP (ht.go:969-996)"""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "go-jpeg2000_amd"))
+    from j2kgfx import entropy
+    assert entropy.block_bound(0, 64, 64) == 16384 and entropy.block_bound(0, 16, 16) == 16384
+    assert entropy.block_bound(0, 128, 128) == 2 * 128 * 128 + 1024 and entropy.block_bound(0, 256, 256) == 2 * 65536 + 1024
+    assert entropy.block_bound(1, 64, 64) == 4096 + 2048 + 4096 + 2 and entropy.block_bound(1, 4, 4) == 32 + 16 + 32 + 2

@@ -478,3 +478,45 @@ def test_stage_calls_with_temporaries():
         plan.ctx.sync()
         assert torch.equal(got, want)
         del junk
+
+
+def _frame_vs_oracle(oracle, frame, nres, cb, coder, prec):
+    import torch
+    from j2kgfx.codec import FramePlan
+    Cn, H, W = frame.shape
+    want = oracle.preprocess([frame[c] for c in range(Cn)], W, H, prec, True, nres)
+    wb, wl, wn = oracle.encode_tile_blocks(want, W, H, nres, cb, cb, coder)
+    plan = FramePlan(W, H, Cn, precision=prec, lossless=True, num_resolutions=nres, cb=(cb, cb), coder=coder)
+    coeff = plan.forward(torch.from_numpy(frame).to(plan.device))
+    stream, offs, lens, nb = plan.encode_stream(coeff)
+    decoded = plan.decode_blocks(stream, offs, lens, nb)
+    plan.ctx.sync()
+    n = int(plan.info.blocks)
+    assert np.array_equal(lens.cpu().numpy()[:n].astype(np.uint32), wl)
+    assert bytes(stream.cpu().numpy()[:int(offs[n].item())]) == bytes(wb)
+    blocks = plan.blocks(); doffs = plan.decoded_offsets(); dh = decoded.cpu().numpy()
+    pos = 0
+    for j in range(n):
+        w_, h_, band = int(blocks[j]["w"]), int(blocks[j]["h"]), int(blocks[j]["band"])
+        chunk = wb[pos:pos + int(wl[j])]; pos += int(wl[j])
+        ref = oracle.ht_decode(chunk, w_, h_) if coder == 1 else oracle.t1_decode(chunk, int(wn[j]), band, w_, h_)
+        assert np.array_equal(dh[int(doffs[j]):int(doffs[j]) + w_ * h_].reshape(h_, w_), ref), j
+
+
+def test_fuzz_regression_walk_with_mixed_block_sizes(oracle):
+    """tools/fuzz_gpu.py, seed 1: a 40 x 33 frame with 16 x 16 code-blocks has blocks of many sizes in one walking wavefront,
+    some of which leave early (all-zero blocks); the wavefront's trip count was reduced over a wave with holes and cut the
+    walk of a 16 x 16 block short (its last two coded rows came out zero)"""
+    import os
+    frame = np.load(os.path.join(os.path.dirname(__file__), "golden", "fuzz_walk_mixed_blocks.npy"))
+    _frame_vs_oracle(oracle, frame, 6, 16, 1, 8)
+
+
+def test_fuzz_regression_deep_mq_blocks_fit_the_references_buffer(oracle):
+    """tools/fuzz_gpu.py, seed 1: 16-bit noise after five lifting levels makes 64 x 64 MQ blocks of ~9.3 KB -- more than
+    2wh + 1024 = 9216 but inside the 16384-byte floor of the reference's mqBuf (t1_fast5.go:47-56): they must be coded"""
+    rng = np.random.default_rng(5)
+    frame = rng.integers(0, 65536, (3, 128, 264)).astype(np.int32)
+    _frame_vs_oracle(oracle, frame, 1, 64, 0, 16)
+    from j2kgfx import entropy
+    assert entropy.block_bound(0, 64, 64) == 16384 and entropy.block_bound(0, 128, 128) == 2 * 128 * 128 + 1024
