@@ -67,6 +67,12 @@ while time.time() - t0 < budget:
             row = planes[tl * Cn + c]
             got = hco[int(row[6]):int(row[6]) + w * h].reshape(h, w)
             assert np.array_equal(got, want_c[c]), ("coefficients", desc, tl, c)
+        if not lossless:            # decode side of the lossy path: tcd ApplyInverseDWT rounding, InverseICT rounding, DC shift
+            levels = nres - 1 if nres - 1 > 0 else 5
+            inv = orc.postprocess([orc.tcd_inverse_dwt(want_c[c], w, h, levels, 0) for c in range(Cn)], prec, False)
+            hb = back.cpu().numpy().reshape(Cn, H, W)
+            for c in range(Cn):
+                assert np.array_equal(hb[c, y0:y0 + h, x0:x0 + w], inv[c]), ("lossy inverse", desc, tl, c)
         try:
             wants.append(orc.encode_tile_blocks(want_c, w, h, nres, cb, cb, coder))
         except ValueError:
