@@ -121,6 +121,7 @@ extern "C" int j2k_ctx_create(int device, j2k_ctx **out) {
     if (const char *e = getenv("J2K_PLANE_WG")) { int v = atoi(e); if (v == 0 || v == 4 || v == 8) ctx->plane_wg = v; }
     if (const char *e = getenv("J2K_L0_FUSE")) { int v = atoi(e); if (v == 0 || v == 8 || v == 10 || v == 16) ctx->l0_fuse = v; }
     if (const char *e = getenv("J2K_L0_WG")) { int v = atoi(e); if (v == 0 || v == 4 || v == 8) ctx->l0_wg = v; }
+    if (const char *e = getenv("J2K_L0_WG97_INV")) { int v = atoi(e); if (v == 0 || v == 6 || v == 8 || v == 10 || v == 12) ctx->l0_wg97_inv = v; }
     if (const char *e = getenv("J2K_L0_WG97")) { int v = atoi(e); if (v == 0 || (v >= 6 && v <= 16 && v % 2 == 0)) ctx->l0_wg97 = v; }
     if (const char *e = getenv("J2K_L0_XCD")) ctx->l0_xcd = atoi(e) != 0;
     if (const char *e = getenv("J2K_HT_ALIAS")) ctx->ht_alias = atoi(e) != 0;
@@ -355,6 +356,27 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
         }
     }
 
+    // XCD-aware order for per-workgroup job tables: workgroup b runs on XCD b % 8, in table order.  Each XCD gets a contiguous
+    // chunk of the FULL bands (neighbouring bands share halo rows: L2 hits) followed by a chunk of the SHORT ones (the last
+    // band of a plane, fewer live waves): a frame whose full bands fill the device a whole number of times then ends with
+    // the short workgroups instead of one more round of full ones (4K, 512-tiles, 5-row bands: 2040 full + 40 short workgroups
+    // on 512 slots).  `is_short(job)`.
+    auto deal_xcd = [](std::vector<DwtJob> &wj, auto is_short) {
+        std::vector<DwtJob> full, shrt;
+        for (const DwtJob &j : wj) (is_short(j) ? shrt : full).push_back(j);
+        std::vector<std::vector<DwtJob>> per(8);
+        for (std::vector<DwtJob> *v : {&full, &shrt}) {
+            const size_t chunk = (v->size() + 7) / 8;
+            for (size_t i = 0; i < v->size(); i++) per[i / std::max<size_t>(chunk, 1)].push_back((*v)[i]);
+        }
+        size_t m = 0;
+        for (auto &v : per) m = std::max(m, v.size());
+        std::vector<DwtJob> perm(m * 8, DwtJob{-1, 0, 0, 0});
+        for (int x = 0; x < 8; x++)
+            for (size_t i = 0; i < per[x].size(); i++) perm[i * 8 + x] = per[x][i];
+        wj.swap(perm);
+    };
+
     // ---- per-level launch tables --------------------------------------------------
     for (int cls = 0; cls < 2; cls++) { P->fwd[cls].resize(L); P->inv[cls].resize(L); }
     for (int dir = 0; dir < 2; dir++) {
@@ -577,18 +599,34 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                         for (size_t i = 0; i < planes.size(); i++)
                             for (int pr = 0; pr < (ph[i] + 1) / 2; pr += nr)
                                 for (int k = 0; k < 3; k++) wj.push_back(DwtJob{(int)i, k, pr, nr});
-                        if (ctx->l0_xcd && wj.size() >= 64) {
-                            const size_t chunk = (wj.size() + 7) / 8;
-                            std::vector<DwtJob> perm(chunk * 8, DwtJob{-1, 0, 0, 0});
-                            for (size_t b = 0; b < perm.size(); b++) {
-                                const size_t j = (b % 8) * chunk + b / 8;
-                                if (j < wj.size()) perm[b] = wj[j];
-                            }
-                            wj.swap(perm);
-                        }
+                        if (ctx->l0_xcd && wj.size() >= 64)
+                            deal_xcd(wj, [&](const DwtJob &j) { return j.prow0 + nr > (ph[j.plane] + 1) / 2; });
                         P->fwd97_wg_njobs = (int)wj.size();
                         P->fwd97_wg_waves = ctx->l0_wg97;
                         r = upload(ctx, &P->d_fwd97_wg_jobs, wj);
+                        if (r != J2K_OK) { j2k_plan_destroy(P); return r; }
+                    }
+                }
+                if (dir == 1 && l == 0 && cls == 1 && S.wavelet == W97 && S.mct && !S.frame_is_f64 && S.quant != Q_NONE && ctx->l0_wg97_inv > 0) {
+                    // workgroup form of the lossy inverse level 0 (dwt97_l0wg_inv.inc): one job per (plane, band of NW - 3
+                    // pair-rows), all three components in the workgroup; dealt XCD-aware like the forward table
+                    bool ok97 = (S.W % 4) == 0;
+                    for (size_t i = 0; i < planes.size() && ok97; i++) {
+                        const DwtPlane &D = planes[i];
+                        if (pw[i] < 16 || pw[i] > 512 || (pw[i] % 8) || ph[i] < 2) ok97 = false;
+                        for (int k = 0; k < 3; k++)
+                            if ((D.src_off[k] % 4) || (D.out_off[k] % 4) || (D.nxt_off[k] % 4)) ok97 = false;
+                    }
+                    if (ok97) {
+                        std::vector<DwtJob> wj;
+                        const int nr = ctx->l0_wg97_inv - 3;
+                        for (size_t i = 0; i < planes.size(); i++)
+                            for (int pr = 0; pr < (ph[i] + 1) / 2; pr += nr) wj.push_back(DwtJob{(int)i, 0, pr, nr});
+                        if (ctx->l0_xcd && wj.size() >= 64)
+                            deal_xcd(wj, [&](const DwtJob &j) { return j.prow0 + nr > (ph[j.plane] + 1) / 2; });
+                        P->inv97_wg_njobs = (int)wj.size();
+                        P->inv97_wg_waves = ctx->l0_wg97_inv;
+                        r = upload(ctx, &P->d_inv97_wg_jobs, wj);
                         if (r != J2K_OK) { j2k_plan_destroy(P); return r; }
                     }
                 }
@@ -702,7 +740,7 @@ extern "C" void j2k_plan_destroy(j2k_plan *P) {
         for (auto &T : P->fwd[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); if (T.d_pjobs) (void)hipFree(T.d_pjobs); }
         for (auto &T : P->inv[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); if (T.d_pjobs) (void)hipFree(T.d_pjobs); }
     }
-    void *ptrs[] = {P->d_tile_job0, P->d_scrA, P->d_scrB, P->d_tail, P->d_bjobs, P->d_djobs, P->d_frame, P->d_coeff, P->d_slots, P->d_stream, P->d_lens, P->d_numbps, P->d_offs, P->d_status, P->d_fwd_pix_jobs, P->d_fwd_wg2_jobs, P->d_fwd_wg_rest_jobs, P->d_fwd_wg_jobs, P->d_fwd97_wg_jobs, P->d_ht_ujobs, P->d_ht_alias_next, P->d_bjobs_alias, P->d_maglens, P->d_mels, P->d_toffs};
+    void *ptrs[] = {P->d_tile_job0, P->d_scrA, P->d_scrB, P->d_tail, P->d_bjobs, P->d_djobs, P->d_frame, P->d_coeff, P->d_slots, P->d_stream, P->d_lens, P->d_numbps, P->d_offs, P->d_status, P->d_fwd_pix_jobs, P->d_fwd_wg2_jobs, P->d_fwd_wg_rest_jobs, P->d_fwd_wg_jobs, P->d_fwd97_wg_jobs, P->d_inv97_wg_jobs, P->d_ht_ujobs, P->d_ht_alias_next, P->d_bjobs_alias, P->d_maglens, P->d_mels, P->d_toffs};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete P;
 }
@@ -866,7 +904,11 @@ static int plan_inverse_impl(j2k_plan *P, const void *d_coeff, void *d_frame, in
             } else {
                 // dst_mode: 0 = f64 scratch (l>0), 1 = f64 frame (unit calls), 2 = int32 frame via int32(v+0.5) (tcd.go:433-435)
                 const int dst_mode = (l > 0) ? 0 : (S.frame_is_f64 ? 1 : 2);
-                HIPCHK(ctx, launch_dwt97_inv(ctx->stream, mk(T), d_coeff, S.quant == Q_NONE ? 1 : 0, (const double *)prev, dst,
+                LevelLaunch L97 = mk(T);
+                if (l == 0 && cls == 1 && dst_mode == 2 && P->d_inv97_wg_jobs) {   // the workgroup form when every plane qualifies
+                    L97.jobs = P->d_inv97_wg_jobs; L97.njobs = P->inv97_wg_njobs; L97.wg_waves = P->inv97_wg_waves;
+                }
+                HIPCHK(ctx, launch_dwt97_inv(ctx->stream, L97, d_coeff, S.quant == Q_NONE ? 1 : 0, (const double *)prev, dst,
                                              l == 0 ? S.dc_shift_inv : 0, l == 0, dst_mode, (cls == 1) ? 1 : 0));
             }
         }

@@ -19,6 +19,7 @@ struct j2k_ctx {
     int l0_fuse = 0;           // forward levels 0 + 1 of RGBA8 frames in one launch: waves per workgroup of the fused bands (J2K_L0_FUSE: 0 off, 8, 16)
     int l0_wg = 4;             // packed RGBA8 level-0 forward, workgroup form: wavefronts per workgroup (J2K_L0_WG: 0 off, 4, 8)
     int l0_wg97 = 8;           // lossy level-0 forward of an RGB triple, workgroup form: waves per workgroup (J2K_L0_WG97: 0 off, 6..16 even; measured 4K: 8 -> 78 us, 16 -> 88 us, general kernel 160 us)
+    int l0_wg97_inv = 8;       // lossy level-0 inverse of an RGB triple, workgroup form: waves per workgroup (J2K_L0_WG97_INV: 0 off, 6 8 10 12)
     bool l0_xcd = true;        // XCD-aware order of the workgroup jobs (J2K_L0_XCD=0: plane-major order)
     bool ht_alias = true;      // j2k_plan_encode_stream (HT): code each distinct block window once (J2K_HT_ALIAS=0: every job)
     int l0_inv_wpe = 5;        // its occupancy variant (J2K_L0_INV_WPE: 5 = all in registers, 26.4 us; 6 = odd row parked in LDS for 6 waves per SIMD, measured slower: 33.6 us)
@@ -137,6 +138,8 @@ struct j2k_plan {
     int ht_nunique = 0;
     j2k::DwtJob *d_fwd97_wg_jobs = nullptr; // 9-7: one job per workgroup = (plane, component, band) of dwt97_fwd_rgb_wg_kernel
     int fwd97_wg_njobs = 0, fwd97_wg_waves = 0;
+    j2k::DwtJob *d_inv97_wg_jobs = nullptr; // 9-7 inverse: one job per workgroup = (plane, band) of dwt97_inv_rgb_wg_kernel
+    int inv97_wg_njobs = 0, inv97_wg_waves = 0;
     j2k::DwtJob *d_fwd_wg2_jobs = nullptr, *d_fwd_wg_rest_jobs = nullptr;   // fused levels 0+1: top-half bands / the remaining bands
     int fwd_wg2_njobs = 0, fwd_wg2_waves = 0, fwd_wg_rest_njobs = 0;
     j2k::DwtJob *d_fwd_wg_jobs = nullptr;   // the same as one job per WORKGROUP (dwt53_fwd_rgba8_wg_kernel), when every plane qualifies

@@ -70,3 +70,29 @@ def test_lossy_level0_knobs(wg):
         ctx.sync()
         res.append(coeff.cpu())
     assert torch.equal(res[0], res[1])
+
+
+@pytest.mark.parametrize("W,H,tile,nres", [(1024, 600, (512, 512), 6), (512, 77, (0, 0), 3), (64, 3, (0, 0), 2), (16, 2, (0, 0), 2),
+                                           (520, 131, (256, 128), 4), (128, 64, (0, 0), 1), (256, 2048, (0, 0), 6)])
+@pytest.mark.parametrize("wg", [6, 8, 12])
+@pytest.mark.parametrize("span", [12, 31])
+def test_lossy_inverse_level0_knobs(W, H, tile, nres, wg, span):
+    """lossy RGB inverse on ARBITRARY int32 coefficients: the general 9-7 kernel (J2K_L0_WG97_INV=0) and the workgroup form
+    (any waves per workgroup) give the same frame -- odd heights, bands that end inside the halo, one level (no float64
+    prefix) and, with span 31, values whose int32(v + 0.5) takes Go's out-of-range conversion (the wave-level redo)"""
+    import torch
+    from j2kgfx.codec import FramePlan
+    rng = np.random.default_rng(W * H + wg + span)
+    kw = dict(precision=12, lossless=False, quality=75, num_resolutions=nres, cb=(64, 64), tile=tile, coder=0)
+    res = []
+    for ctx in (_ctx({"J2K_L0_WG97_INV": 0}), _ctx({"J2K_L0_WG97_INV": wg})):
+        plan = FramePlan(W, H, 3, ctx=ctx, **kw)
+        if not res:
+            n = plan.alloc_coeff().numel()
+            lo, hi = -(1 << span), (1 << span)
+            coef_h = rng.integers(lo, hi, size=n).astype(np.int32)
+            if span == 31: coef_h[rng.random(n) < 0.7] >>= 20          # most windows in range, some not
+        back = plan.inverse(torch.from_numpy(coef_h).to(plan.device))
+        ctx.sync()
+        res.append(back.cpu())
+    assert torch.equal(res[0], res[1])
