@@ -1301,9 +1301,12 @@ hipError_t launch_t1_encode(hipStream_t s, const BlockJob *jobs, int njobs, cons
             if (planes > 31) planes = 31;
             hipLaunchKernelGGL(t1_encode64_kernel<true>, dim3(njobs), dim3(64), 0, s, jobs, njobs, coef, slots, lens, numbps, fault,
                                sym, sym_stride, nsyms, planes, (const uint32_t *)nullptr);
-            // blocks per wavefront: the kernel runs at the latency of one chain while there are no more than about two
-            // wavefronts per SIMD (1024 SIMDs); measured on a 4K 12-bit frame (7005 blocks): K = 4 is the optimum
-            int K = lanes > 0 ? lanes : (njobs + 2047) / 2048;
+            // blocks per wavefront: the kernel runs at the latency of one chain whatever K is, so K decides how much of the
+            // device a frame's chains occupy while they run.  Measured on a 4K 12-bit frame (7005 blocks): one frame alone
+            // 15.8 ms at K = 4, 18.0 at K = 32 (each wavefront waits for its slowest lane); three or more frames in flight
+            // 34.8 ms per frame at K = 4, 28.3 at K = 32 -- the chains of one frame then run beside the other frames' decode
+            // kernels, which are issue-bound.  Default: throughput (njobs / 256, at most 32); J2K_T1_LANES overrides.
+            int K = lanes > 0 ? lanes : std::min(32, (njobs + 255) / 256);
             K = std::min(64, std::max(1, K));
             hipLaunchKernelGGL(t1_mq_lanes_kernel, dim3((njobs + K - 1) / K), dim3(64), 0, s, jobs, njobs, K, sym, sym_stride, nsyms,
                                slots, lens, fault);
