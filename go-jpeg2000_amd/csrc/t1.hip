@@ -1126,9 +1126,10 @@ struct T1Dec64Shared {
 static_assert(sizeof(T1Dec64Shared) <= 5632, "t1_decode64_kernel: LDS per block above 11 granules");
 __global__ __launch_bounds__(64) void t1_decode64_kernel(const BlockJob *__restrict__ jobs, int njobs, const uint8_t *__restrict__ stream,
                                                          const uint64_t *__restrict__ offs, const uint32_t *__restrict__ lens,
-                                                         const uint8_t *__restrict__ numbps, int32_t *__restrict__ decoded) {
+                                                         const uint8_t *__restrict__ numbps, int32_t *__restrict__ decoded, int min_bps) {
     __shared__ T1Dec64Shared S;
     if ((int)blockIdx.x >= njobs) return;
+    if ((int)numbps[blockIdx.x] < min_bps) return;                   // the plane-stepped path took this block
     const int lane = threadIdx.x;
     // The block index as a VECTOR value the compiler cannot prove uniform: everything derived from it (block size, loop
     // counters, flag addresses) then lives in VGPRs and runs on the SIMD's own ALU.  As uniform values they go to the
@@ -1165,6 +1166,252 @@ __global__ __launch_bounds__(64) void t1_decode64_kernel(const BlockJob *__restr
         if (!(S.flags[(i / w + 1) * stride + T1D_XO + (i % w)] & T1SignNeg)) continue;
         const int v = __hip_atomic_load(&out[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // L2, not this CU's L1
         out[i] = (int32_t)(0u - (uint32_t)v);
+    }
+}
+
+// ---- plane-stepped decoder for blocks up to 64x64 -----------------------------------------------------------------
+// A frame at 12 bits and Quality 75 has 18 bit planes per block and ~78 % of its MQ decisions are magnitude refinements
+// (every sample that is already significant takes one per plane).  MagRef's contexts (Mag0 / Mag1 / Mag2) depend only on
+// flags the pass does not change for other samples, so the pass is a LIST of contexts known before its first decision --
+// a pure MQ chain, like the encoder's -- and chains of different blocks can share instructions, one block per LANE.
+// The decoder therefore runs as a sequence of launches, launch k working on every block's k-th plane from ITS OWN top,
+// p = numBPS - 1 - k (so the planes in which a block's samples turn significant -- its first three, where nearly all of
+// the ZC and sign decisions are -- coincide for all blocks and those launches fill the device):
+//   t1_dec_step_kernel(k)          one block per wavefront, its LDS image (flags, context entries, tables) reloaded from
+//                                  the workspace: apply the MagRef decisions of plane p + 1, Cleanup(p + 1), SigProp(p),
+//                                  write MagRef(p)'s context list (one code per member, coding order), save the image;
+//   t1_dec_magref_lanes_kernel(k)  lane l of wavefront g runs the MQ decoder of block 64 g + l over its list, all lanes in
+//                                  lock step (select-only step, no divergent branch), and leaves one bit per decision.
+// The MagRef chains -- 64 per wavefront, a hundred wavefronts per 4K frame -- cost a per-mille of the device's issue slots and
+// run at the latency of one chain, beside the step kernels of other frames in flight; what stays issue-bound is SigProp and
+// Cleanup (t1_decode64_kernel's wave-level passes, unchanged).  The launch sequence is fixed (32 + 31 launches: the host does
+// not know the blocks' bit-plane counts); a block is finished after launch k = numBPS, later launches find nothing to do.  Blocks with more than 31 planes (bit 0 for p >= 32, t1.go:1291) and blocks larger than
+// 64x64 keep the one-launch kernels.
+struct T1DecState { uint32_t C, A, CT, nmr; long long bp, len; };
+#define T1DS_IMG ((sizeof(T1Dec64Shared) + 15) & ~size_t(15))
+#define T1DS_STATE T1DS_IMG
+#define T1DS_BITS (T1DS_STATE + 32)
+#define T1DS_LIST (T1DS_BITS + 512)
+#define T1DS_STRIDE (T1DS_LIST + 4096)
+#define T1DS_MAXP 31
+size_t t1_dec_split_bytes(size_t njobs) { return njobs * T1DS_STRIDE + 256; }
+
+__global__ __launch_bounds__(64) void t1_dec_step_kernel(const BlockJob *__restrict__ jobs, int njobs, const uint8_t *__restrict__ stream,
+                                                         const uint64_t *__restrict__ offs, const uint32_t *__restrict__ lens,
+                                                         const uint8_t *__restrict__ numbps, int32_t *__restrict__ decoded,
+                                                         uint8_t *__restrict__ ws, int k) {
+    __shared__ T1Dec64Shared S;
+    if ((int)blockIdx.x >= njobs) return;
+    const int nb = (int)numbps[blockIdx.x];
+    const int p = nb - 1 - k;                                        // this launch: SigProp of the block's k-th plane from ITS top
+    const bool first = k == 0;
+    if (nb > T1DS_MAXP || p < -1) return;                            // deep blocks: t1_decode64_kernel; block finished at k = nb
+    const int lane = threadIdx.x;
+    int vzero;                                                       // see t1_decode64_kernel
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+    const int jid = (int)blockIdx.x + vzero;
+    const BlockJob J = jobs[jid];
+    const int w = J.w, h = J.h, stride = T1D_STRIDE(w);
+    if (w > 64 || h > 64) return;                                    // the general kernel takes these
+    const int n = w * h;
+    int32_t *out = decoded + J.out_off;
+    uint8_t *const rec = ws + (size_t)blockIdx.x * T1DS_STRIDE;
+    T1DecState *const st = reinterpret_cast<T1DecState *>(rec + T1DS_STATE);
+    T1DecLane L;                                                     // L.d is lane 0's decoder
+    if (first) {
+        {
+            T1Tables &T = *reinterpret_cast<T1Tables *>(S.flags);
+            build_tables(T, J.band, lane);
+            __syncthreads();
+            for (int q = lane; q < 256; q += 64) { S.zc[q] = T.zc[q]; S.sc[q] = T.sc[q]; }
+            for (int q = lane; q < 94; q += 64) S.mq[q] = T.mq[q];
+            if (lane < 20) S.ent[lane] = lane < NumContexts ? T.mq[lane == CtxUni ? 92 : 0] : 0u;
+            __syncthreads();
+        }
+        for (int i = lane; i < (stride * (h + 2) + 4 + 3) / 4; i += 64) reinterpret_cast<uint32_t *>(S.flags)[i] = 0;
+        for (int i = lane; i < n; i += 64) out[i] = 0;
+        if (lane == 0) mq_dec_init(L.d, stream + offs[jid], (long)lens[jid]);
+    } else {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(rec);
+        for (int i = lane; i < (int)(sizeof(T1Dec64Shared) / 4); i += 64) reinterpret_cast<uint32_t *>(&S)[i] = src[i];
+        if (lane == 0) {
+            const T1DecState t = *st;
+            L.d = MqDec{t.C, t.A, t.CT, (long)t.bp, (long)t.len, stream + offs[jid]};
+        }
+    }
+    __syncthreads();
+    L.ent = S.ent; L.mq = S.mq; L.zc = S.zc; L.sc = S.sc; L.flags = S.flags; L.data = out; L.w = w; L.h = h; L.stride = stride;
+    const uint64_t lt_lane = (1ull << lane) - 1;
+    if (!first && p + 1 < nb) {
+        // MagRef(p + 1), second half (t1.go:1331-1347): the same member ballots as when the list was written -- nothing
+        // touched the flags in between -- give every member its position in the list; its decision is that bit.
+        const int32_t bit = (int32_t)(1u << (p + 1));
+        const uint32_t *bits = reinterpret_cast<const uint32_t *>(rec + T1DS_BITS);
+        int off = 0;
+        for (int y = 0; y < h; y++) {
+            uint8_t *const f = S.flags + (size_t)(y + 1) * stride + T1D_XO + lane;
+            const uint32_t fv = lane < w ? *f : 0u;
+            const bool member = (fv & T1Sig) && !(fv & T1Visit);
+            const uint64_t mask = __ballot(member);
+            if (member) {
+                const int pos = off + __popcll(mask & lt_lane);
+                if ((bits[pos >> 5] >> (pos & 31)) & 1) atomicOr(&out[(size_t)y * w + lane], bit);
+                *f = (uint8_t)(fv | T1Refine);
+            }
+            off += __popcll(mask);
+        }
+        __syncthreads();
+        t1_dec_cleanup_wave(L, bit, S.mrctx, lane);
+    }
+    if (p < 0) {                                                     // t1.go:1281-1289
+        __syncthreads();                                             // includes the wait for the stores and atomics above
+        for (int i = lane; i < n; i += 64) {
+            if (!(S.flags[(i / w + 1) * stride + T1D_XO + (i % w)] & T1SignNeg)) continue;
+            const int v = __hip_atomic_load(&out[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // L2, not this CU's L1
+            out[i] = (int32_t)(0u - (uint32_t)v);
+        }
+        return;
+    }
+    int nmr = 0;
+    if (p < nb) {
+        t1_dec_sigprop_wave(L, (int32_t)(1u << p), S.mrctx, S.mrctx + 64, lane);
+        // MagRef(p), first half: members in coding order (rows, then columns) and their contexts
+        uint8_t *list = rec + T1DS_LIST;
+        for (int y = 0; y < h; y++) {
+            const uint32_t fv = lane < w ? S.flags[(size_t)(y + 1) * stride + T1D_XO + lane] : 0u;
+            const bool member = (fv & T1Sig) && !(fv & T1Visit);
+            const uint64_t mask = __ballot(member);
+            if (member) list[nmr + __popcll(mask & lt_lane)] = (uint8_t)((fv & T1Refine) ? 2 : ((fv & T1HasNb) ? 1 : 0));
+            nmr += __popcll(mask);
+        }
+    }
+    __syncthreads();
+    {
+        uint32_t *dst = reinterpret_cast<uint32_t *>(rec);
+        for (int i = lane; i < (int)(sizeof(T1Dec64Shared) / 4); i += 64) dst[i] = reinterpret_cast<const uint32_t *>(&S)[i];
+        if (lane == 0) *st = T1DecState{L.d.C, L.d.A, L.d.CT, (uint32_t)nmr, (long long)L.d.bp, (long long)L.d.len};
+    }
+}
+
+// The MagRef chains of 64 blocks in lock step (mqc.go:402-497 as a select-only step).  Per lane: A, C, CT, the three
+// context entries, the byte position; compressed bytes come through a per-lane ring in LDS (128 bytes, word-interleaved
+// over the lanes: no bank conflicts) that is topped up from global memory every 8 steps, 32 bytes at a time, the load
+// issued one period before its data is stored -- a step can consume at most three bytes (15 shifts).  Both bytes a
+// byte-in might need, and both successor entries of the context's state, are read at the top of the step, so no memory
+// latency sits on the A / C chain.  Lanes whose list has ended decode with Qe = 0, which changes nothing.
+__global__ __launch_bounds__(64) void t1_dec_magref_lanes_kernel(const BlockJob *__restrict__ jobs, int njobs, const uint8_t *__restrict__ stream,
+                                                                 const uint64_t *__restrict__ offs, const uint8_t *__restrict__ numbps,
+                                                                 uint8_t *__restrict__ ws, int k) {
+    __shared__ uint32_t mqtab[96];
+    __shared__ uint32_t ring[32 * 64];
+    const int lane = threadIdx.x;
+    const long jid = (long)blockIdx.x * 64 + lane;
+    for (int q = lane; q < 94; q += 64) {
+        const int i = q >> 1, m = q & 1;
+        const uint32_t nm = 2 * c_iso_nmps[i] + m;
+        const uint32_t nl = 2 * c_iso_nlps[i] + (c_iso_switch[i] ? 1 - m : m);
+        mqtab[q] = (uint32_t)c_iso_qe[i] | nm << 16 | nl << 24;
+    }
+    bool live = jid < njobs;
+    const BlockJob J = jobs[live ? jid : 0];
+    const int nb = live ? (int)numbps[jid] : 0;
+    live = live && J.w <= 64 && J.h <= 64 && nb <= T1DS_MAXP && nb - 1 - k >= 0;
+    uint8_t *const rec = ws + (size_t)(live ? jid : 0) * T1DS_STRIDE;
+    T1DecState *const stp = reinterpret_cast<T1DecState *>(rec + T1DS_STATE);
+    T1DecState st = *stp;
+    const uint32_t n = live ? st.nmr : 0u;
+    uint32_t nmax = n;
+    for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, o));
+    if (nmax == 0) return;
+    __syncthreads();
+    uint32_t *const ent = reinterpret_cast<uint32_t *>(rec + offsetof(T1Dec64Shared, ent));
+    uint32_t e0 = ent[CtxMag0], e1 = ent[CtxMag1], e2 = ent[CtxMag2];
+    uint32_t A = live ? st.A : 0x8000u, C = st.C, CT = st.CT;
+    // byte positions as absolute addresses: pos = the byte mq_byte_in looks at (data[bp], bp < 0 -> 0), end = data + len
+    const uintptr_t data = (uintptr_t)(stream + offs[live ? jid : 0]);
+    uintptr_t pos = data + (uintptr_t)(st.bp < 0 ? 0 : st.bp);
+    const uintptr_t end = data + (uintptr_t)st.len;
+    const bool bp_neg0 = st.bp < 0;                                   // len == 0: bp stays -1 until the first byte-in sets it to 0
+    // ring: bytes [rbase, filled) of the address space, word k of lane l at ring[(k & 31) * 64 + l]
+    uintptr_t filled = pos & ~uintptr_t(15);
+    auto ld16 = [&](uintptr_t a) -> uint4 {                           // a 16-byte piece that starts before `end` lies in a page of the stream
+        return (live && a < end) ? *reinterpret_cast<const uint4 *>(a) : make_uint4(0, 0, 0, 0);
+    };
+    auto st16 = [&](uintptr_t a, const uint4 v) {
+        const uint32_t k = (uint32_t)(a >> 2);
+        ring[((k + 0) & 31) * 64 + lane] = v.x; ring[((k + 1) & 31) * 64 + lane] = v.y;
+        ring[((k + 2) & 31) * 64 + lane] = v.z; ring[((k + 3) & 31) * 64 + lane] = v.w;
+    };
+    for (int q = 0; q < 4; q++) { st16(filled, ld16(filled)); filled += 16; }       // 64 bytes: at least 49 ahead of pos
+    uint4 pend0 = ld16(filled), pend1 = ld16(filled + 16);
+    const uint8_t *const rb = reinterpret_cast<const uint8_t *>(ring);
+    auto ring_byte_addr = [&](uintptr_t a) -> uint32_t { return (((uint32_t)(a >> 2) & 31u) * 64u + (uint32_t)lane) * 4u + ((uint32_t)a & 3u); };
+    const uint4 *const list = reinterpret_cast<const uint4 *>(rec + T1DS_LIST);
+    uint16_t *const obits = reinterpret_cast<uint16_t *>(rec + T1DS_BITS);
+    uint4 cur = list[0], nxt = list[nmax > 16 ? 1 : 0];
+    uint32_t bpneg = bp_neg0 ? 1u : 0u;
+    for (uint32_t i0 = 0; i0 < nmax; i0 += 16) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+            const uint32_t i = i0 + s;
+            if ((s & 7) == 0) {
+                // top up the ring: store the pieces loaded a period ago if there is room, then start the next load
+                const bool room = (filled - pos) <= 64;
+                if (room) { st16(filled, pend0); st16(filled + 16, pend1); filled += 32; }
+                pend0 = ld16(filled); pend1 = ld16(filled + 16);
+            }
+            const uint32_t wsel = (s >> 2) == 0 ? cur.x : (s >> 2) == 1 ? cur.y : (s >> 2) == 2 ? cur.z : cur.w;
+            const uint32_t code = (wsel >> ((s & 3) * 8)) & 3u;
+            const bool act = i < n;
+            const uint32_t e = code == 2 ? e2 : (code == 1 ? e1 : e0);
+            // speculative reads: successors of the state, the two bytes a byte-in would look at
+            const uint32_t e_nm = mqtab[(e >> 16) & 0xFF], e_nl = mqtab[e >> 24];
+            uint32_t b0 = rb[ring_byte_addr(pos)], b1 = rb[ring_byte_addr(pos + 1)];
+            const uint32_t qe = act ? (e & 0xFFFFu) : 0u;
+            const uint32_t mps = (e >> 16) & 1u;
+            A -= qe;
+            const bool lpsx = (C >> 16) < qe;
+            const bool a_lt = A < qe;
+            C = lpsx ? C : C - (qe << 16);
+            const bool need = lpsx || !(A & 0x8000u);
+            const bool flip = need && (lpsx != a_lt);
+            const uint32_t dec = mps ^ (flip ? 1u : 0u);
+            A = lpsx ? qe : A;
+            const uint32_t e_new = need ? (flip ? e_nl : e_nm) : e;
+            e0 = code == 0 ? e_new : e0;
+            e1 = code == 1 ? e_new : e1;
+            e2 = code == 2 ? e_new : e2;
+            acc |= dec << s;
+            // renormalise (mqc.go:488-497): nsh shifts; a byte-in whenever CT is 0 and a shift is still due
+            uint32_t nsh = need ? (uint32_t)__clz((int)A) - 16u : 0u;
+            for (;;) {
+                const bool bin = nsh > 0 && CT == 0;
+                {   // mq_byte_in (mqc.go:402-439), select-only
+                    const bool past = pos >= end;
+                    const uint32_t nextb = (pos + 1 < end) ? b1 : 0xFFu;
+                    const bool ff = b0 == 0xFF;
+                    const bool stay = past || (ff && nextb > 0x8F);          // C += 0xFF00, CT = 8, bp unchanged
+                    const uint32_t addC = stay ? 0xFF00u : (ff ? nextb << 9 : nextb << 8);
+                    const uint32_t newCT = stay ? 8u : (ff ? 7u : 8u);
+                    if (bin) { C += addC; CT = newCT; bpneg = 0; if (!stay) { pos++; b0 = b1; } }
+                }
+                const uint32_t k = min(nsh, CT);
+                A <<= k; C <<= k; CT -= k; nsh -= k;
+                if (!__any(nsh > 0)) break;
+                b1 = rb[ring_byte_addr(pos + 1)];                             // a second byte-in in the same step (rare)
+            }
+        }
+        if (live && i0 < n) obits[i0 >> 4] = (uint16_t)acc;
+        cur = nxt;
+        const uint32_t nx = (i0 >> 4) + 2;
+        nxt = list[nx < 256 ? nx : 255];
+    }
+    if (live) {
+        ent[CtxMag0] = e0; ent[CtxMag1] = e1; ent[CtxMag2] = e2;
+        st.A = A; st.C = C; st.CT = CT;
+        st.bp = bpneg ? -1 : (long long)(pos - data);
+        *stp = st;
     }
 }
 
@@ -1332,10 +1579,19 @@ hipError_t launch_t1_encode(hipStream_t s, const BlockJob *jobs, int njobs, cons
 // general_only: every block on the general kernel (A/B knob); otherwise blocks up to 64x64 take t1_decode64_kernel
 hipError_t launch_t1_decode(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs,
                             const uint32_t *lens, const uint8_t *numbps, int32_t *decoded, uint8_t *work, size_t work_per_job,
-                            int max_dim, int general_only) {
+                            int max_dim, int general_only, uint8_t *split_ws) {
     if (njobs <= 0) return hipSuccess;
     if (!general_only) {
-        hipLaunchKernelGGL(t1_decode64_kernel, dim3(njobs), dim3(64), 0, s, jobs, njobs, stream, offs, lens, numbps, decoded);
+        if (split_ws) {
+            // plane-stepped path for blocks of at most 31 planes; the one-launch kernel keeps the deeper ones
+            for (int k = 0; k <= T1DS_MAXP; k++) {
+                hipLaunchKernelGGL(t1_dec_step_kernel, dim3(njobs), dim3(64), 0, s, jobs, njobs, stream, offs, lens, numbps, decoded, split_ws, k);
+                if (k < T1DS_MAXP)
+                    hipLaunchKernelGGL(t1_dec_magref_lanes_kernel, dim3((njobs + 63) / 64), dim3(64), 0, s, jobs, njobs, stream, offs, numbps, split_ws, k);
+            }
+        }
+        hipLaunchKernelGGL(t1_decode64_kernel, dim3(njobs), dim3(64), 0, s, jobs, njobs, stream, offs, lens, numbps, decoded,
+                           split_ws ? T1DS_MAXP + 1 : 0);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess || max_dim <= 64) return e;
     }
