@@ -8,6 +8,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 HBM_PEAK_GBS = 8000.0
+# HBM bytes of one launch of the configuration's roofline kernel from the PMC counters (cannot be collected from inside this
+# process: the committed measurement, checked against its source by tests/test_bench_traffic_constant.py)
+TRAFFIC = {"c3": (226166476, "profiles/r02b_c3_pmc_summary.txt: (2 x 49682.8 + 121500.1) KiB")}
 SEED = 0x4A324B30              # "J2K0" 
 
 # coder: 0 = MQ (T1.EncodeFast5 / T1.Decode), 1 = HT.  io: frame format at the boundary.
@@ -262,8 +265,10 @@ def run_config(args, cfgname):
             else:
                 alg = W * H * C * (4 + 3 + 2)
             k_s = (iso_ms / max(iso_n, 1)) * 1e-3
+            # HBM bytes of that launch from the PMC counters: a committed measurement (bench.TRAFFIC), default kernel settings only
+            traffic, traffic_src = (TRAFFIC[cfgname] if cfgname in TRAFFIC and not os.environ.get("J2K_L0_WG97") else (None, None))
             ach = alg / k_s / 1e9 if iso_n else 0.0
-            kern = {"c3": "dwt97_fwd_kernel (level 0: DC shift + ICT + rounding + 9-7 lifting + quantisation, fused)",
+            kern = {"c3": "dwt97_fwd_rgb_wg_kernel<8,1,7> (level 0: DC shift + ICT + rounding + 9-7 lifting + quantisation, fused; VALU-bound in float64)",
                     "c5": "dwt53_fwd_plane_wg_kernel<4,1,true,8> (level 0: Gray16 unpack + DC shift + 5-3 lifting, fused; four 512-column strips)"}.get(cfgname, "level-0 forward kernel")
             out = {"metric": cfg["metric"], "value": round(world * F * W * H / (dt / args.steps) / 1e6, 1), "unit": "Mpixels/s", "n_gpus": world,
                    "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
@@ -276,7 +281,7 @@ def run_config(args, cfgname):
                               "achieved_compression_ratio": round(W * H * C * ((cfg["prec"] + 7) // 8) / max(total_bytes, 1), 2),
                               "frames_in_flight": F, "frame_io": cfg["io"], "parallelism": "frames/rank" if world > 1 else "single GPU"},
                    "roofline": {"bound": "hbm", "kernel": kern, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": alg,
+                                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg,
                                 "avg_launch_us": round(k_s * 1e6, 2), "launches_timed": int(iso_n),
                                 "avg_launch_us_in_timed_region": round(conc_ms / max(conc_n, 1) * 1e3, 2),
                                 "measured": "HIP start/stop events stamped by the level-0 dispatch itself on the library stream, one frame "

@@ -24,3 +24,20 @@ def test_traffic_constant_matches_committed_pmc_summary():
     assert abs(measured - nbytes) <= 0.001 * nbytes, (measured, nbytes)
     alg = 3840 * 2160 * 16                                  # one RGBA8 dword in, three int32 out per pixel
     assert 1.0 <= nbytes / alg < 1.03                       # halo re-reads are L2 hits: traffic ~= algorithmic bytes
+
+
+def test_c3_traffic_constant_matches_committed_pmc_summary():
+    import bench_extra
+    nbytes, src = bench_extra.TRAFFIC["c3"]
+    path = os.path.join(ROOT, src.split(":")[0])
+    assert os.path.exists(path), path
+    vals = {}
+    for ln in open(path):
+        m = re.match(r"\s*(\S.*?)\s+(FETCH_SIZE|WRITE_SIZE) n=\d+ avg=([0-9.]+)", ln)
+        if m and m.group(1).startswith("dwt97_fwd_rgb_wg_kernel"):
+            vals[m.group(2)] = float(m.group(3))
+    assert set(vals) == {"FETCH_SIZE", "WRITE_SIZE"}
+    measured = (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024
+    assert abs(measured - nbytes) <= 0.001 * nbytes, (measured, nbytes)
+    alg = 3840 * 2160 * 27                                  # 12 B in; 3/4 int32 + 1/4 float64 out per sample, three components
+    assert 1.0 <= nbytes / alg < 1.03

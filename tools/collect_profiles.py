@@ -22,3 +22,12 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         csv.writer(f).writerows(keep)
 open(os.path.join(P, tag + "_bench_inflight1_pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
 print(open(os.path.join(P, tag + "_bench_inflight1_pmc_summary.txt")).read())
+if glob.glob(os.path.join(O, "stats_c3bench/*/*kernel_stats.csv")):
+    shutil.copy(newest("stats_c3bench/*/*kernel_stats.csv"), os.path.join(P, tag + "_c3_bench_kernel_stats.csv"))
+    lines = ["# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), python bench.py --config c3 --steps 2 --warmup 1 --no-cpu-baseline --inflight 1;",
+             "# per-kernel average, KiB, transform kernels only (gfx950: double FETCH_SIZE for wide coalesced reads; WRITE_SIZE is exact)"]
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = subprocess.run([sys.executable, os.path.join(R, "tools", "pmc_sum.py"), os.path.join(O, "pmc_c3_" + c), "dwt97"], capture_output=True, text=True).stdout
+        lines += [l for l in out.splitlines() if l.strip()]
+    open(os.path.join(P, tag + "_c3_pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
+    print(open(os.path.join(P, tag + "_c3_pmc_summary.txt")).read())

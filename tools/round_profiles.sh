@@ -13,3 +13,10 @@ tail -1 $O/stats_default.log; tail -1 $O/stats_inflight1.log
 # C3-like frame (9-7, 12 bit, MQ coder): per-stage kernel stats of tools/bench_c3.py (T1 encoder / decoder kernels)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c3 -- python $R/tools/bench_c3.py 0 0 > $O/stats_c3.log 2>&1
 tail -7 $O/stats_c3.log
+# the same configuration through bench.py (`--config c3`): kernel stats of the bench command itself, and the HBM traffic of its
+# transform kernels with one frame in flight
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c3bench -- python $R/bench.py --config c3 --steps 3 --warmup 1 --no-cpu-baseline > $O/stats_c3bench.log 2>&1
+tail -1 $O/stats_c3bench.log | cut -c1-200
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_c3_$c -- python $R/bench.py --config c3 --steps 2 --warmup 1 --no-cpu-baseline --inflight 1 > $O/pmc_c3_$c.log 2>&1
+done
