@@ -3,6 +3,7 @@
 // context's HIP stream, host<->device staging for the one-call-per-reference-function
 // entry points.  All arithmetic lives in the .hip kernels; there is no CPU fallback.
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -97,6 +98,10 @@ extern "C" const char *j2k_ctx_last_error(j2k_ctx *ctx) { return ctx ? ctx->last
 // ------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------
+// contexts of this process that have built an MQ-coder plan: two or more = frames in flight, the MQ kernels then take their
+// throughput settings (t1.hip: blocks per wavefront of the encode chains, plane-stepped decoder), one = latency settings
+static std::atomic<int> g_mq_ctxs{0};
+static bool mq_throughput_mode() { return g_mq_ctxs.load(std::memory_order_relaxed) >= 2; }
 extern "C" int j2k_ctx_create(int device, j2k_ctx **out) {
     if (!out) return J2K_ERR_INVALID_ARG;
     *out = nullptr;
@@ -142,7 +147,7 @@ extern "C" int j2k_ctx_create(int device, j2k_ctx **out) {
     if (const char *e = getenv("J2K_T1_SPLIT")) ctx->t1_split = atoi(e) != 0;
     if (const char *e = getenv("J2K_T1_SYM_MB")) { long v = atol(e); if (v >= 0) ctx->t1_sym_mb = v; }
     if (const char *e = getenv("J2K_T1_DEC_GENERAL")) ctx->t1_dec_general = atoi(e) != 0;
-    if (const char *e = getenv("J2K_T1_DEC_SPLIT")) { int v = atoi(e); if (v >= 0) ctx->t1_dec_split = v; }
+    if (const char *e = getenv("J2K_T1_DEC_SPLIT")) { int v = atoi(e); if (v >= -1) ctx->t1_dec_split = v; }
     if (const char *e = getenv("J2K_T1_LANES")) { int v = atoi(e); if (v >= 0 && v <= 64) ctx->t1_lanes = v; }
     if (const char *e = getenv("J2K_CPL0")) { int v = atoi(e); if (v == 2 || v == 4 || v == 8) ctx->cpl0 = v; }
     *out = ctx;
@@ -151,6 +156,7 @@ extern "C" int j2k_ctx_create(int device, j2k_ctx **out) {
 
 extern "C" void j2k_ctx_destroy(j2k_ctx *ctx) {
     if (!ctx) return;
+    if (ctx->counted_mq) g_mq_ctxs.fetch_sub(1, std::memory_order_relaxed);
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (j2k_plan *p : ctx->cache) j2k_plan_destroy(p);
@@ -767,6 +773,7 @@ static int spec_from_params(j2k_ctx *ctx, const j2k_params *p, PlanSpec &S) {
     S.coder = p->coder;
     S.tile_first = p->tile_first; S.tile_count = p->tile_count;
     if (S.coder != J2K_CODER_MQ && S.coder != J2K_CODER_HT) return fail(ctx, J2K_ERR_INVALID_ARG, "coder");
+    if (S.coder == J2K_CODER_MQ && !ctx->counted_mq) { ctx->counted_mq = true; g_mq_ctxs.fetch_add(1, std::memory_order_relaxed); }
     return J2K_OK;
 }
 
@@ -1224,7 +1231,8 @@ extern "C" int j2k_plan_encode_blocks(j2k_plan *P, const int32_t *d_coeff, uint8
         if (r != J2K_OK) return r;
         uint8_t *ws = (uint8_t *)ctx->stage[2];
         HIPCHK(ctx, launch_t1_encode(ctx->stream, P->d_bjobs, n, d_coeff, d_slots, d_lens, d_numbps, ws, wpj, d_fault, max_dim,
-                                     W.stride ? ws + W.off_sym : nullptr, W.stride, (uint32_t *)(ws + W.off_nsyms), ctx->t1_lanes));
+                                     W.stride ? ws + W.off_sym : nullptr, W.stride, (uint32_t *)(ws + W.off_nsyms),
+                                     ctx->t1_lanes > 0 ? ctx->t1_lanes : (mq_throughput_mode() ? -1 : 0)));
     }
     return J2K_OK;
 }
@@ -1384,7 +1392,8 @@ extern "C" int j2k_plan_decode_blocks(j2k_plan *P, const uint8_t *d_stream, cons
         for (const j2k_block &b : P->blocks) { wpj = std::max(wpj, t1_flag_bytes(b.w, b.h)); max_dim = std::max(max_dim, std::max(b.w, b.h)); }
         wpj = (wpj + 255) & ~size_t(255);
         // plane-stepped path (t1.hip): frames of at least t1_dec_split blocks, 16-byte aligned stream (its 16-byte loads)
-        const bool split = ctx->t1_dec_split > 0 && n >= ctx->t1_dec_split && !ctx->t1_dec_general && !((uintptr_t)d_stream & 15);
+        const int split_min = ctx->t1_dec_split >= 0 ? ctx->t1_dec_split : (mq_throughput_mode() ? 512 : 0);
+        const bool split = split_min > 0 && n >= split_min && !ctx->t1_dec_general && !((uintptr_t)d_stream & 15);
         const size_t gen_bytes = (wpj * (size_t)n + 255) & ~size_t(255);
         int r = stage_reserve(ctx, 2, gen_bytes + 256 + (split ? j2k::t1_dec_split_bytes((size_t)n) : 0));
         if (r != J2K_OK) return r;
@@ -1629,7 +1638,7 @@ extern "C" int j2k_decode_blocks(j2k_ctx *ctx, int coder, const uint8_t *bytes, 
         TRY(hipMalloc(&d_work, ht_decode_scratch_words((int)nblocks) * 4 + 256));
         TRY(launch_ht_decode(ctx->stream, (BlockJob *)d_jobs, (int)nblocks, (uint8_t *)d_bytes, (uint64_t *)d_offs, (uint32_t *)d_lens, (int32_t *)d_dec, (uint32_t *)d_work));
     } else {
-        const bool split = ctx->t1_dec_split > 0 && (int)nblocks >= ctx->t1_dec_split && !ctx->t1_dec_general;
+        const bool split = ctx->t1_dec_split > 0 && (int)nblocks >= ctx->t1_dec_split && !ctx->t1_dec_general;     // host unit call: only when asked for
         const size_t gen_bytes = (wpj * nblocks + 255) & ~size_t(255);
         TRY(hipMalloc(&d_work, gen_bytes + 256 + (split ? j2k::t1_dec_split_bytes(nblocks) : 0)));
         int max_dim = 0;

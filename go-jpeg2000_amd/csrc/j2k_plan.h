@@ -37,9 +37,12 @@ struct j2k_ctx {
     int t1_split = 1;          // J2K_T1_SPLIT=0: T1 encoder as one kernel (contexts + MQ chain on lane 0) instead of two
     long t1_sym_mb = 8192;     // J2K_T1_SYM_MB: cap of the T1 symbol workspace; blocks with more bit planes than fit take the one-kernel path
     int t1_dec_general = 0;    // J2K_T1_DEC_GENERAL=1: every block on the general T1 decode kernel (A/B against t1_decode64_kernel)
-    int t1_dec_split = 512;    // J2K_T1_DEC_SPLIT: MQ decode of frames with at least this many blocks runs plane by plane with the MagRef chains
-                               // of 64 blocks per wavefront in lock step (t1.hip); 0: always the one-launch kernels
-    int t1_lanes = 0;          // J2K_T1_LANES: blocks per wavefront of the lane-parallel MQ kernel (0: njobs / 256, between 1 and 32)
+    int t1_dec_split = -1;     // J2K_T1_DEC_SPLIT: MQ decode of frames with at least this many blocks runs plane by plane with the MagRef chains
+                               // of 64 blocks per wavefront in lock step (t1.hip); 0: always the one-launch kernels; -1 (default): 512 while
+                               // at least two contexts of this process code with the MQ coder (frames in flight: throughput), else 0 (one
+                               // frame at a time: latency)
+    bool counted_mq = false;   // this context has built an MQ-coder plan (counted in g_mq_ctxs)
+    int t1_lanes = 0;          // J2K_T1_LANES: blocks per wavefront of the lane-parallel MQ kernel (0: blocks / 256, at most 32, while at least two contexts code with the MQ coder, else blocks / 2048)
     // cached single-plane plans for the host (unit) calls
     std::vector<j2k_plan *> cache;
     // host-call staging buffers (device)

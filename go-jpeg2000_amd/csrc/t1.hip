@@ -1552,8 +1552,9 @@ hipError_t launch_t1_encode(hipStream_t s, const BlockJob *jobs, int njobs, cons
             // device a frame's chains occupy while they run.  Measured on a 4K 12-bit frame (7005 blocks): one frame alone
             // 15.8 ms at K = 4, 18.0 at K = 32 (each wavefront waits for its slowest lane); three or more frames in flight
             // 34.8 ms per frame at K = 4, 28.3 at K = 32 -- the chains of one frame then run beside the other frames' decode
-            // kernels, which are issue-bound.  Default: throughput (njobs / 256, at most 32); J2K_T1_LANES overrides.
-            int K = lanes > 0 ? lanes : std::min(32, (njobs + 255) / 256);
+            // kernels, which are issue-bound.  lanes > 0: as given (J2K_T1_LANES); 0: latency (blocks / 2048); < 0: throughput
+            // (blocks / 256, at most 32) -- the caller passes < 0 while several contexts code with the MQ coder.
+            int K = lanes > 0 ? lanes : (lanes < 0 ? std::min(32, (njobs + 255) / 256) : (njobs + 2047) / 2048);
             K = std::min(64, std::max(1, K));
             hipLaunchKernelGGL(t1_mq_lanes_kernel, dim3((njobs + K - 1) / K), dim3(64), 0, s, jobs, njobs, K, sym, sym_stride, nsyms,
                                slots, lens, fault);
