@@ -494,8 +494,8 @@ static hipError_t fwd97_wg_go(hipStream_t s, const LevelLaunch &L, const void *s
                               int dc_shift, int quant, double step) {
     const int32_t *p = reinterpret_cast<const int32_t *>(src);
     const double rstep = 1.0 / step;          // RN(1 / step): the reciprocal of the Markstein division (dwt97_l0wg.inc)
-#define J2K_WG97(Q) hipExtLaunchKernelGGL((dwt97_fwd_rgb_wg_kernel<NW, Q, 7>), dim3(L.njobs), dim3(NW * 64), 0, s, L.ev_start, L.ev_stop, 0, \
-                                           L.jobs, L.njobs, L.planes, p, out_i32, out_f64, nxt, dc_shift, step, rstep)
+#define J2K_WG97(Q) hipExtLaunchKernelGGL((dwt97_fwd_rgb_wg_kernel<NW, Q, 7, 0>), dim3(L.njobs), dim3(NW * 64), 0, s, L.ev_start, L.ev_stop, 0, \
+                                           L.jobs, L.njobs, L.planes, p, (const double *)nullptr, out_i32, out_f64, nxt, dc_shift, step, rstep)
     if (quant == Q_ENCODER_) J2K_WG97(Q_ENCODER_);
     else if (quant == Q_TCD_) J2K_WG97(Q_TCD_);
     else J2K_WG97(Q_NONE_);
@@ -515,6 +515,16 @@ hipError_t launch_dwt97_fwd(hipStream_t s, const LevelLaunch &L, const void *src
         if (L.wg_waves == 14) return fwd97_wg_go<14>(s, L, src, out_i32, out_f64, nxt, dc_shift, quant, step);
         if (L.wg_waves == 16) return fwd97_wg_go<16>(s, L, src, out_i32, out_f64, nxt, dc_shift, quant, step);
         return hipErrorInvalidValue;
+    }
+    if (L.pwaves == 8 && L.pnjobs > 0 && L.ncomp == 1 && src_is_f64 && quant != Q_NONE_) {   // a deeper level, single planes, workgroup form
+        const double *pf = reinterpret_cast<const double *>(src);
+        const double rstep = 1.0 / step;
+#define J2K_PWG97(Q) hipExtLaunchKernelGGL((dwt97_fwd_rgb_wg_kernel<8, Q, 7, 1>), dim3(L.pnjobs), dim3(512), 0, s, L.ev_start, L.ev_stop, 0, \
+                                            L.pjobs, L.pnjobs, L.planes, (const int32_t *)nullptr, pf, out_i32, out_f64, nxt, dc_shift, step, rstep)
+        if (quant == Q_ENCODER_) J2K_PWG97(Q_ENCODER_);
+        else J2K_PWG97(Q_TCD_);
+#undef J2K_PWG97
+        return hipGetLastError();
     }
     const int blocks = (L.njobs + 3) / 4;
     if (L.ncomp == 3) {
@@ -542,6 +552,11 @@ hipError_t launch_dwt97_inv(hipStream_t s, const LevelLaunch &L, const void *coe
         else if (L.wg_waves == 12) J2K_WG97I(12);
         else return hipErrorInvalidValue;
 #undef J2K_WG97I
+        return hipGetLastError();
+    }
+    if (L.pwaves == 8 && L.pnjobs > 0 && L.ncomp == 1 && !coef_is_f64 && dst_mode == DST_F64_SCRATCH) {   // a deeper level, workgroup form
+        hipLaunchKernelGGL((dwt97_inv_plane_wg_kernel<8, 6>), dim3(L.pnjobs), dim3(512), 0, s, L.pjobs, L.pnjobs, L.planes,
+                           reinterpret_cast<const int32_t *>(coef), prev, reinterpret_cast<double *>(dst));
         return hipGetLastError();
     }
     const int blocks = (L.njobs + 3) / 4;

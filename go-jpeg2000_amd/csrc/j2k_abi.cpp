@@ -127,6 +127,7 @@ extern "C" int j2k_ctx_create(int device, j2k_ctx **out) {
     if (const char *e = getenv("J2K_PLANE_WG")) { int v = atoi(e); if (v == 0 || v == 4 || v == 8) ctx->plane_wg = v; }
     if (const char *e = getenv("J2K_L0_FUSE")) { int v = atoi(e); if (v == 0 || v == 8 || v == 10 || v == 16) ctx->l0_fuse = v; }
     if (const char *e = getenv("J2K_L0_WG")) { int v = atoi(e); if (v == 0 || v == 4 || v == 8) ctx->l0_wg = v; }
+    if (const char *e = getenv("J2K_PLANE_WG97")) { int v = atoi(e); if (v == 0 || v == 8) ctx->plane_wg97 = v; }
     if (const char *e = getenv("J2K_L0_WG97_INV")) { int v = atoi(e); if (v == 0 || v == 6 || v == 8 || v == 10 || v == 12) ctx->l0_wg97_inv = v; }
     if (const char *e = getenv("J2K_L0_WG97")) { int v = atoi(e); if (v == 0 || (v >= 6 && v <= 16 && v % 2 == 0)) ctx->l0_wg97 = v; }
     if (const char *e = getenv("J2K_L0_XCD")) ctx->l0_xcd = atoi(e) != 0;
@@ -523,6 +524,27 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                             pj.swap(perm);
                         }
                         T.pnjobs = (int)pj.size(); T.pwaves = ctx->plane_wg; T.pmulti = multi;
+                        r = upload(ctx, &T.d_pjobs, pj);
+                        if (r != J2K_OK) { j2k_plan_destroy(P); return r; }
+                    }
+                }
+                if (S.wavelet == W97 && cls == 0 && l >= 1 && ctx->plane_wg97 > 0 && S.quant != Q_NONE && !S.frame_is_f64) {
+                    // the deeper 9-7 levels in workgroup form (dwt97_l0wg.inc SRC = 1, dwt97_l0wg_inv.inc: single float64 planes,
+                    // int32 coefficients): one job per (plane, band of NW - 3 pair-rows)
+                    bool ok = true;
+                    for (size_t i = 0; i < planes.size() && ok; i++) {
+                        const DwtPlane &D = planes[i];
+                        if (pw[i] < 16 || pw[i] > 512 || (pw[i] % 8) || ph[i] < 2) ok = false;
+                        if ((D.src_off[0] % 4) || (D.out_off[0] % 4) || (D.nxt_off[0] % 4)) ok = false;
+                    }
+                    if (ok) {
+                        std::vector<DwtJob> pj;
+                        const int nr = ctx->plane_wg97 - 3;
+                        for (size_t i = 0; i < planes.size(); i++)
+                            for (int pr = 0; pr < (ph[i] + 1) / 2; pr += nr) pj.push_back(DwtJob{(int)i, 0, pr, nr});
+                        if (ctx->l0_xcd && pj.size() >= 64)
+                            deal_xcd(pj, [&](const DwtJob &j) { return j.prow0 + nr > (ph[j.plane] + 1) / 2; });
+                        T.pnjobs = (int)pj.size(); T.pwaves = ctx->plane_wg97; T.pmulti = 0;
                         r = upload(ctx, &T.d_pjobs, pj);
                         if (r != J2K_OK) { j2k_plan_destroy(P); return r; }
                     }

@@ -19,6 +19,7 @@ struct j2k_ctx {
     int l0_fuse = 0;           // forward levels 0 + 1 of RGBA8 frames in one launch: waves per workgroup of the fused bands (J2K_L0_FUSE: 0 off, 8, 16)
     int l0_wg = 4;             // packed RGBA8 level-0 forward, workgroup form: wavefronts per workgroup (J2K_L0_WG: 0 off, 4, 8)
     int l0_wg97 = 8;           // lossy level-0 forward of an RGB triple, workgroup form: waves per workgroup (J2K_L0_WG97: 0 off, 6..16 even; measured 4K: 8 -> 78 us, 16 -> 88 us, general kernel 160 us)
+    int plane_wg97 = 8;        // deeper 9-7 levels (single float64 planes) in workgroup form: waves per workgroup (J2K_PLANE_WG97: 0 = general kernels, 8)
     int l0_wg97_inv = 8;       // lossy level-0 inverse of an RGB triple, workgroup form: waves per workgroup (J2K_L0_WG97_INV: 0 off, 6 8 10 12)
     bool l0_xcd = true;        // XCD-aware order of the workgroup jobs (J2K_L0_XCD=0: plane-major order)
     bool ht_alias = true;      // j2k_plan_encode_stream (HT): code each distinct block window once (J2K_HT_ALIAS=0: every job)

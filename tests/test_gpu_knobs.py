@@ -121,3 +121,28 @@ def test_mq_decode_split_knob(W, H, tile, cb, prec, lossless):
         res.append((dec.cpu(), nb.cpu()))
     assert int(res[0][1].max()) > 8
     assert torch.equal(res[0][0], res[1][0])
+
+
+@pytest.mark.parametrize("W,H,tile,nres,quality", [(1024, 600, (512, 512), 6, 75), (512, 77, (0, 0), 4, 30), (256, 2048, (0, 0), 6, 8000),
+                                                   (520, 131, (256, 128), 4, 75), (64, 36, (0, 0), 3, 1)])
+def test_lossy_deeper_levels_knob(W, H, tile, nres, quality):
+    """lossy RGB frame: levels >= 1 of the 9-7 transform on the general marching kernels (J2K_PLANE_WG97=0) and in workgroup
+    form give the same quantised coefficients, and the same frame back from ARBITRARY int32 coefficients (odd heights, planes
+    down to 16 columns where lanes idle, planes too narrow for the workgroup form next to ones that are not)"""
+    import torch
+    from j2kgfx.codec import FramePlan
+    rng = np.random.default_rng(W * 3 + H + quality)
+    frame_h = rng.integers(0, 4096, size=(3, H, W)).astype(np.int32)
+    kw = dict(precision=12, lossless=False, quality=quality, num_resolutions=nres, cb=(64, 64), tile=tile, coder=0)
+    res = []
+    coef_h = None
+    for ctx in (_ctx({"J2K_PLANE_WG97": 0}), _ctx({"J2K_PLANE_WG97": 8})):
+        plan = FramePlan(W, H, 3, ctx=ctx, **kw)
+        coeff = plan.forward(torch.from_numpy(frame_h).to(plan.device))
+        if coef_h is None:
+            coef_h = rng.integers(-(1 << 20), 1 << 20, size=coeff.numel()).astype(np.int32)
+        back = plan.inverse(torch.from_numpy(coef_h).to(plan.device))
+        ctx.sync()
+        res.append((coeff.cpu(), back.cpu()))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])

@@ -21,7 +21,10 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 t0 = time.time()
 n = npanic = 0
+t_say = t0
 while time.time() - t0 < budget:
+    if time.time() - t_say > 60:                          # (a run that prints nothing for minutes is taken to be hung)
+        t_say = time.time(); print("... %d frames, %.0f s" % (n, t_say - t0), flush=True)
     Cn = int(rng.choice([1, 3]))
     W = int(rng.choice([16, 24, 40, 64, 100, 128, 200, 256, 264, 512, 520, 776, 1024, 1032]))
     H = int(rng.choice([2, 3, 5, 16, 33, 64, 75, 128, 200]))

@@ -20,7 +20,10 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 t0 = time.time()
 n = npanic = npix = 0
+t_say = t0
 while time.time() - t0 < budget:
+    if time.time() - t_say > 60:                          # (a run that prints nothing for minutes is taken to be hung)
+        t_say = time.time(); print("... %d frames, %.0f s" % (n, t_say - t0), flush=True)
     Cn = int(rng.choice([1, 3]))
     tile = int(rng.choice([32, 64, 128, 256, 512]))
     W = int(rng.choice([tile, tile + 8, 2 * tile, 2 * tile + 24, 3 * tile - 16, 100, 264, 520, 1032]))
