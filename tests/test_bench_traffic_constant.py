@@ -34,7 +34,7 @@ def test_c3_traffic_constant_matches_committed_pmc_summary():
     vals = {}
     for ln in open(path):
         m = re.match(r"\s*(\S.*?)\s+(FETCH_SIZE|WRITE_SIZE) n=\d+ avg=([0-9.]+)", ln)
-        if m and m.group(1).startswith("dwt97_fwd_rgb_wg_kernel"):
+        if m and m.group(1).startswith("dwt97_fwd_rgb_wg_kernel<8, 1, 7, 0>"):        # level 0 (<..., 1>: the deeper levels)
             vals[m.group(2)] = float(m.group(3))
     assert set(vals) == {"FETCH_SIZE", "WRITE_SIZE"}
     measured = (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024
