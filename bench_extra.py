@@ -28,7 +28,7 @@ CONFIGS = {
                metric="Mpixels/s encode (8K sRGB 10-bit, 5-3 lossless + HT, tiles sharded over the ranks)",
                workload="7680x4320 sRGB rescaled to 10 bit (v*1023/255), 512x512 tiles (135), 5-3 lossless + HT block coder, 64x64 "
                         "code-blocks (BASELINE configs[3])"),
-    "c5": dict(W=2048, H=2048, C=1, prec=16, lossless=True, quality=0, tile=0, nres=6, cb=64, coder=1, io="gray16", inflight=4,
+    "c5": dict(W=2048, H=2048, C=1, prec=16, lossless=True, quality=0, tile=0, nres=6, cb=64, coder=1, io="gray16", inflight=8,
                metric="Mpixels/s encode+decode (2048x2048 16-bit gray frames, 5-3 lossless)",
                workload="independent 2048x2048 16-bit gray frames (BASELINE configs[4]: a batch of 256, frame f -> rank f mod N), "
                         "untiled, 5-3 lossless + HT block coder, 64x64 code-blocks, 6 resolutions"),
