@@ -251,6 +251,38 @@ def run_config(args, cfgname):
         ln0 = lanes[0]
         info = ln0["p"].info
         total_bytes = int(ln0["offs"][ln0["n"]].item())
+        self_check = None
+        if cfg["coder"] == 0 and rank == 0:
+            # MQ coder: with several contexts alive the library runs its throughput kernels (32 chains per wavefront in the
+            # encoder, plane-stepped decoder); what they produced must be what the latency kernels produce from the same
+            # coefficients.  (Buffers zeroed first: block starts are 4-aligned, the padding is never written.)
+            saved = {k: os.environ.get(k) for k in ("J2K_T1_DEC_SPLIT", "J2K_T1_LANES")}
+            os.environ.update({"J2K_T1_DEC_SPLIT": "0", "J2K_T1_LANES": "4"})
+            try:
+                cctx = Context(local)
+            finally:
+                for k, v in saved.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+            cp = FramePlan(W, H, C, precision=cfg["prec"], lossless=cfg["lossless"], quality=cfg["quality"], num_resolutions=cfg["nres"],
+                           cb=(cfg["cb"], cfg["cb"]), tile=(cfg["tile"], cfg["tile"]), coder=cfg["coder"], ctx=cctx, track_streams=False)
+            ln0["ctx"].sync(); torch.cuda.synchronize()
+            ln0["decoded"].zero_(); torch.cuda.synchronize()
+            ln0["p"].decode_blocks(ln0["stream"], ln0["offs"], ln0["lens"], ln0["nb"], ln0["decoded"])
+            ln0["ctx"].sync()
+            c_stream, c_offs, c_lens, c_nb = cp.encode_stream(ln0["coeff"])
+            c_dec = torch.zeros_like(ln0["decoded"]); torch.cuda.synchronize()
+            cp.decode_blocks(c_stream, c_offs, c_lens, c_nb, c_dec)
+            cctx.sync(); torch.cuda.synchronize()
+            n0 = ln0["n"]
+            assert torch.equal(c_lens[:n0], ln0["lens"][:n0]) and torch.equal(c_nb[:n0], ln0["nb"][:n0]), "MQ encoder: lengths differ between kernel settings"
+            assert torch.equal(c_stream[:total_bytes], ln0["stream"][:total_bytes]), "MQ encoder: bytes differ between kernel settings"
+            assert torch.equal(c_dec, ln0["decoded"]), "MQ decoder: decoded blocks differ between kernel settings"
+            self_check = ("block bytes and decoded blocks of the timed (throughput) kernels identical to the latency kernels' "
+                          "(4 chains per wavefront, one-launch decoder) on frame 0")
+            del cp, cctx
         psnr = None     # (no PSNR against the source: the reference's decode path never dequantises -- tcd.go:416-437, decoder.go:375-411
         #                    is a placeholder -- so "inverse" of quantised coefficients is not a reconstruction of the source;
         #                    GPU vs oracle on this path is bit-identical, tests/test_gpu_dwt97.py)
@@ -288,6 +320,8 @@ def run_config(args, cfgname):
                                             "in flight, right after the timed region"}}
             if psnr is not None:
                 out["config"]["psnr_db_vs_source"] = round(float(psnr), 2)
+            if self_check is not None:
+                out["config"]["self_check"] = self_check
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(cfgname, budget_s=8.0)
             print(json.dumps(out))
