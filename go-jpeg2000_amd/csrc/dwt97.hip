@@ -481,6 +481,9 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 #include "dwt97_l0wg.inc"
 // waves per SIMD of the inverse workgroup kernel: 4 (128 VGPRs, a dozen of them spilled; two 8-wave workgroups per CU) measured
 // 67 us on a 4K frame against 85 us at 3 (136 VGPRs, no spill, one workgroup per CU)
+#ifndef J2K_WG97F_WPE
+#define J2K_WG97F_WPE 7
+#endif
 #ifndef J2K_WG97I_WPE
 #define J2K_WG97I_WPE 4
 #endif
@@ -494,7 +497,7 @@ static hipError_t fwd97_wg_go(hipStream_t s, const LevelLaunch &L, const void *s
                               int dc_shift, int quant, double step) {
     const int32_t *p = reinterpret_cast<const int32_t *>(src);
     const double rstep = 1.0 / step;          // RN(1 / step): the reciprocal of the Markstein division (dwt97_l0wg.inc)
-#define J2K_WG97(Q) hipExtLaunchKernelGGL((dwt97_fwd_rgb_wg_kernel<NW, Q, 7, 0>), dim3(L.njobs), dim3(NW * 64), 0, s, L.ev_start, L.ev_stop, 0, \
+#define J2K_WG97(Q) hipExtLaunchKernelGGL((dwt97_fwd_rgb_wg_kernel<NW, Q, J2K_WG97F_WPE, 0>), dim3(L.njobs), dim3(NW * 64), 0, s, L.ev_start, L.ev_stop, 0, \
                                            L.jobs, L.njobs, L.planes, p, (const double *)nullptr, out_i32, out_f64, nxt, dc_shift, step, rstep)
     if (quant == Q_ENCODER_) J2K_WG97(Q_ENCODER_);
     else if (quant == Q_TCD_) J2K_WG97(Q_TCD_);
