@@ -134,6 +134,41 @@ def test_t1_batch_both_decoder_kernels(ent, oracle, general, monkeypatch):
         assert np.array_equal(got[j], wants[j]), (j, blocks[j], general)
 
 
+def test_t1_batch_plane_stepped_decoder(ent, oracle, monkeypatch):
+    """The plane-stepped T1.Decode (J2K_T1_DEC_SPLIT=1: step kernels + MagRef chains in lock step) on a batch of mixed block
+    sizes against the oracle: encoder output, arbitrary bytes (streams that end early, 0xFF runs), zero-length streams,
+    bit-plane counts from 0 to 40 (above 31 the one-launch kernel takes the block: bit 0 for p >= 32, t1.go:1291) and
+    blocks wider than 64 (general kernel) in the same call."""
+    from j2kgfx import Context
+    monkeypatch.setenv("J2K_T1_DEC_SPLIT", "1")                    # read when a context is created
+    ctx = Context(0)
+    rng = np.random.default_rng(77)
+    dims = [(64, 64), (33, 64), (64, 7), (5, 3), (1, 1), (9, 64), (128, 32), (16, 16), (64, 64), (70, 9), (8, 8), (17, 5), (64, 64), (40, 40)]
+    blocks, streams, nbs, wants = [], [], [], []
+    for j, (w, h) in enumerate(dims * 5):
+        band = j % 4
+        kind = j % 5
+        if kind == 2:                                              # not encoder output
+            g = rng.integers(0, 256, int(rng.integers(0, 400))).astype(np.uint8)
+            nb = int(rng.integers(0, 41))
+        elif kind == 3:                                            # 0xFF-rich bytes, deep
+            g = np.where(rng.random(int(rng.integers(1, 200))) < 0.5, 0xFF, rng.integers(0, 256)).astype(np.uint8)
+            nb = int(rng.integers(25, 33))
+        elif kind == 4 and j % 2:                                  # nothing at all
+            g = np.zeros(0, np.uint8); nb = int(rng.integers(0, 6))
+        else:
+            x = rng.integers(-(1 << int(rng.integers(1, 20))), 1 << int(rng.integers(1, 20)), (h, w)).astype(np.int32)
+            g, nb = oracle.t1_encode(x, w, h, band)
+        blocks.append((0, band, 0, 0, w, h)); streams.append(np.asarray(g, np.uint8)); nbs.append(nb)
+        wants.append(oracle.t1_decode(streams[-1], nb, band, w, h).reshape(h, w))
+    blk = np.array(blocks, dtype=ent.BLOCK_DTYPE)
+    lens = np.array([g.size for g in streams], np.uint32)
+    offs = np.concatenate(([0], np.cumsum(lens)[:-1])).astype(np.uint64)
+    got = ent.decode_blocks(0, np.concatenate(streams), offs, lens, np.array(nbs, np.uint8), blk, ctx=ctx)
+    for j in range(len(blocks)):
+        assert np.array_equal(got[j], wants[j]), (j, blocks[j], nbs[j])
+
+
 HT_SHAPES = [(4, 4), (8, 8), (16, 16), (64, 64), (32, 32), (8, 5), (13, 9), (7, 4), (5, 8), (12, 16), (64, 7), (3, 16), (128, 128),
              (128, 32), (256, 16), (1024, 4), (512, 8), (128, 31), (252, 16), (1020, 3)]
 
