@@ -131,6 +131,7 @@ extern "C" int j2k_ctx_create(int device, j2k_ctx **out) {
     if (const char *e = getenv("J2K_L0_WG97_INV")) { int v = atoi(e); if (v == 0 || v == 6 || v == 8 || v == 10 || v == 12) ctx->l0_wg97_inv = v; }
     if (const char *e = getenv("J2K_L0_WG97")) { int v = atoi(e); if (v == 0 || (v >= 6 && v <= 16 && v % 2 == 0)) ctx->l0_wg97 = v; }
     if (const char *e = getenv("J2K_L0_XCD")) ctx->l0_xcd = atoi(e) != 0;
+    if (const char *e = getenv("J2K_L0_DEAL")) ctx->l0_deal = atoi(e) != 0;
     if (const char *e = getenv("J2K_HT_ALIAS")) ctx->ht_alias = atoi(e) != 0;
     if (const char *e = getenv("J2K_L0_INV_WPE")) { int v = atoi(e); if (v >= 5 && v <= 7) ctx->l0_inv_wpe = v; }
     if (const char *e = getenv("J2K_L0_WG_INV")) ctx->l0_wg_inv = atoi(e) != 0;
@@ -566,7 +567,9 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                         const int nr = ctx->l0_wg - 1;
                         for (size_t i = 0; i < planes.size(); i++)
                             for (int pr = 0; pr < (ph[i] + 1) / 2; pr += nr) wj.push_back(DwtJob{(int)i, 0, pr, nr});
-                        if (ctx->l0_xcd && wj.size() >= 64) {
+                        if (ctx->l0_xcd && wj.size() >= 64 && ctx->l0_deal) {
+                            deal_xcd(wj, [&](const DwtJob &j) { return j.prow0 + nr > (ph[j.plane] + 1) / 2; });
+                        } else if (ctx->l0_xcd && wj.size() >= 64) {
                             // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one), so
                             // workgroup b takes job (b % 8) * chunk + b / 8: vertically adjacent bands -- which share three
                             // halo rows -- run on one XCD at about the same time and the re-read is an L2 hit.  Speed only.

@@ -18,6 +18,7 @@ struct j2k_ctx {
     int plane_wg = 4;          // single-component planes (every level > 0, gray level 0) in workgroup form: waves per workgroup (J2K_PLANE_WG: 0 off, 4, 8)
     int l0_fuse = 0;           // forward levels 0 + 1 of RGBA8 frames in one launch: waves per workgroup of the fused bands (J2K_L0_FUSE: 0 off, 8, 16)
     int l0_wg = 4;             // packed RGBA8 level-0 forward, workgroup form: wavefronts per workgroup (J2K_L0_WG: 0 off, 4, 8)
+    bool l0_deal = true;       // J2K_L0_DEAL (0 = one contiguous chunk per XCD): the RGBA8 level-0 job table deals each XCD's short bands after its full ones (as the 9-7 tables do)
     int l0_wg97 = 8;           // lossy level-0 forward of an RGB triple, workgroup form: waves per workgroup (J2K_L0_WG97: 0 off, 6..16 even; measured 4K: 8 -> 78 us, 16 -> 88 us, general kernel 160 us)
     int plane_wg97 = 8;        // deeper 9-7 levels (single float64 planes) in workgroup form: waves per workgroup (J2K_PLANE_WG97: 0 = general kernels, 8)
     int l0_wg97_inv = 8;       // lossy level-0 inverse of an RGB triple, workgroup form: waves per workgroup (J2K_L0_WG97_INV: 0 off, 6 8 10 12)

@@ -24,7 +24,7 @@ def _ctx(env):
 
 
 @pytest.mark.parametrize("env", [{"J2K_L0_FUSE": 8}, {"J2K_L0_FUSE": 16}, {"J2K_L0_WG": 0}, {"J2K_L0_WG": 8}, {"J2K_L0_WG": 4, "J2K_L0_XCD": 0}, {"J2K_L0_STORE": 0}, {"J2K_L0_STORE": 4},
-                                 {"J2K_L0_WG_INV": 0}, {"J2K_L0_INV_WPE": 6}, {"J2K_HT_ALIAS": 0}])
+                                 {"J2K_L0_WG_INV": 0}, {"J2K_L0_INV_WPE": 6}, {"J2K_HT_ALIAS": 0}, {"J2K_L0_DEAL": 0}])
 def test_rgba8_pipeline_knobs(env):
     """packed RGBA8 frame (tiles of 512, 256-wide and short edge tiles): coefficients, HT stream + arrays and reconstructed
     pixels are identical whatever level-0 kernel / store flavour / job order / alias setting produced them"""
