@@ -59,6 +59,7 @@ def run(state):
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", type=int, default=-1, help="--config c3|c5: replay each frame's plan calls as one HIP graph (1), launch them one by one (0); -1: the configuration's default")
     ap.add_argument("--io", choices=["planes", "rgba8"], default=os.environ.get("J2K_BENCH_IO", "rgba8"),
                     help="frame format at the boundary: packed 8-bit RGBA pixels (image.RGBA.Pix) read / written directly by "
                          "the level-0 kernels (extractImageData / createImage fused, SURVEY 8f rank 2; the default), or "

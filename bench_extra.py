@@ -219,7 +219,22 @@ def run_config(args, cfgname):
                 dist.barrier()
             torch.cuda.synchronize()
 
-        for _ in range(args.warmup):
+        for _ in range(max(args.warmup, 1)):
+            for ln in lanes:
+                code(ln)
+        use_graph = cfg.get("graph", 0) if getattr(args, "graph", -1) < 0 else bool(args.graph)
+        if use_graph:
+            # one HIP graph per frame in flight: its plan calls recorded once (after the warm-up sized every workspace) and
+            # replayed with one launch per step -- same kernels, same buffers, no per-kernel launch from the host
+            barrier()
+            for ln in lanes:
+                with ln["ctx"].capture() as g:
+                    code(ln)
+                ln["graph"] = g
+            direct = code
+
+            def code(ln, _direct=direct):                      # noqa: F811
+                ln["graph"].launch()
             for ln in lanes:
                 code(ln)
         barrier()
@@ -232,6 +247,8 @@ def run_config(args, cfgname):
         barrier()
         dt = time.perf_counter() - t0
         conc_n, conc_ms = ctx0.profile_read()
+        if use_graph:
+            code = direct                                      # the roofline pass stamps events: direct launches
         for _ in range(2):
             code(lanes[0])
         ctx0.sync()
@@ -311,7 +328,7 @@ def run_config(args, cfgname):
                               "decode halves are checked separately)",
                               "tiles": int(info.tiles), "code_blocks": ln0["n"], "compressed_bytes_per_frame": total_bytes,
                               "achieved_compression_ratio": round(W * H * C * ((cfg["prec"] + 7) // 8) / max(total_bytes, 1), 2),
-                              "frames_in_flight": F, "frame_io": cfg["io"], "parallelism": "frames/rank" if world > 1 else "single GPU"},
+                              "frames_in_flight": F, "hip_graph_per_frame": bool(use_graph), "frame_io": cfg["io"], "parallelism": "frames/rank" if world > 1 else "single GPU"},
                    "roofline": {"bound": "hbm", "kernel": kern, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg,
                                 "avg_launch_us": round(k_s * 1e6, 2), "launches_timed": int(iso_n),

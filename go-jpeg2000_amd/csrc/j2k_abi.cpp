@@ -169,10 +169,56 @@ extern "C" void j2k_ctx_destroy(j2k_ctx *ctx) {
     delete ctx;
 }
 
+// ---- HIP graphs: a recorded sequence of plan calls replayed with one launch --------------------------------------------
+// (No counterpart in the reference.)  A frame's pipeline is a dozen or two dependent kernel launches on one stream; for small
+// frames each is too short to hide the next one's launch, and the host pays for every one.  Between capture_begin and
+// capture_end the asynchronous plan calls of this context (j2k_plan_forward* / encode_stream / decode_blocks / inverse* /
+// assemble) are recorded instead of run; the graph replays them on the context's stream with the same device pointers.
+// The calls must have run once before (workspaces sized, lazy tables uploaded): nothing may allocate or synchronise while
+// the stream captures.
+struct j2k_graph { j2k_ctx *ctx; hipGraph_t graph; hipGraphExec_t exec; bool arms_fault; };
+extern "C" int j2k_ctx_capture_begin(j2k_ctx *ctx) {
+    if (!ctx || ctx->capturing) return J2K_ERR_INVALID_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->fault_armed_before_capture = ctx->fault_armed;
+    HIPCHK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    ctx->capturing = true;
+    return J2K_OK;
+}
+extern "C" int j2k_ctx_capture_end(j2k_ctx *ctx, j2k_graph **out) {
+    if (!ctx || !out || !ctx->capturing) return J2K_ERR_INVALID_ARG;
+    *out = nullptr;
+    ctx->capturing = false;
+    hipGraph_t g = nullptr;
+    HIPCHK(ctx, hipStreamEndCapture(ctx->stream, &g));
+    hipGraphExec_t ex = nullptr;
+    hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) { (void)hipGraphDestroy(g); return fail_hip(ctx, e, "hipGraphInstantiate"); }
+    *out = new j2k_graph{ctx, g, ex, ctx->fault_armed};
+    ctx->fault_armed = ctx->fault_armed_before_capture;      // nothing ran yet
+    return J2K_OK;
+}
+extern "C" int j2k_graph_launch(j2k_graph *G) {
+    if (!G || !G->ctx || G->ctx->capturing) return J2K_ERR_INVALID_ARG;
+    j2k_ctx *ctx = G->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipGraphLaunch(G->exec, ctx->stream));
+    if (G->arms_fault) ctx->fault_armed = true;
+    return J2K_OK;
+}
+extern "C" void j2k_graph_destroy(j2k_graph *G) {
+    if (!G) return;
+    if (G->ctx) { (void)hipSetDevice(G->ctx->device); (void)hipStreamSynchronize(G->ctx->stream); }
+    if (G->exec) (void)hipGraphExecDestroy(G->exec);
+    if (G->graph) (void)hipGraphDestroy(G->graph);
+    delete G;
+}
+
 // The block-encode kernels report inputs outside the reference's domain (Go panic) or a slot overflow in a STICKY
 // device word (first int of stage[3]): it is armed by every encode launch, read and cleared at the next
 // synchronisation point (j2k_ctx_sync or a synchronous call), so the asynchronous plan calls fail loudly too.
 static int check_fault(j2k_ctx *ctx) {
+    if (ctx->capturing) return fail(ctx, J2K_ERR_INVALID_ARG, "a synchronising call while the context captures a graph");
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (!ctx->fault_armed || !ctx->stage[3]) return J2K_OK;
     int f = 0;
@@ -217,7 +263,7 @@ extern "C" int j2k_ctx_profile_read(j2k_ctx *ctx, int64_t *launches, double *tot
 }
 // next free event of the pool (grows on demand, capped), or nullptr
 static hipEvent_t profile_event(j2k_ctx *ctx) {
-    if (!ctx->profile || ctx->ev_used >= 8192) return nullptr;
+    if (!ctx->profile || ctx->capturing || ctx->ev_used >= 8192) return nullptr;
     if (ctx->ev_used >= ctx->ev.size()) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) return nullptr;
@@ -228,6 +274,7 @@ static hipEvent_t profile_event(j2k_ctx *ctx) {
 
 static int stage_reserve(j2k_ctx *ctx, int slot, size_t bytes) {
     if (ctx->stage_bytes[slot] >= bytes) return J2K_OK;
+    if (ctx->capturing) return fail(ctx, J2K_ERR_INVALID_ARG, "capture: a workspace would have to grow -- run the same calls once before j2k_ctx_capture_begin");
     if (ctx->stage[slot]) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         HIPCHK(ctx, hipFree(ctx->stage[slot]));
@@ -1277,6 +1324,7 @@ extern "C" int j2k_plan_encode_stream(j2k_plan *P, const int32_t *d_coeff, uint8
         for (const j2k_block &b : P->blocks)
             if ((int64_t)((b.h + 3) / 4) * b.w > ht_fast_max_samples()) P->all_blocks_fast = false;
         if (P->all_blocks_fast) {
+            if (ctx->capturing) return fail(ctx, J2K_ERR_INVALID_ARG, "capture: run the same calls once before j2k_ctx_capture_begin");
             HIPCHK(ctx, hipMalloc((void **)&P->d_status, (size_t)n * 8));
             HIPCHK(ctx, hipMemsetAsync(P->d_status, 0, (size_t)n * 8, ctx->stream));
         }
@@ -1293,10 +1341,14 @@ extern "C" int j2k_plan_encode_stream(j2k_plan *P, const int32_t *d_coeff, uint8
                                             P->epoch, (int *)ctx->stage[3]));
         return J2K_OK;
     }
-    if (!P->d_slots) HIPCHK(ctx, hipMalloc(&P->d_slots, (size_t)P->bytes_cap + 64));
+    if (!P->d_slots) {
+        if (ctx->capturing) return fail(ctx, J2K_ERR_INVALID_ARG, "capture: run the same calls once before j2k_ctx_capture_begin");
+        HIPCHK(ctx, hipMalloc(&P->d_slots, (size_t)P->bytes_cap + 64));
+    }
     if (P->spec.coder == J2K_CODER_HT) {
         // the slot buffer is private here: the MEL zero bytes are not written into it, the gather emits them (compact.hip)
         if (!P->d_maglens) {
+            if (ctx->capturing) return fail(ctx, J2K_ERR_INVALID_ARG, "capture: run the same calls once before j2k_ctx_capture_begin");
             HIPCHK(ctx, hipMalloc((void **)&P->d_maglens, (size_t)n * 4));
             HIPCHK(ctx, hipMalloc((void **)&P->d_mels, (size_t)n * 4));
             HIPCHK(ctx, hipMalloc((void **)&P->d_toffs, ((size_t)n + 1) * 8));

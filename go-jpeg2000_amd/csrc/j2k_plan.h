@@ -43,6 +43,8 @@ struct j2k_ctx {
                                // of 64 blocks per wavefront in lock step (t1.hip); 0: always the one-launch kernels; -1 (default): 512 while
                                // at least two contexts of this process code with the MQ coder (frames in flight: throughput), else 0 (one
                                // frame at a time: latency)
+    bool capturing = false;    // between j2k_ctx_capture_begin / _end: the plan calls are recorded into a HIP graph, nothing may allocate or synchronise
+    bool fault_armed_before_capture = false;
     bool counted_mq = false;   // this context has built an MQ-coder plan (counted in g_mq_ctxs)
     int t1_lanes = 0;          // J2K_T1_LANES: blocks per wavefront of the lane-parallel MQ kernel (0: blocks / 256, at most 32, while at least two contexts code with the MQ coder, else blocks / 2048)
     // cached single-plane plans for the host (unit) calls

@@ -41,6 +41,7 @@ class PlanInfo(C.Structure):
 SYMBOLS = [
     "j2k_ctx_create", "j2k_ctx_destroy", "j2k_ctx_sync", "j2k_ctx_stream", "j2k_ctx_last_error",
     "j2k_status_string", "j2k_version", "j2k_ctx_profile_enable", "j2k_ctx_profile_read",
+    "j2k_ctx_capture_begin", "j2k_ctx_capture_end", "j2k_graph_launch", "j2k_graph_destroy",
     "j2k_dc_level_shift_forward", "j2k_dc_level_shift_inverse", "j2k_forward_rct", "j2k_inverse_rct",
     "j2k_forward_ict", "j2k_inverse_ict",
     "j2k_forward53", "j2k_inverse53", "j2k_forward97", "j2k_inverse97",
@@ -94,6 +95,11 @@ def lib():
         L.j2k_ctx_destroy.argtypes = [C.c_void_p]
         L.j2k_ctx_destroy.restype = None
         L.j2k_ctx_sync.argtypes = [C.c_void_p]
+        L.j2k_ctx_capture_begin.argtypes = [C.c_void_p]
+        L.j2k_ctx_capture_end.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.j2k_graph_launch.argtypes = [C.c_void_p]
+        L.j2k_graph_destroy.argtypes = [C.c_void_p]
+        L.j2k_graph_destroy.restype = None
         L.j2k_plan_destroy.argtypes = [C.c_void_p]
         L.j2k_plan_destroy.restype = None
         L.j2k_plan_pack_bound.restype = C.c_size_t

@@ -63,6 +63,13 @@ class Context:
         finally:
             self._held.clear()
 
+    def capture(self):
+        """Record the asynchronous plan calls made inside the `with` block into a HIP graph instead of running them
+        (j2k_ctx_capture_begin / _end); the calls must have run once before.  Returns a Graph through `as`:
+            with ctx.capture() as g: plan.forward(x, co); plan.encode_stream(co, ...)
+            g.launch()          # replays on the context's stream with the same buffers"""
+        return _Capture(self)
+
     def profile_enable(self, on=True):
         self.check(self.L.j2k_ctx_profile_enable(self.h, int(bool(on))))
 
@@ -102,3 +109,48 @@ def default_context():
     if _default is None:
         _default = Context(0)
     return _default
+
+
+class Graph:
+    """A recorded sequence of plan calls (j2k_graph).  Keeps the tensors the calls used alive."""
+
+    def __init__(self, ctx, handle, held):
+        self.ctx, self.h, self._held = ctx, handle, held
+
+    def launch(self):
+        self.ctx.check(self.ctx.L.j2k_graph_launch(self.h))
+
+    def close(self):
+        if self.h and self.ctx.h:
+            self.ctx.L.j2k_graph_destroy(self.h)
+        self.h = None
+        self._held = []
+
+    def __del__(self):
+        try:
+            if not sys.is_finalizing():
+                self.close()
+        except Exception:
+            pass
+
+
+class _Capture:
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.graph = Graph(ctx, None, [])
+
+    def __enter__(self):
+        self.mark = len(self.ctx._held)
+        self.ctx.check(self.ctx.L.j2k_ctx_capture_begin(self.ctx.h))
+        return self.graph
+
+    def __exit__(self, et, ev, tb):
+        h = C.c_void_p()
+        rc = self.ctx.L.j2k_ctx_capture_end(self.ctx.h, C.byref(h))
+        if et is None:
+            self.ctx.check(rc)
+            self.graph.h = h
+            self.graph._held = list(self.ctx._held[self.mark:])
+        elif rc == 0 and h:
+            self.ctx.L.j2k_graph_destroy(h)
+        return False

@@ -66,6 +66,19 @@ const char *j2k_version(void);
 int j2k_ctx_profile_enable(j2k_ctx *ctx, int on);
 int j2k_ctx_profile_read(j2k_ctx *ctx, int64_t *launches, double *total_ms);
 
+/* HIP graphs (no counterpart in the reference: a launch-overhead facility of this boundary).  Between
+ * capture_begin and capture_end the asynchronous device-pointer calls of this context (section 2: j2k_plan_forward*,
+ * j2k_plan_encode_stream, j2k_plan_decode_blocks, j2k_plan_inverse*, j2k_plan_assemble_tiles_device ...) are recorded
+ * instead of run; j2k_graph_launch replays them on the context's stream with the same device pointers (new contents in
+ * the same buffers).  The same calls must have run once before the capture (workspaces sized): a call that would have to
+ * allocate fails with J2K_ERR_INVALID_ARG and the capture must be ended and discarded.  Synchronous calls (anything in
+ * section 1, j2k_ctx_sync, j2k_ctx_profile_read) are not allowed while capturing. */
+typedef struct j2k_graph j2k_graph;
+int j2k_ctx_capture_begin(j2k_ctx *ctx);
+int j2k_ctx_capture_end(j2k_ctx *ctx, j2k_graph **out);
+int j2k_graph_launch(j2k_graph *g);
+void j2k_graph_destroy(j2k_graph *g);
+
 /* ==== 1. host calls: one per reference function ============================= */
 
 /* mct.DCLevelShiftForward / Inverse   (internal/mct/mct.go:96-101, 113-118) */
