@@ -993,26 +993,27 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void dwt53_tail_inv_kernel(const T
 }
 
 hipError_t launch_dwt53_tail_fwd(hipStream_t s, const TailPlane *planes, int nplanes, size_t lds_bytes, const int32_t *scr,
-                                 int32_t *coef) {
+                                 int32_t *coef, hipEvent_t ev0, hipEvent_t ev1) {
     if (nplanes <= 0) return hipSuccess;
     if (lds_bytes > 64 * 1024) {   // above the default dynamic-LDS limit: raise it (gfx950 has 160 KiB per workgroup)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(dwt53_tail_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(dwt53_tail_fwd_kernel, dim3(nplanes), dim3(64 * TAIL_WAVES), lds_bytes, s, planes, scr, coef);
+    hipExtLaunchKernelGGL(dwt53_tail_fwd_kernel, dim3(nplanes), dim3(64 * TAIL_WAVES), lds_bytes, s, ev0, ev1, 0, planes, scr, coef);
     return hipGetLastError();
 }
 hipError_t launch_dwt53_tail_inv(hipStream_t s, const TailPlane *planes, int nplanes, size_t lds_bytes, const int32_t *coef,
-                                 int32_t *scr) {
+                                 int32_t *scr, hipEvent_t ev0, hipEvent_t ev1) {
     if (nplanes <= 0) return hipSuccess;
     if (lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(dwt53_tail_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(dwt53_tail_inv_kernel, dim3(nplanes), dim3(64 * TAIL_WAVES), lds_bytes, s, planes, coef, scr);
+    hipExtLaunchKernelGGL(dwt53_tail_inv_kernel, dim3(nplanes), dim3(64 * TAIL_WAVES), lds_bytes, s, ev0, ev1, 0, planes, coef, scr);
     return hipGetLastError();
 }
 
+#include "dwt53_deep.inc"
 #include "dwt53_l0pix.inc"
 #include "dwt53_plane_wg.inc"
 
@@ -1072,12 +1073,12 @@ static hipError_t inv_go(hipStream_t s, const LevelLaunch &L, const int32_t *coe
     const int blocks = (L.njobs + 3) / 4;
     if constexpr (CPL == 8 && (NC == 3 || NC == 1) && VEC) {
         if (L.pix_stride > 0) {
-            hipLaunchKernelGGL((dwt53_inv_kernel<CPL, NC, VEC, true>), dim3(blocks), dim3(256), 0, s, L.jobs, L.njobs, L.planes, coef, prev, dst, dc, fin, L.pix_stride);
+            hipExtLaunchKernelGGL((dwt53_inv_kernel<CPL, NC, VEC, true>), dim3(blocks), dim3(256), 0, s, L.ev_start, L.ev_stop, 0, L.jobs, L.njobs, L.planes, coef, prev, dst, dc, fin, L.pix_stride);
             return hipGetLastError();
         }
     }
     if (L.pix_stride > 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((dwt53_inv_kernel<CPL, NC, VEC, false>), dim3(blocks), dim3(256), 0, s, L.jobs, L.njobs, L.planes, coef, prev, dst, dc, fin, 0);
+    hipExtLaunchKernelGGL((dwt53_inv_kernel<CPL, NC, VEC, false>), dim3(blocks), dim3(256), 0, s, L.ev_start, L.ev_stop, 0, L.jobs, L.njobs, L.planes, coef, prev, dst, dc, fin, 0);
     return hipGetLastError();
 }
 
@@ -1136,7 +1137,7 @@ hipError_t launch_dwt53_inv(hipStream_t s, const LevelLaunch &L, const int32_t *
     }
     if (L.pwaves > 0 && L.pnjobs > 0 && (L.ncomp == 1 || L.pix_stride <= 0)) {     // planes in workgroup form (dwt53_plane_wg.inc)
         if (L.pix_stride > 0 && !final_level) return hipErrorInvalidValue;
-#define J2K_PWG(NW, NC, DST, MULTI, WPE) hipLaunchKernelGGL((dwt53_inv_plane_wg_kernel<NW, NC, DST, MULTI, WPE>), dim3(L.pnjobs), dim3(NW * 64), 0, s, \
+#define J2K_PWG(NW, NC, DST, MULTI, WPE) hipExtLaunchKernelGGL((dwt53_inv_plane_wg_kernel<NW, NC, DST, MULTI, WPE>), dim3(L.pnjobs), dim3(NW * 64), 0, s, L.ev_start, L.ev_stop, 0, \
                                                  L.pjobs, L.pnjobs, L.planes, coef, prev, (void *)dst, dc_shift, final_level, L.pix_stride)
 #define J2K_PWG2(NW) do { if (L.ncomp == 3) { if (L.pmulti) J2K_PWG(NW, 3, 0, true, 3); else J2K_PWG(NW, 3, 0, false, 5); } \
                           else if (L.pix_stride > 0) { if (L.pmulti) J2K_PWG(NW, 1, 1, true, 8); else J2K_PWG(NW, 1, 1, false, 8); } \

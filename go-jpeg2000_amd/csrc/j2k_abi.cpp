@@ -145,6 +145,7 @@ extern "C" int j2k_ctx_create(int device, j2k_ctx **out) {
     if (const char *e = getenv("J2K_BAND_PROWS_INV")) { int v = atoi(e); if (v >= 1 && v <= 4096) ctx->band_prows_inv = v; }
     if (const char *e = getenv("J2K_FWD_PF")) ctx->fwd_pf = atoi(e) != 0;
     if (const char *e = getenv("J2K_TAIL")) ctx->use_tail = atoi(e) != 0;
+    if (const char *e = getenv("J2K_DEEP")) ctx->use_deep = atoi(e) != 0;
     if (const char *e = getenv("J2K_XCD_MAP")) ctx->xcd_map = atoi(e) != 0;
     if (const char *e = getenv("J2K_T1_SPLIT")) ctx->t1_split = atoi(e) != 0;
     if (const char *e = getenv("J2K_T1_SYM_MB")) { long v = atol(e); if (v >= 0) ctx->t1_sym_mb = v; }
@@ -242,7 +243,7 @@ extern "C" int j2k_ctx_profile_enable(j2k_ctx *ctx, int on) {
     if (!ctx) return J2K_ERR_INVALID_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->profile = on ? 1 : 0;
+    ctx->profile = on < 0 ? 0 : on;          // 1: the forward level-0 dispatch only; 2: every 5-3 transform dispatch, tagged
     ctx->ev_used = 0;
     return J2K_OK;
 }
@@ -251,14 +252,34 @@ extern "C" int j2k_ctx_profile_read(j2k_ctx *ctx, int64_t *launches, double *tot
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     double tot = 0;
+    int64_t n = 0;
     for (size_t i = 0; i + 1 < ctx->ev_used; i += 2) {
+        if (ctx->ev_tag[i / 2] != 0) continue;          // the forward level-0 dispatches (the roofline kernel)
         float ms = 0;
         HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));
-        tot += ms;
+        tot += ms; n++;
     }
-    *launches = (int64_t)(ctx->ev_used / 2);
+    *launches = n;
     *total_ms = tot;
     ctx->ev_used = 0;
+    return J2K_OK;
+}
+// Sum over the stamped dispatches carrying `tag` (0 forward level 0, 1 forward deeper levels, 2 inverse level 0, 3 inverse
+// deeper levels) since the last j2k_ctx_profile_read / _enable; does not reset (call per tag, then j2k_ctx_profile_read).
+extern "C" int j2k_ctx_profile_read_tag(j2k_ctx *ctx, int tag, int64_t *launches, double *total_ms) {
+    if (!ctx || !launches || !total_ms) return J2K_ERR_INVALID_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    double tot = 0;
+    int64_t n = 0;
+    for (size_t i = 0; i + 1 < ctx->ev_used; i += 2) {
+        if (ctx->ev_tag[i / 2] != tag) continue;
+        float ms = 0;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));
+        tot += ms; n++;
+    }
+    *launches = n;
+    *total_ms = tot;
     return J2K_OK;
 }
 // next free event of the pool (grows on demand, capped), or nullptr
@@ -270,6 +291,18 @@ static hipEvent_t profile_event(j2k_ctx *ctx) {
         ctx->ev.push_back(e);
     }
     return ctx->ev[ctx->ev_used++];
+}
+// an event pair for one dispatch, or {nullptr, nullptr}: tag 0 in any profile mode, the other tags in mode 2 only
+static bool profile_pair(j2k_ctx *ctx, int tag, hipEvent_t &e0, hipEvent_t &e1) {
+    e0 = e1 = nullptr;
+    if (!ctx->profile || (tag != 0 && ctx->profile < 2) || ctx->capturing || ctx->ev_used + 2 > 8192) return false;
+    const size_t pair = ctx->ev_used / 2;
+    e0 = profile_event(ctx);
+    e1 = e0 ? profile_event(ctx) : nullptr;
+    if (!e1) { e0 = nullptr; ctx->ev_used = pair * 2; return false; }
+    if (ctx->ev_tag.size() <= pair) ctx->ev_tag.resize(pair + 1, 0);
+    ctx->ev_tag[pair] = tag;
+    return true;
 }
 
 static int stage_reserve(j2k_ctx *ctx, int slot, size_t bytes) {
@@ -409,6 +442,55 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
             }
             P->ntail = (int)tp.size();
             int r = upload(ctx, &P->d_tail, tp);
+            if (r != J2K_OK) { j2k_plan_destroy(P); return r; }
+        }
+    }
+
+    // ---- every level below level 0 in one launch per direction (dwt53_deep.inc) ------------------
+    // levels deep_l0 .. L-1, deep_l0 = the level above the first one that fits LDS: it streams from memory in the same workgroups
+    int lds_l0 = -1;        // the first level whose input fits the LDS buffers (the tail above needs two such levels, this one)
+    if (S.wavelet == W53) {
+        for (int l0 = 1; l0 <= L - 1 && lds_l0 < 0; l0++) {
+            bool fits = true;
+            for (const Group &g : P->groups) {
+                int w = g.w, h = g.h;
+                for (int i = 0; i < l0; i++) { w = (w + 1) / 2; h = (h + 1) / 2; }
+                if (w > 128 || (int64_t)w * h > 16384) fits = false;
+            }
+            if (fits) lds_l0 = l0;
+        }
+    }
+    if (lds_l0 >= 2 && ctx->use_deep) {
+        const int l0 = lds_l0 - 1;
+        bool ok = true;
+        std::vector<TailPlane> tp;
+        std::vector<DwtJob> deep, flat;
+        size_t lds = 0;
+        for (const Group &g : P->groups) {
+            int w = g.w, h = g.h;
+            for (int i = 0; i < l0; i++) { w = (w + 1) / 2; h = (h + 1) / 2; }
+            if (w < 8 || w > 256 || (w % 4) || h < 2 || h > 256) { ok = false; break; }
+            const int w1 = w / 2, h1 = (h + 1) / 2, w2 = (w1 + 1) / 2, h2 = (h1 + 1) / 2;
+            if (w1 > 128 || (int64_t)w1 * h1 > 16384) { ok = false; break; }
+            lds = std::max(lds, (size_t)(2 * 16 * 64 * 4 + ((w1 * h1 + 3) & ~3) + ((w2 * h2 + 3) & ~3) + 8) * 4);
+            for (int k = 0; k < g.nc; k++) {
+                const int64_t so = ((l0 & 1) ? g.scrA_off : g.scrB_off)[k];
+                if ((so % 4) || (g.coef_off[k] % 4)) ok = false;
+                TailPlane T{};
+                T.scr_off = so; T.coef_off = g.coef_off[k];
+                T.w = w; T.h = h; T.nlev = L - l0;
+                const int pi = (int)tp.size();
+                tp.push_back(T);
+                const int halfH = h1, top = (halfH + 1) / 2;      // pair-rows whose low-pass rows feed level l0 + 1
+                deep.push_back(DwtJob{pi, 1, 0, top});
+                for (int q = top; q < halfH; q += 64) flat.push_back(DwtJob{pi, 0, q, std::min(64, halfH - q)});
+            }
+        }
+        if (ok && !tp.empty()) {
+            deep.insert(deep.end(), flat.begin(), flat.end());
+            P->deep_l0 = l0; P->ndeep_jobs = (int)deep.size(); P->deep_lds = lds;
+            int r = upload(ctx, &P->d_deep_planes, tp);
+            if (r == J2K_OK) r = upload(ctx, &P->d_deep_jobs, deep);
             if (r != J2K_OK) { j2k_plan_destroy(P); return r; }
         }
     }
@@ -634,7 +716,7 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                         if (r != J2K_OK) { j2k_plan_destroy(P); return r; }
                         // levels 0 + 1 in one launch (dwt53_fwd_rgba8_wg2_kernel): needs a level 1 (levels >= 2), only RGB
                         // triples in the frame (the level-1 plane table is then three planes per level-0 plane, same order)
-                        if (ctx->l0_fuse > 0 && L >= 2 && S.C == 3 && (P->tail_l0 < 0 || P->tail_l0 >= 2)) {
+                        if (ctx->l0_fuse > 0 && L >= 2 && S.C == 3 && (P->tail_l0 < 0 || P->tail_l0 >= 2) && (P->deep_l0 < 0 || P->deep_l0 >= 2)) {
                             auto xcd = [&](std::vector<DwtJob> &v) {
                                 if (!ctx->l0_xcd || v.size() < 64) return;
                                 const size_t chunk = (v.size() + 7) / 8;
@@ -820,7 +902,7 @@ extern "C" void j2k_plan_destroy(j2k_plan *P) {
         for (auto &T : P->fwd[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); if (T.d_pjobs) (void)hipFree(T.d_pjobs); }
         for (auto &T : P->inv[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); if (T.d_pjobs) (void)hipFree(T.d_pjobs); }
     }
-    void *ptrs[] = {P->d_tile_job0, P->d_scrA, P->d_scrB, P->d_tail, P->d_bjobs, P->d_djobs, P->d_frame, P->d_coeff, P->d_slots, P->d_stream, P->d_lens, P->d_numbps, P->d_offs, P->d_status, P->d_fwd_pix_jobs, P->d_fwd_wg2_jobs, P->d_fwd_wg_rest_jobs, P->d_fwd_wg_jobs, P->d_fwd97_wg_jobs, P->d_inv97_wg_jobs, P->d_ht_ujobs, P->d_ht_alias_next, P->d_bjobs_alias, P->d_maglens, P->d_mels, P->d_toffs};
+    void *ptrs[] = {P->d_deep_planes, P->d_deep_jobs, P->d_tile_job0, P->d_scrA, P->d_scrB, P->d_tail, P->d_bjobs, P->d_djobs, P->d_frame, P->d_coeff, P->d_slots, P->d_stream, P->d_lens, P->d_numbps, P->d_offs, P->d_status, P->d_fwd_pix_jobs, P->d_fwd_wg2_jobs, P->d_fwd_wg_rest_jobs, P->d_fwd_wg_jobs, P->d_fwd97_wg_jobs, P->d_inv97_wg_jobs, P->d_ht_ujobs, P->d_ht_alias_next, P->d_bjobs_alias, P->d_maglens, P->d_mels, P->d_toffs};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete P;
 }
@@ -907,7 +989,7 @@ static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff, in
     if (((uintptr_t)d_frame & 15) || ((uintptr_t)d_coeff & 15)) return fail(ctx, J2K_ERR_INVALID_ARG, "device pointers must be 16-byte aligned");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const double step = 1.0 / (double)S.quality;   // encoder.go:269
-    const int nlevel_launches = (P->tail_l0 >= 0) ? P->tail_l0 : S.levels;
+    const int nlevel_launches = (P->deep_l0 >= 0) ? P->deep_l0 : ((P->tail_l0 >= 0) ? P->tail_l0 : S.levels);
     bool fused_l1 = false;             // level 1 ran inside the level-0 launch (packed RGBA8 frames, dwt53_fwd_rgba8_wg2_kernel)
     for (int l = 0; l < nlevel_launches; l++)
     for (int rep_ = 0; rep_ < dev_reps(l == 0 ? 1 : (l == 1 ? 2 : 4)); rep_++) {      // (always once outside dev builds)
@@ -917,11 +999,11 @@ static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff, in
         // profiling (bench.py's roofline line): the level-0 dispatch of the RGB triples stamps its own begin / end
         // (the RGB triples' launch when the plan has any, else the single-component one; 5-3 and 9-7 alike)
         const int prof_cls = P->fwd[1][0].njobs ? 1 : 0;
-        hipEvent_t ev0 = (l == 0 && P->fwd[prof_cls][0].njobs) ? profile_event(ctx) : nullptr;
-        hipEvent_t ev1 = ev0 ? profile_event(ctx) : nullptr;
         for (int cls = 0; cls < 2; cls++) {
             const LevelTab &T = P->fwd[cls][l];
             if (!T.njobs) continue;
+            hipEvent_t ev0 = nullptr, ev1 = nullptr;
+            if (l == 0 ? cls == prof_cls : S.wavelet == W53) profile_pair(ctx, l == 0 ? 0 : 1, ev0, ev1);
             if (S.wavelet == W53) {
                 LevelLaunch L = mk(T, ctx->fwd_pf);
                 if (l == 0 && cls == pix_cls && pix_stride > 0) {         // packed frame (j2k_plan_forward_rgba8 / _pixels)
@@ -937,7 +1019,7 @@ static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff, in
                         }
                     }
                 }
-                if (l == 0 && cls == prof_cls && ev1) { L.ev_start = ev0; L.ev_stop = ev1; }
+                if (ev1) { L.ev_start = ev0; L.ev_stop = ev1; }
                 HIPCHK(ctx, launch_dwt53_fwd(ctx->stream, L, (const int32_t *)in, (int32_t *)d_coeff, (int32_t *)nx, l == 0 ? S.dc_shift : 0));
             } else {
                 const int src_f64 = (l > 0) || S.frame_is_f64;
@@ -951,9 +1033,18 @@ static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff, in
             }
         }
     }
-    for (int rep_ = 0; P->tail_l0 >= 0 && rep_ < dev_reps(4); rep_++)
+    for (int rep_ = 0; P->deep_l0 >= 0 && rep_ < dev_reps(4); rep_++) {
+        hipEvent_t e0, e1;
+        profile_pair(ctx, 1, e0, e1);
+        HIPCHK(ctx, launch_dwt53_deep_fwd(ctx->stream, P->d_deep_jobs, P->ndeep_jobs, P->d_deep_planes, P->deep_lds,
+                                          (const int32_t *)((P->deep_l0 & 1) ? P->d_scrA : P->d_scrB), (int32_t *)d_coeff, e0, e1));
+    }
+    for (int rep_ = 0; P->deep_l0 < 0 && P->tail_l0 >= 0 && rep_ < dev_reps(4); rep_++) {
+        hipEvent_t e0, e1;
+        profile_pair(ctx, 1, e0, e1);
         HIPCHK(ctx, launch_dwt53_tail_fwd(ctx->stream, P->d_tail, P->ntail, P->tail_lds_fwd,
-                                          (const int32_t *)((P->tail_l0 & 1) ? P->d_scrA : P->d_scrB), (int32_t *)d_coeff));
+                                          (const int32_t *)((P->tail_l0 & 1) ? P->d_scrA : P->d_scrB), (int32_t *)d_coeff, e0, e1));
+    }
     return J2K_OK;
 }
 
@@ -962,10 +1053,19 @@ static int plan_inverse_impl(j2k_plan *P, const void *d_coeff, void *d_frame, in
     const PlanSpec &S = P->spec;
     if (((uintptr_t)d_frame & 15) || ((uintptr_t)d_coeff & 15)) return fail(ctx, J2K_ERR_INVALID_ARG, "device pointers must be 16-byte aligned");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    for (int rep_ = 0; P->tail_l0 >= 0 && rep_ < dev_reps(0x100); rep_++)
+    for (int rep_ = 0; P->deep_l0 >= 0 && rep_ < dev_reps(0x100); rep_++) {
+        hipEvent_t e0, e1;
+        profile_pair(ctx, 3, e0, e1);
+        HIPCHK(ctx, launch_dwt53_deep_inv(ctx->stream, P->d_deep_jobs, P->ndeep_jobs, P->d_deep_planes, P->deep_lds, (const int32_t *)d_coeff,
+                                          (int32_t *)((P->deep_l0 & 1) ? P->d_scrA : P->d_scrB), e0, e1));
+    }
+    for (int rep_ = 0; P->deep_l0 < 0 && P->tail_l0 >= 0 && rep_ < dev_reps(0x100); rep_++) {
+        hipEvent_t e0, e1;
+        profile_pair(ctx, 3, e0, e1);
         HIPCHK(ctx, launch_dwt53_tail_inv(ctx->stream, P->d_tail, P->ntail, P->tail_lds_inv, (const int32_t *)d_coeff,
-                                          (int32_t *)((P->tail_l0 & 1) ? P->d_scrA : P->d_scrB)));
-    for (int l = ((P->tail_l0 >= 0) ? P->tail_l0 : S.levels) - 1; l >= 0; l--)
+                                          (int32_t *)((P->tail_l0 & 1) ? P->d_scrA : P->d_scrB), e0, e1));
+    }
+    for (int l = ((P->deep_l0 >= 0) ? P->deep_l0 : ((P->tail_l0 >= 0) ? P->tail_l0 : S.levels)) - 1; l >= 0; l--)
     for (int rep_ = 0; rep_ < dev_reps(l == 0 ? 0x400 : (l == 1 ? 0x200 : 0x100)); rep_++) {
         void *prev = (l & 1) ? P->d_scrB : P->d_scrA;                     // X_{l+1}
         void *dst = (l == 0) ? d_frame : ((l & 1) ? P->d_scrA : P->d_scrB);  // X_l
@@ -980,6 +1080,7 @@ static int plan_inverse_impl(j2k_plan *P, const void *d_coeff, void *d_frame, in
                     // of the inverse level table is the forward one)
                     L.jobs = P->d_fwd_wg_jobs; L.njobs = P->fwd_wg_njobs; L.wg_waves = P->fwd_wg_waves; L.wg_store = ctx->l0_inv_wpe;
                 }
+                profile_pair(ctx, l == 0 ? 2 : 3, L.ev_start, L.ev_stop);
                 HIPCHK(ctx, launch_dwt53_inv(ctx->stream, L, (const int32_t *)d_coeff, (const int32_t *)prev, (int32_t *)dst,
                                              l == 0 ? S.dc_shift_inv : 0, l == 0));
             } else {

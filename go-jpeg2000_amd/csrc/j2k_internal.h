@@ -89,9 +89,15 @@ hipError_t launch_dwt53_fwd(hipStream_t s, const LevelLaunch &L, const int32_t *
 hipError_t launch_dwt53_inv(hipStream_t s, const LevelLaunch &L, const int32_t *coef, const int32_t *prev,
                             int32_t *dst, int dc_shift, int final_level);
 hipError_t launch_dwt53_tail_fwd(hipStream_t s, const TailPlane *planes, int nplanes, size_t lds_bytes, const int32_t *scr,
-                                 int32_t *coef);
+                                 int32_t *coef, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 hipError_t launch_dwt53_tail_inv(hipStream_t s, const TailPlane *planes, int nplanes, size_t lds_bytes, const int32_t *coef,
-                                 int32_t *scr);
+                                 int32_t *scr, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+
+// every level below level 0 in one launch (dwt53_deep.inc); ev0 / ev1: optional begin / end events stamped by the dispatch
+hipError_t launch_dwt53_deep_fwd(hipStream_t s, const DwtJob *jobs, int njobs, const TailPlane *planes, size_t lds_bytes, const int32_t *scr,
+                                 int32_t *coef, hipEvent_t ev0, hipEvent_t ev1);
+hipError_t launch_dwt53_deep_inv(hipStream_t s, const DwtJob *jobs, int njobs, const TailPlane *planes, size_t lds_bytes, const int32_t *coef,
+                                 int32_t *scr, hipEvent_t ev0, hipEvent_t ev1);
 
 hipError_t launch_unpack_pixels(hipStream_t s, const uint8_t *pix, size_t stride, int format, int w, int h, int src_max, int dst_max,
                                 int32_t *planes);

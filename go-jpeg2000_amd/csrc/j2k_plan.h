@@ -33,6 +33,7 @@ struct j2k_ctx {
     int fwd_pf = 0;            // forward 5-3 level kernels: software prefetch of the next pair-row (J2K_FWD_PF)
     int band_prows = 5;        // pair-rows per wavefront band (tunable: J2K_BAND_PROWS)
     int use_tail = 1;          // J2K_TAIL=0: every level as its own launch (A/B)
+    int use_deep = 1;          // J2K_DEEP=0: level tail_l0 - 1 as its own launch + the LDS tail (round 2) instead of ONE launch for every level below 0 (dwt53_deep.inc)
     int xcd_map = 0;           // J2K_XCD_MAP=0: plain job order (A/B)
     int cpl0 = 0;              // J2K_CPL0: force columns-per-lane of the level-0 5-3 kernels (tuning)
     int force_novec = 0;       // J2K_FORCE_NOVEC=1: always take the scalar-access kernels (testing)
@@ -56,6 +57,7 @@ struct j2k_ctx {
     // level-0 kernel timing (j2k_ctx_profile_*)
     int profile = 0;
     std::vector<hipEvent_t> ev;     // pool of event pairs
+    std::vector<int> ev_tag;        // per pair: 0 = forward level 0, 1 = forward deeper levels, 2 = inverse level 0, 3 = inverse deeper levels
     size_t ev_used = 0;             // events recorded since the last read
 };
 
@@ -125,6 +127,12 @@ struct j2k_plan {
     j2k::TailPlane *d_tail = nullptr;
     int ntail = 0;
     size_t tail_lds_fwd = 0, tail_lds_inv = 0;
+    // every level below level 0 in one launch per direction (dwt53_deep.inc): levels deep_l0 .. levels-1; -1 = not used
+    int deep_l0 = -1;
+    j2k::TailPlane *d_deep_planes = nullptr;    // dims at level deep_l0
+    j2k::DwtJob *d_deep_jobs = nullptr;         // deep workgroups first, then the flat ones
+    int ndeep_jobs = 0;
+    size_t deep_lds = 0;
     // code-block jobs
     std::vector<j2k_block> blocks;          // plane = shard-local tile-component index
     std::vector<int32_t> block_tile;        // tile of each job

@@ -1,0 +1,89 @@
+"""GPU: every 5-3 level below level 0 in one launch per direction (dwt53_deep.inc, J2K_DEEP) against the per-level launches
+and the oracle (dwt.go:524-548).
+
+Shapes chosen for the boundaries of that kernel: the level it streams from memory at 256 / 252 / 128 columns, heights that
+leave the deep workgroup 1, 2 or 64 pair-rows and the flat ones none, one or a partial band, odd heights at every level
+(missing odd row, mirrored d), a next-level matrix that ends in the middle of a row (odd ceil(h/2)), two to five levels inside
+the launch, RGB tiles incl. ragged edge tiles, a frame that does not qualify (falls back), full-range int32 input
+(wraparound in both directions)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(**env):
+    from j2kgfx import Context
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return Context(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+SHAPES = [(512, 512, 0, 6), (512, 200, 0, 5), (1024, 64, 0, 6), (512, 130, 0, 4), (256, 512, 0, 6), (520, 37, 0, 5), (504, 10, 0, 4),
+          (512, 5, 0, 4), (512, 3, 0, 4), (512, 510, 0, 6), (512, 259, 0, 6), (2048, 2048, 0, 6), (1024, 1024, 0, 5), (776, 300, 256, 5),
+          (16, 16, 0, 3)]
+
+
+@pytest.mark.parametrize("W,H,tile,nres", SHAPES)
+def test_deep_levels_single_component(oracle, W, H, tile, nres):
+    import torch
+    from j2kgfx.codec import FramePlan
+    rng = np.random.default_rng(W * 7 + H + nres)
+    full = rng.integers(-2 ** 31, 2 ** 31, (1, H, W), dtype=np.int64).astype(np.int32)
+    small = rng.integers(0, 65536, (1, H, W)).astype(np.int32)
+    outs = {}
+    for deep in (0, 1):
+        plan = FramePlan(W, H, 1, precision=16, lossless=True, num_resolutions=nres, cb=(64, 64), tile=(tile, tile), coder=1,
+                         ctx=_ctx(J2K_DEEP=deep))
+        res = []
+        for frame_h in (full, small):
+            for rep in range(2):                      # the second pass starts on an idle device (scheduling-dependent bugs)
+                frame = torch.from_numpy(frame_h).to(plan.device)
+                coeff = plan.forward(frame)
+                back = plan.inverse(coeff)
+                plan.ctx.sync()
+                c, b = coeff.cpu().numpy(), back.cpu().numpy()
+                assert np.array_equal(b.reshape(1, H, W), frame_h)
+            res += [c, b]
+        outs[deep] = res
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
+    if W * H <= 1 << 18 and tile == 0:
+        want = oracle.preprocess([small[0]], W, H, 16, True, nres)
+        assert np.array_equal(outs[1][2].reshape(H, W), want[0])
+
+
+@pytest.mark.parametrize("W,H,tile", [(1280, 624, 512), (1536, 1024, 512), (768, 300, 256)])
+def test_deep_levels_rgb_tiles(oracle, W, H, tile):
+    import torch
+    from j2kgfx.codec import FramePlan
+    rng = np.random.default_rng(W + H)
+    frame_h = rng.integers(0, 256, (3, H, W)).astype(np.int32)
+    got = []
+    for deep in (0, 1):
+        plan = FramePlan(W, H, 3, precision=8, lossless=True, num_resolutions=6, cb=(64, 64), tile=(tile, tile), coder=1,
+                         ctx=_ctx(J2K_DEEP=deep))
+        frame = torch.from_numpy(frame_h).to(plan.device)
+        coeff = plan.forward(frame)
+        back = plan.inverse(coeff)
+        # a decoder's input is arbitrary: the inverse alone on full-range coefficients must agree too
+        junk = torch.from_numpy(rng.integers(-2 ** 31, 2 ** 31, coeff.numel(), dtype=np.int64).astype(np.int32)).to(plan.device)
+        back2 = plan.inverse(junk) if deep == 0 else plan.inverse(got[0][2].to(plan.device))
+        plan.ctx.sync()
+        got.append((coeff.cpu().numpy(), back2.cpu().numpy(), junk.cpu()))
+        assert np.array_equal(back.cpu().numpy().reshape(3, H, W), frame_h)
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+    # one tile against the oracle's pipeline on the cropped image (top-left tile)
+    tw, th = min(tile, W), min(tile, H)
+    want = oracle.preprocess([np.ascontiguousarray(frame_h[c, :th, :tw]) for c in range(3)], tw, th, 8, True, 6)
+    for c in range(3):
+        assert np.array_equal(got[1][0][c * tw * th:(c + 1) * tw * th].reshape(th, tw), want[c])
