@@ -842,54 +842,149 @@ __global__ __launch_bounds__(256) void dwt53_inv_kernel(const DwtJob *__restrict
 // column pair per lane, DPP neighbours, register sliding window), final coefficients go straight to global
 // memory and the prefix that feeds the next level goes to the other LDS buffer.
 #define TAIL_WAVES 16   /* 1024-thread workgroups: 16 wavefronts share one plane's levels */
-__device__ __forceinline__ void tail_fwd_level(const int32_t *cur, int32_t *nxt, int32_t *gout, int w, int h, int n_next,
-                                               int wave, int lane) {
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for the wave's outstanding GLOBAL stores
+// (s_waitcnt vmcnt(0)): in the level loops below every level ends with final coefficients on their way to memory, and a
+// barrier that waits for their acknowledgement costs a store round trip (1.5-2 us) per level (measured with phase stamps:
+// 4.3 + 2.1 + 1.5 us for three LDS levels whose arithmetic is a few hundred cycles).  Nothing another wave reads goes
+// through memory here.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// Explicit address spaces for the "LDS or memory, by index" accesses of the level routines: left to the compiler they become
+// FLAT loads / stores (a select of two pointers), which tick both memory counters -- the next LDS wait (s_waitcnt lgkmcnt(0))
+// then also waits for every flat STORE on its way to memory, i.e. a store round trip per loop iteration.
+typedef __attribute__((address_space(3))) int32_t lds_i32_t;
+typedef __attribute__((address_space(1))) int32_t glb_i32_t;
+__device__ __forceinline__ int ld_lds(const int32_t *p) { return *(const lds_i32_t *)p; }
+__device__ __forceinline__ int ld_glb(const int32_t *p) { return *(const glb_i32_t *)p; }
+__device__ __forceinline__ void st_lds(int32_t *p, int v) { *(lds_i32_t *)p = v; }
+#ifdef J2K_DEEP_NOSTORE_TAIL
+__device__ __forceinline__ void st_glb(int32_t *p, int v) { }      // dev timing variant: results are wrong
+#else
+__device__ __forceinline__ void st_glb(int32_t *p, int v) { *(glb_i32_t *)p = v; }
+#endif
+
+// One forward level whose input lives in LDS (w <= 128, any h): cur, nxt: LDS; gout: memory.  A wave takes PER consecutive
+// pair-rows at a time (2 columns per lane), requests ALL the rows they need up front -- 2 PER + 3 rows: the pair-row above for
+// its d, the even row below -- and only then computes; the halo rows' horizontal pass is recomputed instead of exchanged
+// (LDS reads are cheap, a barrier per level is all that is left).  Round 2's version marched row by row with a wait per
+// LDS read and a branch per edge rule: 3.6 / 1.9 / 1.4 us for levels of 128 / 64 / 32 columns (phase stamps) against a few
+// hundred cycles of arithmetic.
+template <int PER>
+__device__ __forceinline__ void lds_fwd_level(const int32_t *cur, int32_t *nxt, int32_t *gout, int w, int h, int n_next,
+                                              int wave, int lane) {
     const int halfW = (w + 1) >> 1, halfH = (h + 1) >> 1;
     const int c = 2 * lane;
     const bool owned = c < w;
-    const int per = (halfH + TAIL_WAVES - 1) / TAIL_WAVES;
-    const int q0 = wave * per, q1 = min(q0 + per, halfH);
-    if (q0 >= q1) return;
-    auto load = [&](int r, int &lo, int &hi) {
-        int x[2];
-        x[0] = (c < w) ? cur[r * w + c] : 0;
-        x[1] = (c + 1 < w) ? cur[r * w + c + 1] : 0;
-        int l1[1], h1[1];
-        hfwd<2, true>(x, c, w, l1, h1);
-        lo = l1[0]; hi = h1[0];
-    };
+    constexpr int NROW = 2 * PER + 3;
     auto store = [&](int ro, int lo, int hi) {
         if (!owned) return;
         const int idxL = ro * w + lane, idxH = idxL + halfW;
-        if (lane < halfW) { if (idxL < n_next) nxt[idxL] = lo; else gout[idxL] = lo; }
-        if (lane < w - halfW) { if (idxH < n_next) nxt[idxH] = hi; else gout[idxH] = hi; }
+        if (lane < halfW) { if (idxL < n_next) st_lds(nxt + idxL, lo); else st_glb(gout + idxL, lo); }
+        if (lane < w - halfW) { if (idxH < n_next) st_lds(nxt + idxH, hi); else st_glb(gout + idxH, hi); }
     };
-    int ye_lo, ye_hi, dvp_lo = 0, dvp_hi = 0;
-    load(2 * q0, ye_lo, ye_hi);
-    if (h < 2) { if (q0 == 0) store(0, ye_lo, ye_hi); return; }
-    if (q0 > 0) {
-        int a_lo, a_hi, b_lo, b_hi;
-        load(2 * q0 - 2, a_lo, a_hi);
-        load(2 * q0 - 1, b_lo, b_hi);
-        dvp_lo = wsub(b_lo, avg1(a_lo, ye_lo));
-        dvp_hi = wsub(b_hi, avg1(a_hi, ye_hi));
+    const int c0 = owned ? c : 0, c1 = (c + 1 < w) ? c + 1 : 0;             // clamped: every lane reads a valid address
+    for (int qa = wave * PER; qa < halfH; qa += TAIL_WAVES * PER) {
+        int lo[NROW], hi[NROW];
+        {
+            int x[NROW][2];
+#pragma unroll
+            for (int i = 0; i < NROW; i++) {
+                const int r = min(max(2 * qa - 2 + i, 0), h - 1);
+                x[i][0] = ld_lds(cur + r * w + c0);
+                x[i][1] = ld_lds(cur + r * w + c1);
+            }
+#pragma unroll
+            for (int i = 0; i < NROW; i++) {
+                if (!owned) x[i][0] = 0;
+                if (c + 1 >= w) x[i][1] = 0;
+                int l1[1], h1[1];
+                hfwd<2, true>(x[i], c, w, l1, h1);
+                lo[i] = l1[0]; hi[i] = h1[0];
+            }
+        }
+        if (h < 2) { store(0, lo[2], hi[2]); return; }                       // dwt.go:74-76 down the columns: untouched
+        // d of the pair-row above (rows 2qa-2, 2qa-1 and 2qa all exist when qa > 0)
+        int dpl = wsub(lo[1], avg1(lo[0], lo[2])), dph = wsub(hi[1], avg1(hi[0], hi[2]));
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int q = qa + k;
+            if (q >= halfH) break;
+            const bool has_odd = 2 * q + 1 < h, has_next = 2 * q + 2 < h;
+            const int el = lo[2 + 2 * k], eh = hi[2 + 2 * k];
+            int dl = wsub(lo[3 + 2 * k], has_next ? avg1(el, lo[4 + 2 * k]) : el);
+            int dh = wsub(hi[3 + 2 * k], has_next ? avg1(eh, hi[4 + 2 * k]) : eh);
+            if (!has_odd) { dl = dpl; dh = dph; }                             // odd height, last row: its d mirrors d[n-2] (dwt.go:112-114)
+            const int pl = (q == 0) ? dl : dpl, ph = (q == 0) ? dh : dph;   // d[-1] mirrors d[0] (dwt.go:99)
+            store(q, wadd(el, avg2(pl, dl)), wadd(eh, avg2(ph, dh)));
+            if (has_odd) store(halfH + q, dl, dh);
+            dpl = dl; dph = dh;
+        }
     }
-    for (int q = q0; q < q1; q++) {
-        const int r1 = 2 * q + 1, r2 = 2 * q + 2;
-        const bool has_odd = r1 < h, has_next = r2 < h;
-        int yo_lo = 0, yo_hi = 0, yn_lo = 0, yn_hi = 0;
-        if (has_odd) load(r1, yo_lo, yo_hi);
-        if (has_next) load(r2, yn_lo, yn_hi);
-        int dl, dh;
-        if (has_odd) {
-            dl = wsub(yo_lo, has_next ? avg1(ye_lo, yn_lo) : ye_lo);
-            dh = wsub(yo_hi, has_next ? avg1(ye_hi, yn_hi) : ye_hi);
-        } else { dl = dvp_lo; dh = dvp_hi; }
-        const int pl = (q == 0) ? dl : dvp_lo, ph = (q == 0) ? dh : dvp_hi;
-        store(q, wadd(ye_lo, avg2(pl, dl)), wadd(ye_hi, avg2(ph, dh)));
-        if (has_odd) store(halfH + q, dl, dh);
-        dvp_lo = dl; dvp_hi = dh; ye_lo = yn_lo; ye_hi = yn_hi;
+}
+// The same for the shapes that matter (w even, w / 2 a divisor of 64, h >= 2: the levels of power-of-two tiles): lane = one
+// column PAIR, 64 / (w/2) bands side by side in a wave (the DPP shifts cross band boundaries, where the mirror rules
+// override them), 8-byte LDS reads, no clamps or width tests per element.  About a third of the general routine's
+// instructions; the deep workgroup's levels are bound by instruction issue on its one CU (16 waves, 4 per SIMD).
+typedef int tl_v2i __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) tl_v2i lds_tl_v2i_t;
+template <int PER>
+__device__ __forceinline__ void lds_fwd_level_fast(const int32_t *cur, int32_t *nxt, int32_t *gout, int w, int h, int n_next,
+                                                   int wave, int lane) {
+    const int HW = w >> 1, halfH = (h + 1) >> 1;
+    const int R = 64 / HW;                          // bands per wave
+    const int cp = lane & (HW - 1), g = lane / HW;
+    const bool first = cp == 0, last = cp == HW - 1;
+    constexpr int NROW = 2 * PER + 3;
+    auto store = [&](int idx, int v) { if (idx < n_next) st_lds(nxt + idx, v); else st_glb(gout + idx, v); };
+    for (int q0 = wave * R * PER; q0 < halfH; q0 += TAIL_WAVES * R * PER) {
+        const int qa = q0 + g * PER;
+        int lo[NROW], hi[NROW];
+        {
+            tl_v2i x[NROW];
+#pragma unroll
+            for (int i = 0; i < NROW; i++) x[i] = *(const lds_tl_v2i_t *)(cur + min(max(2 * qa - 2 + i, 0), h - 1) * w + 2 * cp);
+#pragma unroll
+            for (int i = 0; i < NROW; i++) {
+                const int xr = from_right(x[i].x);
+                const int d = wsub(x[i].y, last ? x[i].x : avg1(x[i].x, xr));
+                int dl = from_left(d);
+                if (first) dl = d;
+                lo[i] = wadd(x[i].x, avg2(dl, d));
+                hi[i] = d;
+            }
+        }
+        int dpl = wsub(lo[1], avg1(lo[0], lo[2])), dph = wsub(hi[1], avg1(hi[0], hi[2]));
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int q = qa + k;
+            const bool live = q < halfH, has_odd = 2 * q + 1 < h, has_next = 2 * q + 2 < h;
+            const int el = lo[2 + 2 * k], eh = hi[2 + 2 * k];
+            int dl = wsub(lo[3 + 2 * k], has_next ? avg1(el, lo[4 + 2 * k]) : el);
+            int dh = wsub(hi[3 + 2 * k], has_next ? avg1(eh, hi[4 + 2 * k]) : eh);
+            if (!has_odd) { dl = dpl; dh = dph; }
+            const int pl = (q == 0) ? dl : dpl, ph = (q == 0) ? dh : dph;
+            if (live) {
+                store(q * w + cp, wadd(el, avg2(pl, dl)));
+                store(q * w + HW + cp, wadd(eh, avg2(ph, dh)));
+                if (has_odd) { st_glb(gout + (halfH + q) * w + cp, dl); st_glb(gout + (halfH + q) * w + HW + cp, dh); }   // never in the prefix
+            }
+            dpl = dl; dph = dh;
+        }
     }
+}
+__device__ __forceinline__ bool tail_level_fast_shape(int w, int h) { return !(w & 1) && w >= 2 && w <= 128 && (64 % (w >> 1)) == 0 && h >= 2; }
+__device__ __forceinline__ void tail_fwd_level(const int32_t *cur, int32_t *nxt, int32_t *gout, int w, int h, int n_next,
+                                               int wave, int lane) {
+    const int halfH = (h + 1) >> 1;                  // uniform for the workgroup
+    if (tail_level_fast_shape(w, h)) {
+        const int per_band = (halfH + TAIL_WAVES * (128 / w) - 1) / (TAIL_WAVES * (128 / w));      // pair-rows per band if every band is used once
+        if (per_band > 2) lds_fwd_level_fast<4>(cur, nxt, gout, w, h, n_next, wave, lane);
+        else if (per_band > 1) lds_fwd_level_fast<2>(cur, nxt, gout, w, h, n_next, wave, lane);
+        else lds_fwd_level_fast<1>(cur, nxt, gout, w, h, n_next, wave, lane);
+        return;
+    }
+    if (halfH > 2 * TAIL_WAVES) lds_fwd_level<4>(cur, nxt, gout, w, h, n_next, wave, lane);
+    else if (halfH > TAIL_WAVES) lds_fwd_level<2>(cur, nxt, gout, w, h, n_next, wave, lane);
+    else lds_fwd_level<1>(cur, nxt, gout, w, h, n_next, wave, lane);
 }
 
 __global__ __launch_bounds__(64 * TAIL_WAVES) void dwt53_tail_fwd_kernel(const TailPlane *__restrict__ planes, const int32_t *__restrict__ scr,
@@ -913,62 +1008,151 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void dwt53_tail_fwd_kernel(const T
         const int wn = (w + 1) >> 1, hn = (h + 1) >> 1;
         const int n_next = (l == P.nlev - 1) ? 0 : wn * hn;
         tail_fwd_level(cur, nxt, gout, w, h, n_next, wave, lane);
-        __syncthreads();
+        lds_barrier();
         int32_t *t = cur; cur = nxt; nxt = t;
         w = wn; h = hn;
     }
 }
 
-__device__ __forceinline__ void tail_inv_level(const int32_t *prev, const int32_t *gcoef, int32_t *dst, int w, int h, int n_next,
-                                               int wave, int lane) {
+// One inverse level whose output fits LDS.  prev: LDS (the coarser level's result = elements below n_next); gcoef: the level's
+// coefficients, LDS (coef_lds) or memory; dst: LDS (dst_lds) or memory -- both flags uniform for the workgroup.  Same shape as
+// lds_fwd_level: a wave takes PER pair-rows at a time and requests all their rows first (low-pass rows q .. q+PER, high-pass
+// rows q-1 .. q+PER), then runs the vertical steps (dwt.go:132-146 down the columns) and the horizontal inverse of each row.
+template <int PER>
+__device__ __forceinline__ void lds_inv_level(const int32_t *prev, const int32_t *gcoef, int32_t *dst, int w, int h, int n_next,
+                                              int wave, int lane, bool coef_lds, bool dst_lds) {
     const int halfW = (w + 1) >> 1, halfH = (h + 1) >> 1, nhigh = h - halfH;
     const int c = 2 * lane;
     const bool owned = c < w;
-    const int per = (halfH + TAIL_WAVES - 1) / TAIL_WAVES;
-    const int q0 = wave * per, q1 = min(q0 + per, halfH);
-    if (q0 >= q1) return;
-    auto load = [&](int ri, int &lo, int &hi) {
-        const int idxL = ri * w + lane, idxH = idxL + halfW;
-        lo = (lane < halfW) ? ((idxL < n_next) ? prev[idxL] : gcoef[idxL]) : 0;
-        hi = (lane < w - halfW) ? ((idxH < n_next) ? prev[idxH] : gcoef[idxH]) : 0;
-    };
+    const int lL = (lane < halfW) ? lane : 0, lH = (lane < w - halfW) ? lane : 0;      // clamped: valid addresses for every lane
+    auto ld1 = [&](int idx) { return (idx < n_next) ? ld_lds(prev + idx) : (coef_lds ? ld_lds(gcoef + idx) : ld_glb(gcoef + idx)); };
     auto finish = [&](int ro, int lo, int hi) {
         int l1[1] = {lo}, h1[1] = {hi}, x[2];
         hinv<2>(l1, h1, c, w, x);
         if (!owned) return;
-        dst[ro * w + c] = x[0];
-        if (c + 1 < w) dst[ro * w + c + 1] = x[1];
+        if (dst_lds) { st_lds(dst + ro * w + c, x[0]); if (c + 1 < w) st_lds(dst + ro * w + c + 1, x[1]); }
+        else { st_glb(dst + ro * w + c, x[0]); if (c + 1 < w) st_glb(dst + ro * w + c + 1, x[1]); }
     };
-    if (h < 2) { if (q0 == 0) { int lo, hi; load(0, lo, hi); finish(0, lo, hi); } return; }
-    auto xe_of = [&](int q, int s_lo, int s_hi, int dp_lo, int dp_hi, int dc_lo, int dc_hi, int &xl, int &xh) {
-        const bool has_d = q < nhigh;
-        int a_lo = dp_lo, a_hi = dp_hi;
-        const int b_lo = has_d ? dc_lo : a_lo, b_hi = has_d ? dc_hi : a_hi;
-        if (q == 0) { a_lo = b_lo; a_hi = b_hi; }
-        xl = wsub(s_lo, avg2(a_lo, b_lo));
-        xh = wsub(s_hi, avg2(a_hi, b_hi));
-    };
-    int s_lo, s_hi, dc_lo = 0, dc_hi = 0, dp_lo = 0, dp_hi = 0, xe_lo, xe_hi;
-    load(q0, s_lo, s_hi);
-    if (q0 < nhigh) load(halfH + q0, dc_lo, dc_hi);
-    if (q0 > 0) load(halfH + q0 - 1, dp_lo, dp_hi);
-    xe_of(q0, s_lo, s_hi, dp_lo, dp_hi, dc_lo, dc_hi, xe_lo, xe_hi);
-    for (int q = q0; q < q1; q++) {
-        const bool has_d = q < nhigh, has_next = (q + 1) < halfH;
-        int sn_lo = 0, sn_hi = 0, dn_lo = 0, dn_hi = 0, xn_lo = 0, xn_hi = 0;
-        if (has_next) {
-            load(q + 1, sn_lo, sn_hi);
-            if (q + 1 < nhigh) load(halfH + q + 1, dn_lo, dn_hi);
-            xe_of(q + 1, sn_lo, sn_hi, dc_lo, dc_hi, dn_lo, dn_hi, xn_lo, xn_hi);
+    for (int qa = wave * PER; qa < halfH; qa += TAIL_WAVES * PER) {
+        int sl[PER + 1], sh[PER + 1], dl[PER + 2], dh[PER + 2];                  // s_{qa+k}, d_{qa-1+k}
+#pragma unroll
+        for (int k = 0; k <= PER; k++) {
+            const int row = min(qa + k, halfH - 1) * w;
+            sl[k] = ld1(row + lL); sh[k] = ld1(row + halfW + lH);
         }
-        finish(2 * q, xe_lo, xe_hi);
-        if (has_d) {
-            const int xo_lo = wadd(dc_lo, has_next ? avg1(xe_lo, xn_lo) : xe_lo);
-            const int xo_hi = wadd(dc_hi, has_next ? avg1(xe_hi, xn_hi) : xe_hi);
-            finish(2 * q + 1, xo_lo, xo_hi);
+#pragma unroll
+        for (int k = 0; k < PER + 2; k++) {
+            const int row = (halfH + min(max(qa - 1 + k, 0), max(nhigh - 1, 0))) * w;
+            dl[k] = (nhigh > 0) ? ld1(row + lL) : 0; dh[k] = (nhigh > 0) ? ld1(row + halfW + lH) : 0;
         }
-        xe_lo = xn_lo; xe_hi = xn_hi; dc_lo = dn_lo; dc_hi = dn_hi;
+        if (lane >= halfW) {
+#pragma unroll
+            for (int k = 0; k <= PER; k++) sl[k] = 0;
+#pragma unroll
+            for (int k = 0; k < PER + 2; k++) dl[k] = 0;
+        }
+        if (lane >= w - halfW) {
+#pragma unroll
+            for (int k = 0; k <= PER; k++) sh[k] = 0;
+#pragma unroll
+            for (int k = 0; k < PER + 2; k++) dh[k] = 0;
+        }
+        if (h < 2) { finish(0, sl[0], sh[0]); return; }
+        // undo update: e_q = s_q - ((d_{q-1} + d_q + 2) >> 2); d_{-1} := d_0; no d_q (odd height, last row): d_q := d_{q-1}
+        int el[PER + 1], eh[PER + 1];
+#pragma unroll
+        for (int k = 0; k <= PER; k++) {
+            const int q = qa + k;
+            const bool has_d = q < nhigh;
+            int al = dl[k], ah = dh[k];
+            const int bl = has_d ? dl[k + 1] : al, bh = has_d ? dh[k + 1] : ah;
+            if (q == 0) { al = bl; ah = bh; }
+            el[k] = wsub(sl[k], avg2(al, bl));
+            eh[k] = wsub(sh[k], avg2(ah, bh));
+        }
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int q = qa + k;
+            if (q >= halfH) break;
+            const bool has_next = q + 1 < halfH;
+            finish(2 * q, el[k], eh[k]);
+            if (q < nhigh)       // undo predict: o_q = d_q + ((e_q + e_{q+1}) >> 1); no e_{q+1}: o_q = d_q + e_q
+                finish(2 * q + 1, wadd(dl[k + 1], has_next ? avg1(el[k], el[k + 1]) : el[k]), wadd(dh[k + 1], has_next ? avg1(eh[k], eh[k + 1]) : eh[k]));
+        }
     }
+}
+// The fast shapes (see lds_fwd_level_fast): lane = column pair, several bands per wave, 8-byte stores of the finished rows.
+template <int PER>
+__device__ __forceinline__ void lds_inv_level_fast(const int32_t *prev, const int32_t *gcoef, int32_t *dst, int w, int h, int n_next,
+                                                   int wave, int lane, bool coef_lds, bool dst_lds) {
+    const int HW = w >> 1, halfH = (h + 1) >> 1, nhigh = h - halfH;       // h >= 2: nhigh >= 1
+    const int R = 64 / HW;
+    const int cp = lane & (HW - 1), g = lane / HW;
+    const bool first = cp == 0, last = cp == HW - 1;
+    auto ld1 = [&](int idx) { return (idx < n_next) ? ld_lds(prev + idx) : (coef_lds ? ld_lds(gcoef + idx) : ld_glb(gcoef + idx)); };
+    auto finish = [&](int ro, int lo, int hi) {
+        int dl = from_left(hi);
+        if (first) dl = hi;
+        const int e = wsub(lo, avg2(dl, hi));
+        const int er = from_right(e);
+        const int o = wadd(hi, last ? e : avg1(e, er));
+        return (tl_v2i){e, o};
+    };
+    auto put = [&](int ro, const tl_v2i &v) {
+        if (dst_lds) *(lds_tl_v2i_t *)(dst + ro * w + 2 * cp) = v;
+        else *(__attribute__((address_space(1))) tl_v2i *)(dst + ro * w + 2 * cp) = v;
+    };
+    for (int q0 = wave * R * PER; q0 < halfH; q0 += TAIL_WAVES * R * PER) {
+        const int qa = q0 + g * PER;
+        int sl[PER + 1], sh[PER + 1], dl[PER + 2], dh[PER + 2];
+#pragma unroll
+        for (int k = 0; k <= PER; k++) {
+            const int row = min(qa + k, halfH - 1) * w + cp;
+            sl[k] = ld1(row); sh[k] = ld1(row + HW);
+        }
+#pragma unroll
+        for (int k = 0; k < PER + 2; k++) {
+            const int row = (halfH + min(max(qa - 1 + k, 0), nhigh - 1)) * w + cp;
+            dl[k] = ld1(row); dh[k] = ld1(row + HW);
+        }
+        int el[PER + 1], eh[PER + 1];
+#pragma unroll
+        for (int k = 0; k <= PER; k++) {
+            const int q = qa + k;
+            const bool has_d = q < nhigh;
+            int al = dl[k], ah = dh[k];
+            const int bl = has_d ? dl[k + 1] : al, bh = has_d ? dh[k + 1] : ah;
+            if (q == 0) { al = bl; ah = bh; }
+            el[k] = wsub(sl[k], avg2(al, bl));
+            eh[k] = wsub(sh[k], avg2(ah, bh));
+        }
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int q = qa + k;
+            const bool has_next = q + 1 < halfH;
+            // (the DPP shifts inside finish() need every lane: compute first, store under the lane's own condition)
+            const tl_v2i re = finish(2 * q, el[k], eh[k]);
+            const tl_v2i ro = finish(2 * q + 1, wadd(dl[k + 1], has_next ? avg1(el[k], el[k + 1]) : el[k]), wadd(dh[k + 1], has_next ? avg1(eh[k], eh[k + 1]) : eh[k]));
+            if (q < halfH) {
+                put(2 * q, re);
+                if (q < nhigh) put(2 * q + 1, ro);
+            }
+        }
+    }
+}
+__device__ __forceinline__ void tail_inv_level(const int32_t *prev, const int32_t *gcoef, int32_t *dst, int w, int h, int n_next,
+                                               int wave, int lane, bool coef_lds, bool dst_lds) {
+    const int halfH = (h + 1) >> 1;
+    if (tail_level_fast_shape(w, h)) {
+        const int per_band = (halfH + TAIL_WAVES * (128 / w) - 1) / (TAIL_WAVES * (128 / w));
+        if (per_band > 2) lds_inv_level_fast<4>(prev, gcoef, dst, w, h, n_next, wave, lane, coef_lds, dst_lds);
+        else if (per_band > 1) lds_inv_level_fast<2>(prev, gcoef, dst, w, h, n_next, wave, lane, coef_lds, dst_lds);
+        else lds_inv_level_fast<1>(prev, gcoef, dst, w, h, n_next, wave, lane, coef_lds, dst_lds);
+        return;
+    }
+    if (halfH > 2 * TAIL_WAVES) lds_inv_level<4>(prev, gcoef, dst, w, h, n_next, wave, lane, coef_lds, dst_lds);
+    else if (halfH > TAIL_WAVES) lds_inv_level<2>(prev, gcoef, dst, w, h, n_next, wave, lane, coef_lds, dst_lds);
+    else lds_inv_level<1>(prev, gcoef, dst, w, h, n_next, wave, lane, coef_lds, dst_lds);
 }
 
 __global__ __launch_bounds__(64 * TAIL_WAVES) void dwt53_tail_inv_kernel(const TailPlane *__restrict__ planes, const int32_t *__restrict__ coef,
@@ -987,8 +1171,8 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void dwt53_tail_inv_kernel(const T
         const int n_next = (l == P.nlev - 1) ? 0 : ws[l + 1] * hs[l + 1];
         const int32_t *prev = ((l + 1) & 1) ? bufA : bufB;
         int32_t *dst = (l == 0) ? scr + P.scr_off : ((l & 1) ? bufA : bufB);
-        tail_inv_level(prev, gcoef, dst, ws[l], hs[l], n_next, wave, lane);
-        __syncthreads();
+        tail_inv_level(prev, gcoef, dst, ws[l], hs[l], n_next, wave, lane, false, l != 0);
+        lds_barrier();
     }
 }
 

@@ -472,7 +472,9 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
             if (w < 8 || w > 256 || (w % 4) || h < 2 || h > 256) { ok = false; break; }
             const int w1 = w / 2, h1 = (h + 1) / 2, w2 = (w1 + 1) / 2, h2 = (h1 + 1) / 2;
             if (w1 > 128 || (int64_t)w1 * h1 > 16384) { ok = false; break; }
-            lds = std::max(lds, (size_t)(2 * 16 * 64 * 4 + ((w1 * h1 + 3) & ~3) + ((w2 * h2 + 3) & ~3) + 8) * 4);
+            const size_t n1a = (size_t)((w1 * h1 + 3) & ~3), n2a = (size_t)((w2 * h2 + 3) & ~3), slots = 16 * 64 * 4;   // (ints)
+            lds = std::max(lds, (2 * slots + n1a + n2a + 8) * 4);                       // forward: slotE, slotD | bufA | bufB
+            lds = std::max(lds, (n1a + n2a + std::max(n1a, slots) + 8) * 4);            // inverse: bufA | bufB | bufC (= slotE later)
             for (int k = 0; k < g.nc; k++) {
                 const int64_t so = ((l0 & 1) ? g.scrA_off : g.scrB_off)[k];
                 if ((so % 4) || (g.coef_off[k] % 4)) ok = false;
@@ -487,6 +489,17 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
             }
         }
         if (ok && !tp.empty()) {
+            if (const char *e = getenv("J2K_DEEP_ORDER")) {           // dev: placement experiments (1: rows of 8 alternate deep / flat)
+                if (atoi(e) == 1) {
+                    std::vector<DwtJob> mix;
+                    size_t a = 0, b = 0;
+                    while (a < deep.size() || b < flat.size()) {
+                        for (int i = 0; i < 8 && a < deep.size(); i++) mix.push_back(deep[a++]);
+                        for (int i = 0; i < 8 && b < flat.size(); i++) mix.push_back(flat[b++]);
+                    }
+                    deep.swap(mix); flat.clear();
+                }
+            }
             deep.insert(deep.end(), flat.begin(), flat.end());
             P->deep_l0 = l0; P->ndeep_jobs = (int)deep.size(); P->deep_lds = lds;
             int r = upload(ctx, &P->d_deep_planes, tp);
