@@ -29,6 +29,7 @@ import bench_extra  # noqa: E402  (workload definitions, CPU baseline, the C3 / 
 W, H, C, TILE, NRES, CB, PREC = 3840, 2160, 3, 512, 6, 64, 8
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 SEED = 0x4A324B30              # "J2K0" 
+MIN_TIMED_S = 0.1              # floor of the timed region, whatever --steps says
 # sha256 of the int32 `decoded` buffer (every code-block of frame 0 as HTDecoder.Decode returns it, job order) -- what the
 # block decoder must have produced in the timed region; tests/test_bench_digest.py recomputes it with the oracle on CPU
 DECODED_SHA256 = "76eab55b1f63e2eb3644d138c6d655d4b16975c46310378f3f9f1bc509de7d5e"
@@ -363,6 +364,20 @@ def run(state):
     for _ in range(args.warmup):
         step()
     barrier()
+    # The timed region lasts at least MIN_TIMED_S whatever --steps says (a 20-step C2 run is 8 ms: thinner than a record
+    # should be): a few calibration steps, every rank takes the largest step count any rank needs, `steps` in the JSON line
+    # is the number actually timed and `steps_requested` the flag.
+    steps_requested = args.steps
+    tc = time.perf_counter()
+    for _ in range(5):
+        step()
+    barrier()
+    need = int(np.ceil(MIN_TIMED_S / max((time.perf_counter() - tc) / 5, 1e-6)))
+    if world > 1:
+        tn = torch.tensor([need], dtype=torch.int64, device=plan.device if os.environ.get("J2K_BENCH_BACKEND", "nccl") == "nccl" else "cpu")
+        dist.all_reduce(tn, op=dist.ReduceOp.MAX)
+        need = int(tn.item())
+    args.steps = max(args.steps, min(need, 20000))
     timed_profile = os.environ.get("J2K_BENCH_TIMED_PROFILE", "1") != "0"
     if timed_profile:
         ctx.profile_enable(True)
@@ -380,14 +395,16 @@ def run(state):
     # ---- roofline pass: the same step with ONE frame in flight, so the dominant kernel's duration is its own (with
     #      several frames in flight it shares the chip with the other frames' kernels) ----
     iso_launches, iso_ms = 0, 0.0
+    tags = [(0, 0.0)] * 4
     if rank == 0:
         for _ in range(3):
             lanes[0].code()
         ctx.sync()
-        ctx.profile_enable(True)
-        for _ in range(min(args.steps, 30)):
+        ctx.profile_enable(2)                     # every transform dispatch stamps its own begin / end, tagged by level group
+        for _ in range(30):
             lanes[0].code()
         ctx.sync()
+        tags = [ctx.profile_read_tag(t) for t in range(4)]   # forward level 0 / deeper levels, inverse level 0 / deeper levels
         iso_launches, iso_ms = ctx.profile_read()
         ctx.profile_enable(False)
     # ---- practical HBM roofline of this box ("measure a device-to-device copy ... and report both"):
@@ -457,10 +474,17 @@ def run(state):
         # level 0 moves 3 int32 planes in + 3 out (24 B/px) or, with packed pixels, one RGBA8 dword in + 3 int32 out (16 B/px)
         alg_bytes = int(info.dwt_level0_bytes) if args.io == "planes" else int(info.dwt_level0_bytes) * 16 // 24
         achieved = alg_bytes / k_avg_s / 1e9 if iso_launches else 0.0
+        # the WHOLE transform, each way: sum of the algorithmic bytes of every level (2 s w_l h_l per level and
+        # plane; level 0 with packed pixels 16 B/px) over the sum of the kernel durations of all its dispatches per frame
+        tr_bytes = int(info.dwt_bytes) - int(info.dwt_level0_bytes) + alg_bytes
+        nfr = max(iso_launches, 1)
+        us = [t[1] * 1e3 / nfr for t in tags]                 # per frame: fwd level 0, fwd deeper, inv level 0, inv deeper
+        def frac(b, t_us):
+            return round(b / (t_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if t_us > 0 else None
         out = {
             "metric": "Mpixels/s encode+decode (4K sRGB, 5-3 lossless)",
             "value": round((world * F - root_idle_all) * px / (dt / args.steps) / 1e6, 1),
-            "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "steps_requested": steps_requested, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 4), "host_issue_ms_per_step": round(dt_issue / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "3840x2160 sRGB 8-bit, 512x512 tiles, 5-3 lossless + HT block coder, 64x64 code-blocks, "
@@ -481,10 +505,17 @@ def run(state):
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": TRAFFIC[args.io][0],
                          "algorithmic_bytes_per_launch": alg_bytes,
+                         "inv_level0_frac": frac(alg_bytes, us[2]), "inv_level0_us": round(us[2], 2),
+                         "transform_fwd_frac": frac(tr_bytes, us[0] + us[1]), "transform_inv_frac": frac(tr_bytes, us[2] + us[3]),
+                         "transform_algorithmic_bytes": tr_bytes,
+                         "transform_fwd_us": [round(us[0], 2), round(us[1], 2)], "transform_inv_us": [round(us[2], 2), round(us[3], 2)],
+                         "transform_dispatches_per_frame": [round(t[0] / nfr, 2) for t in tags],
                          "avg_launch_us": round(k_avg_s * 1e6, 2), "launches_timed": int(iso_launches),
-                         "measured": "HIP start/stop events stamped by every level-0 dispatch on the library stream "
-                                     "(hipExtLaunchKernelGGL), in a pass with one frame in flight run right after the timed "
-                                     "region (same process, same buffers)",
+                         "measured": "HIP start/stop events stamped by every transform dispatch on the library stream "
+                                     "(hipExtLaunchKernelGGL), in a pass of 30 frames with one frame in flight run right after the "
+                                     "timed region (same process, same buffers, the whole pipeline running); frac = the level-0 "
+                                     "forward kernel, inv_level0_frac its inverse, transform_*_frac = all levels of one direction "
+                                     "(sum of algorithmic bytes / sum of kernel durations)",
                          "avg_launch_us_in_timed_region": round(k_conc_s * 1e6, 2), "launches_in_timed_region": int(launches),
                          "traffic_source": TRAFFIC[args.io][1],
                          "copy_gbs_measured": round(copy_gbs, 1) if copy_gbs else None,

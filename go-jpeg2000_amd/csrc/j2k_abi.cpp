@@ -127,6 +127,7 @@ extern "C" int j2k_ctx_create(int device, j2k_ctx **out) {
     if (const char *e = getenv("J2K_PLANE_WG")) { int v = atoi(e); if (v == 0 || v == 4 || v == 8) ctx->plane_wg = v; }
     if (const char *e = getenv("J2K_L0_FUSE")) { int v = atoi(e); if (v == 0 || v == 8 || v == 10 || v == 16) ctx->l0_fuse = v; }
     if (const char *e = getenv("J2K_L0_WG")) { int v = atoi(e); if (v == 0 || v == 4 || v == 8) ctx->l0_wg = v; }
+    if (const char *e = getenv("J2K_L0_WG_INVW")) { int v = atoi(e); if (v == 0 || v == 4 || v == 8) ctx->l0_wg_invw = v; }
     if (const char *e = getenv("J2K_PLANE_WG97")) { int v = atoi(e); if (v == 0 || v == 8) ctx->plane_wg97 = v; }
     if (const char *e = getenv("J2K_L0_WG97_INV")) { int v = atoi(e); if (v == 0 || v == 6 || v == 8 || v == 10 || v == 12) ctx->l0_wg97_inv = v; }
     if (const char *e = getenv("J2K_L0_WG97")) { int v = atoi(e); if (v == 0 || (v >= 6 && v <= 16 && v % 2 == 0)) ctx->l0_wg97 = v; }
@@ -705,27 +706,40 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                     for (size_t i = 0; i < planes.size() && wg_ok; i++)
                         if (pw[i] < 16 || pw[i] > 512 || (pw[i] % 8) || ph[i] < 2) wg_ok = false;
                     if (wg_ok) {
-                        std::vector<DwtJob> wj;
-                        const int nr = ctx->l0_wg - 1;
-                        for (size_t i = 0; i < planes.size(); i++)
-                            for (int pr = 0; pr < (ph[i] + 1) / 2; pr += nr) wj.push_back(DwtJob{(int)i, 0, pr, nr});
-                        if (ctx->l0_xcd && wj.size() >= 64 && ctx->l0_deal) {
-                            deal_xcd(wj, [&](const DwtJob &j) { return j.prow0 + nr > (ph[j.plane] + 1) / 2; });
-                        } else if (ctx->l0_xcd && wj.size() >= 64) {
-                            // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one), so
-                            // workgroup b takes job (b % 8) * chunk + b / 8: vertically adjacent bands -- which share three
-                            // halo rows -- run on one XCD at about the same time and the re-read is an L2 hit.  Speed only.
-                            const size_t chunk = (wj.size() + 7) / 8;
-                            std::vector<DwtJob> perm(chunk * 8, DwtJob{-1, 0, 0, 0});
-                            for (size_t b = 0; b < perm.size(); b++) {
-                                const size_t j = (b % 8) * chunk + b / 8;
-                                if (j < wj.size()) perm[b] = wj[j];
+                        // one table per direction: the forward kernel measures best with 8 waves per workgroup (7 pair-rows:
+                        // 3 halo rows per 14), the inverse with 4 (A/B on one box: forward 22.5-23.0 / 21.8-21.9 us at 4 / 8,
+                        // inverse 25.5 / 26.2)
+                        auto wg_table = [&](int waves) {
+                            std::vector<DwtJob> wj;
+                            const int nr = waves - 1;
+                            for (size_t i = 0; i < planes.size(); i++)
+                                for (int pr = 0; pr < (ph[i] + 1) / 2; pr += nr) wj.push_back(DwtJob{(int)i, 0, pr, nr});
+                            if (ctx->l0_xcd && wj.size() >= 64 && ctx->l0_deal) {
+                                deal_xcd(wj, [&](const DwtJob &j) { return j.prow0 + nr > (ph[j.plane] + 1) / 2; });
+                            } else if (ctx->l0_xcd && wj.size() >= 64) {
+                                // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one), so
+                                // workgroup b takes job (b % 8) * chunk + b / 8: vertically adjacent bands -- which share three
+                                // halo rows -- run on one XCD at about the same time and the re-read is an L2 hit.  Speed only.
+                                const size_t chunk = (wj.size() + 7) / 8;
+                                std::vector<DwtJob> perm(chunk * 8, DwtJob{-1, 0, 0, 0});
+                                for (size_t b = 0; b < perm.size(); b++) {
+                                    const size_t j = (b % 8) * chunk + b / 8;
+                                    if (j < wj.size()) perm[b] = wj[j];
+                                }
+                                wj.swap(perm);
                             }
-                            wj.swap(perm);
-                        }
+                            return wj;
+                        };
+                        std::vector<DwtJob> wj = wg_table(ctx->l0_wg);
                         P->fwd_wg_njobs = (int)wj.size();
                         P->fwd_wg_waves = ctx->l0_wg;
                         r = upload(ctx, &P->d_fwd_wg_jobs, wj);
+                        if (r != J2K_OK) { j2k_plan_destroy(P); return r; }
+                        const int invw = ctx->l0_wg_invw > 0 ? ctx->l0_wg_invw : ctx->l0_wg;
+                        std::vector<DwtJob> ij = wg_table(invw);
+                        P->inv_wg_njobs = (int)ij.size();
+                        P->inv_wg_waves = invw;
+                        r = upload(ctx, &P->d_inv_wg_jobs, ij);
                         if (r != J2K_OK) { j2k_plan_destroy(P); return r; }
                         // levels 0 + 1 in one launch (dwt53_fwd_rgba8_wg2_kernel): needs a level 1 (levels >= 2), only RGB
                         // triples in the frame (the level-1 plane table is then three planes per level-0 plane, same order)
@@ -915,7 +929,7 @@ extern "C" void j2k_plan_destroy(j2k_plan *P) {
         for (auto &T : P->fwd[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); if (T.d_pjobs) (void)hipFree(T.d_pjobs); }
         for (auto &T : P->inv[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); if (T.d_pjobs) (void)hipFree(T.d_pjobs); }
     }
-    void *ptrs[] = {P->d_deep_planes, P->d_deep_jobs, P->d_tile_job0, P->d_scrA, P->d_scrB, P->d_tail, P->d_bjobs, P->d_djobs, P->d_frame, P->d_coeff, P->d_slots, P->d_stream, P->d_lens, P->d_numbps, P->d_offs, P->d_status, P->d_fwd_pix_jobs, P->d_fwd_wg2_jobs, P->d_fwd_wg_rest_jobs, P->d_fwd_wg_jobs, P->d_fwd97_wg_jobs, P->d_inv97_wg_jobs, P->d_ht_ujobs, P->d_ht_alias_next, P->d_bjobs_alias, P->d_maglens, P->d_mels, P->d_toffs};
+    void *ptrs[] = {P->d_inv_wg_jobs, P->d_deep_planes, P->d_deep_jobs, P->d_tile_job0, P->d_scrA, P->d_scrB, P->d_tail, P->d_bjobs, P->d_djobs, P->d_frame, P->d_coeff, P->d_slots, P->d_stream, P->d_lens, P->d_numbps, P->d_offs, P->d_status, P->d_fwd_pix_jobs, P->d_fwd_wg2_jobs, P->d_fwd_wg_rest_jobs, P->d_fwd_wg_jobs, P->d_fwd97_wg_jobs, P->d_inv97_wg_jobs, P->d_ht_ujobs, P->d_ht_alias_next, P->d_bjobs_alias, P->d_maglens, P->d_mels, P->d_toffs};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete P;
 }
@@ -1088,10 +1102,10 @@ static int plan_inverse_impl(j2k_plan *P, const void *d_coeff, void *d_frame, in
             if (S.wavelet == W53) {
                 LevelLaunch L = mk(T);
                 if (l == 0 && cls == pix_cls) L.pix_stride = pix_stride;  // packed frame (j2k_plan_inverse_rgba8 / _pixels)
-                if (l == 0 && cls == 1 && pix_cls == 1 && pix_stride > 0 && P->d_fwd_wg_jobs && ctx->l0_wg_inv) {
+                if (l == 0 && cls == 1 && pix_cls == 1 && pix_stride > 0 && P->d_inv_wg_jobs && ctx->l0_wg_inv) {
                     // RGBA8: the workgroup form when every plane qualifies (same job table as the forward: the plane order
                     // of the inverse level table is the forward one)
-                    L.jobs = P->d_fwd_wg_jobs; L.njobs = P->fwd_wg_njobs; L.wg_waves = P->fwd_wg_waves; L.wg_store = ctx->l0_inv_wpe;
+                    L.jobs = P->d_inv_wg_jobs; L.njobs = P->inv_wg_njobs; L.wg_waves = P->inv_wg_waves; L.wg_store = ctx->l0_inv_wpe;
                 }
                 profile_pair(ctx, l == 0 ? 2 : 3, L.ev_start, L.ev_stop);
                 HIPCHK(ctx, launch_dwt53_inv(ctx->stream, L, (const int32_t *)d_coeff, (const int32_t *)prev, (int32_t *)dst,

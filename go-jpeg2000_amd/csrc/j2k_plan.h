@@ -17,7 +17,8 @@ struct j2k_ctx {
     bool plane_wg3 = false;    // ... also level 0 of RGB triples of int32 planes (J2K_PLANE_WG3; measured equal to the general kernel on 4K frames: 43 vs 41 us)
     int plane_wg = 4;          // single-component planes (every level > 0, gray level 0) in workgroup form: waves per workgroup (J2K_PLANE_WG: 0 off, 4, 8)
     int l0_fuse = 0;           // forward levels 0 + 1 of RGBA8 frames in one launch: waves per workgroup of the fused bands (J2K_L0_FUSE: 0 off, 8, 16)
-    int l0_wg = 4;             // packed RGBA8 level-0 forward, workgroup form: wavefronts per workgroup (J2K_L0_WG: 0 off, 4, 8)
+    int l0_wg = 8;             // packed RGBA8 level-0 forward, workgroup form: wavefronts per workgroup (J2K_L0_WG: 0 off, 4, 8)
+    int l0_wg_invw = 4;        // ... of the inverse (J2K_L0_WG_INVW: 0 = same as the forward, 4, 8)
     bool l0_deal = true;       // J2K_L0_DEAL (0 = one contiguous chunk per XCD): the RGBA8 level-0 job table deals each XCD's short bands after its full ones (as the 9-7 tables do)
     int l0_wg97 = 8;           // lossy level-0 forward of an RGB triple, workgroup form: waves per workgroup (J2K_L0_WG97: 0 off, 6..16 even; measured 4K: 8 -> 78 us, 16 -> 88 us, general kernel 160 us)
     int plane_wg97 = 8;        // deeper 9-7 levels (single float64 planes) in workgroup form: waves per workgroup (J2K_PLANE_WG97: 0 = general kernels, 8)
@@ -161,6 +162,8 @@ struct j2k_plan {
     int fwd_wg2_njobs = 0, fwd_wg2_waves = 0, fwd_wg_rest_njobs = 0;
     j2k::DwtJob *d_fwd_wg_jobs = nullptr;   // the same as one job per WORKGROUP (dwt53_fwd_rgba8_wg_kernel), when every plane qualifies
     int fwd_wg_njobs = 0, fwd_wg_waves = 0;
+    j2k::DwtJob *d_inv_wg_jobs = nullptr;   // the inverse kernel's table (its own waves per workgroup)
+    int inv_wg_njobs = 0, inv_wg_waves = 0;
     uint32_t *d_maglens = nullptr;          // j2k_plan_encode_stream: end of each block's MagSgn bytes (the MEL hole starts there)
     uint32_t *d_mels = nullptr;      // per job: bytes of MEL zero run of an HT block (max(64, 2wh) / 4), built with d_maglens
     const void *last_stream = nullptr, *last_lens = nullptr;   // outputs of the last j2k_plan_encode_stream: what d_maglens / d_toffs describe

@@ -40,7 +40,7 @@ class PlanInfo(C.Structure):
 # every symbol include/j2kgfx.h declares (tests/test_abi_symbols.py checks the header against this list)
 SYMBOLS = [
     "j2k_ctx_create", "j2k_ctx_destroy", "j2k_ctx_sync", "j2k_ctx_stream", "j2k_ctx_last_error",
-    "j2k_status_string", "j2k_version", "j2k_ctx_profile_enable", "j2k_ctx_profile_read",
+    "j2k_status_string", "j2k_version", "j2k_ctx_profile_enable", "j2k_ctx_profile_read", "j2k_ctx_profile_read_tag",
     "j2k_ctx_capture_begin", "j2k_ctx_capture_end", "j2k_graph_launch", "j2k_graph_destroy",
     "j2k_dc_level_shift_forward", "j2k_dc_level_shift_inverse", "j2k_forward_rct", "j2k_inverse_rct",
     "j2k_forward_ict", "j2k_inverse_ict",
@@ -95,6 +95,9 @@ def lib():
         L.j2k_ctx_destroy.argtypes = [C.c_void_p]
         L.j2k_ctx_destroy.restype = None
         L.j2k_ctx_sync.argtypes = [C.c_void_p]
+        L.j2k_ctx_profile_enable.argtypes = [C.c_void_p, C.c_int]
+        L.j2k_ctx_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+        L.j2k_ctx_profile_read_tag.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
         L.j2k_ctx_capture_begin.argtypes = [C.c_void_p]
         L.j2k_ctx_capture_end.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.j2k_graph_launch.argtypes = [C.c_void_p]

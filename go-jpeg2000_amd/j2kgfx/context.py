@@ -71,7 +71,15 @@ class Context:
         return _Capture(self)
 
     def profile_enable(self, on=True):
-        self.check(self.L.j2k_ctx_profile_enable(self.h, int(bool(on))))
+        """on: False / True (the forward level-0 dispatches) / 2 (every 5-3 transform dispatch, tagged)"""
+        self.check(self.L.j2k_ctx_profile_enable(self.h, int(on)))
+
+    def profile_read_tag(self, tag):
+        """(launches, total_ms) of the dispatches with this tag (0 forward level 0, 1 forward deeper levels, 2 inverse level 0,
+        3 inverse deeper levels) since the last profile_read / profile_enable; does not reset."""
+        n = C.c_int64(0); ms = C.c_double(0)
+        self.check(self.L.j2k_ctx_profile_read_tag(self.h, int(tag), C.byref(n), C.byref(ms)))
+        return n.value, ms.value
 
     def profile_read(self):
         """(launches, total_ms) of the level-0 DWT launches recorded since the last read."""

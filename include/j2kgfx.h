@@ -58,13 +58,15 @@ void *j2k_ctx_stream(j2k_ctx *ctx);             /* the hipStream_t, for event ti
 const char *j2k_ctx_last_error(j2k_ctx *ctx);   /* text of the last non-OK status */
 const char *j2k_status_string(int status);
 const char *j2k_version(void);
-/* Kernel timing for bench.py's roofline line: while enabled, every j2k_plan_forward has the
- * level-0 5-3 dispatch of its RGB triples stamp a HIP event pair with the kernel's own begin and
- * end (hipExtLaunchKernelGGL start/stop events on the ctx stream).  j2k_ctx_profile_read
- * synchronises, returns the number of recorded launches and their summed duration in ms, and
- * resets the counters. */
+/* Kernel timing for bench.py's roofline lines: while enabled, the dispatches of the 5-3 transform stamp a HIP event pair
+ * with the kernel's own begin and end (hipExtLaunchKernelGGL start/stop events on the ctx stream).  on = 1: the level-0
+ * dispatch of every j2k_plan_forward* only (tag 0; cheapest, used inside bench.py's timed region); on = 2: every
+ * dispatch of j2k_plan_forward* and j2k_plan_inverse*, tagged 0 = forward level 0, 1 = forward deeper levels, 2 = inverse
+ * level 0, 3 = inverse deeper levels.  j2k_ctx_profile_read_tag synchronises and returns the number of recorded dispatches
+ * with that tag and their summed duration in ms; j2k_ctx_profile_read does the same for tag 0 and resets the counters. */
 int j2k_ctx_profile_enable(j2k_ctx *ctx, int on);
 int j2k_ctx_profile_read(j2k_ctx *ctx, int64_t *launches, double *total_ms);
+int j2k_ctx_profile_read_tag(j2k_ctx *ctx, int tag, int64_t *launches, double *total_ms);
 
 /* HIP graphs (no counterpart in the reference: a launch-overhead facility of this boundary).  Between
  * capture_begin and capture_end the asynchronous device-pointer calls of this context (section 2: j2k_plan_forward*,
