@@ -9,13 +9,9 @@
 
 namespace j2k {
 
-// Go int32(float64): truncation; NaN and out-of-range values go through the 64-bit convert on amd64 (NaN -> MinInt64 -> 0)
-__device__ __forceinline__ int cs_int32(double v) {
-    if (v != v) return 0;
-    if (v > -2147483648.0 && v < 2147483648.0) return (int)v;
-    if (v >= 9223372036854775808.0 || v < -9223372036854775808.0) return 0;
-    return (int)(long long)v;
-}
+// Go int32(float64) on amd64 = CVTTSD2SL: truncation toward zero, 0x80000000 for NaN and for anything that does not fit
+// (v_cvt_i32_f64 saturates instead: right at the negative end, INT_MAX at the positive one, 0 for NaN)
+__device__ __forceinline__ int cs_int32(double v) { return v < 2147483648.0 ? (int)v : (int)0x80000000; }
 __device__ __forceinline__ int clamp_to_int32(double v, double lo, double hi) {      // colorspace.go:483-491
     if (v < lo) return cs_int32(lo);
     if (v > hi) return cs_int32(hi);

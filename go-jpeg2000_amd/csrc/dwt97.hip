@@ -44,11 +44,11 @@ __device__ __forceinline__ double dshift(double v, int ctrl_shr) {
 __device__ __forceinline__ double dleft(double v) { return dshift(v, 1); }    // lane i <- lane i-1
 __device__ __forceinline__ double dright(double v) { return dshift(v, 0); }   // lane i <- lane i+1
 
-// Go int32(float64): truncation toward zero; on amd64 out-of-range values go through a 64-bit convert
-__device__ __forceinline__ int go_int32(double v) {
-    if (v > -2147483648.0 && v < 2147483648.0) return (int)v;
-    return (int)(long long)v;
-}
+// Go int32(float64) on amd64: the compiler lowers it to CVTTSD2SL -- truncation toward zero, and the x86 "integer indefinite"
+// 0x80000000 for NaN and every value whose truncation does not fit.  v_cvt_i32_f64 saturates: the same at the negative end,
+// INT_MAX at the positive one, 0 for NaN -- one comparison puts those right.  (Round 2 had a 64-bit convert + truncation
+// here; the oracle's plain C casts compile to CVTTSD2SI r32 like Go's, and the new out-of-range test showed the difference.)
+__device__ __forceinline__ int go_int32(double v) { return v < 2147483648.0 ? (int)v : (int)0x80000000; }
 __device__ __forceinline__ int round_half_away(double v) { return v >= 0 ? go_int32(v + 0.5) : go_int32(v - 0.5); }
 
 enum { SRC_I32 = 0, SRC_F64 = 1 };

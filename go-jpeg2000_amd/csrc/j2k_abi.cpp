@@ -1447,6 +1447,10 @@ extern "C" int j2k_plan_encode_stream(j2k_plan *P, const int32_t *d_coeff, uint8
     const int n = (int)P->blocks.size();
     if (!n) { HIPCHK(ctx, hipMemsetAsync(d_offs, 0, 8, ctx->stream)); return J2K_OK; }
     bool fused = P->spec.coder == J2K_CODER_HT && ctx->fuse_compact;
+    // The one-kernel path tags its look-back status words with a launch epoch that is a KERNEL ARGUMENT: a captured launch
+    // would replay the same tag, read the previous replay's words as valid and place blocks at stale offsets.
+    if (fused && ctx->capturing)
+        return fail(ctx, J2K_ERR_UNSUPPORTED, "capture: the one-kernel HT path (J2K_FUSE_COMPACT=1) cannot be replayed from a graph -- unset it");
     if (fused && !P->d_status) {
         P->all_blocks_fast = true;
         for (const j2k_block &b : P->blocks)

@@ -13,6 +13,7 @@ from . import _lib
 # __del__ does nothing once the interpreter is finalizing.
 _live_contexts = weakref.WeakSet()
 _live_plans = weakref.WeakSet()
+_live_graphs = weakref.WeakSet()
 
 
 def register_plan(plan):
@@ -21,6 +22,11 @@ def register_plan(plan):
 
 @atexit.register
 def _close_all():
+    for g in list(_live_graphs):          # graphs first: they hold a pointer to their context
+        try:
+            g.close()
+        except Exception:
+            pass
     for p in list(_live_plans):
         try:
             p.close()
@@ -44,6 +50,9 @@ class Context:
         self.device = int(device)
         self.L = L
         self._held = []          # tensors in use by work queued on this context's stream (FramePlan stage calls)
+        self._capturing = False
+        self._ext = None
+        self._graphs = weakref.WeakSet()     # closed with the context: a j2k_graph keeps a pointer to its j2k_ctx
         _live_contexts.add(self)
 
     def check(self, st):
@@ -54,8 +63,8 @@ class Context:
     def hold(self, t):
         """Keep `t` alive until the next sync(): kernels queued on the library stream may still read or write it."""
         self._held.append(t)
-        if len(self._held) > 8192:           # a caller that never synchronises: do it for them rather than grow for ever
-            self.sync()
+        if len(self._held) > 8192 and not self._capturing:   # a caller that never synchronises: do it for them rather than grow
+            self.sync()                                      # for ever (not while capturing: a synchronising call fails there)
 
     def sync(self):
         try:
@@ -93,6 +102,8 @@ class Context:
 
     def close(self):
         if self.h:
+            for g in list(self._graphs):
+                g.close()
             try:
                 self.L.j2k_ctx_sync(self.h)      # drain the stream before its buffers and the stream itself go away
             finally:
@@ -124,8 +135,20 @@ class Graph:
 
     def __init__(self, ctx, handle, held):
         self.ctx, self.h, self._held = ctx, handle, held
+        _live_graphs.add(self)
+        ctx._graphs.add(self)
 
     def launch(self):
+        """Replay on the context's stream.  Ordering contract: the replay is ordered behind everything queued so far on torch's
+        CURRENT stream of the context's device (e.g. a frame.copy_(new) just before) -- the wait that the stage calls issue
+        when they run directly is not part of the recorded graph -- and behind earlier work on the context's own stream.
+        Results are ready after ctx.sync().  Raises once the context or the graph has been closed."""
+        if self.h is None or self.ctx.h is None:
+            raise _lib.J2KError(_lib.ERR_INVALID_ARG, "graph launch after the graph or its context was closed")
+        import torch
+        if self.ctx._ext is None:
+            self.ctx._ext = torch.cuda.ExternalStream(int(self.ctx.stream), device=torch.device("cuda", self.ctx.device))
+        self.ctx._ext.wait_stream(torch.cuda.current_stream(self.ctx.device))
         self.ctx.check(self.ctx.L.j2k_graph_launch(self.h))
 
     def close(self):
@@ -150,10 +173,12 @@ class _Capture:
     def __enter__(self):
         self.mark = len(self.ctx._held)
         self.ctx.check(self.ctx.L.j2k_ctx_capture_begin(self.ctx.h))
+        self.ctx._capturing = True
         return self.graph
 
     def __exit__(self, et, ev, tb):
         h = C.c_void_p()
+        self.ctx._capturing = False
         rc = self.ctx.L.j2k_ctx_capture_end(self.ctx.h, C.byref(h))
         if et is None:
             self.ctx.check(rc)

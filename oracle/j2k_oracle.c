@@ -283,8 +283,17 @@ void orc_reconstruct97(double *d, int w, int h, int levels) {         /* dwt.go:
 /* caller glue                                                               */
 /* ======================================================================== */
 
+/* Go's int32(float64), amd64: the compiler lowers the conversion (SSA op Cvt64Fto32) to CVTTSD2SL -- truncation toward zero,
+ * and the x86 "integer indefinite" 0x80000000 for NaN and for every value whose truncation does not fit int32.  (Round 2
+ * believed in a 64-bit convert + truncation there and restated that in cs_go_int32 and in the product's go_int32, while the
+ * plain C casts of this file happened to compile to the same CVTTSD2SI r32 as Go's: two answers for one conversion.  A plain
+ * cast of an out-of-range double is undefined in C, so it is spelled out now, once, for every conversion of this path.)
+ * A value in (-2^31 - 1, -2^31] truncates to -2^31, which is the indefinite value anyway: one comparison is enough. */
+static int32_t go_int32(double v) {
+    return (v < 2147483648.0 && v > -2147483649.0) ? (int32_t)v : INT32_MIN;     /* NaN: both comparisons false */
+}
 static int32_t round_half_away(double v) {       /* encoder.go:238-242, tcd.go:527-531 */
-    return v >= 0 ? (int32_t)(v + 0.5) : (int32_t)(v - 0.5);
+    return v >= 0 ? go_int32(v + 0.5) : go_int32(v - 0.5);
 }
 
 void orc_preprocess(int32_t **planes, int ncomp, int w, int h, int precision,
@@ -321,7 +330,7 @@ void orc_preprocess(int32_t **planes, int ncomp, int w, int h, int precision,
             double step = 1.0 / (double)q;
             for (size_t i = 0; i < n; i++) {
                 double v = f[i];
-                planes[c][i] = v >= 0 ? (int32_t)(v / step + 0.5) : (int32_t)(v / step - 0.5);
+                planes[c][i] = v >= 0 ? go_int32(v / step + 0.5) : go_int32(v / step - 0.5);
             }
             free(f);
         }
@@ -344,17 +353,12 @@ void orc_tcd_inverse_dwt(int32_t *d, int w, int h, int levels, int reversible) {
     double *f = (double *)malloc(n * sizeof(double));
     for (size_t i = 0; i < n; i++) f[i] = (double)d[i];
     orc_reconstruct97(f, w, h, levels);
-    for (size_t i = 0; i < n; i++) d[i] = (int32_t)(f[i] + 0.5);      /* trunc: negatives round toward + */
+    for (size_t i = 0; i < n; i++) d[i] = go_int32(f[i] + 0.5);       /* trunc: negatives round toward + */
     free(f);
 }
 
 /* ---- colorspace.go:54-501 ---------------------------------------------------------------------- */
-static int32_t cs_go_int32(double v) {                               /* Go int32(float64) on amd64 */
-    if (v != v) return 0;
-    if (v > -2147483648.0 && v < 2147483648.0) return (int32_t)v;
-    if (v >= 9223372036854775808.0 || v < -9223372036854775808.0) return 0;
-    return (int32_t)(int64_t)v;
-}
+static int32_t cs_go_int32(double v) { return go_int32(v); }       /* Go int32(float64) on amd64: see go_int32 */
 static int32_t cs_clamp_to_int32(double v, double lo, double hi) {   /* colorspace.go:483-491 */
     if (v < lo) return cs_go_int32(lo);
     if (v > hi) return cs_go_int32(hi);
@@ -556,7 +560,7 @@ void orc_postprocess(int32_t **planes, int ncomp, size_t n, int precision,
             }
             orc_ict_inv(f[0], f[1], f[2], n);
             for (int c = 0; c < 3; c++) {
-                for (size_t i = 0; i < n; i++) planes[c][i] = (int32_t)(f[c][i] + 0.5);
+                for (size_t i = 0; i < n; i++) planes[c][i] = go_int32(f[c][i] + 0.5);
                 free(f[c]);
             }
         }

@@ -74,3 +74,77 @@ def test_capture_refuses_calls_that_would_allocate():
             _run(p, frame, b)                                 # never run before: the encoder's slot buffer does not exist yet
     _run(p, frame, b)                                         # the context is usable afterwards
     ctx.sync()
+
+
+def test_capture_refuses_the_one_kernel_ht_path():
+    """with J2K_FUSE_COMPACT=1 the look-back epoch is a kernel argument, so a replay would reuse the previous
+    replay's status words -- the capture is refused (and the direct calls keep working)."""
+    import os
+    import torch
+    from j2kgfx import Context, J2KError
+    from j2kgfx.codec import FramePlan
+    old = os.environ.get("J2K_FUSE_COMPACT")
+    os.environ["J2K_FUSE_COMPACT"] = "1"
+    try:
+        ctx = Context(0)
+    finally:
+        if old is None:
+            os.environ.pop("J2K_FUSE_COMPACT", None)
+        else:
+            os.environ["J2K_FUSE_COMPACT"] = old
+    p = FramePlan(256, 256, 3, ctx=ctx, precision=8, lossless=True, num_resolutions=4, cb=(64, 64), coder=1)
+    b = _buffers(p, torch)
+    rng = np.random.default_rng(3)
+    frame = torch.from_numpy(rng.integers(0, 256, (3, 256, 256)).astype(np.int32)).to(p.device)
+    _run(p, frame, b)
+    ctx.sync()
+    ref = b["stream"].clone()
+    with pytest.raises(J2KError):
+        with ctx.capture():
+            _run(p, frame, b)
+    _run(p, frame, b)
+    ctx.sync()
+    n = b["n"]
+    assert torch.equal(b["stream"][:int(b["offs"][n].item())], ref[:int(b["offs"][n].item())])
+
+
+def test_graph_launch_is_ordered_behind_the_current_stream_and_refuses_a_closed_context():
+    """g.launch() right after frame.copy_(new) WITHOUT a device synchronisation must see the new frame (the launch
+    orders the library stream behind torch's current stream); after ctx.close() a launch raises instead of touching a freed
+    context."""
+    import torch
+    from j2kgfx import Context, J2KError
+    from j2kgfx.codec import FramePlan
+    W = H = 512
+    rng = np.random.default_rng(9)
+    ctx = Context(0)
+    p = FramePlan(W, H, 3, ctx=ctx, precision=8, lossless=True, num_resolutions=5, cb=(64, 64), coder=1)
+    b = _buffers(p, torch)
+    frames = [torch.from_numpy(rng.integers(0, 256, (3, H, W)).astype(np.int32)).to(p.device) for _ in range(4)]
+    frame = frames[0].clone()
+    _run(p, frame, b)
+    ctx.sync()
+    with ctx.capture() as g:
+        _run(p, frame, b)
+    for f in frames[1:]:
+        frame.copy_(f)                                        # queued on torch's current stream; no synchronize here
+        g.launch()
+        ctx.sync()
+        assert torch.equal(b["back"], f)                      # lossless: the replay saw the new contents
+    ctx.close()
+    with pytest.raises(J2KError):
+        g.launch()
+
+
+def test_interpreter_exit_with_live_plans_is_clean():
+    """a process that exits with plans / contexts / queued work alive (tools/dbg/exit_order.py: SystemExit(3), nothing
+    closed) must leave with that exit code and no abort text -- the package's atexit hook closes graphs, plans, contexts in
+    that order while torch and the HIP runtime are still up."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "dbg", "exit_order.py")], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 3, (out.returncode, out.stderr[-2000:])
+    for bad in ("terminate called", "bad_variant_access", "Segmentation", "core dumped", "Aborted"):
+        assert bad not in out.stderr, out.stderr[-2000:]

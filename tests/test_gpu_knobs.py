@@ -72,6 +72,33 @@ def test_lossy_level0_knobs(wg):
     assert torch.equal(res[0], res[1])
 
 
+@pytest.mark.parametrize("quality", [75, 8000])
+@pytest.mark.parametrize("wg", [8, 12])
+def test_lossy_level0_samples_outside_the_precision(oracle, wg, quality):
+    """j2k_plan_forward takes arbitrary int32 planes, and the 9-7 workgroup kernel's fast conversions (v_cvt_i32_f64
+    saturates, Go's int32(float64) does not) are only proved for samples inside the declared precision.  Rows with samples
+    outside -- up to the full int32 range, where the ICT rounding and the quantiser leave int32 -- must come out as the
+    general kernel (go_int32) and the oracle give them; rows inside keep the fast path in the same frame."""
+    import torch
+    from j2kgfx.codec import FramePlan
+    W, H = 512, 96
+    rng = np.random.default_rng(quality + wg)
+    frame_h = rng.integers(0, 4096, size=(3, H, W)).astype(np.int32)
+    frame_h[:, 10:13, :] = rng.integers(-2 ** 31, 2 ** 31, size=(3, 3, W), dtype=np.int64).astype(np.int32)   # rows far outside 12 bits
+    frame_h[1, 40, 100:108] = [2 ** 31 - 1, -2 ** 31, 2 ** 31 - 1, 4096, -1, 2 ** 30, -2 ** 30, 65536]
+    frame_h[:, 70, :] = 2 ** 31 - 1                                                                       # y + 0.5 lands on 2^31 exactly
+    kw = dict(precision=12, lossless=False, quality=quality, num_resolutions=3, cb=(64, 64), tile=(0, 0), coder=0)
+    res = []
+    for ctx in (_ctx({"J2K_L0_WG97": 0}), _ctx({"J2K_L0_WG97": wg})):
+        plan = FramePlan(W, H, 3, ctx=ctx, **kw)
+        coeff = plan.forward(torch.from_numpy(frame_h).to(plan.device))
+        ctx.sync()
+        res.append(coeff.cpu())
+    assert torch.equal(res[0], res[1])
+    want = oracle.preprocess([frame_h[c] for c in range(3)], W, H, 12, False, 3, quality)
+    assert np.array_equal(res[1].numpy().reshape(3, H, W), np.stack(want))
+
+
 @pytest.mark.parametrize("W,H,tile,nres", [(1024, 600, (512, 512), 6), (512, 77, (0, 0), 3), (64, 3, (0, 0), 2), (16, 2, (0, 0), 2),
                                            (520, 131, (256, 128), 4), (128, 64, (0, 0), 1), (256, 2048, (0, 0), 6)])
 @pytest.mark.parametrize("wg", [6, 8, 12])
