@@ -65,6 +65,11 @@ def run(state):
                     help="frame format at the boundary: packed 8-bit RGBA pixels (image.RGBA.Pix) read / written directly by "
                          "the level-0 kernels (extractImageData / createImage fused, SURVEY 8f rank 2; the default), or "
                          "int32 component planes (e.componentData, the boundary of SURVEY 8a-e)")
+    ap.add_argument("--decode-rows", choices=["coded", "all"], default=os.environ.get("J2K_BENCH_DECODE_ROWS", "coded"),
+                    help="HT block decode: 'coded' = j2k_plan_set_decode_coded_rows_only -- the rows the reference's decoder never "
+                         "writes are left alone in a buffer zeroed once before the run (the pooled HTDecoder, ht.go:1393-1429); "
+                         "'all' = every call writes all w x h samples of every block (a fresh NewHTDecoder).  Same buffer contents, "
+                         "same digest, either way")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("J2K_BENCH_INFLIGHT", "3")),
                     help="independent frames coded concurrently per step, each on its own context/stream")
     ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c2",
@@ -154,6 +159,8 @@ def run(state):
             self.offss = [p.empty(self.n + 1, torch.int64) for _ in range(nb)]
             self.stream, self.lens, self.numbps, self.offs = self.streams[0], self.lenss[0], self.numbpss[0], self.offss[0]
             self.decoded = torch.zeros(max(int(i.decoded_elems), 4), dtype=torch.int32, device=p.device)   # (padding between blocks stays 0: digest)
+            if args.decode_rows == "coded":
+                p.set_decode_coded_rows_only(True)     # `decoded` was zeroed just above, once: the uncoded rows stay zero
             self.back = p.alloc_frame()
             self.gather_bufs = [None] * nb
             # N > 1: what travels is the transport form of the stream (j2k_plan_pack_stream: the blocks without the
@@ -498,6 +505,8 @@ def run(state):
                        "decoded_sha256": decoded_sha,
                        "tiles": int(info.tiles), "code_blocks": n, "compressed_bytes_per_frame": total_bytes,
                        "frames_in_flight": F, "frames_in_flight_rank0": F - root_idle_all, "frame_io": args.io,
+                       "decode_rows": args.decode_rows + (" (the rows the reference's HT decoder never writes are not re-zeroed on every call: the "
+                                                          "buffer was zeroed once, as a pooled HTDecoder's slice is; digest unchanged)" if args.decode_rows == "coded" else ""),
                        "parallelism": "frames/rank" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm",
                          "kernel": ("dwt53_fwd_rgba8_wg_kernel (level 0: RGBA8 unpack + DC shift + RCT + 5-3 lifting, fused)" if args.io == "rgba8"

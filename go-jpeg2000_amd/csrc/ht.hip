@@ -1500,7 +1500,7 @@ __device__ bool ht_extract_fast(HtDecShared &S, const uint8_t *__restrict__ data
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void ht_decode_kernel(const BlockJob *__restrict__ jobs, int njobs,
                                                         const uint8_t *__restrict__ stream, const uint64_t *__restrict__ offs,
                                                         const uint32_t *__restrict__ lens, int32_t *__restrict__ decoded,
-                                                        const uint32_t *__restrict__ pairs) {
+                                                        const uint32_t *__restrict__ pairs, int coded_rows_only) {
     __shared__ HtDecShared S4[4];
     HtDecShared &S = S4[threadIdx.x >> 6];
     const int jid = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1525,7 +1525,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     // stores would wait for all of them).  Other paths zero everything up front.
     // (row index kept incrementally: a 64-bit i / wq per iteration costs ~150 VALU instructions and made this
     //  loop the most expensive part of the kernel)
+    // coded_rows_only (j2k_plan_set_decode_coded_rows_only): the rows the reference's decoder never writes (y % 4 != 0,
+    // SURVEY fact 3 / row a16) are not written here either -- the caller owns a buffer it zeroed once, as a POOLED
+    // HTDecoder's data slice is (ht.go:1393-1429: GetHTDecoder hands back a decoder whose slice is not cleared on the
+    // normal path) -- so three quarters of this kernel's store stream disappear.  The coded rows are always written in
+    // full, zeros included.
     auto zero_fill = [&](bool skip_coded) {
+        if (coded_rows_only) {
+            if (skip_coded) return;                              // fast path: nothing but the coded rows, which the extraction writes
+            // other paths: zero the coded rows, which the serial decoder (or nobody: invalid stream) then writes
+            const uint32_t uw = (uint32_t)w, nrow = (uint32_t)(h + 3) >> 2;
+            for (uint32_t i = lane; i < uw * nrow; i += 64) out[(size_t)(i / uw) * 4 * uw + i % uw] = 0;
+            return;
+        }
         if (w == 64 && (J.out_off & 3) == 0) {
             // 16 quads per row: the 64 lanes cover four rows per step, lanes 0..15 always the coded one
             if (skip_coded && lane < 16) return;
@@ -1770,7 +1782,7 @@ int ht_fast_max_samples() { return HT_FAST_MAX_SAMPLES; }
 size_t ht_decode_scratch_words(int njobs) { return (size_t)njobs * (HT_WALK_REC + HT_VBITS_WORDS); }
 
 hipError_t launch_ht_decode(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs,
-                            const uint32_t *lens, int32_t *decoded, uint32_t *scratch) {
+                            const uint32_t *lens, int32_t *decoded, uint32_t *scratch, int coded_rows_only) {
     if (njobs <= 0) return hipSuccess;
     hipError_t e;
     if ((e = ht_tables_ready(s)) != hipSuccess) return e;
@@ -1782,7 +1794,7 @@ hipError_t launch_ht_decode(hipStream_t s, const BlockJob *jobs, int njobs, cons
     hipLaunchKernelGGL(ht_walk_kernel, dim3((njobs + HT_WALK_BLOCKS - 1) / HT_WALK_BLOCKS), dim3(256), sizeof(HtWalkShared), s, jobs, njobs, vbits, pairs);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     for (int rep_ = 0; rep_ < dev_reps(128); rep_++)
-    hipLaunchKernelGGL(ht_decode_kernel, dim3((njobs + 3) / 4), dim3(256), 0, s, jobs, njobs, stream, offs, lens, decoded, pairs);
+    hipLaunchKernelGGL(ht_decode_kernel, dim3((njobs + 3) / 4), dim3(256), 0, s, jobs, njobs, stream, offs, lens, decoded, pairs, coded_rows_only);
     return hipGetLastError();
 }
 

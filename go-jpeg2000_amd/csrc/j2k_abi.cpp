@@ -29,7 +29,7 @@ hipError_t launch_ht_encode(hipStream_t s, const BlockJob *jobs, int njobs, cons
                             uint32_t *lens, uint8_t *numbps, int *fault, uint32_t *maglens = nullptr, const HtUJob *utab = nullptr, int nunique = 0,
                             const int *alias_ids = nullptr);
 hipError_t launch_ht_decode(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs,
-                            const uint32_t *lens, int32_t *decoded, uint32_t *scratch);
+                            const uint32_t *lens, int32_t *decoded, uint32_t *scratch, int coded_rows_only = 0);
 size_t ht_decode_scratch_words(int njobs);
 hipError_t launch_ht_encode_stream(hipStream_t s, const BlockJob *jobs, int njobs, const int32_t *coef, uint8_t *stream,
                                    uint64_t *offs, uint32_t *lens, uint8_t *numbps, uint64_t *status, uint32_t epoch, int *fault);
@@ -1584,6 +1584,12 @@ extern "C" int j2k_plan_compact(j2k_plan *P, const uint8_t *d_slots, const uint3
     return J2K_OK;
 }
 
+extern "C" int j2k_plan_set_decode_coded_rows_only(j2k_plan *P, int on) {
+    if (!P) return J2K_ERR_INVALID_ARG;
+    P->dec_coded_rows_only = on != 0;
+    return J2K_OK;
+}
+
 extern "C" int j2k_plan_decode_blocks(j2k_plan *P, const uint8_t *d_stream, const uint64_t *d_offs, const uint32_t *d_lens,
                                       const uint8_t *d_numbps, int32_t *d_decoded) {
     if (!P || !d_stream || !d_offs || !d_lens || !d_numbps || !d_decoded) return J2K_ERR_INVALID_ARG;
@@ -1594,7 +1600,8 @@ extern "C" int j2k_plan_decode_blocks(j2k_plan *P, const uint8_t *d_stream, cons
     if (P->spec.coder == J2K_CODER_HT) {
         int r = stage_reserve(ctx, 2, ht_decode_scratch_words(n) * 4 + 256);
         if (r != J2K_OK) return r;
-        HIPCHK(ctx, launch_ht_decode(ctx->stream, P->d_djobs, n, d_stream, d_offs, d_lens, d_decoded, (uint32_t *)ctx->stage[2]));
+        HIPCHK(ctx, launch_ht_decode(ctx->stream, P->d_djobs, n, d_stream, d_offs, d_lens, d_decoded, (uint32_t *)ctx->stage[2],
+                                     P->dec_coded_rows_only ? 1 : 0));
     } else {
         size_t wpj = 0;                                  // the one-block decoder's workspace holds the flags only
         int max_dim = 0;

@@ -172,4 +172,5 @@ struct j2k_plan {
     uint64_t *d_status = nullptr;
     uint32_t epoch = 0;
     bool all_blocks_fast = false;           // every job on the parallel HT path
+    bool dec_coded_rows_only = false;       // j2k_plan_set_decode_coded_rows_only: HT decode leaves the rows the reference's decoder never writes alone
 };

@@ -50,7 +50,7 @@ SYMBOLS = [
     "j2k_decompose_multilevel97", "j2k_reconstruct_multilevel97",
     "j2k_tcd_apply_forward_dwt", "j2k_tcd_apply_inverse_dwt",
     "j2k_encode_blocks", "j2k_decode_blocks", "j2k_block_bound",
-    "j2k_plan_create", "j2k_plan_destroy", "j2k_plan_get_info", "j2k_plan_get_blocks", "j2k_plan_get_planes",
+    "j2k_plan_set_decode_coded_rows_only", "j2k_plan_create", "j2k_plan_destroy", "j2k_plan_get_info", "j2k_plan_get_blocks", "j2k_plan_get_planes",
     "j2k_plan_forward", "j2k_plan_inverse", "j2k_plan_encode_blocks", "j2k_plan_compact", "j2k_plan_encode_stream",
     "j2k_plan_decode_blocks", "j2k_plan_get_decoded_offsets", "j2k_encode_frame",
     "j2k_mq_encode", "j2k_mq_decode", "j2k_raw_encode", "j2k_raw_decode",

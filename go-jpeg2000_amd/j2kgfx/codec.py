@@ -165,6 +165,11 @@ class FramePlan:
                                                          self._p(numbps)))
         return slots, lens, numbps
 
+    def set_decode_coded_rows_only(self, on=True):
+        """HT coder: decode_blocks leaves the rows the reference's decoder never writes (y % 4 != 0) untouched -- the pooled
+        HTDecoder's behaviour; the caller owns a buffer it zeroed once (j2k_plan_set_decode_coded_rows_only)."""
+        self.ctx.check(self.ctx.L.j2k_plan_set_decode_coded_rows_only(self.h, int(bool(on))))
+
     @_stage
     def forward_pixels(self, fmt, pix, coeff=None):
         """extractImageData (+ rescale to the plan's precision) + preprocess: pix = device uint8 [H, stride] in a Go Pix layout."""

@@ -232,6 +232,14 @@ int j2k_plan_unpack_streams(j2k_plan *plan, int count, const uint8_t *const *d_p
  * + lens + numbps -> d_decoded (decoded_elems int32, block j dense at its job offset). */
 int j2k_plan_decode_blocks(j2k_plan *plan, const uint8_t *d_stream, const uint64_t *d_offs,
                            const uint32_t *d_lens, const uint8_t *d_numbps, int32_t *d_decoded);
+/* HT coder only; default off.  The reference's HT decoder writes ONE row in four of a block (ht.go:589-711: only row y of each
+ * 4-row stripe is coded) and returns its internal slice: a fresh decoder's slice is zero elsewhere -- what
+ * j2k_plan_decode_blocks reproduces by default, writing all w x h samples -- while a pooled decoder (GetHTDecoder /
+ * PutHTDecoder, ht.go:1393-1429) is not cleared on that path and keeps whatever those rows held.  With `on` the call
+ * behaves like the pooled decoder: rows y % 4 != 0 of every block in d_decoded are left untouched (the caller zeroed the
+ * buffer once, or does not read them), the coded rows are written in full as before.  Three quarters of the decoder's
+ * store stream (77 of 103 MB per 4K frame) disappear. */
+int j2k_plan_set_decode_coded_rows_only(j2k_plan *plan, int on);
 /* job j's offset (in int32 elements) into d_decoded */
 int j2k_plan_get_decoded_offsets(const j2k_plan *plan, uint64_t *offs, size_t cap);
 

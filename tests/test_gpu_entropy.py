@@ -297,6 +297,63 @@ def test_plan_decode_blocks_matches_decoders(oracle, coder):
         big += int(np.abs(want).max() >= (1 << 31) - 1) if want.size else 0
 
 
+@pytest.mark.parametrize("W,H,cb,corrupt", [(512, 512, 64, False), (200, 150, 32, False), (264, 75, 16, False), (512, 512, 64, True)])
+def test_plan_decode_coded_rows_only(oracle, W, H, cb, corrupt):
+    """j2k_plan_set_decode_coded_rows_only: the pooled HTDecoder's behaviour (ht.go:1393-1429 -- its data slice is not cleared
+    between blocks; the decoder writes row y of every 4-row stripe only, ht.go:589-711).  Into a buffer poisoned with a
+    sentinel: the coded rows equal the fresh decoder's (orc_ht_decode) on every block, every other row keeps the sentinel;
+    into a zeroed buffer the result IS the fresh decoder's.  `corrupt`: streams with broken SCUP bytes / truncated blocks --
+    the invalid-stream and serial-decoder paths must clear the coded rows themselves."""
+    import torch
+    from j2kgfx.codec import FramePlan
+    rng = np.random.default_rng(W + H + cb)
+    yy, xx = np.mgrid[0:H, 0:W]
+    base = np.stack([xx * 255 // W, yy * 255 // H, (xx + yy) * 127 // max(W, H)])
+    frame = np.clip(base + rng.integers(-16, 17, size=(3, H, W)), 0, 255).astype(np.int32)
+    plan = FramePlan(W, H, 3, precision=8, lossless=True, num_resolutions=5, cb=(cb, cb), coder=1)
+    coeff = plan.forward(torch.from_numpy(frame).to(plan.device))
+    stream, offs, lens, nb = plan.encode_stream(coeff)
+    plan.ctx.sync()
+    n = int(plan.info.blocks)
+    ho, hl = offs.cpu().numpy(), lens.cpu().numpy()
+    hs = stream.cpu().numpy().copy()
+    if corrupt:
+        for j in range(0, n, 3):                              # every third block: SCUP out of range, zero, or bytes flipped
+            a, l = int(ho[j]), int(hl[j])
+            if l < 4:
+                continue
+            k = (j // 3) % 3
+            if k == 0: hs[a + l - 1] = 0xFF; hs[a + l - 2] |= 0x0F
+            elif k == 1: hs[a + l - 1] = 0; hs[a + l - 2] &= 0xF0
+            else: hs[a + l // 2: a + l // 2 + 8] ^= 0x5A
+        stream = torch.from_numpy(hs).to(plan.device)
+    fresh = plan.decode_blocks(stream, offs, lens, nb)
+    plan.ctx.sync()
+    plan.set_decode_coded_rows_only(True)
+    SENT = -123456789
+    poisoned = torch.full((int(plan.info.decoded_elems),), SENT, dtype=torch.int32, device=plan.device)
+    zeroed = torch.zeros_like(poisoned)
+    plan.decode_blocks(stream, offs, lens, nb, decoded=poisoned)
+    plan.decode_blocks(stream, offs, lens, nb, decoded=zeroed)
+    plan.ctx.sync()
+    plan.set_decode_coded_rows_only(False)
+    again = plan.decode_blocks(stream, offs, lens, nb)
+    plan.ctx.sync()
+    hf, hp, hz, ha = fresh.cpu().numpy(), poisoned.cpu().numpy(), zeroed.cpu().numpy(), again.cpu().numpy()
+    blocks, doffs = plan.blocks(), plan.decoded_offsets()
+    for j in range(n):
+        w, h = int(blocks[j]["w"]), int(blocks[j]["h"])
+        o = int(doffs[j])
+        want = oracle.ht_decode(hs[int(ho[j]):int(ho[j]) + int(hl[j])], w, h)
+        assert np.array_equal(hf[o:o + w * h].reshape(h, w), want), ("fresh", j)
+        assert np.array_equal(ha[o:o + w * h].reshape(h, w), want), ("switched off again", j)
+        got = hp[o:o + w * h].reshape(h, w)
+        assert np.array_equal(got[0::4], want[0::4]), ("coded rows", j)
+        for r in (1, 2, 3):
+            assert (got[r::4] == SENT).all(), ("untouched rows", j, r)
+        assert np.array_equal(hz[o:o + w * h].reshape(h, w), want), ("zeroed buffer == fresh decoder", j)
+
+
 def test_standalone_mq_and_raw_coders(ent, oracle):
     """MQEncoder / MQDecoder / RawEncoder / RawDecoder as batch calls, byte-exact against the oracle."""
     rng = np.random.default_rng(14)
