@@ -213,6 +213,7 @@ def run(state):
         ln.codes = False
     ctx, plan = lanes[0].ctx, lanes[0].plan
     info, n = plan.info, lanes[0].n
+    plan_pack_bound = plan.pack_bound()
     ext = torch.cuda.ExternalStream(ctx.stream)
 
     exts = [torch.cuda.ExternalStream(ln.ctx.stream) for ln in lanes]
@@ -227,6 +228,39 @@ def run(state):
     coded = [False] * NSETS         # set b holds a step's streams whose exchange has not been started yet
     stepno = [0]
 
+    # ---- the transfers themselves: j2k_gather_streams at the C ABI (RCCL send / recv on the library's own stream; what a Go
+    #      host would call), or torch.distributed's batched isend / irecv (J2K_BENCH_GATHER=torch; always for the gloo rehearsal)
+    backend_name = os.environ.get("J2K_BENCH_BACKEND", "nccl")
+    use_cabi = multi and backend_name == "nccl" and os.environ.get("J2K_BENCH_GATHER", "cabi") == "cabi" and (world > 1 or pr_mode == "5")
+    comm, recv_bufs = None, [None] * NSETS
+    if use_cabi:
+        try:
+            comm = jdist.Comm(lanes[0].ctx, rank, world, group=size_group)
+            state["comm"] = comm
+            if rank == 0:
+                cap = max(world - 1, 1) * F * (plan_pack_bound + 16) + 64
+                recv_bufs = [torch.empty(cap, dtype=torch.uint8, device=lanes[0].plan.device) for _ in range(NSETS)]
+        except Exception as exc:                        # (a box without a usable RCCL for the library: say so, use torch's)
+            print("bench.py: j2k_comm_create failed (%s); falling back to torch.distributed transfers" % exc, file=sys.stderr)
+            use_cabi, comm = False, None
+    gather_path = "j2k_gather_streams (C ABI: ncclSend/ncclRecv peer->root on the library's stream)" if use_cabi else (
+        "torch.distributed batch_isend_irecv" if multi else None)
+
+    class CabiGather:
+        def __init__(self, offs, totals):
+            self.offs, self.totals = offs, totals
+        def wait(self):
+            out = []
+            peers = [0] if pr_mode == "5" else list(range(1, world))
+            for f in range(F):
+                pks = []
+                if rank == 0:
+                    for r in peers:
+                        o, nb_ = int(self.offs[r * F + f]), int(self.totals[r][f])
+                        pks.append(self.buf[o:o + nb_])
+                out.append(pks)
+            return out
+
     def finish_gather(b):
         """The transfers that read buffer set b are complete (and the library streams know it)."""
         xdone[b].wait()                                 # the helper has started (or never had) this set's exchange
@@ -236,6 +270,18 @@ def run(state):
         if g is None:
             return
         res = g.wait()
+        if isinstance(g, CabiGather):
+            for ln in lanes:                            # every library stream waits, on the device, for the transfers
+                comm.wait(ln.ctx)
+            for ln, pks in zip(lanes, res):
+                if pks:
+                    ln.plan.unpack_streams(pks, ln.assembled)
+            keep[b] = res
+            if rank == 0:
+                for ev, e in zip(unpacked[b], exts):
+                    ev.record(e)
+            pending[b] = None
+            return
         staged = []
         for ln, (buf, offsets) in zip(lanes, res):
             ln.gather_bufs[b] = buf
@@ -279,6 +325,27 @@ def run(state):
             sizes = [0] * len(lanes)                    # (also the dev modes 2 and 4)
         else:                                           # written by the asynchronous copies queued before enc_done
             sizes = size_pin[b].tolist()
+        if use_cabi:
+            # every rank's byte counts through the gloo group (host integers), then ONE j2k_gather_streams for the F packs
+            mine = torch.tensor([int(v) for v in sizes], dtype=torch.int64)
+            totals = torch.empty(world * F, dtype=torch.int64)
+            if world > 1 and size_group is not None:
+                dist.all_gather_into_tensor(totals, mine, group=size_group)
+            elif world > 1:
+                td = torch.empty(world * F, dtype=torch.int64, device=lanes[0].plan.device)
+                dist.all_gather_into_tensor(td, mine.to(td.device))
+                totals = td.cpu()
+            else:
+                totals = mine
+            if rank == 0 and keep[b] is not None:
+                for ev in unpacked[b]:                  # the unpacks that read this receive buffer three steps ago (long done)
+                    ev.synchronize()
+            offs_ = comm.gather([ln.packs[b] for ln in lanes], [int(v) for v in sizes], recv=recv_bufs[b] if rank == 0 else None,
+                                all_bytes=totals.numpy(), self_loop=pr_mode == "5")
+            g = CabiGather(offs_, totals.numpy().reshape(world, F))
+            g.buf = recv_bufs[b]
+            pending[b] = g
+            return
         items = [(ln.packs[b], int(sz)) for ln, sz in zip(lanes, sizes)]
         if os.environ.get("J2K_BENCH_BACKEND", "nccl") != "nccl":
             items = [(t[:n_].cpu(), n_) for t, n_ in items]
@@ -507,7 +574,7 @@ def run(state):
                        "frames_in_flight": F, "frames_in_flight_rank0": F - root_idle_all, "frame_io": args.io,
                        "decode_rows": args.decode_rows + (" (the rows the reference's HT decoder never writes are not re-zeroed on every call: the "
                                                           "buffer was zeroed once, as a pooled HTDecoder's slice is; digest unchanged)" if args.decode_rows == "coded" else ""),
-                       "parallelism": "frames/rank" if world > 1 else "single GPU"},
+                       "parallelism": "frames/rank" if world > 1 else "single GPU", "gather": gather_path},
             "roofline": {"bound": "hbm",
                          "kernel": ("dwt53_fwd_rgba8_wg_kernel (level 0: RGBA8 unpack + DC shift + RCT + 5-3 lifting, fused)" if args.io == "rgba8"
                                     else "dwt53_fwd_kernel<8,3,true,false,false> (level 0: DC shift + RCT + 5-3 lifting, fused)"),
@@ -544,7 +611,7 @@ def main():
         run(state)
         ok = True
     finally:
-        bench_extra.teardown(state.get("lanes", []), state.get("multi", False), state.get("helper"), state.get("stop_helper"), ok=ok)
+        bench_extra.teardown(state.get("lanes", []), state.get("multi", False), state.get("helper"), state.get("stop_helper"), ok=ok, comm=state.get("comm"))
 
 
 if __name__ == "__main__":

@@ -140,3 +140,74 @@ def gather_streams_start(items, group=None, outs=None, size_group=None, self_loo
             results.append((None, offsets))
     works = dist.batch_isend_irecv(ops) if ops else []
     return StreamGather(works, results)
+
+
+# ---- the same exchange at the C ABI (include/j2kgfx.h: j2k_comm_*, j2k_gather_streams) -----------------------------
+class Comm:
+    """j2k_comm: an RCCL communicator owned by libj2kgfx.so (its own HIP stream for the transfers).  A thin caller: the
+    128-byte id is made on rank 0 (j2k_comm_get_unique_id) and carried to the other ranks by whatever the host has -- here
+    torch.distributed's object broadcast on `group` (any backend), or nothing for a one-rank communicator."""
+
+    def __init__(self, ctx, rank=0, world=1, group=None, id_bytes=None):
+        import ctypes as C
+        from . import _lib
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        L = ctx.L
+        if id_bytes is None:
+            buf = (C.c_uint8 * 128)()
+            if self.rank == 0:
+                st = L.j2k_comm_get_unique_id(buf)
+                if st != _lib.OK:
+                    raise _lib.J2KError(st, "j2k_comm_get_unique_id: " + L.j2k_status_string(st).decode())
+            id_bytes = bytes(buf)
+            if self.world > 1:
+                import torch.distributed as dist
+                box = [id_bytes]
+                dist.broadcast_object_list(box, src=0, group=group)
+                id_bytes = box[0]
+        h = C.c_void_p()
+        idb = (C.c_uint8 * 128).from_buffer_copy(id_bytes)
+        ctx.check(L.j2k_comm_create(ctx.h, idb, self.rank, self.world, C.byref(h)))
+        self.h = h
+
+    def gather(self, sends, nbytes, recv=None, producers=(), all_bytes=None, self_loop=False):
+        """j2k_gather_streams: sends = list of device uint8 tensors, nbytes = their byte counts (host ints), recv = rank 0's
+        device uint8 buffer, producers = the contexts whose streams are producing `sends`, all_bytes = every rank's counts
+        (world x count) if the host already has them.  Returns the offsets array (world * count + 1): stream f of rank r is
+        recv[offs[r * count + f] : ... + its byte count] on rank 0.  The transfers are queued, not finished: wait()."""
+        import ctypes as C
+        import numpy as np
+        k = len(sends)
+        VP = C.c_void_p * k
+        ptrs = VP(*[int(t.data_ptr()) for t in sends])
+        nb = (C.c_uint64 * k)(*[int(n) for n in nbytes])
+        offs = (C.c_uint64 * (self.world * k + 1))()
+        ab = None
+        if all_bytes is not None:
+            flat = [int(v) for v in np.asarray(all_bytes).reshape(-1)]
+            assert len(flat) == self.world * k
+            ab = (C.c_uint64 * len(flat))(*flat)
+        prod = (C.c_void_p * max(len(producers), 1))(*[p.h.value for p in producers]) if producers else None
+        self.ctx.check(self.ctx.L.j2k_gather_streams(self.h, k, ptrs, nb, ab, prod, len(producers),
+                                                     C.c_void_p(int(recv.data_ptr())) if recv is not None else None,
+                                                     C.c_size_t(int(recv.numel()) if recv is not None else 0), offs,
+                                                     1 if self_loop else 0))
+        self._keep = (sends, recv)          # alive until the next gather / wait
+        return np.array(offs[:], dtype=np.uint64)
+
+    def wait(self, consumer=None):
+        """consumer = a Context whose stream must see the gathered bytes (device-side wait), or None: the host waits."""
+        self.ctx.check(self.ctx.L.j2k_comm_wait(self.h, consumer.h if consumer is not None else None))
+
+    def close(self):
+        if self.h and self.ctx.h:
+            self.ctx.L.j2k_comm_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        import sys
+        try:
+            if not sys.is_finalizing():
+                self.close()
+        except Exception:
+            pass

@@ -243,6 +243,44 @@ int j2k_plan_set_decode_coded_rows_only(j2k_plan *plan, int on);
 /* job j's offset (in int32 elements) into d_decoded */
 int j2k_plan_get_decoded_offsets(const j2k_plan *plan, uint64_t *offs, size_t cap);
 
+/* ---- the multi-GPU exchange -------------------------------------------------------------------------------
+ * One process per GPU, each with its own j2k_ctx; a frame's tiles are sharded by j2k_params.tile_first / tile_count and coded
+ * independently (no halo).  The ONE exchange step is the gather of the compressed streams to rank 0 for codestream assembly
+ * -- it replaces the in-process collection of encoder.encodeTile's job results (encoder.go:690-742) when the jobs ran on other
+ * GPUs: ncclAllGather of the byte counts, then inside one ncclGroupStart / ncclGroupEnd every rank != 0 ncclSend()s its
+ * streams to rank 0, which posts the matching ncclRecv()s -- direct peer -> root over each peer's own xGMI link, no ring.
+ * RCCL is bound at run time (dlopen), so a single-GPU host does not need it: the calls return J2K_ERR_UNSUPPORTED without it.
+ *
+ *   j2k_comm_get_unique_id   rank 0 makes the 128-byte RCCL id; the HOST carries it to the other ranks (the Go side: any
+ *                            channel it has -- a pipe to its worker processes, a file, MPI; the Python tests: torch.distributed)
+ *   j2k_comm_create          collective (every rank): ncclCommInitRank on ctx's device; the communicator owns a HIP stream
+ *                            of its own for the transfers
+ *   j2k_gather_streams       collective.  Rank r passes `count` device buffers d_send[f] of send_bytes[f] bytes (normally the
+ *                            packs of j2k_plan_pack_stream, one per frame slot).  all_bytes: the byte counts of every rank,
+ *                            rank-major (world x count), when the host already knows them (it usually does: a 16-byte
+ *                            message per rank on whatever channel carried the id) -- else NULL and the call gathers them
+ *                            with ncclAllGather, which costs a stream synchronisation.  producers: the contexts on whose
+ *                            streams the send buffers are being produced; the transfers are ordered behind their work so
+ *                            far.  On rank 0, stream f of rank r lands at d_recv + recv_offs[r * count + f] (16-byte
+ *                            aligned; recv_offs has world * count + 1 entries, host memory, filled on every rank), its own
+ *                            streams by a device copy; J2K_ERR_CAPACITY when recv_cap is too small.  Returns once the
+ *                            transfers are QUEUED on the communicator's stream.
+ *   j2k_comm_wait            consumer != NULL: that context's stream waits (on the device) for the last gather -- follow with
+ *                            j2k_plan_unpack_streams on it; NULL: the host waits.
+ * flags: J2K_GATHER_SELF_LOOP (world == 1 only): the lone rank sends to itself through RCCL -- the transfer calls on one GPU. */
+typedef struct j2k_comm j2k_comm;
+#define J2K_COMM_ID_BYTES 128
+#define J2K_GATHER_SELF_LOOP 1
+int j2k_comm_get_unique_id(uint8_t *id128);
+int j2k_comm_create(j2k_ctx *ctx, const uint8_t *id128, int rank, int world, j2k_comm **out);
+void j2k_comm_destroy(j2k_comm *comm);
+const char *j2k_comm_last_error(j2k_comm *comm);
+void *j2k_comm_stream(j2k_comm *comm);
+int j2k_gather_streams(j2k_comm *comm, int count, const uint8_t *const *d_send, const uint64_t *send_bytes,
+                       const uint64_t *all_bytes, j2k_ctx *const *producers, int nproducers,
+                       uint8_t *d_recv, size_t recv_cap, uint64_t *recv_offs, int flags);
+int j2k_comm_wait(j2k_comm *comm, j2k_ctx *consumer);
+
 /* ---- stand-alone arithmetic / bypass coders (internal/entropy/mqc.go), host buffers ------------
  * MQEncoder: NewMQEncoder, n x Encode(ctxs[i], decisions[i]), Flush (mqc.go:169-349); *out_len = 0
  * is Flush's nil.  A context >= 19 is the Go index panic (J2K_ERR_GO_PANIC). */

@@ -260,3 +260,53 @@ def test_device_tile_part_assembly_equals_host(W, H, tile, first, count):
     assert got == want
     parts = codestream.parse_tile_parts(got)
     assert [p.TileIndex for p, _ in parts] == list(range(first, first + len(starts) - 1))
+
+
+def test_c_abi_gather_streams_self_loop():
+    """j2k_comm_* / j2k_gather_streams on this box's one GPU: a one-rank RCCL communicator made through the C ABI, the packs of
+    three frame slots (j2k_plan_pack_stream) sent to the rank itself with ncclSend / ncclRecv in one group on the
+    communicator's stream -- once with the byte counts given by the host, once gathered by ncclAllGather inside the call --
+    then rebuilt with j2k_plan_unpack_streams on a context that waits for the transfer on the device (j2k_comm_wait): stream,
+    offsets, lengths and bit-plane counts byte for byte those of the encoder."""
+    import torch
+    from j2kgfx import Context
+    from j2kgfx.codec import FramePlan
+    from j2kgfx import dist as jdist
+    W, H = 1280, 624
+    rng = np.random.default_rng(77)
+    ctxs = [Context(0) for _ in range(3)]
+    kw = dict(precision=8, lossless=True, num_resolutions=6, cb=(64, 64), tile=(512, 512), coder=1, tile_first=1, tile_count=4)
+    plans = [FramePlan(W, H, 3, ctx=c, **kw) for c in ctxs]
+    root_ctx = Context(0)
+    root_plan = FramePlan(W, H, 3, ctx=root_ctx, **kw)
+    comm = jdist.Comm(root_ctx, 0, 1)
+    for given in (True, False, True):
+        enc, packs = [], []
+        for p in plans:
+            frame = torch.from_numpy(rng.integers(0, 256, (3, H, W)).astype(np.int32)).to(p.device)
+            st = p.encode_stream(p.forward(frame))
+            enc.append(st)
+            packs.append(p.pack_stream(*st))
+        for c in ctxs:
+            c.sync()                                            # (the host needs the pack sizes: first int64 of each pack)
+        nbytes = [int(pk[:8].view(torch.int64).item()) for pk in packs]
+        assert all(0 < n <= pk.numel() for n, pk in zip(nbytes, packs))
+        recv = torch.full((sum((n + 15) & ~15 for n in nbytes) + 64,), 0xEE, dtype=torch.uint8, device=root_plan.device)
+        offs = comm.gather(packs, nbytes, recv=recv, producers=ctxs, all_bytes=[nbytes] if given else None, self_loop=True)
+        assert len(offs) == 4 and int(offs[0]) == 0 and all(int(o) % 16 == 0 for o in offs)
+        comm.wait(root_ctx)
+        n = int(root_plan.info.blocks)
+        outs = [(root_plan.empty(root_plan.info.bytes_cap, torch.uint8), root_plan.empty(n + 1, torch.int64), root_plan.empty(n, torch.int32),
+                 root_plan.empty(n, torch.uint8)) for _ in packs]
+        root_plan.unpack_streams([recv[int(offs[f]):int(offs[f]) + nbytes[f]] for f in range(3)], outs)
+        root_ctx.sync()
+        assert int(recv[int(offs[3]):].min().item()) == 0xEE     # nothing written past the gathered bytes
+        for (s0, o0, l0, b0), (s1, o1, l1, b1) in zip(enc, outs):
+            tot = int(o0[n].item())
+            assert torch.equal(o1[:n + 1], o0[:n + 1]) and torch.equal(l1[:n], l0[:n]) and torch.equal(b1[:n], b0[:n])
+            assert torch.equal(s1[:tot], s0[:tot])
+    # a receive buffer that is too small is refused before anything is posted
+    from j2kgfx import J2KError
+    with pytest.raises(J2KError):
+        comm.gather(packs, nbytes, recv=recv[:1024], producers=ctxs, all_bytes=[nbytes], self_loop=True)
+    comm.close()
