@@ -72,7 +72,7 @@ def run(state):
                          "same digest, either way")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("J2K_BENCH_INFLIGHT", "3")),
                     help="independent frames coded concurrently per step, each on its own context/stream")
-    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c2",
+    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5", "c1gpu"], default="c2",
                     help="BASELINE.json configuration: c2 (default, the headline: 4K RGB8 5-3 + HT), c3 (4K RGB 12-bit, 9-7 lossy + MQ), "
                          "c5 (2048x2048 gray16 frames, 5-3 + HT); c4 only with --shard tiles")
     ap.add_argument("--shard", choices=["frames", "tiles"], default="frames",

@@ -28,6 +28,14 @@ CONFIGS = {
                metric="Mpixels/s encode (8K sRGB 10-bit, 5-3 lossless + HT, tiles sharded over the ranks)",
                workload="7680x4320 sRGB rescaled to 10 bit (v*1023/255), 512x512 tiles (135), 5-3 lossless + HT block coder, 64x64 "
                         "code-blocks (BASELINE configs[3])"),
+    # BASELINE configs[0] ("pure-Go CPU path, plumbing") on the GPU: the reference's DEFAULT code-block size, 1 << (6 + 2) = 256
+    # (encoder.go:606-607), i.e. the blocks above 64 x 64 that take the general T1 kernels; 21 blocks per frame (9 of 256 x 256,
+    # 12 of 128 x 128): a handful of serial MQ chains, not a throughput configuration
+    "c1gpu": dict(W=512, H=512, C=3, prec=8, lossless=True, quality=0, tile=0, nres=3, cb=256, coder=0, io="planes", inflight=2, content="c1",
+                  metric="Mpixels/s encode+decode (512x512 sRGB, 5-3 lossless, 256x256 code-blocks, MQ coder)",
+                  workload="512x512 sRGB 8-bit, single tile, 5-3 lossless, NumResolutions 3, CodeBlockSize{6,6} = 256x256 code-blocks (the "
+                           "reference's default, encoder.go:606-607), MQ block coder (BASELINE configs[0] run on the GPU); even frames = the "
+                           "reference's benchmark gradient (jpeg2000_test.go:340-352), odd frames = uniform random bytes"),
     "c5": dict(W=2048, H=2048, C=1, prec=16, lossless=True, quality=0, tile=0, nres=6, cb=64, coder=1, io="gray16", inflight=8,
                metric="Mpixels/s encode+decode (2048x2048 16-bit gray frames, 5-3 lossless)",
                workload="independent 2048x2048 16-bit gray frames (BASELINE configs[4]: a batch of 256, frame f -> rank f mod N), "
@@ -48,6 +56,11 @@ def synth_rgb(np, W, H, index):
 def synth_frame(np, cfg, index):
     """component planes int32 [C, H, W] at the config's precision"""
     W, H, prec = cfg["W"], cfg["H"], cfg["prec"]
+    if cfg.get("content") == "c1":     # SURVEY 8d, C1: the reference's own benchmark gradient, and a uniform-random variant
+        yy, xx = np.mgrid[0:H, 0:W]
+        if index % 2 == 0:
+            return np.stack([xx * 255 // W, yy * 255 // H, (xx + yy) * 127 // W]).astype(np.int32)
+        return np.random.default_rng(SEED + index).integers(0, 256, (3, H, W)).astype(np.int32)
     if cfg["C"] == 1:     # full-range noise + gradient (SURVEY 8d, C5)
         rng = np.random.default_rng(SEED + index)
         yy, xx = np.mgrid[0:H, 0:W]
@@ -238,6 +251,19 @@ def run_config(args, cfgname):
             for ln in lanes:
                 code(ln)
         barrier()
+        # the timed region lasts at least 0.1 s whatever --steps says (calibrated on two steps; every rank takes the largest count)
+        steps_requested = args.steps
+        tc = time.perf_counter()
+        for _ in range(2):
+            for ln in lanes:
+                code(ln)
+        barrier()
+        need = int(np.ceil(0.1 / max((time.perf_counter() - tc) / 2, 1e-6)))
+        if world > 1:
+            tn = torch.tensor([need], dtype=torch.int64, device=lanes[0]["p"].device if backend == "nccl" else "cpu")
+            dist.all_reduce(tn, op=dist.ReduceOp.MAX)
+            need = int(tn.item())
+        args.steps = max(args.steps, min(need, 20000))
         ctx0 = lanes[0]["ctx"]
         ctx0.profile_enable(True)
         t0 = time.perf_counter()
@@ -320,7 +346,7 @@ def run_config(args, cfgname):
             kern = {"c3": "dwt97_fwd_rgb_wg_kernel<8,1,7> (level 0: DC shift + ICT + rounding + 9-7 lifting + quantisation, fused; VALU-bound in float64)",
                     "c5": "dwt53_fwd_plane_wg_kernel<4,1,true,8> (level 0: Gray16 unpack + DC shift + 5-3 lifting, fused; four 512-column strips)"}.get(cfgname, "level-0 forward kernel")
             out = {"metric": cfg["metric"], "value": round(world * F * W * H / (dt / args.steps) / 1e6, 1), "unit": "Mpixels/s", "n_gpus": world,
-                   "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+                   "steps": args.steps, "steps_requested": steps_requested, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
                    "scaling": "weak", "vs_baseline": None, "dtype": "int32" if cfg["lossless"] else "f64", "data": "synthetic",
                    "config": {"workload": cfg["workload"] + "; frames_in_flight independent frames per rank per step, each on its own HIP stream; "
                               "a step = forward transform + block coding + stream compaction, then block decode of that stream + inverse "

@@ -1521,10 +1521,14 @@ hipError_t launch_raw_decode(hipStream_t s, const uint8_t *data, size_t len, siz
     return hipGetLastError();
 }
 
-static int lds_for(size_t work_per_job) {
+// gfx950 has 160 KB of LDS per workgroup; above 64 KB of dynamic LDS the kernel attribute has to be raised first.  The
+// reference's default 256 x 256 code-block (encoder.go:606-607) has 67 KB of decoder flags: with them in LDS instead of
+// global memory every flag access of the lane-0 chain is a ds_read instead of a memory round trip.
+#define T1_LDS_BIG_LIMIT (150 * 1024)
+static int lds_for(size_t work_per_job, size_t limit = T1_LDS_LIMIT) {
     const size_t tab = (sizeof(T1Tables) + 15) & ~size_t(15);
     size_t wb = work_per_job;
-    if (tab + wb > T1_LDS_LIMIT) wb = 0;       // largest block does not fit: LDS holds the tables only
+    if (tab + wb > limit) wb = 0;              // largest block does not fit: LDS holds the tables only
     return (int)wb;
 }
 
@@ -1596,8 +1600,16 @@ hipError_t launch_t1_decode(hipStream_t s, const BlockJob *jobs, int njobs, cons
         hipError_t e = hipGetLastError();
         if (e != hipSuccess || max_dim <= 64) return e;
     }
-    const int wb = lds_for(work_per_job);     // work_per_job = flag bytes of the largest block
+    const int wb = lds_for(work_per_job, T1_LDS_BIG_LIMIT);     // work_per_job = flag bytes of the largest block
     const size_t lds = ((sizeof(T1Tables) + 15) & ~size_t(15)) + (size_t)wb;
+    if (lds > 64 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(t1_decode_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, T1_LDS_BIG_LIMIT);
+            if (e != hipSuccess) return e;
+            raised = true;
+        }
+    }
     if (wb) hipLaunchKernelGGL(t1_decode_kernel<true>, dim3(njobs), dim3(64), lds, s, jobs, njobs, stream, offs, lens, numbps, decoded,
                                work, work_per_job, wb, general_only ? 0 : 1);
     else hipLaunchKernelGGL(t1_decode_kernel<false>, dim3(njobs), dim3(64), lds, s, jobs, njobs, stream, offs, lens, numbps, decoded,
