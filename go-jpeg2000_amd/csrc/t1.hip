@@ -26,16 +26,33 @@ enum { CtxSC0 = 9, CtxMag0 = 14, CtxMag1 = 15, CtxMag2 = 16, CtxRL = 17, CtxUni 
 
 // ISO/IEC 15444-1 Table C.2 (Qe, NMPS, NLPS, SWITCH); expanded to the reference's 94-entry
 // MPS-interleaved form (mqc.go:21-116) by rule: state 2i+m, nmps = 2*NMPS+m, nlps = 2*NLPS + (SWITCH ? 1-m : m).
-__device__ __constant__ uint16_t c_iso_qe[47] = {
-    0x5601, 0x3401, 0x1801, 0x0AC1, 0x0521, 0x0221, 0x5601, 0x5401, 0x4801, 0x3801, 0x3001, 0x2401, 0x1C01, 0x1601, 0x5601, 0x5401,
-    0x5101, 0x4801, 0x3801, 0x3401, 0x3001, 0x2801, 0x2401, 0x2201, 0x1C01, 0x1801, 0x1601, 0x1401, 0x1201, 0x1101, 0x0AC1, 0x09C1,
-    0x08A1, 0x0521, 0x0441, 0x02A1, 0x0221, 0x0141, 0x0111, 0x0085, 0x0049, 0x0025, 0x0015, 0x0009, 0x0005, 0x0001, 0x5601};
-__device__ __constant__ uint8_t c_iso_nmps[47] = {1, 2, 3, 4, 5, 38, 7, 8, 9, 10, 11, 12, 13, 29, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24,
-                                                  25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 45, 46};
-__device__ __constant__ uint8_t c_iso_nlps[47] = {1, 6, 9, 12, 29, 33, 6, 14, 14, 14, 17, 18, 20, 21, 14, 14, 15, 16, 17, 18, 19, 19, 20, 21,
-                                                  22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 46};
-__device__ __constant__ uint8_t c_iso_switch[47] = {1, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0,
-                                                    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define J2K_ISO_QE {0x5601, 0x3401, 0x1801, 0x0AC1, 0x0521, 0x0221, 0x5601, 0x5401, 0x4801, 0x3801, 0x3001, 0x2401, 0x1C01, 0x1601, 0x5601, 0x5401, \
+    0x5101, 0x4801, 0x3801, 0x3401, 0x3001, 0x2801, 0x2401, 0x2201, 0x1C01, 0x1801, 0x1601, 0x1401, 0x1201, 0x1101, 0x0AC1, 0x09C1, \
+    0x08A1, 0x0521, 0x0441, 0x02A1, 0x0221, 0x0141, 0x0111, 0x0085, 0x0049, 0x0025, 0x0015, 0x0009, 0x0005, 0x0001, 0x5601}
+#define J2K_ISO_NMPS {1, 2, 3, 4, 5, 38, 7, 8, 9, 10, 11, 12, 13, 29, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, \
+    25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 45, 46}
+#define J2K_ISO_NLPS {1, 6, 9, 12, 29, 33, 6, 14, 14, 14, 17, 18, 20, 21, 14, 14, 15, 16, 17, 18, 19, 19, 20, 21, \
+    22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 46}
+#define J2K_ISO_SWITCH {1, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, \
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+__device__ __constant__ uint16_t c_iso_qe[47] = J2K_ISO_QE;
+__device__ __constant__ uint8_t c_iso_nmps[47] = J2K_ISO_NMPS;
+__device__ __constant__ uint8_t c_iso_nlps[47] = J2K_ISO_NLPS;
+__device__ __constant__ uint8_t c_iso_switch[47] = J2K_ISO_SWITCH;
+// the same 94 entries (qe | nmps << 16 | nlps << 24) as a constant table in memory, for the decoders whose LDS budget has
+// no room for it (t1_decode64_kernel): read only when a context changes state
+struct Mq94 {
+    uint32_t v[94];
+    constexpr Mq94() : v{} {
+        constexpr uint16_t qe[47] = J2K_ISO_QE;
+        constexpr uint8_t nmps[47] = J2K_ISO_NMPS, nlps[47] = J2K_ISO_NLPS, sw[47] = J2K_ISO_SWITCH;
+        for (int s = 0; s < 94; s++) {
+            const int i = s >> 1, m = s & 1;
+            v[s] = (uint32_t)qe[i] | (uint32_t)(2 * nmps[i] + m) << 16 | (uint32_t)(2 * nlps[i] + (sw[i] ? 1 - m : m)) << 24;
+        }
+    }
+};
+__device__ __constant__ Mq94 c_mq94 = Mq94();
 
 // LDS-resident tables shared by encoder and decoder
 struct T1Tables {
@@ -885,13 +902,13 @@ struct T1DecLane {
     MqDec d;
     uint32_t *ent;
     const uint32_t *mq;
-    const uint8_t *zc, *sc;
+    const uint8_t *zcsc;     // zc[i] in the low nibble, sc[i] (sign context | prediction << 3) in the high one
     uint8_t *flags;
     int32_t *data;
     int w, h, stride;
 };
 __device__ __forceinline__ void dec_sign(T1DecLane &L, uint8_t *f) {   // t1.go:1322-1328
-    const uint32_t sc = L.sc[sc_index(f[-1], f[1], f[-L.stride], f[L.stride])];
+    const uint32_t sc = (uint32_t)L.zcsc[sc_index(f[-1], f[1], f[-L.stride], f[L.stride])] >> 4;
     if (mq_decode(L.d, L.ent, L.mq, CtxSC0 + (sc & 7)) ^ (int)(sc >> 3)) *f |= T1SignNeg;
 }
 // MagRef by the whole wavefront (t1.go:1331-1347).  Its contexts depend only on flags that the pass does not change for
@@ -955,10 +972,10 @@ __device__ __forceinline__ void t1_dec_sigprop_wave(T1DecLane &L, int32_t bit, u
                     const uint64_t bx = 1ull << xi;
                     const uint32_t wnew = xi > 0 ? (uint32_t)(newsig >> (xi - 1)) & 1u : 0u;   // (column x0 - 1: already in the flags)
                     vis |= bx;
-                    if (mq_decode(L.d, L.ent, L.mq, L.zc[zcl[xi] | wnew])) {
+                    if (mq_decode(L.d, L.ent, L.mq, L.zcsc[zcl[xi] | wnew] & 15)) {
                         uint32_t sci = scl[xi];
                         if (wnew) sci |= 1u | ((uint32_t)(newneg >> (xi - 1)) & 1u) << 1;
-                        const uint32_t sc = L.sc[sci];
+                        const uint32_t sc = (uint32_t)L.zcsc[sci] >> 4;
                         const uint64_t neg = (uint64_t)(mq_decode(L.d, L.ent, L.mq, CtxSC0 + (sc & 7)) ^ (int)(sc >> 3));
                         newsig |= bx;
                         newneg |= neg << xi;
@@ -1037,7 +1054,7 @@ __device__ __forceinline__ void t1_dec_cleanup_wave(T1DecLane &L, int32_t bit, u
                     for (int i = first; i < 4; i++) {
                         if (!((mem >> i) & 1)) continue;
                         uint8_t *f = L.flags + (size_t)(y + i + 1) * stride + T1D_XO + xx;
-                        if (mq_decode(L.d, L.ent, L.mq, L.zc[zc_packed(f, stride)])) {
+                        if (mq_decode(L.d, L.ent, L.mq, L.zcsc[zc_packed(f, stride)] & 15)) {
                             L.data[(size_t)(y + i) * w + xx] = bit;
                             dec_sign(L, f);
                             set_significant_dec(f, stride);
@@ -1092,11 +1109,12 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(const BlockJob *__restric
     for (size_t i = lane; i < n; i += 64) out[i] = 0;
     __syncthreads();
     init_dec_contexts(T, lane);
+    for (int p = lane; p < 256; p += 64) T.zc[p] = (uint8_t)(T.zc[p] | T.sc[p] << 4);     // the decoders' packed look-up (T1DecLane::zcsc)
     __syncthreads();
     {
         T1DecLane L;
         if (lane == 0) mq_dec_init(L.d, stream + offs[jid], (long)lens[jid]);
-        L.ent = T.ent; L.mq = T.mq; L.zc = T.zc; L.sc = T.sc; L.flags = flags; L.data = out; L.w = w; L.h = h; L.stride = stride;
+        L.ent = T.ent; L.mq = T.mq; L.zcsc = T.zc; L.flags = flags; L.data = out; L.w = w; L.h = h; L.stride = stride;
         t1_decode_block_wave(L, __shfl((int)numbps[jid], 0), T.mrctx, lane);
     }
     __syncthreads();                                                      // includes the wait for the stores and atomics above
@@ -1112,18 +1130,22 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(const BlockJob *__restric
 // (Tried and removed: K blocks per wavefront on K lanes of this same code -- the loops are the same for every block, so
 // lanes stay position-synchronous and share the scans -- K = 2: 62.7 ms, 4: 96.9, 12: 138: two blocks rarely take a
 // decision at the same sample of the same pass, so the decoder's instructions are not shared, only serialised.)
-// LDS per block decides how many chains are resident: 7005 blocks of a 4K frame need 28 workgroups per CU, i.e. at most
-// 5632 bytes each (LDS is handed out in 512-byte granules) -- hence tables without the encoder's fields.
+// LDS per block decides how many chains are resident.  The 7005 blocks of a 4K frame are 27.4 per CU on 256 CUs; round 2 fitted
+// exactly 28 per CU (5632 bytes = 11 granules of 512, 157.7 of 160 KB) -- and ran at 28 ms per frame on four boxes and 58-63 ms on
+// two others with the SAME code object, LDS size, register counts and grid (rocprofv3 traces of six runs):
+// every other kernel of those runs took the same time on both kinds of box, only this one doubled.  At 27.4 of 28 slots there is
+// no slack: a CU that holds one block fewer (LDS allocations of finished blocks free in a different order and fragment, a box
+// with fewer enabled CUs) pushes the overflow into a second round of 28 ms chains.  Now 10 granules: 32 blocks per CU = the
+// wave limit, 8192 slots for 7005 blocks.  What went: the 94-entry MQ table (read from constant memory: it is consulted only
+// when a context changes state; the current entry of every context stays in LDS), and zc / sc share one byte per index.
 #define T1D64_FLAGS ((66 * T1D_STRIDE(64) + 4 + 15) & ~15)
 struct T1Dec64Shared {
-    uint32_t mq[94];
     uint32_t ent[20];
-    uint8_t zc[256];
-    uint8_t sc[256];
+    uint8_t zcsc[256];                           // lutZCCtx in the low nibble, lutSignCtx | lutSignPred << 3 in the high one
     alignas(16) uint8_t flags[T1D64_FLAGS];      // doubles as the scratch the tables are built in
     uint8_t mrctx[128];                          // per-column context lists of the wave-level passes (two of 64 bytes)
 };
-static_assert(sizeof(T1Dec64Shared) <= 5632, "t1_decode64_kernel: LDS per block above 11 granules");
+static_assert(sizeof(T1Dec64Shared) <= 5120, "t1_decode64_kernel: LDS per block above 10 granules (32 blocks per CU)");
 __global__ __launch_bounds__(64) void t1_decode64_kernel(const BlockJob *__restrict__ jobs, int njobs, const uint8_t *__restrict__ stream,
                                                          const uint64_t *__restrict__ offs, const uint32_t *__restrict__ lens,
                                                          const uint8_t *__restrict__ numbps, int32_t *__restrict__ decoded, int min_bps) {
@@ -1147,8 +1169,7 @@ __global__ __launch_bounds__(64) void t1_decode64_kernel(const BlockJob *__restr
         T1Tables &T = *reinterpret_cast<T1Tables *>(S.flags);
         build_tables(T, J.band, lane);
         __syncthreads();
-        for (int p = lane; p < 256; p += 64) { S.zc[p] = T.zc[p]; S.sc[p] = T.sc[p]; }
-        for (int p = lane; p < 94; p += 64) S.mq[p] = T.mq[p];
+        for (int p = lane; p < 256; p += 64) S.zcsc[p] = (uint8_t)(T.zc[p] | T.sc[p] << 4);
         if (lane < 20) S.ent[lane] = lane < NumContexts ? T.mq[lane == CtxUni ? 92 : 0] : 0u;
         __syncthreads();
     }
@@ -1158,7 +1179,7 @@ __global__ __launch_bounds__(64) void t1_decode64_kernel(const BlockJob *__restr
     {
         T1DecLane L;                                              // L.d is lane 0's decoder
         if (lane == 0) mq_dec_init(L.d, stream + offs[jid], (long)lens[jid]);
-        L.ent = S.ent; L.mq = S.mq; L.zc = S.zc; L.sc = S.sc; L.flags = S.flags; L.data = out; L.w = w; L.h = h; L.stride = stride;
+        L.ent = S.ent; L.mq = c_mq94.v; L.zcsc = S.zcsc; L.flags = S.flags; L.data = out; L.w = w; L.h = h; L.stride = stride;
         t1_decode_block_wave(L, __shfl((int)numbps[jid], 0), S.mrctx, lane);
     }
     __syncthreads();                                                      // includes the wait for lane 0's stores and atomics
@@ -1223,8 +1244,7 @@ __global__ __launch_bounds__(64) void t1_dec_step_kernel(const BlockJob *__restr
             T1Tables &T = *reinterpret_cast<T1Tables *>(S.flags);
             build_tables(T, J.band, lane);
             __syncthreads();
-            for (int q = lane; q < 256; q += 64) { S.zc[q] = T.zc[q]; S.sc[q] = T.sc[q]; }
-            for (int q = lane; q < 94; q += 64) S.mq[q] = T.mq[q];
+            for (int q = lane; q < 256; q += 64) S.zcsc[q] = (uint8_t)(T.zc[q] | T.sc[q] << 4);
             if (lane < 20) S.ent[lane] = lane < NumContexts ? T.mq[lane == CtxUni ? 92 : 0] : 0u;
             __syncthreads();
         }
@@ -1240,7 +1260,7 @@ __global__ __launch_bounds__(64) void t1_dec_step_kernel(const BlockJob *__restr
         }
     }
     __syncthreads();
-    L.ent = S.ent; L.mq = S.mq; L.zc = S.zc; L.sc = S.sc; L.flags = S.flags; L.data = out; L.w = w; L.h = h; L.stride = stride;
+    L.ent = S.ent; L.mq = c_mq94.v; L.zcsc = S.zcsc; L.flags = S.flags; L.data = out; L.w = w; L.h = h; L.stride = stride;
     const uint64_t lt_lane = (1ull << lane) - 1;
     if (!first && p + 1 < nb) {
         // MagRef(p + 1), second half (t1.go:1331-1347): the same member ballots as when the list was written -- nothing
