@@ -105,7 +105,7 @@ hipError_t launch_colorspace(hipStream_t s, int cs, int32_t *planes, int ncomp, 
 hipError_t launch_pack_pixels(hipStream_t s, const int32_t *planes, int ncomp, int precision, int w, int h, uint8_t *pix, size_t stride);
 
 // DEV BUILDS ONLY (make CXXFLAGS+=-DJ2K_DEV; env J2K_DEV_SKIP = bit mask): launches left out to measure what each kernel
-// costs with several frames in flight (tools/ab_skip.sh).  Results are wrong with any bit set, so the shipped library
+// costs with several frames in flight (`J2K_DEV_SKIP=<mask> bash tools/ab.sh ...` on a -DJ2K_DEV build).  Results are wrong with any bit set, so the shipped library
 // does not have the switch at all: g_dev_skip is the constant 0 and every test of it folds away.
 #ifdef J2K_DEV
 extern int g_dev_skip, g_dev_dup;      // J2K_DEV_DUP: the same bits, launches issued TWICE (every one is idempotent: results stay valid)

@@ -137,14 +137,14 @@ def test_graph_launch_is_ordered_behind_the_current_stream_and_refuses_a_closed_
 
 
 def test_interpreter_exit_with_live_plans_is_clean():
-    """a process that exits with plans / contexts / queued work alive (tools/dbg/exit_order.py: SystemExit(3), nothing
+    """a process that exits with plans / contexts / queued work alive (tests/helpers_exit_order.py: SystemExit(3), nothing
     closed) must leave with that exit code and no abort text -- the package's atexit hook closes graphs, plans, contexts in
     that order while torch and the HIP runtime are still up."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "dbg", "exit_order.py")], cwd=root, capture_output=True, text=True, timeout=300)
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "helpers_exit_order.py")], cwd=root, capture_output=True, text=True, timeout=300)
     assert out.returncode == 3, (out.returncode, out.stderr[-2000:])
     for bad in ("terminate called", "bad_variant_access", "Segmentation", "core dumped", "Aborted"):
         assert bad not in out.stderr, out.stderr[-2000:]
