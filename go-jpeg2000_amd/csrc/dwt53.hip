@@ -1197,8 +1197,8 @@ hipError_t launch_dwt53_tail_inv(hipStream_t s, const TailPlane *planes, int npl
     return hipGetLastError();
 }
 
-#include "dwt53_deep.inc"
 #include "dwt53_l0pix.inc"
+#include "dwt53_deep.inc"
 #include "dwt53_plane_wg.inc"
 
 // ================================================================================

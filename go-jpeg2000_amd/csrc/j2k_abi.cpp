@@ -147,6 +147,7 @@ extern "C" int j2k_ctx_create(int device, j2k_ctx **out) {
     if (const char *e = getenv("J2K_FWD_PF")) ctx->fwd_pf = atoi(e) != 0;
     if (const char *e = getenv("J2K_TAIL")) ctx->use_tail = atoi(e) != 0;
     if (const char *e = getenv("J2K_DEEP")) ctx->use_deep = atoi(e) != 0;
+    if (const char *e = getenv("J2K_MEGA")) { int v = atoi(e); if (v >= 0 && v <= 2) ctx->mega = v; }
     if (const char *e = getenv("J2K_XCD_MAP")) ctx->xcd_map = atoi(e) != 0;
     if (const char *e = getenv("J2K_T1_SPLIT")) ctx->t1_split = atoi(e) != 0;
     if (const char *e = getenv("J2K_T1_SYM_MB")) { long v = atol(e); if (v >= 0) ctx->t1_sym_mb = v; }
@@ -501,6 +502,7 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                     deep.swap(mix); flat.clear();
                 }
             }
+            P->deep_jobs_host = deep; P->flat_jobs_host = flat;      // (the merged launches below put level-0 bands between them)
             deep.insert(deep.end(), flat.begin(), flat.end());
             P->deep_l0 = l0; P->ndeep_jobs = (int)deep.size(); P->deep_lds = lds;
             int r = upload(ctx, &P->d_deep_planes, tp);
@@ -709,11 +711,16 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                         // one table per direction: the forward kernel measures best with 8 waves per workgroup (7 pair-rows:
                         // 3 halo rows per 14), the inverse with 4 (A/B on one box: forward 22.5-23.0 / 21.8-21.9 us at 4 / 8,
                         // inverse 25.5 / 26.2)
-                        auto wg_table = [&](int waves) {
+                        // top_only: just the bands that cover the low-pass rows feeding level 1 (the merged launches take the rest)
+                        auto split_row = [&](size_t i, int nr) {       // first pair-row of plane i that the top bands of nr rows do not cover
+                            const int halfH0 = (ph[i] + 1) / 2, tb = (halfH0 + 1) / 2;
+                            return std::min(halfH0, ((tb + nr - 1) / nr) * nr);
+                        };
+                        auto wg_table = [&](int waves, bool top_only = false) {
                             std::vector<DwtJob> wj;
                             const int nr = waves - 1;
                             for (size_t i = 0; i < planes.size(); i++)
-                                for (int pr = 0; pr < (ph[i] + 1) / 2; pr += nr) wj.push_back(DwtJob{(int)i, 0, pr, nr});
+                                for (int pr = 0; pr < (top_only ? split_row(i, nr) : (ph[i] + 1) / 2); pr += nr) wj.push_back(DwtJob{(int)i, 0, pr, nr});
                             if (ctx->l0_xcd && wj.size() >= 64 && ctx->l0_deal) {
                                 deal_xcd(wj, [&](const DwtJob &j) { return j.prow0 + nr > (ph[j.plane] + 1) / 2; });
                             } else if (ctx->l0_xcd && wj.size() >= 64) {
@@ -741,6 +748,34 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                         P->inv_wg_waves = invw;
                         r = upload(ctx, &P->d_inv_wg_jobs, ij);
                         if (r != J2K_OK) { j2k_plan_destroy(P); return r; }
+                        // merged launches (dwt53_mega_*_kernel): every level below 0 + the level-0 bands that neither feed nor
+                        // need them, for frames of RGB triples only whose deep launch starts at level 1
+                        if (ctx->mega && P->deep_l0 == 1 && S.C == 3 && planes.size() == P->groups.size() && !P->deep_jobs_host.empty()) {
+                            const int order = ctx->mega;       // 1: deep, level-0 bands, flat; 2: deep, flat, level-0 bands
+                            for (int d2 = 0; d2 < 2; d2++) {
+                                const int nr_top = (d2 == 0 ? ctx->l0_wg : invw) - 1;
+                                std::vector<DwtJob> l0b;
+                                for (size_t i = 0; i < planes.size(); i++)
+                                    for (int pr = split_row(i, nr_top); pr < (ph[i] + 1) / 2; pr += 15) l0b.push_back(DwtJob{(int)i, 2, pr, 15});
+                                std::vector<DwtJob> mj = P->deep_jobs_host;
+                                if (order == 2) mj.insert(mj.end(), P->flat_jobs_host.begin(), P->flat_jobs_host.end());
+                                mj.insert(mj.end(), l0b.begin(), l0b.end());
+                                if (order != 2) mj.insert(mj.end(), P->flat_jobs_host.begin(), P->flat_jobs_host.end());
+                                std::vector<DwtJob> top = wg_table(nr_top + 1, true);
+                                int64_t top_px = 0;
+                                for (size_t i = 0; i < planes.size(); i++) top_px += (int64_t)std::min(2 * split_row(i, nr_top), ph[i]) * pw[i];
+                                if (d2 == 0) {
+                                    P->mega_fwd_njobs = (int)mj.size(); P->fwd_top_njobs = (int)top.size(); P->fwd_top_bytes = top_px * 16;
+                                    r = upload(ctx, &P->d_mega_fwd_jobs, mj);
+                                    if (r == J2K_OK) r = upload(ctx, &P->d_fwd_top_jobs, top);
+                                } else {
+                                    P->mega_inv_njobs = (int)mj.size(); P->inv_top_njobs = (int)top.size(); P->inv_top_bytes = top_px * 16;
+                                    r = upload(ctx, &P->d_mega_inv_jobs, mj);
+                                    if (r == J2K_OK) r = upload(ctx, &P->d_inv_top_jobs, top);
+                                }
+                                if (r != J2K_OK) { j2k_plan_destroy(P); return r; }
+                            }
+                        }
                         // levels 0 + 1 in one launch (dwt53_fwd_rgba8_wg2_kernel): needs a level 1 (levels >= 2), only RGB
                         // triples in the frame (the level-1 plane table is then three planes per level-0 plane, same order)
                         if (ctx->l0_fuse > 0 && L >= 2 && S.C == 3 && (P->tail_l0 < 0 || P->tail_l0 >= 2) && (P->deep_l0 < 0 || P->deep_l0 >= 2)) {
@@ -929,7 +964,7 @@ extern "C" void j2k_plan_destroy(j2k_plan *P) {
         for (auto &T : P->fwd[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); if (T.d_pjobs) (void)hipFree(T.d_pjobs); }
         for (auto &T : P->inv[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); if (T.d_pjobs) (void)hipFree(T.d_pjobs); }
     }
-    void *ptrs[] = {P->d_inv_wg_jobs, P->d_deep_planes, P->d_deep_jobs, P->d_tile_job0, P->d_scrA, P->d_scrB, P->d_tail, P->d_bjobs, P->d_djobs, P->d_frame, P->d_coeff, P->d_slots, P->d_stream, P->d_lens, P->d_numbps, P->d_offs, P->d_status, P->d_fwd_pix_jobs, P->d_fwd_wg2_jobs, P->d_fwd_wg_rest_jobs, P->d_fwd_wg_jobs, P->d_fwd97_wg_jobs, P->d_inv97_wg_jobs, P->d_ht_ujobs, P->d_ht_alias_next, P->d_bjobs_alias, P->d_maglens, P->d_mels, P->d_toffs};
+    void *ptrs[] = {P->d_mega_fwd_jobs, P->d_mega_inv_jobs, P->d_fwd_top_jobs, P->d_inv_top_jobs, P->d_inv_wg_jobs, P->d_deep_planes, P->d_deep_jobs, P->d_tile_job0, P->d_scrA, P->d_scrB, P->d_tail, P->d_bjobs, P->d_djobs, P->d_frame, P->d_coeff, P->d_slots, P->d_stream, P->d_lens, P->d_numbps, P->d_offs, P->d_status, P->d_fwd_pix_jobs, P->d_fwd_wg2_jobs, P->d_fwd_wg_rest_jobs, P->d_fwd_wg_jobs, P->d_fwd97_wg_jobs, P->d_inv97_wg_jobs, P->d_ht_ujobs, P->d_ht_alias_next, P->d_bjobs_alias, P->d_maglens, P->d_mels, P->d_toffs};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete P;
 }
@@ -1018,6 +1053,7 @@ static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff, in
     const double step = 1.0 / (double)S.quality;   // encoder.go:269
     const int nlevel_launches = (P->deep_l0 >= 0) ? P->deep_l0 : ((P->tail_l0 >= 0) ? P->tail_l0 : S.levels);
     bool fused_l1 = false;             // level 1 ran inside the level-0 launch (packed RGBA8 frames, dwt53_fwd_rgba8_wg2_kernel)
+    bool mega = false;                 // level 0 ran its top bands only: the merged launch below takes the rest with the deep levels
     for (int l = 0; l < nlevel_launches; l++)
     for (int rep_ = 0; rep_ < dev_reps(l == 0 ? 1 : (l == 1 ? 2 : 4)); rep_++) {      // (always once outside dev builds)
         if (l == 1 && fused_l1) continue;
@@ -1038,6 +1074,10 @@ static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff, in
                     if (cls == 1 && P->d_fwd_pix_jobs) { L.jobs = P->d_fwd_pix_jobs; L.njobs = P->fwd_pix_njobs; }
                     if (cls == 1 && P->d_fwd_wg_jobs) {   // RGBA8: the workgroup form when every plane qualifies
                         L.jobs = P->d_fwd_wg_jobs; L.njobs = P->fwd_wg_njobs; L.wg_waves = P->fwd_wg_waves; L.wg_store = ctx->l0_store;
+                        if (P->d_mega_fwd_jobs && !P->d_fwd_wg2_jobs) {   // ... only its top bands: the rest runs beside the deep levels
+                            L.jobs = P->d_fwd_top_jobs; L.njobs = P->fwd_top_njobs;
+                            mega = true;
+                        }
                         if (P->d_fwd_wg2_jobs) {           // ... with level 1 fused into the bands of the top half of every plane
                             L.jobs2 = P->d_fwd_wg2_jobs; L.njobs2 = P->fwd_wg2_njobs; L.wg2_waves = P->fwd_wg2_waves;
                             L.jobs = P->d_fwd_wg_rest_jobs; L.njobs = P->fwd_wg_rest_njobs;
@@ -1060,7 +1100,14 @@ static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff, in
             }
         }
     }
-    for (int rep_ = 0; P->deep_l0 >= 0 && rep_ < dev_reps(4); rep_++) {
+    for (int rep_ = 0; mega && rep_ < dev_reps(4); rep_++) {
+        hipEvent_t e0, e1;
+        profile_pair(ctx, 1, e0, e1);
+        HIPCHK(ctx, launch_dwt53_mega_fwd(ctx->stream, P->d_mega_fwd_jobs, P->mega_fwd_njobs, P->d_deep_planes, P->fwd[1][0].d_planes, P->deep_lds,
+                                          (const int32_t *)P->d_scrA, (int32_t *)d_coeff, (const uint32_t *)d_frame, (int32_t *)P->d_scrA,
+                                          S.dc_shift, pix_stride, e0, e1));
+    }
+    for (int rep_ = 0; !mega && P->deep_l0 >= 0 && rep_ < dev_reps(4); rep_++) {
         hipEvent_t e0, e1;
         profile_pair(ctx, 1, e0, e1);
         HIPCHK(ctx, launch_dwt53_deep_fwd(ctx->stream, P->d_deep_jobs, P->ndeep_jobs, P->d_deep_planes, P->deep_lds,
@@ -1080,7 +1127,15 @@ static int plan_inverse_impl(j2k_plan *P, const void *d_coeff, void *d_frame, in
     const PlanSpec &S = P->spec;
     if (((uintptr_t)d_frame & 15) || ((uintptr_t)d_coeff & 15)) return fail(ctx, J2K_ERR_INVALID_ARG, "device pointers must be 16-byte aligned");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    for (int rep_ = 0; P->deep_l0 >= 0 && rep_ < dev_reps(0x100); rep_++) {
+    const bool mega = P->d_mega_inv_jobs && pix_cls == 1 && pix_stride > 0 && ctx->l0_wg_inv && S.wavelet == W53;
+    for (int rep_ = 0; mega && rep_ < dev_reps(0x100); rep_++) {
+        hipEvent_t e0, e1;
+        profile_pair(ctx, 3, e0, e1);
+        HIPCHK(ctx, launch_dwt53_mega_inv(ctx->stream, P->d_mega_inv_jobs, P->mega_inv_njobs, P->d_deep_planes, P->inv[1][0].d_planes, P->deep_lds,
+                                          (const int32_t *)d_coeff, (int32_t *)P->d_scrA, (const int32_t *)P->d_scrA, (uint32_t *)d_frame,
+                                          S.dc_shift_inv, pix_stride, e0, e1));
+    }
+    for (int rep_ = 0; !mega && P->deep_l0 >= 0 && rep_ < dev_reps(0x100); rep_++) {
         hipEvent_t e0, e1;
         profile_pair(ctx, 3, e0, e1);
         HIPCHK(ctx, launch_dwt53_deep_inv(ctx->stream, P->d_deep_jobs, P->ndeep_jobs, P->d_deep_planes, P->deep_lds, (const int32_t *)d_coeff,
@@ -1106,6 +1161,7 @@ static int plan_inverse_impl(j2k_plan *P, const void *d_coeff, void *d_frame, in
                     // RGBA8: the workgroup form when every plane qualifies (same job table as the forward: the plane order
                     // of the inverse level table is the forward one)
                     L.jobs = P->d_inv_wg_jobs; L.njobs = P->inv_wg_njobs; L.wg_waves = P->inv_wg_waves; L.wg_store = ctx->l0_inv_wpe;
+                    if (mega) { L.jobs = P->d_inv_top_jobs; L.njobs = P->inv_top_njobs; }   // the bottom bands ran beside the deep levels
                 }
                 profile_pair(ctx, l == 0 ? 2 : 3, L.ev_start, L.ev_stop);
                 HIPCHK(ctx, launch_dwt53_inv(ctx->stream, L, (const int32_t *)d_coeff, (const int32_t *)prev, (int32_t *)dst,

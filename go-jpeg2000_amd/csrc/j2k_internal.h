@@ -99,6 +99,12 @@ hipError_t launch_dwt53_deep_fwd(hipStream_t s, const DwtJob *jobs, int njobs, c
 hipError_t launch_dwt53_deep_inv(hipStream_t s, const DwtJob *jobs, int njobs, const TailPlane *planes, size_t lds_bytes, const int32_t *coef,
                                  int32_t *scr, hipEvent_t ev0, hipEvent_t ev1);
 
+hipError_t launch_dwt53_mega_fwd(hipStream_t s, const DwtJob *jobs, int njobs, const TailPlane *tplanes, const DwtPlane *l0planes, size_t lds_bytes,
+                                 const int32_t *scr, int32_t *coef, const uint32_t *pix, int32_t *nxt0, int dc_shift, int pix_stride,
+                                 hipEvent_t ev0, hipEvent_t ev1);
+hipError_t launch_dwt53_mega_inv(hipStream_t s, const DwtJob *jobs, int njobs, const TailPlane *tplanes, const DwtPlane *l0planes, size_t lds_bytes,
+                                 const int32_t *coef, int32_t *scr, const int32_t *prev0, uint32_t *pix, int dc_shift, int pix_stride,
+                                 hipEvent_t ev0, hipEvent_t ev1);
 hipError_t launch_unpack_pixels(hipStream_t s, const uint8_t *pix, size_t stride, int format, int w, int h, int src_max, int dst_max,
                                 int32_t *planes);
 hipError_t launch_colorspace(hipStream_t s, int cs, int32_t *planes, int ncomp, size_t n, int precision);

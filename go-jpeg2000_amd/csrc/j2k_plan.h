@@ -34,6 +34,10 @@ struct j2k_ctx {
     int fwd_pf = 0;            // forward 5-3 level kernels: software prefetch of the next pair-row (J2K_FWD_PF)
     int band_prows = 5;        // pair-rows per wavefront band (tunable: J2K_BAND_PROWS)
     int use_tail = 1;          // J2K_TAIL=0: every level as its own launch (A/B)
+    int mega = 0;              // J2K_MEGA: packed-RGBA8 frames: the deep levels and the level-0 bands independent of them in ONE launch per direction
+                               // (dwt53_mega_*_kernel); 0 (default) = level 0 as one launch + the deep launch; 1 / 2 = job order (deep, bands, flat / deep, flat, bands).
+                               // Measured (C2, one frame in flight): forward 14.3 + 23.9 us against 22.2 + 15.6, inverse 29.5 + 16.3 against 16.0 + 25.0 -- the launch's
+                               // LDS size is that of its largest role (112-144 KB), so the level-0 bands run one 16-wave workgroup per CU and lose what the overlap gains
     int use_deep = 1;          // J2K_DEEP=0: level tail_l0 - 1 as its own launch + the LDS tail (round 2) instead of ONE launch for every level below 0 (dwt53_deep.inc)
     int xcd_map = 0;           // J2K_XCD_MAP=0: plain job order (A/B)
     int cpl0 = 0;              // J2K_CPL0: force columns-per-lane of the level-0 5-3 kernels (tuning)
@@ -134,6 +138,11 @@ struct j2k_plan {
     j2k::DwtJob *d_deep_jobs = nullptr;         // deep workgroups first, then the flat ones
     int ndeep_jobs = 0;
     size_t deep_lds = 0;
+    std::vector<j2k::DwtJob> deep_jobs_host, flat_jobs_host;
+    // merged launches for packed RGBA8 frames (dwt53_mega_*_kernel) and the level-0 TOP band tables that go with them
+    j2k::DwtJob *d_mega_fwd_jobs = nullptr, *d_mega_inv_jobs = nullptr, *d_fwd_top_jobs = nullptr, *d_inv_top_jobs = nullptr;
+    int mega_fwd_njobs = 0, mega_inv_njobs = 0, fwd_top_njobs = 0, inv_top_njobs = 0;
+    int64_t fwd_top_bytes = 0, inv_top_bytes = 0;        // algorithmic bytes of the top-band launches (16 B per pixel)
     // code-block jobs
     std::vector<j2k_block> blocks;          // plane = shard-local tile-component index
     std::vector<int32_t> block_tile;        // tile of each job

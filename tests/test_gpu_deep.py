@@ -87,3 +87,38 @@ def test_deep_levels_rgb_tiles(oracle, W, H, tile):
     want = oracle.preprocess([np.ascontiguousarray(frame_h[c, :th, :tw]) for c in range(3)], tw, th, 8, True, 6)
     for c in range(3):
         assert np.array_equal(got[1][0][c * tw * th:(c + 1) * tw * th].reshape(th, tw), want[c])
+
+
+@pytest.mark.parametrize("W,H,tile", [(1280, 624, 512), (3840, 2160, 512), (512, 512, 0), (768, 300, 256), (1536, 130, 512), (512, 36, 0)])
+def test_merged_launches_rgba8(oracle, W, H, tile):
+    """J2K_MEGA: the deep levels and the level-0 bands independent of them in one launch per direction (dwt53_mega_*_kernel)
+    against level 0 + deep as separate launches (J2K_MEGA=0): same coefficients from packed RGBA8 pixels, same pixels back
+    from arbitrary coefficients, both job orders; one tile against the oracle.  Heights that leave no bottom band (36), a single
+    short one (130), ragged edge tiles (624 = 512 + 112)."""
+    import torch
+    from j2kgfx.codec import FramePlan
+    rng = np.random.default_rng(W + H + tile)
+    pix = rng.integers(0, 256, (H, W * 4)).astype(np.uint8)
+    got = []
+    junk_h = None
+    for mega in (0, 1, 2):
+        plan = FramePlan(W, H, 3, precision=8, lossless=True, num_resolutions=6, cb=(64, 64), tile=(tile, tile), coder=1,
+                         ctx=_ctx(J2K_MEGA=mega))
+        dpix = torch.from_numpy(pix).to(plan.device)
+        for rep in range(2):
+            coeff = plan.forward_rgba8(dpix)
+            back = plan.inverse_rgba8(coeff)
+            plan.ctx.sync()
+            assert np.array_equal(back.cpu().numpy().reshape(H, W, 4)[..., :3], pix.reshape(H, W, 4)[..., :3])
+        if junk_h is None:
+            junk_h = rng.integers(-2 ** 31, 2 ** 31, coeff.numel(), dtype=np.int64).astype(np.int32)
+        back2 = plan.inverse_rgba8(torch.from_numpy(junk_h).to(plan.device))
+        plan.ctx.sync()
+        got.append((coeff.cpu().numpy(), back2.cpu().numpy()))
+    for g in got[1:]:
+        assert np.array_equal(got[0][0], g[0]) and np.array_equal(got[0][1], g[1])
+    tw, th = min(tile or W, W), min(tile or H, H)
+    crop = np.ascontiguousarray(pix.reshape(H, W, 4)[:th, :tw].reshape(th, tw * 4))
+    want = oracle.preprocess(oracle.extract_image_data(crop, 2, tw, th), tw, th, 8, True, 6)
+    for c in range(3):
+        assert np.array_equal(got[1][0][c * tw * th:(c + 1) * tw * th].reshape(th, tw), want[c])
