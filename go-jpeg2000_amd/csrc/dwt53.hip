@@ -870,7 +870,7 @@ __device__ __forceinline__ void st_glb(int32_t *p, int v) { *(glb_i32_t *)p = v;
 // hundred cycles of arithmetic.
 template <int PER>
 __device__ __forceinline__ void lds_fwd_level(const int32_t *cur, int32_t *nxt, int32_t *gout, int w, int h, int n_next,
-                                              int wave, int lane) {
+                                              int wave, int lane, int qlo, int qhi) {
     const int halfW = (w + 1) >> 1, halfH = (h + 1) >> 1;
     const int c = 2 * lane;
     const bool owned = c < w;
@@ -882,7 +882,7 @@ __device__ __forceinline__ void lds_fwd_level(const int32_t *cur, int32_t *nxt, 
         if (lane < w - halfW) { if (idxH < n_next) st_lds(nxt + idxH, hi); else st_glb(gout + idxH, hi); }
     };
     const int c0 = owned ? c : 0, c1 = (c + 1 < w) ? c + 1 : 0;             // clamped: every lane reads a valid address
-    for (int qa = wave * PER; qa < halfH; qa += TAIL_WAVES * PER) {
+    for (int qa = qlo + wave * PER; qa < qhi; qa += TAIL_WAVES * PER) {
         int lo[NROW], hi[NROW];
         {
             int x[NROW][2];
@@ -907,7 +907,7 @@ __device__ __forceinline__ void lds_fwd_level(const int32_t *cur, int32_t *nxt, 
 #pragma unroll
         for (int k = 0; k < PER; k++) {
             const int q = qa + k;
-            if (q >= halfH) break;
+            if (q >= qhi) break;
             const bool has_odd = 2 * q + 1 < h, has_next = 2 * q + 2 < h;
             const int el = lo[2 + 2 * k], eh = hi[2 + 2 * k];
             int dl = wsub(lo[3 + 2 * k], has_next ? avg1(el, lo[4 + 2 * k]) : el);
@@ -928,20 +928,22 @@ typedef int tl_v2i __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) tl_v2i lds_tl_v2i_t;
 template <int PER>
 __device__ __forceinline__ void lds_fwd_level_fast(const int32_t *cur, int32_t *nxt, int32_t *gout, int w, int h, int n_next,
-                                                   int wave, int lane) {
+                                                   int wave, int lane, int qlo, int qhi) {
     const int HW = w >> 1, halfH = (h + 1) >> 1;
     const int R = 64 / HW;                          // bands per wave
     const int cp = lane & (HW - 1), g = lane / HW;
     const bool first = cp == 0, last = cp == HW - 1;
     constexpr int NROW = 2 * PER + 3;
     auto store = [&](int idx, int v) { if (idx < n_next) st_lds(nxt + idx, v); else st_glb(gout + idx, v); };
-    for (int q0 = wave * R * PER; q0 < halfH; q0 += TAIL_WAVES * R * PER) {
+    for (int q0 = qlo + wave * R * PER; q0 < qhi; q0 += TAIL_WAVES * R * PER) {
         const int qa = q0 + g * PER;
+        // (a band past the range repeats the reads of the range's last pair-row: the caller may hold only the rows the range needs)
+        const int qr = min(qa, qhi - 1);
         int lo[NROW], hi[NROW];
         {
             tl_v2i x[NROW];
 #pragma unroll
-            for (int i = 0; i < NROW; i++) x[i] = *(const lds_tl_v2i_t *)(cur + min(max(2 * qa - 2 + i, 0), h - 1) * w + 2 * cp);
+            for (int i = 0; i < NROW; i++) x[i] = *(const lds_tl_v2i_t *)(cur + min(max(2 * qr - 2 + i, 0), min(h - 1, 2 * qhi)) * w + 2 * cp);
 #pragma unroll
             for (int i = 0; i < NROW; i++) {
                 const int xr = from_right(x[i].x);
@@ -956,7 +958,7 @@ __device__ __forceinline__ void lds_fwd_level_fast(const int32_t *cur, int32_t *
 #pragma unroll
         for (int k = 0; k < PER; k++) {
             const int q = qa + k;
-            const bool live = q < halfH, has_odd = 2 * q + 1 < h, has_next = 2 * q + 2 < h;
+            const bool live = q < qhi, has_odd = 2 * q + 1 < h, has_next = 2 * q + 2 < h;
             const int el = lo[2 + 2 * k], eh = hi[2 + 2 * k];
             int dl = wsub(lo[3 + 2 * k], has_next ? avg1(el, lo[4 + 2 * k]) : el);
             int dh = wsub(hi[3 + 2 * k], has_next ? avg1(eh, hi[4 + 2 * k]) : eh);
@@ -972,19 +974,24 @@ __device__ __forceinline__ void lds_fwd_level_fast(const int32_t *cur, int32_t *
     }
 }
 __device__ __forceinline__ bool tail_level_fast_shape(int w, int h) { return !(w & 1) && w >= 2 && w <= 128 && (64 % (w >> 1)) == 0 && h >= 2; }
+// pair-rows [qlo, qhi) of the level (the whole level: 0, ceil(h / 2)); only the rows 2 qlo - 2 .. 2 qhi of `cur` are read
 __device__ __forceinline__ void tail_fwd_level(const int32_t *cur, int32_t *nxt, int32_t *gout, int w, int h, int n_next,
-                                               int wave, int lane) {
-    const int halfH = (h + 1) >> 1;                  // uniform for the workgroup
+                                               int wave, int lane, int qlo, int qhi) {
+    const int nq = qhi - qlo;                        // uniform for the workgroup
+    if (nq <= 0) return;
     if (tail_level_fast_shape(w, h)) {
-        const int per_band = (halfH + TAIL_WAVES * (128 / w) - 1) / (TAIL_WAVES * (128 / w));      // pair-rows per band if every band is used once
-        if (per_band > 2) lds_fwd_level_fast<4>(cur, nxt, gout, w, h, n_next, wave, lane);
-        else if (per_band > 1) lds_fwd_level_fast<2>(cur, nxt, gout, w, h, n_next, wave, lane);
-        else lds_fwd_level_fast<1>(cur, nxt, gout, w, h, n_next, wave, lane);
+        const int per_band = (nq + TAIL_WAVES * (128 / w) - 1) / (TAIL_WAVES * (128 / w));      // pair-rows per band if every band is used once
+        if (per_band > 2) lds_fwd_level_fast<4>(cur, nxt, gout, w, h, n_next, wave, lane, qlo, qhi);
+        else if (per_band > 1) lds_fwd_level_fast<2>(cur, nxt, gout, w, h, n_next, wave, lane, qlo, qhi);
+        else lds_fwd_level_fast<1>(cur, nxt, gout, w, h, n_next, wave, lane, qlo, qhi);
         return;
     }
-    if (halfH > 2 * TAIL_WAVES) lds_fwd_level<4>(cur, nxt, gout, w, h, n_next, wave, lane);
-    else if (halfH > TAIL_WAVES) lds_fwd_level<2>(cur, nxt, gout, w, h, n_next, wave, lane);
-    else lds_fwd_level<1>(cur, nxt, gout, w, h, n_next, wave, lane);
+    if (nq > 2 * TAIL_WAVES) lds_fwd_level<4>(cur, nxt, gout, w, h, n_next, wave, lane, qlo, qhi);
+    else if (nq > TAIL_WAVES) lds_fwd_level<2>(cur, nxt, gout, w, h, n_next, wave, lane, qlo, qhi);
+    else lds_fwd_level<1>(cur, nxt, gout, w, h, n_next, wave, lane, qlo, qhi);
+}
+__device__ __forceinline__ void tail_fwd_level(const int32_t *cur, int32_t *nxt, int32_t *gout, int w, int h, int n_next, int wave, int lane) {
+    tail_fwd_level(cur, nxt, gout, w, h, n_next, wave, lane, 0, (h + 1) >> 1);
 }
 
 __global__ __launch_bounds__(64 * TAIL_WAVES) void dwt53_tail_fwd_kernel(const TailPlane *__restrict__ planes, const int32_t *__restrict__ scr,
@@ -1020,7 +1027,7 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void dwt53_tail_fwd_kernel(const T
 // rows q-1 .. q+PER), then runs the vertical steps (dwt.go:132-146 down the columns) and the horizontal inverse of each row.
 template <int PER>
 __device__ __forceinline__ void lds_inv_level(const int32_t *prev, const int32_t *gcoef, int32_t *dst, int w, int h, int n_next,
-                                              int wave, int lane, bool coef_lds, bool dst_lds) {
+                                              int wave, int lane, bool coef_lds, bool dst_lds, int qlo, int qhi) {
     const int halfW = (w + 1) >> 1, halfH = (h + 1) >> 1, nhigh = h - halfH;
     const int c = 2 * lane;
     const bool owned = c < w;
@@ -1033,7 +1040,7 @@ __device__ __forceinline__ void lds_inv_level(const int32_t *prev, const int32_t
         if (dst_lds) { st_lds(dst + ro * w + c, x[0]); if (c + 1 < w) st_lds(dst + ro * w + c + 1, x[1]); }
         else { st_glb(dst + ro * w + c, x[0]); if (c + 1 < w) st_glb(dst + ro * w + c + 1, x[1]); }
     };
-    for (int qa = wave * PER; qa < halfH; qa += TAIL_WAVES * PER) {
+    for (int qa = qlo + wave * PER; qa < qhi; qa += TAIL_WAVES * PER) {
         int sl[PER + 1], sh[PER + 1], dl[PER + 2], dh[PER + 2];                  // s_{qa+k}, d_{qa-1+k}
 #pragma unroll
         for (int k = 0; k <= PER; k++) {
@@ -1073,7 +1080,7 @@ __device__ __forceinline__ void lds_inv_level(const int32_t *prev, const int32_t
 #pragma unroll
         for (int k = 0; k < PER; k++) {
             const int q = qa + k;
-            if (q >= halfH) break;
+            if (q >= qhi) break;
             const bool has_next = q + 1 < halfH;
             finish(2 * q, el[k], eh[k]);
             if (q < nhigh)       // undo predict: o_q = d_q + ((e_q + e_{q+1}) >> 1); no e_{q+1}: o_q = d_q + e_q
@@ -1084,7 +1091,7 @@ __device__ __forceinline__ void lds_inv_level(const int32_t *prev, const int32_t
 // The fast shapes (see lds_fwd_level_fast): lane = column pair, several bands per wave, 8-byte stores of the finished rows.
 template <int PER>
 __device__ __forceinline__ void lds_inv_level_fast(const int32_t *prev, const int32_t *gcoef, int32_t *dst, int w, int h, int n_next,
-                                                   int wave, int lane, bool coef_lds, bool dst_lds) {
+                                                   int wave, int lane, bool coef_lds, bool dst_lds, int qlo, int qhi) {
     const int HW = w >> 1, halfH = (h + 1) >> 1, nhigh = h - halfH;       // h >= 2: nhigh >= 1
     const int R = 64 / HW;
     const int cp = lane & (HW - 1), g = lane / HW;
@@ -1102,17 +1109,18 @@ __device__ __forceinline__ void lds_inv_level_fast(const int32_t *prev, const in
         if (dst_lds) *(lds_tl_v2i_t *)(dst + ro * w + 2 * cp) = v;
         else *(__attribute__((address_space(1))) tl_v2i *)(dst + ro * w + 2 * cp) = v;
     };
-    for (int q0 = wave * R * PER; q0 < halfH; q0 += TAIL_WAVES * R * PER) {
+    for (int q0 = qlo + wave * R * PER; q0 < qhi; q0 += TAIL_WAVES * R * PER) {
         const int qa = q0 + g * PER;
+        // (rows clamped to what the range needs -- s rows up to qhi, d rows qlo - 1 .. qhi: the caller may have staged only those)
         int sl[PER + 1], sh[PER + 1], dl[PER + 2], dh[PER + 2];
 #pragma unroll
         for (int k = 0; k <= PER; k++) {
-            const int row = min(qa + k, halfH - 1) * w + cp;
+            const int row = min(qa + k, min(halfH - 1, qhi)) * w + cp;
             sl[k] = ld1(row); sh[k] = ld1(row + HW);
         }
 #pragma unroll
         for (int k = 0; k < PER + 2; k++) {
-            const int row = (halfH + min(max(qa - 1 + k, 0), nhigh - 1)) * w + cp;
+            const int row = (halfH + min(max(qa - 1 + k, 0), min(nhigh - 1, qhi))) * w + cp;
             dl[k] = ld1(row); dh[k] = ld1(row + HW);
         }
         int el[PER + 1], eh[PER + 1];
@@ -1133,26 +1141,32 @@ __device__ __forceinline__ void lds_inv_level_fast(const int32_t *prev, const in
             // (the DPP shifts inside finish() need every lane: compute first, store under the lane's own condition)
             const tl_v2i re = finish(2 * q, el[k], eh[k]);
             const tl_v2i ro = finish(2 * q + 1, wadd(dl[k + 1], has_next ? avg1(el[k], el[k + 1]) : el[k]), wadd(dh[k + 1], has_next ? avg1(eh[k], eh[k + 1]) : eh[k]));
-            if (q < halfH) {
+            if (q < qhi) {
                 put(2 * q, re);
                 if (q < nhigh) put(2 * q + 1, ro);
             }
         }
     }
 }
+// pair-rows [qlo, qhi) of the level (the whole level: 0, ceil(h / 2)): output rows 2 qlo .. 2 qhi - 1
 __device__ __forceinline__ void tail_inv_level(const int32_t *prev, const int32_t *gcoef, int32_t *dst, int w, int h, int n_next,
-                                               int wave, int lane, bool coef_lds, bool dst_lds) {
-    const int halfH = (h + 1) >> 1;
+                                               int wave, int lane, bool coef_lds, bool dst_lds, int qlo, int qhi) {
+    const int nq = qhi - qlo;
+    if (nq <= 0) return;
     if (tail_level_fast_shape(w, h)) {
-        const int per_band = (halfH + TAIL_WAVES * (128 / w) - 1) / (TAIL_WAVES * (128 / w));
-        if (per_band > 2) lds_inv_level_fast<4>(prev, gcoef, dst, w, h, n_next, wave, lane, coef_lds, dst_lds);
-        else if (per_band > 1) lds_inv_level_fast<2>(prev, gcoef, dst, w, h, n_next, wave, lane, coef_lds, dst_lds);
-        else lds_inv_level_fast<1>(prev, gcoef, dst, w, h, n_next, wave, lane, coef_lds, dst_lds);
+        const int per_band = (nq + TAIL_WAVES * (128 / w) - 1) / (TAIL_WAVES * (128 / w));
+        if (per_band > 2) lds_inv_level_fast<4>(prev, gcoef, dst, w, h, n_next, wave, lane, coef_lds, dst_lds, qlo, qhi);
+        else if (per_band > 1) lds_inv_level_fast<2>(prev, gcoef, dst, w, h, n_next, wave, lane, coef_lds, dst_lds, qlo, qhi);
+        else lds_inv_level_fast<1>(prev, gcoef, dst, w, h, n_next, wave, lane, coef_lds, dst_lds, qlo, qhi);
         return;
     }
-    if (halfH > 2 * TAIL_WAVES) lds_inv_level<4>(prev, gcoef, dst, w, h, n_next, wave, lane, coef_lds, dst_lds);
-    else if (halfH > TAIL_WAVES) lds_inv_level<2>(prev, gcoef, dst, w, h, n_next, wave, lane, coef_lds, dst_lds);
-    else lds_inv_level<1>(prev, gcoef, dst, w, h, n_next, wave, lane, coef_lds, dst_lds);
+    if (nq > 2 * TAIL_WAVES) lds_inv_level<4>(prev, gcoef, dst, w, h, n_next, wave, lane, coef_lds, dst_lds, qlo, qhi);
+    else if (nq > TAIL_WAVES) lds_inv_level<2>(prev, gcoef, dst, w, h, n_next, wave, lane, coef_lds, dst_lds, qlo, qhi);
+    else lds_inv_level<1>(prev, gcoef, dst, w, h, n_next, wave, lane, coef_lds, dst_lds, qlo, qhi);
+}
+__device__ __forceinline__ void tail_inv_level(const int32_t *prev, const int32_t *gcoef, int32_t *dst, int w, int h, int n_next,
+                                               int wave, int lane, bool coef_lds, bool dst_lds) {
+    tail_inv_level(prev, gcoef, dst, w, h, n_next, wave, lane, coef_lds, dst_lds, 0, (h + 1) >> 1);
 }
 
 __global__ __launch_bounds__(64 * TAIL_WAVES) void dwt53_tail_inv_kernel(const TailPlane *__restrict__ planes, const int32_t *__restrict__ coef,

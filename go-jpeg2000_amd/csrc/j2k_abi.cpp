@@ -147,6 +147,8 @@ extern "C" int j2k_ctx_create(int device, j2k_ctx **out) {
     if (const char *e = getenv("J2K_FWD_PF")) ctx->fwd_pf = atoi(e) != 0;
     if (const char *e = getenv("J2K_TAIL")) ctx->use_tail = atoi(e) != 0;
     if (const char *e = getenv("J2K_DEEP")) ctx->use_deep = atoi(e) != 0;
+    if (const char *e = getenv("J2K_DEEP_MID")) ctx->deep_mid = atoi(e) != 0;
+    if (const char *e = getenv("J2K_DEEP_MID_INV")) { int v = atoi(e); if (v >= 0 && v <= 2) ctx->deep_mid_inv = v; }
     if (const char *e = getenv("J2K_MEGA")) { int v = atoi(e); if (v >= 0 && v <= 2) ctx->mega = v; }
     if (const char *e = getenv("J2K_XCD_MAP")) ctx->xcd_map = atoi(e) != 0;
     if (const char *e = getenv("J2K_T1_SPLIT")) ctx->t1_split = atoi(e) != 0;
@@ -466,47 +468,67 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
         const int l0 = lds_l0 - 1;
         bool ok = true;
         std::vector<TailPlane> tp;
-        std::vector<DwtJob> deep, flat;
-        size_t lds = 0;
+        std::vector<DwtJob> deep_f, flat_f, deep_i, flat_i;      // forward / inverse: the deep and mid jobs own different level-l0 rows
+        size_t lds = 0, lds_f = 0;
         for (const Group &g : P->groups) {
             int w = g.w, h = g.h;
             for (int i = 0; i < l0; i++) { w = (w + 1) / 2; h = (h + 1) / 2; }
             if (w < 8 || w > 256 || (w % 4) || h < 2 || h > 256) { ok = false; break; }
             const int w1 = w / 2, h1 = (h + 1) / 2, w2 = (w1 + 1) / 2, h2 = (h1 + 1) / 2;
             if (w1 > 128 || (int64_t)w1 * h1 > 16384) { ok = false; break; }
-            const size_t n1a = (size_t)((w1 * h1 + 3) & ~3), n2a = (size_t)((w2 * h2 + 3) & ~3), slots = 16 * 64 * 4;   // (ints)
-            lds = std::max(lds, (2 * slots + n1a + n2a + 8) * 4);                       // forward: slotE, slotD | bufA | bufB
-            lds = std::max(lds, (n1a + n2a + std::max(n1a, slots) + 8) * 4);            // inverse: bufA | bufB | bufC (= slotE later)
+            const int halfH = h1, T = (halfH + 1) / 2, T1 = (T + 1) / 2;   // pair-rows of level l0; of level l0+1; those feeding level l0+2
+            // the top half split once more (dwt53_deep.inc): level l0+1 must take the pair-column LDS routines, whole 16-byte runs
+            const bool has_mid = ctx->deep_mid && T >= 2 && (w % 8) == 0 && (w1 & 1) == 0 && (64 % (w1 / 2)) == 0 && h1 >= 2;
+            const size_t a_ints = has_mid ? (size_t)(2 * T1 + 2) * w1 : (size_t)w1 * h1;
+            const size_t n1a = (a_ints + 3) & ~size_t(3), n2a = (size_t)((w2 * h2 + 3) & ~3), nc = (size_t)((w1 * h1 + 3) & ~3), slots = 16 * 64 * 4;   // (ints)
+            lds_f = std::max(lds_f, (std::max(2 * slots, n2a) + n1a + 8) * 4);          // forward: slotE, slotD (later bufB) | bufA
+            const size_t n1i = (has_mid && ctx->deep_mid_inv) ? n1a : nc;                 // (the inverse takes the split only on request)
+            lds = std::max(lds, (n1i + n2a + std::max(nc, slots) + 8) * 4);             // inverse: bufA | bufB | bufC (= slotE later)
+            const int flag = has_mid ? 0x10000 : 0;
             for (int k = 0; k < g.nc; k++) {
                 const int64_t so = ((l0 & 1) ? g.scrA_off : g.scrB_off)[k];
                 if ((so % 4) || (g.coef_off[k] % 4)) ok = false;
-                TailPlane T{};
-                T.scr_off = so; T.coef_off = g.coef_off[k];
-                T.w = w; T.h = h; T.nlev = L - l0;
+                TailPlane T_{};
+                T_.scr_off = so; T_.coef_off = g.coef_off[k];
+                T_.w = w; T_.h = h; T_.nlev = L - l0;
                 const int pi = (int)tp.size();
-                tp.push_back(T);
-                const int halfH = h1, top = (halfH + 1) / 2;      // pair-rows whose low-pass rows feed level l0 + 1
-                deep.push_back(DwtJob{pi, 1, 0, top});
-                for (int q = top; q < halfH; q += 64) flat.push_back(DwtJob{pi, 0, q, std::min(64, halfH - q)});
+                tp.push_back(T_);
+                // The inverse launch cannot share a CU between two workgroups (113 KB of LDS, 95 registers), so a third job per
+                // plane waits for a CU and the split gains nothing there (J2K_DEEP_MID_INV: 0 = deep + flat, 16.2 us on a C2 frame;
+                // 1 = deep + mid + flat, 16.5; 2 = deep + mid, each rebuilding half of the bottom rows first, 18.2).  The forward
+                // launch fits two per CU (65 KB, 64 registers): 16.3 -> 13.8 us.
+                const int mid_inv = has_mid ? ctx->deep_mid_inv : 0;
+                if (has_mid) {
+                    deep_f.push_back(DwtJob{pi, 1, 0, std::min(T1 + 1, T) | flag});
+                    deep_f.push_back(DwtJob{pi, 3, T1 - 1, (T - (T1 - 1)) | flag});
+                } else deep_f.push_back(DwtJob{pi, 1, 0, T});
+                if (mid_inv == 2) {
+                    const int nf = halfH - T, fa = (nf + 1) / 2;
+                    deep_i.push_back(DwtJob{pi, 1 | fa << 8, 0, T1 | flag});
+                    deep_i.push_back(DwtJob{pi, 3 | (nf - fa) << 8 | fa << 16, T1, (T - T1) | flag});
+                } else if (mid_inv == 1) {
+                    deep_i.push_back(DwtJob{pi, 1, 0, T1 | flag});
+                    deep_i.push_back(DwtJob{pi, 3, T1, (T - T1) | flag});
+                } else deep_i.push_back(DwtJob{pi, 1, 0, T});
+                for (int q = T; q < halfH; q += 64) {
+                    flat_f.push_back(DwtJob{pi, 0, q, std::min(64, halfH - q)});
+                    if (mid_inv != 2) flat_i.push_back(DwtJob{pi, 0, q, std::min(64, halfH - q)});
+                }
             }
         }
         if (ok && !tp.empty()) {
-            if (const char *e = getenv("J2K_DEEP_ORDER")) {           // dev: placement experiments (1: rows of 8 alternate deep / flat)
-                if (atoi(e) == 1) {
-                    std::vector<DwtJob> mix;
-                    size_t a = 0, b = 0;
-                    while (a < deep.size() || b < flat.size()) {
-                        for (int i = 0; i < 8 && a < deep.size(); i++) mix.push_back(deep[a++]);
-                        for (int i = 0; i < 8 && b < flat.size(); i++) mix.push_back(flat[b++]);
-                    }
-                    deep.swap(mix); flat.clear();
-                }
-            }
-            P->deep_jobs_host = deep; P->flat_jobs_host = flat;      // (the merged launches below put level-0 bands between them)
-            deep.insert(deep.end(), flat.begin(), flat.end());
-            P->deep_l0 = l0; P->ndeep_jobs = (int)deep.size(); P->deep_lds = lds;
+            // deep jobs first (the longest chains), mid jobs behind them, then the flat ones
+            auto order = [](std::vector<DwtJob> &d, const std::vector<DwtJob> &f) {
+                std::stable_sort(d.begin(), d.end(), [](const DwtJob &a, const DwtJob &b) { return (a.col0 & 0xff) < (b.col0 & 0xff); });
+                d.insert(d.end(), f.begin(), f.end());
+            };
+            P->deep_jobs_host = deep_f; P->flat_jobs_host = flat_f;      // (J2K_MEGA's merged launches put level-0 bands between them)
+            P->deep_jobs_host_inv = deep_i; P->flat_jobs_host_inv = flat_i;
+            order(deep_f, flat_f); order(deep_i, flat_i);
+            P->deep_l0 = l0; P->ndeep_jobs = (int)deep_f.size(); P->ndeep_jobs_inv = (int)deep_i.size(); P->deep_lds = lds; P->deep_lds_fwd = lds_f;
             int r = upload(ctx, &P->d_deep_planes, tp);
-            if (r == J2K_OK) r = upload(ctx, &P->d_deep_jobs, deep);
+            if (r == J2K_OK) r = upload(ctx, &P->d_deep_jobs, deep_f);
+            if (r == J2K_OK) r = upload(ctx, &P->d_deep_jobs_inv, deep_i);
             if (r != J2K_OK) { j2k_plan_destroy(P); return r; }
         }
     }
@@ -757,10 +779,11 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                                 std::vector<DwtJob> l0b;
                                 for (size_t i = 0; i < planes.size(); i++)
                                     for (int pr = split_row(i, nr_top); pr < (ph[i] + 1) / 2; pr += 15) l0b.push_back(DwtJob{(int)i, 2, pr, 15});
-                                std::vector<DwtJob> mj = P->deep_jobs_host;
-                                if (order == 2) mj.insert(mj.end(), P->flat_jobs_host.begin(), P->flat_jobs_host.end());
+                                std::vector<DwtJob> mj = d2 == 0 ? P->deep_jobs_host : P->deep_jobs_host_inv;
+                                const std::vector<DwtJob> &fj = d2 == 0 ? P->flat_jobs_host : P->flat_jobs_host_inv;
+                                if (order == 2) mj.insert(mj.end(), fj.begin(), fj.end());
                                 mj.insert(mj.end(), l0b.begin(), l0b.end());
-                                if (order != 2) mj.insert(mj.end(), P->flat_jobs_host.begin(), P->flat_jobs_host.end());
+                                if (order != 2) mj.insert(mj.end(), fj.begin(), fj.end());
                                 std::vector<DwtJob> top = wg_table(nr_top + 1, true);
                                 int64_t top_px = 0;
                                 for (size_t i = 0; i < planes.size(); i++) top_px += (int64_t)std::min(2 * split_row(i, nr_top), ph[i]) * pw[i];
@@ -964,7 +987,7 @@ extern "C" void j2k_plan_destroy(j2k_plan *P) {
         for (auto &T : P->fwd[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); if (T.d_pjobs) (void)hipFree(T.d_pjobs); }
         for (auto &T : P->inv[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); if (T.d_pjobs) (void)hipFree(T.d_pjobs); }
     }
-    void *ptrs[] = {P->d_mega_fwd_jobs, P->d_mega_inv_jobs, P->d_fwd_top_jobs, P->d_inv_top_jobs, P->d_inv_wg_jobs, P->d_deep_planes, P->d_deep_jobs, P->d_tile_job0, P->d_scrA, P->d_scrB, P->d_tail, P->d_bjobs, P->d_djobs, P->d_frame, P->d_coeff, P->d_slots, P->d_stream, P->d_lens, P->d_numbps, P->d_offs, P->d_status, P->d_fwd_pix_jobs, P->d_fwd_wg2_jobs, P->d_fwd_wg_rest_jobs, P->d_fwd_wg_jobs, P->d_fwd97_wg_jobs, P->d_inv97_wg_jobs, P->d_ht_ujobs, P->d_ht_alias_next, P->d_bjobs_alias, P->d_maglens, P->d_mels, P->d_toffs};
+    void *ptrs[] = {P->d_deep_jobs_inv, P->d_mega_fwd_jobs, P->d_mega_inv_jobs, P->d_fwd_top_jobs, P->d_inv_top_jobs, P->d_inv_wg_jobs, P->d_deep_planes, P->d_deep_jobs, P->d_tile_job0, P->d_scrA, P->d_scrB, P->d_tail, P->d_bjobs, P->d_djobs, P->d_frame, P->d_coeff, P->d_slots, P->d_stream, P->d_lens, P->d_numbps, P->d_offs, P->d_status, P->d_fwd_pix_jobs, P->d_fwd_wg2_jobs, P->d_fwd_wg_rest_jobs, P->d_fwd_wg_jobs, P->d_fwd97_wg_jobs, P->d_inv97_wg_jobs, P->d_ht_ujobs, P->d_ht_alias_next, P->d_bjobs_alias, P->d_maglens, P->d_mels, P->d_toffs};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete P;
 }
@@ -1103,14 +1126,14 @@ static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff, in
     for (int rep_ = 0; mega && rep_ < dev_reps(4); rep_++) {
         hipEvent_t e0, e1;
         profile_pair(ctx, 1, e0, e1);
-        HIPCHK(ctx, launch_dwt53_mega_fwd(ctx->stream, P->d_mega_fwd_jobs, P->mega_fwd_njobs, P->d_deep_planes, P->fwd[1][0].d_planes, P->deep_lds,
+        HIPCHK(ctx, launch_dwt53_mega_fwd(ctx->stream, P->d_mega_fwd_jobs, P->mega_fwd_njobs, P->d_deep_planes, P->fwd[1][0].d_planes, P->deep_lds_fwd,
                                           (const int32_t *)P->d_scrA, (int32_t *)d_coeff, (const uint32_t *)d_frame, (int32_t *)P->d_scrA,
                                           S.dc_shift, pix_stride, e0, e1));
     }
     for (int rep_ = 0; !mega && P->deep_l0 >= 0 && rep_ < dev_reps(4); rep_++) {
         hipEvent_t e0, e1;
         profile_pair(ctx, 1, e0, e1);
-        HIPCHK(ctx, launch_dwt53_deep_fwd(ctx->stream, P->d_deep_jobs, P->ndeep_jobs, P->d_deep_planes, P->deep_lds,
+        HIPCHK(ctx, launch_dwt53_deep_fwd(ctx->stream, P->d_deep_jobs, P->ndeep_jobs, P->d_deep_planes, P->deep_lds_fwd,
                                           (const int32_t *)((P->deep_l0 & 1) ? P->d_scrA : P->d_scrB), (int32_t *)d_coeff, e0, e1));
     }
     for (int rep_ = 0; P->deep_l0 < 0 && P->tail_l0 >= 0 && rep_ < dev_reps(4); rep_++) {
@@ -1138,7 +1161,7 @@ static int plan_inverse_impl(j2k_plan *P, const void *d_coeff, void *d_frame, in
     for (int rep_ = 0; !mega && P->deep_l0 >= 0 && rep_ < dev_reps(0x100); rep_++) {
         hipEvent_t e0, e1;
         profile_pair(ctx, 3, e0, e1);
-        HIPCHK(ctx, launch_dwt53_deep_inv(ctx->stream, P->d_deep_jobs, P->ndeep_jobs, P->d_deep_planes, P->deep_lds, (const int32_t *)d_coeff,
+        HIPCHK(ctx, launch_dwt53_deep_inv(ctx->stream, P->d_deep_jobs_inv, P->ndeep_jobs_inv, P->d_deep_planes, P->deep_lds, (const int32_t *)d_coeff,
                                           (int32_t *)((P->deep_l0 & 1) ? P->d_scrA : P->d_scrB), e0, e1));
     }
     for (int rep_ = 0; P->deep_l0 < 0 && P->tail_l0 >= 0 && rep_ < dev_reps(0x100); rep_++) {

@@ -38,6 +38,8 @@ struct j2k_ctx {
                                // (dwt53_mega_*_kernel); 0 (default) = level 0 as one launch + the deep launch; 1 / 2 = job order (deep, bands, flat / deep, flat, bands).
                                // Measured (C2, one frame in flight): forward 14.3 + 23.9 us against 22.2 + 15.6, inverse 29.5 + 16.3 against 16.0 + 25.0 -- the launch's
                                // LDS size is that of its largest role (112-144 KB), so the level-0 bands run one 16-wave workgroup per CU and lose what the overlap gains
+    int deep_mid_inv = 0;      // J2K_DEEP_MID_INV: the same split in the inverse launch (0 off: measured no gain; 1 = deep + mid + flat; 2 = deep + mid, flat rows inside them)
+    int deep_mid = 1;          // J2K_DEEP_MID=0: the deep workgroup keeps the whole top half of its plane (no mid workgroup beside it)
     int use_deep = 1;          // J2K_DEEP=0: level tail_l0 - 1 as its own launch + the LDS tail (round 2) instead of ONE launch for every level below 0 (dwt53_deep.inc)
     int xcd_map = 0;           // J2K_XCD_MAP=0: plain job order (A/B)
     int cpl0 = 0;              // J2K_CPL0: force columns-per-lane of the level-0 5-3 kernels (tuning)
@@ -137,8 +139,10 @@ struct j2k_plan {
     j2k::TailPlane *d_deep_planes = nullptr;    // dims at level deep_l0
     j2k::DwtJob *d_deep_jobs = nullptr;         // deep workgroups first, then the flat ones
     int ndeep_jobs = 0;
-    size_t deep_lds = 0;
-    std::vector<j2k::DwtJob> deep_jobs_host, flat_jobs_host;
+    size_t deep_lds = 0, deep_lds_fwd = 0;      // dynamic LDS of the inverse / forward launch
+    std::vector<j2k::DwtJob> deep_jobs_host, deep_jobs_host_inv, flat_jobs_host, flat_jobs_host_inv;
+    j2k::DwtJob *d_deep_jobs_inv = nullptr;     // the inverse launch's table (deep / mid jobs own other level-l0 rows than in the forward one)
+    int ndeep_jobs_inv = 0;
     // merged launches for packed RGBA8 frames (dwt53_mega_*_kernel) and the level-0 TOP band tables that go with them
     j2k::DwtJob *d_mega_fwd_jobs = nullptr, *d_mega_inv_jobs = nullptr, *d_fwd_top_jobs = nullptr, *d_inv_top_jobs = nullptr;
     int mega_fwd_njobs = 0, mega_inv_njobs = 0, fwd_top_njobs = 0, inv_top_njobs = 0;

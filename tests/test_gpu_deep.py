@@ -41,9 +41,10 @@ def test_deep_levels_single_component(oracle, W, H, tile, nres):
     full = rng.integers(-2 ** 31, 2 ** 31, (1, H, W), dtype=np.int64).astype(np.int32)
     small = rng.integers(0, 65536, (1, H, W)).astype(np.int32)
     outs = {}
-    for deep in (0, 1):
+    for deep in (0, 1, 2, 3, 4):                    # 0: per-level launches; 1: default; 2-4: the mid-job variants of both directions
+        env = {0: dict(J2K_DEEP=0), 1: dict(J2K_DEEP=1), 2: dict(J2K_DEEP_MID=0), 3: dict(J2K_DEEP_MID_INV=1), 4: dict(J2K_DEEP_MID_INV=2)}[deep]
         plan = FramePlan(W, H, 1, precision=16, lossless=True, num_resolutions=nres, cb=(64, 64), tile=(tile, tile), coder=1,
-                         ctx=_ctx(J2K_DEEP=deep))
+                         ctx=_ctx(**env))
         res = []
         for frame_h in (full, small):
             for rep in range(2):                      # the second pass starts on an idle device (scheduling-dependent bugs)
@@ -55,8 +56,9 @@ def test_deep_levels_single_component(oracle, W, H, tile, nres):
                 assert np.array_equal(b.reshape(1, H, W), frame_h)
             res += [c, b]
         outs[deep] = res
-    for a, b in zip(outs[0], outs[1]):
-        assert np.array_equal(a, b)
+    for k in (1, 2, 3, 4):
+        for a, b in zip(outs[0], outs[k]):
+            assert np.array_equal(a, b), k
     if W * H <= 1 << 18 and tile == 0:
         want = oracle.preprocess([small[0]], W, H, 16, True, nres)
         assert np.array_equal(outs[1][2].reshape(H, W), want[0])
