@@ -147,6 +147,7 @@ extern "C" int j2k_ctx_create(int device, j2k_ctx **out) {
     if (const char *e = getenv("J2K_FWD_PF")) ctx->fwd_pf = atoi(e) != 0;
     if (const char *e = getenv("J2K_TAIL")) ctx->use_tail = atoi(e) != 0;
     if (const char *e = getenv("J2K_DEEP")) ctx->use_deep = atoi(e) != 0;
+    if (const char *e = getenv("J2K_L0_XCD_GROUP")) ctx->l0_xcd_group = std::max(0, atoi(e));     // (inverse table)
     if (const char *e = getenv("J2K_DEEP_MID")) ctx->deep_mid = atoi(e) != 0;
     if (const char *e = getenv("J2K_DEEP_MID_INV")) { int v = atoi(e); if (v >= 0 && v <= 2) ctx->deep_mid_inv = v; }
     if (const char *e = getenv("J2K_MEGA")) { int v = atoi(e); if (v >= 0 && v <= 2) ctx->mega = v; }
@@ -738,12 +739,23 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                             const int halfH0 = (ph[i] + 1) / 2, tb = (halfH0 + 1) / 2;
                             return std::min(halfH0, ((tb + nr - 1) / nr) * nr);
                         };
-                        auto wg_table = [&](int waves, bool top_only = false) {
+                        auto wg_table = [&](int waves, bool top_only = false, int xcd_group = 0) {
                             std::vector<DwtJob> wj;
                             const int nr = waves - 1;
                             for (size_t i = 0; i < planes.size(); i++)
                                 for (int pr = 0; pr < (top_only ? split_row(i, nr) : (ph[i] + 1) / 2); pr += nr) wj.push_back(DwtJob{(int)i, 0, pr, nr});
-                            if (ctx->l0_xcd && wj.size() >= 64 && ctx->l0_deal) {
+                            if (ctx->l0_xcd && wj.size() >= 64 && xcd_group > 0) {
+                                // XCD-aware in small groups: G consecutive bands (which share halo rows) go to ONE XCD, one after the
+                                // other, and the eight XCDs work on eight neighbouring groups at a time -- the halo re-reads still hit
+                                // that XCD's L2 (G - 1 of G boundaries) while the device as a whole sweeps memory in order, as the
+                                // plain job order does (tools/probe/l0_inv_probe.hip: 5.7 TB/s in plain order, 5.4-5.5 in any order
+                                // that gives every XCD a region of its own).  Table position p runs on XCD p % 8.
+                                const size_t G = (size_t)xcd_group, ng = (wj.size() + G - 1) / G, rows = (ng + 7) / 8 * G;
+                                std::vector<DwtJob> perm(rows * 8, DwtJob{-1, 0, 0, 0});
+                                for (size_t g = 0; g < ng; g++)
+                                    for (size_t j = 0; j < G && g * G + j < wj.size(); j++) perm[((g / 8) * G + j) * 8 + g % 8] = wj[g * G + j];
+                                wj.swap(perm);
+                            } else if (ctx->l0_xcd && wj.size() >= 64 && ctx->l0_deal) {
                                 deal_xcd(wj, [&](const DwtJob &j) { return j.prow0 + nr > (ph[j.plane] + 1) / 2; });
                             } else if (ctx->l0_xcd && wj.size() >= 64) {
                                 // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one), so
@@ -765,7 +777,7 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                         r = upload(ctx, &P->d_fwd_wg_jobs, wj);
                         if (r != J2K_OK) { j2k_plan_destroy(P); return r; }
                         const int invw = ctx->l0_wg_invw > 0 ? ctx->l0_wg_invw : ctx->l0_wg;
-                        std::vector<DwtJob> ij = wg_table(invw);
+                        std::vector<DwtJob> ij = wg_table(invw, false, ctx->l0_xcd_group);      // (measured: inverse 25.2 -> 24.5 us at groups of 8; the forward table loses 0.5 us with it)
                         P->inv_wg_njobs = (int)ij.size();
                         P->inv_wg_waves = invw;
                         r = upload(ctx, &P->d_inv_wg_jobs, ij);
@@ -784,7 +796,7 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                                 if (order == 2) mj.insert(mj.end(), fj.begin(), fj.end());
                                 mj.insert(mj.end(), l0b.begin(), l0b.end());
                                 if (order != 2) mj.insert(mj.end(), fj.begin(), fj.end());
-                                std::vector<DwtJob> top = wg_table(nr_top + 1, true);
+                                std::vector<DwtJob> top = wg_table(nr_top + 1, true, d2 == 1 ? ctx->l0_xcd_group : 0);
                                 int64_t top_px = 0;
                                 for (size_t i = 0; i < planes.size(); i++) top_px += (int64_t)std::min(2 * split_row(i, nr_top), ph[i]) * pw[i];
                                 if (d2 == 0) {
