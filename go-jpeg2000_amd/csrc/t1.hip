@@ -214,7 +214,7 @@ __global__ __launch_bounds__(64) void t1_encode_kernel(const BlockJob *__restric
     const int lane = threadIdx.x;
     const BlockJob J = jobs[jid];
     const int w = J.w, h = J.h, stride = w + 2;
-    if (skip_small && w <= 64 && h <= 64) return;   // t1_encode64_kernel takes these
+    if (skip_small && w <= skip_small && h <= skip_small) return;   // skip_small = 64 / 256: t1_encode64_kernel (and t1_encode_big_kernel) take these
     const size_t n = (size_t)w * h;
     T1Tables &T = *reinterpret_cast<T1Tables *>(smem);
     const size_t flag_bytes = ((size_t)(w + 2) * (h + 2) + 15) & ~size_t(15);
@@ -412,23 +412,37 @@ __device__ __forceinline__ void mq_run(MqEnc &e, const uint32_t *mqtab, uint32_t
 #ifdef J2K_T1_NOMQ
     e.C += n; return;     // timing experiment: context formation only
 #endif
+    // Four symbols per trip, their contexts' table entries requested together with the NEXT four symbols: the chain of a lone
+    // lane is latency, and an LDS round trip per symbol (entry after symbol after entry ...) was most of it -- 150 ns per symbol
+    // for the 650 k symbols of a 256 x 256 block of noise.  An entry fetched early is stale only if an earlier symbol of the
+    // same group changed the same context's state (a renormalisation): patched where it happens.
     uint32_t A = e.A, C = e.C, CT = e.CT;
+    uint32_t four = n ? *reinterpret_cast<const uint32_t *>(sym) : 0;
     for (uint32_t i0 = 0; i0 < n; i0 += 4) {
-        uint32_t four = *reinterpret_cast<const uint32_t *>(sym + i0);
+        const uint32_t cur = four;
+        if (i0 + 4 < n) four = *reinterpret_cast<const uint32_t *>(sym + i0 + 4);
         const uint32_t m = min(n - i0, 4u);
-        for (uint32_t k = 0; k < m; k++, four >>= 8) {
-            const uint32_t ctx = four & 31, d = (four >> 5) & 1;
-            const uint32_t ent = ctxent[ctx];
-            const uint32_t qe = ent & 0xFFFF;
+        uint32_t cx[4], ent[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { cx[k] = (cur >> (8 * k)) & 31; ent[k] = ctxent[cx[k]]; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if ((uint32_t)k >= m) break;
+            const uint32_t ctx = cx[k], d = (cur >> (8 * k + 5)) & 1;
+            const uint32_t en = ent[k];
+            const uint32_t qe = en & 0xFFFF;
             const uint32_t A1 = A - qe;
-            const bool isM = d == ((ent >> 16) & 1);
+            const bool isM = d == ((en >> 16) & 1);
             if (isM && (A1 & 0x8000)) { A = A1; C += qe; continue; }      // the common case; everything below is select-only:
             // a divergent branch costs exec-mask bookkeeping on the CU's one scalar unit (measured: as many SALU as VALU
             // instructions per symbol when every `if` of mqc.go:224-255 is a branch)
             const bool lt = A1 < qe;
             C += (isM != lt) ? qe : 0u;                                   // MPS: C += qe unless A < qe; LPS: only if A < qe
             A = (isM == lt) ? qe : A1;
-            ctxent[ctx] = mqtab[isM ? ((ent >> 16) & 0xFF) : (ent >> 24)];
+            const uint32_t ne = mqtab[isM ? ((en >> 16) & 0xFF) : (en >> 24)];
+            ctxent[ctx] = ne;
+#pragma unroll
+            for (int j = k + 1; j < 4; j++) if (cx[j] == ctx) ent[j] = ne;   // the entries fetched ahead for the same context
             uint32_t shift = (uint32_t)__clz(A) - 16;                     // A < 0x8000 here: 1..15 doublings
             A <<= shift;
             if (shift < CT) { C <<= shift; CT -= shift; continue; }
@@ -721,6 +735,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
     lens[jid] = end > 1 ? (uint32_t)(end - 1) : 0;
     numbps[jid] = (uint8_t)numBPS;
 }
+
+#include "t1_big.inc"
 
 // ---- MQ coder, K blocks per wavefront in lock step (mqc.go:224-267, flush t1_fast5.go:878-898) ----
 // t1_encode64_kernel<true> leaves every block's (context, decision) list in memory; here LANE l of workgroup g codes the
@@ -1591,13 +1607,35 @@ hipError_t launch_t1_encode(hipStream_t s, const BlockJob *jobs, int njobs, cons
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess || max_dim <= 64) return e;
+        // blocks above 64 x 64, up to 256 x 256 (the reference's default size): wave-parallel context formation (t1_big.inc)
+        static int big_on = -1;        // J2K_T1_BIG=0: A/B against the serial kernel
+        if (big_on < 0) { const char *en = getenv("J2K_T1_BIG"); big_on = en ? atoi(en) : 1; }
+        if (big_on) {
+            static bool raised = false;
+            if (!raised) {
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(t1_encode_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(T1Big));
+                if (e != hipSuccess) return e;
+                raised = true;
+            }
+            hipLaunchKernelGGL(t1_encode_big_kernel, dim3(njobs), dim3(256), sizeof(T1Big), s, jobs, njobs, coef, slots, lens, numbps, fault);
+            e = hipGetLastError();
+            if (e != hipSuccess || max_dim <= 256) return e;
+        }
+        const int skip = big_on ? 256 : 64;
+        const int wb = lds_for(work_per_job);
+        const size_t lds = ((sizeof(T1Tables) + 15) & ~size_t(15)) + (size_t)wb;
+        if (wb) hipLaunchKernelGGL(t1_encode_kernel<true>, dim3(njobs), dim3(64), lds, s, jobs, njobs, coef, slots, lens, numbps, work,
+                                   work_per_job, wb, fault, skip);
+        else hipLaunchKernelGGL(t1_encode_kernel<false>, dim3(njobs), dim3(64), lds, s, jobs, njobs, coef, slots, lens, numbps, work,
+                                work_per_job, wb, fault, skip);
+        return hipGetLastError();
     }
     const int wb = lds_for(work_per_job);
     const size_t lds = ((sizeof(T1Tables) + 15) & ~size_t(15)) + (size_t)wb;
     if (wb) hipLaunchKernelGGL(t1_encode_kernel<true>, dim3(njobs), dim3(64), lds, s, jobs, njobs, coef, slots, lens, numbps, work,
-                               work_per_job, wb, fault, serial_only ? 0 : 1);
+                               work_per_job, wb, fault, 0);
     else hipLaunchKernelGGL(t1_encode_kernel<false>, dim3(njobs), dim3(64), lds, s, jobs, njobs, coef, slots, lens, numbps, work,
-                            work_per_job, wb, fault, serial_only ? 0 : 1);
+                            work_per_job, wb, fault, 0);
     return hipGetLastError();
 }
 
