@@ -43,6 +43,7 @@ def test_deep_levels_single_component(oracle, W, H, tile, nres):
     outs = {}
     for deep in (0, 1, 2, 3, 4):                    # 0: per-level launches; 1: default; 2-4: the mid-job variants of both directions
         env = {0: dict(J2K_DEEP=0), 1: dict(J2K_DEEP=1), 2: dict(J2K_DEEP_MID=0), 3: dict(J2K_DEEP_MID_INV=1), 4: dict(J2K_DEEP_MID_INV=2)}[deep]
+        env["J2K_DEEP_MIN_PLANES"] = 1              # (by default a frame of fewer than 12 tile-components keeps the per-level launches)
         plan = FramePlan(W, H, 1, precision=16, lossless=True, num_resolutions=nres, cb=(64, 64), tile=(tile, tile), coder=1,
                          ctx=_ctx(**env))
         res = []
@@ -73,7 +74,7 @@ def test_deep_levels_rgb_tiles(oracle, W, H, tile):
     got = []
     for deep in (0, 1):
         plan = FramePlan(W, H, 3, precision=8, lossless=True, num_resolutions=6, cb=(64, 64), tile=(tile, tile), coder=1,
-                         ctx=_ctx(J2K_DEEP=deep))
+                         ctx=_ctx(J2K_DEEP=deep, J2K_DEEP_MIN_PLANES=1))
         frame = torch.from_numpy(frame_h).to(plan.device)
         coeff = plan.forward(frame)
         back = plan.inverse(coeff)
@@ -105,7 +106,7 @@ def test_merged_launches_rgba8(oracle, W, H, tile):
     junk_h = None
     for mega in (0, 1, 2):
         plan = FramePlan(W, H, 3, precision=8, lossless=True, num_resolutions=6, cb=(64, 64), tile=(tile, tile), coder=1,
-                         ctx=_ctx(J2K_MEGA=mega))
+                         ctx=_ctx(J2K_MEGA=mega, J2K_DEEP_MIN_PLANES=1))
         dpix = torch.from_numpy(pix).to(plan.device)
         for rep in range(2):
             coeff = plan.forward_rgba8(dpix)

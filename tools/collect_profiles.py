@@ -31,3 +31,7 @@ if glob.glob(os.path.join(O, "stats_c3bench/*/*kernel_stats.csv")):
         lines += [l for l in out.splitlines() if l.strip()]
     open(os.path.join(P, tag + "_c3_pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
     print(open(os.path.join(P, tag + "_c3_pmc_summary.txt")).read())
+
+for name in ("c1gpu", "c5"):
+    if glob.glob(os.path.join(O, "stats_%s/*/*kernel_stats.csv" % name)):
+        shutil.copy(newest("stats_%s/*/*kernel_stats.csv" % name), os.path.join(P, "%s_%s_bench_kernel_stats.csv" % (tag, name)))

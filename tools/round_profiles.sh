@@ -1,22 +1,24 @@
-# Profiles committed under profiles/ (run on the GPU box): kernel stats for the default bench and for one frame in
-# flight, and the HBM traffic (FETCH_SIZE / WRITE_SIZE in separate passes) with one frame in flight.
+# Profiles committed under profiles/ (run on the GPU box: bash tools/round_profiles.sh): kernel stats for the default bench and for
+# one frame in flight, and the HBM traffic (FETCH_SIZE / WRITE_SIZE in separate passes) with one frame in flight; the same for C3;
+# kernel stats of c1gpu and c5.  python tools/collect_profiles.py <tag> copies the summaries.
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/round
-mkdir -p $O
+rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_default -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $O/stats_default.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_inflight1 -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --inflight 1 > $O/stats_inflight1.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --inflight 1 > $O/pmc_$c.log 2>&1
 done
-tail -1 $O/stats_default.log; tail -1 $O/stats_inflight1.log
-# C3-like frame (9-7, 12 bit, MQ coder): per-stage kernel stats of tools/bench_c3.py (T1 encoder / decoder kernels)
+tail -1 $O/stats_default.log | cut -c1-200; tail -1 $O/stats_inflight1.log | cut -c1-200
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c3 -- python $R/tools/bench_c3.py 0 0 > $O/stats_c3.log 2>&1
 tail -7 $O/stats_c3.log
-# the same configuration through bench.py (`--config c3`): kernel stats of the bench command itself, and the HBM traffic of its
-# transform kernels with one frame in flight
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c3bench -- python $R/bench.py --config c3 --steps 3 --warmup 1 --no-cpu-baseline > $O/stats_c3bench.log 2>&1
 tail -1 $O/stats_c3bench.log | cut -c1-200
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_c3_$c -- python $R/bench.py --config c3 --steps 2 --warmup 1 --no-cpu-baseline --inflight 1 > $O/pmc_c3_$c.log 2>&1
 done
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c1gpu -- python $R/bench.py --config c1gpu --steps 3 --warmup 1 --no-cpu-baseline > $O/stats_c1gpu.log 2>&1
+tail -1 $O/stats_c1gpu.log | cut -c1-200
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c5 -- python $R/bench.py --config c5 --steps 20 --warmup 3 --no-cpu-baseline > $O/stats_c5.log 2>&1
+tail -1 $O/stats_c5.log | cut -c1-200
