@@ -79,6 +79,10 @@ def run(state):
                     help="N > 1: every rank codes its own frames (weak scaling, the default) or ONE frame's tiles are sharded over "
                          "the ranks, gathered and assembled into tile-parts on rank 0 (strong scaling, C4 geometry)")
     args = ap.parse_args()
+    # The HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (4 unless set): with more frames in
+    # flight than queues, frames share a queue and their kernels run one after the other (C3, six frames: 181 ms per step with 4
+    # queues, 104 with 8 or more).  The runtime reads it when it initialises, i.e. before the first torch.cuda call.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import faulthandler
     faulthandler.enable(all_threads=True)   # a native crash in a rank prints every thread's Python stack
     if args.shard == "tiles":
@@ -571,7 +575,7 @@ def run(state):
                                    "the reference's MEL zero runs, rebuilt byte for byte at rank 0 inside the timed region)",
                        "decoded_sha256": decoded_sha,
                        "tiles": int(info.tiles), "code_blocks": n, "compressed_bytes_per_frame": total_bytes,
-                       "frames_in_flight": F, "frames_in_flight_rank0": F - root_idle_all, "frame_io": args.io,
+                       "frames_in_flight": F, "frames_in_flight_rank0": F - root_idle_all, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "frame_io": args.io,
                        "decode_rows": args.decode_rows + (" (the rows the reference's HT decoder never writes are not re-zeroed on every call: the "
                                                           "buffer was zeroed once, as a pooled HTDecoder's slice is; digest unchanged)" if args.decode_rows == "coded" else ""),
                        "parallelism": "frames/rank" if world > 1 else "single GPU", "gather": gather_path},

@@ -1478,7 +1478,7 @@ extern "C" int j2k_plan_inverse_pixels(j2k_plan *P, const int32_t *d_coeff, void
     return j2k_pack_pixels(ctx, (const int32_t *)ctx->stage[0], S.C, S.precision, S.W, S.H, d_pix, stride);
 }
 
-// Workspace of the T1 encoder: [serial-kernel work: wpj * n] [nsyms: n words] [symbol lists: n * stride].  The symbol
+// Workspace of the T1 encoder: [serial-kernel work: wpj * n] [nsyms: n words] [lane order: n + 64 words] [symbol lists: n * stride].  The symbol
 // lists cover 31 bit planes when that fits ctx->t1_sym_mb (default 8192 MiB), fewer otherwise (blocks with more planes
 // take the one-kernel path on the device); ctx->t1_split = 0 turns the two-kernel path off.
 struct T1Workspace { size_t off_nsyms, off_sym, stride, total; };
@@ -1487,7 +1487,7 @@ static T1Workspace t1_workspace(const j2k_ctx *ctx, size_t n, size_t wpj) {
     const int split = ctx->t1_split;
     T1Workspace W{};
     W.off_nsyms = (wpj * n + 255) & ~size_t(255);
-    W.off_sym = (W.off_nsyms + n * 4 + 255) & ~size_t(255);
+    W.off_sym = (W.off_nsyms + (2 * n + 64) * 4 + 255) & ~size_t(255);     // nsyms, then the lane order of the MQ lanes kernel
     W.stride = 0;
     if (split && n) {
         int planes = 31;

@@ -747,12 +747,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
 // list has ended are fed the no-op symbol (context 31: Qe = 0, never renormalises).
 __global__ __launch_bounds__(64) void t1_mq_lanes_kernel(const BlockJob *__restrict__ jobs, int njobs, int K, const uint8_t *__restrict__ gsym,
                                                          size_t sym_stride, const uint32_t *__restrict__ nsyms, uint8_t *__restrict__ slots,
-                                                         uint32_t *__restrict__ lens, int *__restrict__ fault) {
+                                                         uint32_t *__restrict__ lens, int *__restrict__ fault, const uint32_t *__restrict__ perm) {
     __shared__ uint32_t mqtab[96];
     __shared__ uint32_t ce[32 * 64];
     const int lane = threadIdx.x;
-    const long jid = (long)blockIdx.x * K + lane;
-    const bool live = lane < K && jid < njobs;
+    // perm: lane order by symbol count (t1_order_kernel), so that the chains of a wavefront end together
+    const long slot = (long)blockIdx.x * K + lane;
+    const uint32_t pj = (lane < K && slot < njobs) ? (perm ? perm[slot] : (uint32_t)slot) : 0xFFFFFFFFu;
+    const long jid = (long)pj;
+    const bool live = pj != 0xFFFFFFFFu;
     for (int s = lane; s < 94; s += 64) {
         const int i = s >> 1, m = s & 1;
         const uint32_t nm = 2 * c_iso_nmps[i] + m;
@@ -1231,7 +1234,6 @@ struct T1DecState { uint32_t C, A, CT, nmr; long long bp, len; };
 #define T1DS_LIST (T1DS_BITS + 512)
 #define T1DS_STRIDE (T1DS_LIST + 4096)
 #define T1DS_MAXP 31
-size_t t1_dec_split_bytes(size_t njobs) { return njobs * T1DS_STRIDE + 256; }
 
 __global__ __launch_bounds__(64) void t1_dec_step_kernel(const BlockJob *__restrict__ jobs, int njobs, const uint8_t *__restrict__ stream,
                                                          const uint64_t *__restrict__ offs, const uint32_t *__restrict__ lens,
@@ -1337,11 +1339,14 @@ __global__ __launch_bounds__(64) void t1_dec_step_kernel(const BlockJob *__restr
 // latency sits on the A / C chain.  Lanes whose list has ended decode with Qe = 0, which changes nothing.
 __global__ __launch_bounds__(64) void t1_dec_magref_lanes_kernel(const BlockJob *__restrict__ jobs, int njobs, const uint8_t *__restrict__ stream,
                                                                  const uint64_t *__restrict__ offs, const uint8_t *__restrict__ numbps,
-                                                                 uint8_t *__restrict__ ws, int k) {
+                                                                 uint8_t *__restrict__ ws, const uint32_t *__restrict__ perm, int k) {
     __shared__ uint32_t mqtab[96];
     __shared__ uint32_t ring[32 * 64];
     const int lane = threadIdx.x;
-    const long jid = (long)blockIdx.x * 64 + lane;
+    // perm: the lane order of t1_lanes.inc (blocks of similar length share a wavefront); slots without a job read as past the end
+    const long slot = (long)blockIdx.x * 64 + lane;
+    const uint32_t pj = perm ? perm[slot] : (uint32_t)slot;
+    const long jid = pj == 0xFFFFFFFFu ? (long)njobs : (long)pj;
     for (int q = lane; q < 94; q += 64) {
         const int i = q >> 1, m = q & 1;
         const uint32_t nm = 2 * c_iso_nmps[i] + m;
@@ -1450,6 +1455,9 @@ __global__ __launch_bounds__(64) void t1_dec_magref_lanes_kernel(const BlockJob 
         *stp = st;
     }
 }
+
+#include "t1_lanes.inc"
+size_t t1_dec_split_bytes(size_t njobs) { return t1_dec_lanes_bytes(njobs); }
 
 // ---- stand-alone coders: the reference's MQEncoder / MQDecoder / RawEncoder / RawDecoder as batch calls ----
 // mqc.go:169-349: NewMQEncoder, n x Encode(ctx, decision), Flush.  One wavefront, the coder on lane 0 (a single chain).
@@ -1594,10 +1602,17 @@ hipError_t launch_t1_encode(hipStream_t s, const BlockJob *jobs, int njobs, cons
             // 34.8 ms per frame at K = 4, 28.3 at K = 32 -- the chains of one frame then run beside the other frames' decode
             // kernels, which are issue-bound.  lanes > 0: as given (J2K_T1_LANES); 0: latency (blocks / 2048); < 0: throughput
             // (blocks / 256, at most 32) -- the caller passes < 0 while several contexts code with the MQ coder.
-            int K = lanes > 0 ? lanes : (lanes < 0 ? std::min(32, (njobs + 255) / 256) : (njobs + 2047) / 2048);
+            // With the lanes ordered by symbol count (t1_order_kernel; `lane_order`, J2K_T1_ENC_ORDER=0 turns it off) a wavefront's
+            // chains end together, and the throughput setting fills all 64 lanes.
+            static int lane_order = -1;
+            if (lane_order < 0) { const char *en = getenv("J2K_T1_ENC_ORDER"); lane_order = en ? atoi(en) : 1; }
+            int K = lanes > 0 ? lanes : (lanes < 0 ? std::min(lane_order ? 64 : 32, (njobs + 255) / 256) : (njobs + 2047) / 2048);
             K = std::min(64, std::max(1, K));
+            uint32_t *perm = lane_order ? nsyms + njobs : nullptr;       // njobs + 64 words behind nsyms (t1_workspace in j2k_abi.cpp)
+            if (perm) hipLaunchKernelGGL(t1_order_kernel, dim3(1), dim3(1024), 0, s, jobs, njobs, (const uint8_t *)nullptr, (const uint32_t *)nsyms, 1, perm,
+                                         (uint32_t *)nullptr, njobs);
             hipLaunchKernelGGL(t1_mq_lanes_kernel, dim3((njobs + K - 1) / K), dim3(64), 0, s, jobs, njobs, K, sym, sym_stride, nsyms,
-                               slots, lens, fault);
+                               slots, lens, fault, (const uint32_t *)perm);
             if (planes < 31)
                 hipLaunchKernelGGL(t1_encode64_kernel<false>, dim3(njobs), dim3(64), 0, s, jobs, njobs, coef, slots, lens, numbps, fault,
                                    (uint8_t *)nullptr, (size_t)0, (uint32_t *)nullptr, 0, (const uint32_t *)nsyms);
@@ -1647,10 +1662,22 @@ hipError_t launch_t1_decode(hipStream_t s, const BlockJob *jobs, int njobs, cons
     if (!general_only) {
         if (split_ws) {
             // plane-stepped path for blocks of at most 31 planes; the one-launch kernel keeps the deeper ones
+            static int sig_lanes = -1;     // J2K_T1_DEC_LANES=0: round 2's step kernels (SigProp / Cleanup one block per wavefront)
+            if (sig_lanes < 0) { const char *en = getenv("J2K_T1_DEC_LANES"); sig_lanes = en ? atoi(en) : 1; }
+            uint64_t *masks = reinterpret_cast<uint64_t *>(split_ws + t1_dec_lanes_mask_offset((size_t)njobs));
+            const int ngroups = (njobs + 63) / 64;
+            uint32_t *perm = reinterpret_cast<uint32_t *>(split_ws + t1_dec_lanes_perm_offset((size_t)njobs)), *slot_of = perm + (size_t)ngroups * 64;
+            if (sig_lanes) hipLaunchKernelGGL(t1_order_kernel, dim3(1), dim3(1024), 0, s, jobs, njobs, numbps, lens, 0, perm, slot_of, ngroups * 64);
             for (int k = 0; k <= T1DS_MAXP; k++) {
-                hipLaunchKernelGGL(t1_dec_step_kernel, dim3(njobs), dim3(64), 0, s, jobs, njobs, stream, offs, lens, numbps, decoded, split_ws, k);
+                if (sig_lanes) {
+                    hipLaunchKernelGGL(t1_dec_sig_lanes_kernel, dim3(ngroups), dim3(64), 0, s, jobs, njobs, stream, offs, lens, numbps, split_ws, masks, perm, k);
+                    hipLaunchKernelGGL(t1_dec_plane_kernel, dim3(njobs), dim3(64), 0, s, jobs, njobs, numbps, decoded, split_ws, masks, slot_of, k);
+                } else {
+                    hipLaunchKernelGGL(t1_dec_step_kernel, dim3(njobs), dim3(64), 0, s, jobs, njobs, stream, offs, lens, numbps, decoded, split_ws, k);
+                }
                 if (k < T1DS_MAXP)
-                    hipLaunchKernelGGL(t1_dec_magref_lanes_kernel, dim3((njobs + 63) / 64), dim3(64), 0, s, jobs, njobs, stream, offs, numbps, split_ws, k);
+                    hipLaunchKernelGGL(t1_dec_magref_lanes_kernel, dim3(ngroups), dim3(64), 0, s, jobs, njobs, stream, offs, numbps, split_ws,
+                                       sig_lanes ? (const uint32_t *)perm : (const uint32_t *)nullptr, k);
             }
         }
         hipLaunchKernelGGL(t1_decode64_kernel, dim3(njobs), dim3(64), 0, s, jobs, njobs, stream, offs, lens, numbps, decoded,
