@@ -1331,28 +1331,129 @@ __global__ __launch_bounds__(64) void t1_dec_step_kernel(const BlockJob *__restr
     }
 }
 
-// The MagRef chains of 64 blocks in lock step (mqc.go:402-497 as a select-only step).  Per lane: A, C, CT, the three
-// context entries, the byte position; compressed bytes come through a per-lane ring in LDS (128 bytes, word-interleaved
-// over the lanes: no bank conflicts) that is topped up from global memory every 8 steps, 32 bytes at a time, the load
-// issued one period before its data is stored -- a step can consume at most three bytes (15 shifts).  Both bytes a
-// byte-in might need, and both successor entries of the context's state, are read at the top of the step, so no memory
-// latency sits on the A / C chain.  Lanes whose list has ended decode with Qe = 0, which changes nothing.
+// ---- the MQ decoder of one block per lane (mqc.go:402-497 as a select-only step), shared by the lanes kernels ----
+// Per lane: A, C, CT and the byte position as a 32-bit offset from a 16-byte aligned base below the block's first byte.
+// Compressed bytes come through a per-lane ring of 256 bytes in LDS (lane l at l * 260: lanes start in different banks),
+// filled 256 ahead at the start and looked at every 32 steps: a step can consume at most three bytes (15 shifts), so with
+// more than 128 bytes ahead after every look at least 33 are ahead at the next.  The refill is synchronous (16-byte loads
+// issued together, one wait): values loaded one period ahead and carried in registers were copied at every loop header of the
+// callers' nested loops, which made every step wait for memory.  Lanes without a decision pass act = false (Qe = 0 changes
+// nothing); lanes without a block keep A = 0x8000.
+#define T1R_STRIDE 260
+struct MqLaneDec {
+    uint32_t A, C, CT, pos, end, filled, d0, rlane, nstep;
+    uintptr_t abase;
+    bool live;
+    uint8_t *ring;
+
+    // 16 bytes of the stream at offset `off`, bytes at or beyond `end` reading as 0xFF (a piece that starts before `end` lies in
+    // a page of the stream).  The decoder past its last byte then needs no case of its own: data[bp] = 0xFF followed by 0xFF
+    // is byteIn's "marker" branch (C += 0xFF00, CT = 8, bp unchanged), which is also what bp >= len does, and the byte after
+    // the last one reads 0xFF as mqc.go:412-416 has it.
+    __device__ __forceinline__ uint4 ld16(uint32_t off) const {
+        uint4 v = make_uint4(~0u, ~0u, ~0u, ~0u);
+        if (live && off < end) v = *reinterpret_cast<const uint4 *>(abase + off);
+        const uint32_t valid = off < end ? end - off : 0u;
+        auto pad = [&](uint32_t wv, uint32_t first) -> uint32_t {        // bytes first .. first + 3 of the piece
+            const uint32_t nv = valid > first ? min(valid - first, 4u) : 0u;
+            return nv >= 4u ? wv : (wv | (0xFFFFFFFFu << (8u * nv)));
+        };
+        return make_uint4(pad(v.x, 0), pad(v.y, 4), pad(v.z, 8), pad(v.w, 12));
+    }
+    __device__ __forceinline__ void st16(uint32_t off, const uint4 v) {
+        uint32_t *q = reinterpret_cast<uint32_t *>(ring + rlane + (off & 255u));
+        q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
+    }
+    __device__ __forceinline__ void start(const uint8_t *blk, const T1DecState &st, bool lv, uint8_t *rg, int lane) {
+        live = lv; ring = rg; rlane = (uint32_t)lane * T1R_STRIDE; nstep = 0;
+        abase = (uintptr_t)blk & ~uintptr_t(15);
+        d0 = (uint32_t)((uintptr_t)blk - abase);
+        A = lv ? st.A : 0x8000u; C = st.C; CT = st.CT;
+        pos = d0 + (uint32_t)(st.bp < 0 ? 0 : st.bp);
+        end = d0 + (uint32_t)st.len;
+        filled = pos & ~15u;
+        uint4 c[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) c[q] = ld16(filled + 16 * q);
+#pragma unroll
+        for (int q = 0; q < 16; q++) st16(filled + 16 * q, c[q]);
+        filled += 256;
+    }
+    __device__ __forceinline__ void save(T1DecState &st) const {
+        st.A = A; st.C = C; st.CT = CT;
+        st.bp = (long long)(pos - d0);                                // (never negative after NewMQDecoder's first byteIn)
+    }
+    // call before every step (wave-uniform): every 32nd looks at the ring
+    __device__ __forceinline__ void tick() {
+        if ((nstep++ & 31u) == 0) refill();
+    }
+    __device__ __forceinline__ void refill() {                      // at most 32 steps apart
+        const uint32_t ahead = filled - pos;
+        if (!__any(ahead <= 128u)) return;
+        const int nq = ahead <= 128u ? 8 : (ahead <= 192u ? 4 : 0);
+        uint4 c[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) c[q] = q < nq ? ld16(filled + 16 * q) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 8; q++) if (q < nq) st16(filled + 16 * q, c[q]);
+        filled += 16 * nq;
+    }
+    // the two bytes a byte-in of this step would look at (independent of the step's context: callers read them early)
+    __device__ __forceinline__ void peek(uint32_t &b0, uint32_t &b1) const {
+        b0 = ring[rlane + (pos & 255u)]; b1 = ring[rlane + ((pos + 1) & 255u)];
+    }
+    // one decision with the context's table entry e (qe | nmps << 16 | nlps << 24; MPS = parity of nmps); e_new = its entry after
+    __device__ __forceinline__ uint32_t step(uint32_t e, const uint32_t *mqtab, bool act, uint32_t b0, uint32_t b1, uint32_t &e_new) {
+        const uint32_t e_nm = mqtab[(e >> 16) & 0xFF], e_nl = mqtab[e >> 24];          // both successors, off the A / C chain
+        const uint32_t qe = act ? (e & 0xFFFFu) : 0u;
+        A -= qe;
+        const bool lpsx = (C >> 16) < qe;
+        const bool a_lt = A < qe;
+        C -= lpsx ? 0u : qe << 16;
+        const bool need = lpsx || !(A & 0x8000u);
+        const bool flip = need && (lpsx != a_lt);
+        const uint32_t dec = ((e >> 16) & 1u) ^ (flip ? 1u : 0u);
+        A = lpsx ? qe : A;
+        e_new = need ? (flip ? e_nl : e_nm) : e;
+        uint32_t nsh = need ? (uint32_t)__clz((int)A) - 16u : 0u;
+        // renormalise (mqc.go:488-497): a byte-in whenever CT is 0 and a shift is due.  The first round is straight-line code on
+        // the bytes read at the top of the step; further rounds (a second byte-in in the same step, rare) re-read the ring.
+        auto round = [&]() {
+            const bool bin = nsh > 0 && CT == 0;
+            const bool ff = b0 == 0xFF;
+            const bool stay = ff && b1 > 0x8F;                        // C += 0xFF00, CT = 8, bp unchanged (mqc.go:402-439; past the end: ld16)
+            const uint32_t addC = stay ? 0xFF00u : b1 << (ff ? 9 : 8);
+            C += bin ? addC : 0u;
+            CT = bin ? ((ff && !stay) ? 7u : 8u) : CT;
+            const bool adv = bin && !stay;
+            pos += adv ? 1u : 0u;
+            b0 = adv ? b1 : b0;
+            const uint32_t sft = min(nsh, CT);
+            A <<= sft; C <<= sft; CT -= sft; nsh -= sft;
+        };
+        round();
+        while (__any(nsh > 0)) {
+            b1 = ring[rlane + ((pos + 1) & 255u)];
+            round();
+        }
+        return dec;
+    }
+};
+
+// The MagRef chains of 64 blocks in lock step (MqLaneDec above).  Per lane: the decoder and the three context entries in
+// registers.  Both bytes a byte-in might need, and both successor entries of the context's state, are read at the top of the
+// step, so no memory latency sits on the A / C chain.  Lanes whose list has ended decode with Qe = 0, which changes nothing.
 __global__ __launch_bounds__(64) void t1_dec_magref_lanes_kernel(const BlockJob *__restrict__ jobs, int njobs, const uint8_t *__restrict__ stream,
                                                                  const uint64_t *__restrict__ offs, const uint8_t *__restrict__ numbps,
                                                                  uint8_t *__restrict__ ws, const uint32_t *__restrict__ perm, int k) {
     __shared__ uint32_t mqtab[96];
-    __shared__ uint32_t ring[32 * 64];
+    __shared__ __attribute__((aligned(16))) uint8_t ring[64 * T1R_STRIDE];
     const int lane = threadIdx.x;
     // perm: the lane order of t1_lanes.inc (blocks of similar length share a wavefront); slots without a job read as past the end
     const long slot = (long)blockIdx.x * 64 + lane;
     const uint32_t pj = perm ? perm[slot] : (uint32_t)slot;
     const long jid = pj == 0xFFFFFFFFu ? (long)njobs : (long)pj;
-    for (int q = lane; q < 94; q += 64) {
-        const int i = q >> 1, m = q & 1;
-        const uint32_t nm = 2 * c_iso_nmps[i] + m;
-        const uint32_t nl = 2 * c_iso_nlps[i] + (c_iso_switch[i] ? 1 - m : m);
-        mqtab[q] = (uint32_t)c_iso_qe[i] | nm << 16 | nl << 24;
-    }
+    for (int q = lane; q < 94; q += 64) mqtab[q] = c_mq94.v[q];
     bool live = jid < njobs;
     const BlockJob J = jobs[live ? jid : 0];
     const int nb = live ? (int)numbps[jid] : 0;
@@ -1364,84 +1465,30 @@ __global__ __launch_bounds__(64) void t1_dec_magref_lanes_kernel(const BlockJob 
     uint32_t nmax = n;
     for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, o));
     if (nmax == 0) return;
-    __syncthreads();
     uint32_t *const ent = reinterpret_cast<uint32_t *>(rec + offsetof(T1Dec64Shared, ent));
     uint32_t e0 = ent[CtxMag0], e1 = ent[CtxMag1], e2 = ent[CtxMag2];
-    uint32_t A = live ? st.A : 0x8000u, C = st.C, CT = st.CT;
-    // byte positions as absolute addresses: pos = the byte mq_byte_in looks at (data[bp], bp < 0 -> 0), end = data + len
-    const uintptr_t data = (uintptr_t)(stream + offs[live ? jid : 0]);
-    uintptr_t pos = data + (uintptr_t)(st.bp < 0 ? 0 : st.bp);
-    const uintptr_t end = data + (uintptr_t)st.len;
-    const bool bp_neg0 = st.bp < 0;                                   // len == 0: bp stays -1 until the first byte-in sets it to 0
-    // ring: bytes [rbase, filled) of the address space, word k of lane l at ring[(k & 31) * 64 + l]
-    uintptr_t filled = pos & ~uintptr_t(15);
-    auto ld16 = [&](uintptr_t a) -> uint4 {                           // a 16-byte piece that starts before `end` lies in a page of the stream
-        return (live && a < end) ? *reinterpret_cast<const uint4 *>(a) : make_uint4(0, 0, 0, 0);
-    };
-    auto st16 = [&](uintptr_t a, const uint4 v) {
-        const uint32_t k = (uint32_t)(a >> 2);
-        ring[((k + 0) & 31) * 64 + lane] = v.x; ring[((k + 1) & 31) * 64 + lane] = v.y;
-        ring[((k + 2) & 31) * 64 + lane] = v.z; ring[((k + 3) & 31) * 64 + lane] = v.w;
-    };
-    for (int q = 0; q < 4; q++) { st16(filled, ld16(filled)); filled += 16; }       // 64 bytes: at least 49 ahead of pos
-    uint4 pend0 = ld16(filled), pend1 = ld16(filled + 16);
-    const uint8_t *const rb = reinterpret_cast<const uint8_t *>(ring);
-    auto ring_byte_addr = [&](uintptr_t a) -> uint32_t { return (((uint32_t)(a >> 2) & 31u) * 64u + (uint32_t)lane) * 4u + ((uint32_t)a & 3u); };
+    MqLaneDec mq;
+    mq.start(stream + offs[live ? jid : 0], st, live, ring, lane);
+    __syncthreads();
     const uint4 *const list = reinterpret_cast<const uint4 *>(rec + T1DS_LIST);
     uint16_t *const obits = reinterpret_cast<uint16_t *>(rec + T1DS_BITS);
     uint4 cur = list[0], nxt = list[nmax > 16 ? 1 : 0];
-    uint32_t bpneg = bp_neg0 ? 1u : 0u;
     for (uint32_t i0 = 0; i0 < nmax; i0 += 16) {
         uint32_t acc = 0;
+        if ((i0 & 16u) == 0) mq.refill();
 #pragma unroll
         for (int s = 0; s < 16; s++) {
             const uint32_t i = i0 + s;
-            if ((s & 7) == 0) {
-                // top up the ring: store the pieces loaded a period ago if there is room, then start the next load
-                const bool room = (filled - pos) <= 64;
-                if (room) { st16(filled, pend0); st16(filled + 16, pend1); filled += 32; }
-                pend0 = ld16(filled); pend1 = ld16(filled + 16);
-            }
             const uint32_t wsel = (s >> 2) == 0 ? cur.x : (s >> 2) == 1 ? cur.y : (s >> 2) == 2 ? cur.z : cur.w;
             const uint32_t code = (wsel >> ((s & 3) * 8)) & 3u;
-            const bool act = i < n;
             const uint32_t e = code == 2 ? e2 : (code == 1 ? e1 : e0);
-            // speculative reads: successors of the state, the two bytes a byte-in would look at
-            const uint32_t e_nm = mqtab[(e >> 16) & 0xFF], e_nl = mqtab[e >> 24];
-            uint32_t b0 = rb[ring_byte_addr(pos)], b1 = rb[ring_byte_addr(pos + 1)];
-            const uint32_t qe = act ? (e & 0xFFFFu) : 0u;
-            const uint32_t mps = (e >> 16) & 1u;
-            A -= qe;
-            const bool lpsx = (C >> 16) < qe;
-            const bool a_lt = A < qe;
-            C = lpsx ? C : C - (qe << 16);
-            const bool need = lpsx || !(A & 0x8000u);
-            const bool flip = need && (lpsx != a_lt);
-            const uint32_t dec = mps ^ (flip ? 1u : 0u);
-            A = lpsx ? qe : A;
-            const uint32_t e_new = need ? (flip ? e_nl : e_nm) : e;
+            uint32_t b0, b1, e_new;
+            mq.peek(b0, b1);
+            const uint32_t dec = mq.step(e, mqtab, i < n, b0, b1, e_new);
             e0 = code == 0 ? e_new : e0;
             e1 = code == 1 ? e_new : e1;
             e2 = code == 2 ? e_new : e2;
             acc |= dec << s;
-            // renormalise (mqc.go:488-497): nsh shifts; a byte-in whenever CT is 0 and a shift is still due
-            uint32_t nsh = need ? (uint32_t)__clz((int)A) - 16u : 0u;
-            for (;;) {
-                const bool bin = nsh > 0 && CT == 0;
-                {   // mq_byte_in (mqc.go:402-439), select-only
-                    const bool past = pos >= end;
-                    const uint32_t nextb = (pos + 1 < end) ? b1 : 0xFFu;
-                    const bool ff = b0 == 0xFF;
-                    const bool stay = past || (ff && nextb > 0x8F);          // C += 0xFF00, CT = 8, bp unchanged
-                    const uint32_t addC = stay ? 0xFF00u : (ff ? nextb << 9 : nextb << 8);
-                    const uint32_t newCT = stay ? 8u : (ff ? 7u : 8u);
-                    if (bin) { C += addC; CT = newCT; bpneg = 0; if (!stay) { pos++; b0 = b1; } }
-                }
-                const uint32_t k = min(nsh, CT);
-                A <<= k; C <<= k; CT -= k; nsh -= k;
-                if (!__any(nsh > 0)) break;
-                b1 = rb[ring_byte_addr(pos + 1)];                             // a second byte-in in the same step (rare)
-            }
         }
         if (live && i0 < n) obits[i0 >> 4] = (uint16_t)acc;
         cur = nxt;
@@ -1450,8 +1497,7 @@ __global__ __launch_bounds__(64) void t1_dec_magref_lanes_kernel(const BlockJob 
     }
     if (live) {
         ent[CtxMag0] = e0; ent[CtxMag1] = e1; ent[CtxMag2] = e2;
-        st.A = A; st.C = C; st.CT = CT;
-        st.bp = bpneg ? -1 : (long long)(pos - data);
+        mq.save(st);
         *stp = st;
     }
 }

@@ -2,7 +2,7 @@
 oracle -- coefficients (encoder.preprocess), block bytes / lengths / bit-plane counts (encodeTile job order), decoded blocks
 (HTDecoder.Decode / T1.Decode on the oracle's bytes) and the lossless reconstruction.  Untiled frames (the oracle's
 preprocess works on whole components); tiles are covered by the sharded tests.
-    python tools/fuzz_gpu.py [seconds] [seed]"""
+    python tools/fuzz_gpu.py [seconds] [seed]        (J2K_FUZZ_HT_SHARE=0: MQ coder only; with J2K_T1_DEC_SPLIT=1 the lanes decoder)"""
 import os
 import sys
 import time
@@ -32,7 +32,7 @@ while time.time() - t0 < budget:
         continue
     nres = int(rng.integers(1, 7))
     cb = int(rng.choice([16, 32, 64]))
-    coder = CODER_HT if rng.random() < 0.75 else CODER_MQ
+    coder = CODER_HT if rng.random() < float(os.environ.get("J2K_FUZZ_HT_SHARE", "0.75")) else CODER_MQ
     if coder == CODER_MQ and W * H * Cn > 120000:
         coder = CODER_HT
     prec = int(rng.choice([8, 10, 12, 16]))
