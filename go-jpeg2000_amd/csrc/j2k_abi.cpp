@@ -40,7 +40,7 @@ hipError_t launch_t1_encode(hipStream_t s, const BlockJob *jobs, int njobs, cons
 size_t t1_sym_stride(int planes);
 hipError_t launch_t1_decode(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs,
                             const uint32_t *lens, const uint8_t *numbps, int32_t *decoded, uint8_t *work,
-                            size_t work_per_job, int max_dim, int general_only, uint8_t *split_ws);
+                            size_t work_per_job, int max_dim, int general_only, uint8_t *split_ws, int sig_lanes);
 size_t t1_dec_split_bytes(size_t njobs);
 hipError_t launch_mq_encode(hipStream_t s, const uint8_t *ctxs, const uint8_t *decs, size_t n, uint8_t *out, size_t cap, uint32_t *out_len, int *fault);
 hipError_t launch_mq_decode(hipStream_t s, const uint8_t *data, size_t len, const uint8_t *ctxs, size_t n, uint8_t *decs, int *fault);
@@ -157,6 +157,7 @@ extern "C" int j2k_ctx_create(int device, j2k_ctx **out) {
     if (const char *e = getenv("J2K_T1_SYM_MB")) { long v = atol(e); if (v >= 0) ctx->t1_sym_mb = v; }
     if (const char *e = getenv("J2K_T1_DEC_GENERAL")) ctx->t1_dec_general = atoi(e) != 0;
     if (const char *e = getenv("J2K_T1_DEC_SPLIT")) { int v = atoi(e); if (v >= -1) ctx->t1_dec_split = v; }
+    if (const char *e = getenv("J2K_T1_DEC_LANES")) ctx->t1_dec_lanes = atoi(e) != 0;
     if (const char *e = getenv("J2K_T1_LANES")) { int v = atoi(e); if (v >= 0 && v <= 64) ctx->t1_lanes = v; }
     if (const char *e = getenv("J2K_CPL0")) { int v = atoi(e); if (v == 2 || v == 4 || v == 8) ctx->cpl0 = v; }
     *out = ctx;
@@ -1710,7 +1711,7 @@ extern "C" int j2k_plan_decode_blocks(j2k_plan *P, const uint8_t *d_stream, cons
         if (r != J2K_OK) return r;
         HIPCHK(ctx, launch_t1_decode(ctx->stream, P->d_djobs, n, d_stream, d_offs, d_lens, d_numbps, d_decoded,
                                      (uint8_t *)ctx->stage[2], wpj, max_dim, ctx->t1_dec_general,
-                                     split ? (uint8_t *)ctx->stage[2] + gen_bytes : nullptr));
+                                     split ? (uint8_t *)ctx->stage[2] + gen_bytes : nullptr, ctx->t1_dec_lanes));
     }
     return J2K_OK;
 }
@@ -1955,7 +1956,7 @@ extern "C" int j2k_decode_blocks(j2k_ctx *ctx, int coder, const uint8_t *bytes, 
         int max_dim = 0;
         for (size_t j = 0; j < nblocks; j++) max_dim = std::max(max_dim, std::max(bj[j].w, bj[j].h));
         TRY(launch_t1_decode(ctx->stream, (BlockJob *)d_jobs, (int)nblocks, (uint8_t *)d_bytes, (uint64_t *)d_offs, (uint32_t *)d_lens, (uint8_t *)d_nb,
-                             (int32_t *)d_dec, (uint8_t *)d_work, wpj, max_dim, ctx->t1_dec_general, split ? (uint8_t *)d_work + gen_bytes : nullptr));
+                             (int32_t *)d_dec, (uint8_t *)d_work, wpj, max_dim, ctx->t1_dec_general, split ? (uint8_t *)d_work + gen_bytes : nullptr, ctx->t1_dec_lanes));
     }
     for (size_t j = 0; j < nblocks; j++)
         TRY(hipMemcpyAsync(coeffs + coeff_offs[j], (int32_t *)d_dec + bj[j].out_off, (size_t)blocks[j].w * blocks[j].h * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -1703,13 +1703,12 @@ hipError_t launch_t1_encode(hipStream_t s, const BlockJob *jobs, int njobs, cons
 // general_only: every block on the general kernel (A/B knob); otherwise blocks up to 64x64 take t1_decode64_kernel
 hipError_t launch_t1_decode(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs,
                             const uint32_t *lens, const uint8_t *numbps, int32_t *decoded, uint8_t *work, size_t work_per_job,
-                            int max_dim, int general_only, uint8_t *split_ws) {
+                            int max_dim, int general_only, uint8_t *split_ws, int sig_lanes) {
     if (njobs <= 0) return hipSuccess;
     if (!general_only) {
         if (split_ws) {
             // plane-stepped path for blocks of at most 31 planes; the one-launch kernel keeps the deeper ones
-            static int sig_lanes = -1;     // J2K_T1_DEC_LANES=0: round 2's step kernels (SigProp / Cleanup one block per wavefront)
-            if (sig_lanes < 0) { const char *en = getenv("J2K_T1_DEC_LANES"); sig_lanes = en ? atoi(en) : 1; }
+            // sig_lanes (J2K_T1_DEC_LANES): SigProp / Cleanup as lanes kernels (t1_lanes.inc); 0: round 2's step kernels
             uint64_t *masks = reinterpret_cast<uint64_t *>(split_ws + t1_dec_lanes_mask_offset((size_t)njobs));
             const int ngroups = (njobs + 63) / 64;
             uint32_t *perm = reinterpret_cast<uint32_t *>(split_ws + t1_dec_lanes_perm_offset((size_t)njobs)), *slot_of = perm + (size_t)ngroups * 64;

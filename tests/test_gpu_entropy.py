@@ -134,18 +134,21 @@ def test_t1_batch_both_decoder_kernels(ent, oracle, general, monkeypatch):
         assert np.array_equal(got[j], wants[j]), (j, blocks[j], general)
 
 
-def test_t1_batch_plane_stepped_decoder(ent, oracle, monkeypatch):
-    """The plane-stepped T1.Decode (J2K_T1_DEC_SPLIT=1: step kernels + MagRef chains in lock step) on a batch of mixed block
+@pytest.mark.parametrize("lanes", [1, 0])
+def test_t1_batch_plane_stepped_decoder(ent, oracle, monkeypatch, lanes):
+    """The plane-stepped T1.Decode (J2K_T1_DEC_SPLIT=1; lanes = 1: SigProp / Cleanup one block per lane on row masks, t1_lanes.inc;
+    lanes = 0: round 2's step kernels; MagRef chains in lock step in both) on a batch of mixed block
     sizes against the oracle: encoder output, arbitrary bytes (streams that end early, 0xFF runs), zero-length streams,
     bit-plane counts from 0 to 40 (above 31 the one-launch kernel takes the block: bit 0 for p >= 32, t1.go:1291) and
     blocks wider than 64 (general kernel) in the same call."""
     from j2kgfx import Context
     monkeypatch.setenv("J2K_T1_DEC_SPLIT", "1")                    # read when a context is created
+    monkeypatch.setenv("J2K_T1_DEC_LANES", str(lanes))
     ctx = Context(0)
     rng = np.random.default_rng(77)
     dims = [(64, 64), (33, 64), (64, 7), (5, 3), (1, 1), (9, 64), (128, 32), (16, 16), (64, 64), (70, 9), (8, 8), (17, 5), (64, 64), (40, 40)]
     blocks, streams, nbs, wants = [], [], [], []
-    for j, (w, h) in enumerate(dims * 5):
+    for j, (w, h) in enumerate(dims * 10):                          # 140 blocks: three groups of lanes
         band = j % 4
         kind = j % 5
         if kind == 2:                                              # not encoder output
