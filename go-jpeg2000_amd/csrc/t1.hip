@@ -738,6 +738,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
 
 #include "t1_big.inc"
 
+// The lanes kernels run at the latency of one chain on a few hundred wavefronts; with frames in flight they share SIMDs with the
+// device-filling kernels of other frames (context formation, the plane kernels, the transforms), eight wavefronts to a SIMD, and
+// a chain that gets every ninth issue slot takes nine times as long.  Raised wave priority lets the chain issue whenever it can;
+// the throughput wavefronts fill the slots its dependent instructions leave.
+#ifndef J2K_T1_LANES_PRIO
+#define J2K_T1_LANES_PRIO 3
+#endif
+#define T1_LANES_PRIO() __builtin_amdgcn_s_setprio(J2K_T1_LANES_PRIO)
+
 // ---- MQ coder, K blocks per wavefront in lock step (mqc.go:224-267, flush t1_fast5.go:878-898) ----
 // t1_encode64_kernel<true> leaves every block's (context, decision) list in memory; here LANE l of workgroup g codes the
 // list of block g*K + l.  One serial chain per block is bound by instruction issue (≈45 wave instructions per symbol,
@@ -750,6 +759,7 @@ __global__ __launch_bounds__(64) void t1_mq_lanes_kernel(const BlockJob *__restr
                                                          uint32_t *__restrict__ lens, int *__restrict__ fault, const uint32_t *__restrict__ perm) {
     __shared__ uint32_t mqtab[96];
     __shared__ uint32_t ce[32 * 64];
+    T1_LANES_PRIO();
     const int lane = threadIdx.x;
     // perm: lane order by symbol count (t1_order_kernel), so that the chains of a wavefront end together
     const long slot = (long)blockIdx.x * K + lane;
@@ -1448,6 +1458,7 @@ __global__ __launch_bounds__(64) void t1_dec_magref_lanes_kernel(const BlockJob 
                                                                  uint8_t *__restrict__ ws, const uint32_t *__restrict__ perm, int k) {
     __shared__ uint32_t mqtab[96];
     __shared__ __attribute__((aligned(16))) uint8_t ring[64 * T1R_STRIDE];
+    T1_LANES_PRIO();
     const int lane = threadIdx.x;
     // perm: the lane order of t1_lanes.inc (blocks of similar length share a wavefront); slots without a job read as past the end
     const long slot = (long)blockIdx.x * 64 + lane;
