@@ -211,6 +211,16 @@ def test_bench_rccl_self_loop_rehearsal():
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["value"] > 0
+    assert "j2k_gather_streams" in d["config"]["gather"], d["config"]["gather"]     # the probe exchange passed: the C-ABI path ran
+    # the probe's fall-back: the same run with the probe made to fail goes through torch.distributed's transfers
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env2 = dict(env, J2K_BENCH_PROBE_FAIL="1", MASTER_PORT=str(port))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline"],
+                         env=env2, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "falling back to torch.distributed" in out.stderr
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["value"] > 0 and "torch.distributed" in d["config"]["gather"], d["config"]["gather"]
 
 
 def test_c4_full_size_sampled_tiles_match_oracle():
