@@ -80,9 +80,14 @@ def run(state):
                          "the ranks, gathered and assembled into tile-parts on rank 0 (strong scaling, C4 geometry)")
     args = ap.parse_args()
     # The HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (4 unless set): with more frames in
-    # flight than queues, frames share a queue and their kernels run one after the other (C3, six frames: 181 ms per step with 4
-    # queues, 104 with 8 or more).  The runtime reads it when it initialises, i.e. before the first torch.cuda call.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    # flight than queues, frames share a queue and their kernels run one after the other.  The MQ coder's kernels run at the
+    # latency of their longest chain on a tenth of the device and want every frame on a queue of its own (C3, six frames: 181 ms
+    # per step with 4 queues, 95 with 8 or more; twenty frames want more than 16).  The bandwidth-bound kernels of the HT
+    # configurations want the opposite: C5's eight frames in flight run at 72-74 Gpixel/s on 4 or 8 queues and at 41 on 16 or 32
+    # (eight frames' transforms truly at once evict each other's lines).  Read when the runtime initialises, i.e. before the first
+    # torch.cuda call.
+    if args.config == "c3":
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
     import faulthandler
     faulthandler.enable(all_threads=True)   # a native crash in a rank prints every thread's Python stack
     if args.shard == "tiles":

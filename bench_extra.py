@@ -19,7 +19,7 @@ CONFIGS = {
                metric="Mpixels/s encode+decode (4K sRGB, 5-3 lossless)",
                workload="3840x2160 sRGB 8-bit, 512x512 tiles, 5-3 lossless + HT block coder, 64x64 code-blocks, 6 resolutions "
                         "(BASELINE configs[1])"),
-    "c3": dict(W=3840, H=2160, C=3, prec=12, lossless=False, quality=75, tile=512, nres=6, cb=64, coder=0, io="planes", inflight=12,
+    "c3": dict(W=3840, H=2160, C=3, prec=12, lossless=False, quality=75, tile=512, nres=6, cb=64, coder=0, io="planes", inflight=20,
                metric="Mpixels/s encode+decode (4K sRGB 12-bit, 9-7 lossy)",
                workload="3840x2160 sRGB rescaled to 12 bit (v*4095/255, encoder.go:198-210), 512x512 tiles, ICT + 9-7 + quantisation "
                         "(Quality 75; the reference ignores CompressionRatio) + MQ block coder (T1.EncodeFast5 / T1.Decode), 64x64 "
