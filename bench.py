@@ -37,7 +37,7 @@ DECODED_SHA256 = "76eab55b1f63e2eb3644d138c6d655d4b16975c46310378f3f9f1bc509de7d
 # cannot be collected from inside this process, so it is the committed measurement (see profiles/)
 TRAFFIC = {   # frame_io -> (bytes per level-0 forward launch, source)
     "planes": (207044198, "profiles/r01_bench_v3_inflight1_pmc_{FETCH,WRITE}_SIZE.csv: (2 x 52495.8 + 97200.0) KiB"),
-    "rgba8": (133270528, "profiles/r03_bench_inflight1_pmc_summary.txt: (2 x 16431.0 + 97285.0) KiB"),
+    "rgba8": (133236070, "profiles/r03_bench_inflight1_pmc_summary.txt: (2 x 16430.8 + 97251.9) KiB"),
 }
 
 

@@ -32,6 +32,10 @@ if glob.glob(os.path.join(O, "stats_c3bench/*/*kernel_stats.csv")):
     open(os.path.join(P, tag + "_c3_pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
     print(open(os.path.join(P, tag + "_c3_pmc_summary.txt")).read())
 
+if glob.glob(os.path.join(O, "stats_c3lanes/*/*kernel_stats.csv")):
+    shutil.copy(newest("stats_c3lanes/*/*kernel_stats.csv"), os.path.join(P, tag + "_c3_lanes_kernel_stats.csv"))
+    if os.path.exists(os.path.join(O, "c3lanes_per_launch.txt")):
+        shutil.copy(os.path.join(O, "c3lanes_per_launch.txt"), os.path.join(P, tag + "_c3_lanes_per_launch.txt"))
 for name in ("c1gpu", "c5"):
     if glob.glob(os.path.join(O, "stats_%s/*/*kernel_stats.csv" % name)):
         shutil.copy(newest("stats_%s/*/*kernel_stats.csv" % name), os.path.join(P, "%s_%s_bench_kernel_stats.csv" % (tag, name)))

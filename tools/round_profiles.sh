@@ -13,6 +13,11 @@ done
 tail -1 $O/stats_default.log | cut -c1-200; tail -1 $O/stats_inflight1.log | cut -c1-200
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c3 -- python $R/tools/bench_c3.py 0 0 > $O/stats_c3.log 2>&1
 tail -7 $O/stats_c3.log
+export J2K_T1_DEC_SPLIT=1        # the same frame through the plane-stepped decoder (lanes kernels), alone: the latency of its chains
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c3lanes -- python $R/tools/bench_c3.py 0 0 > $O/stats_c3lanes.log 2>&1
+unset J2K_T1_DEC_SPLIT
+tail -7 $O/stats_c3lanes.log
+python $R/tools/t1_trace.py $O/stats_c3lanes > $O/c3lanes_per_launch.txt 2>&1; cat $O/c3lanes_per_launch.txt | cut -c1-200
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c3bench -- python $R/bench.py --config c3 --steps 3 --warmup 1 --no-cpu-baseline > $O/stats_c3bench.log 2>&1
 tail -1 $O/stats_c3bench.log | cut -c1-200
 for c in FETCH_SIZE WRITE_SIZE; do
