@@ -1453,6 +1453,9 @@ struct MqLaneDec {
 // The MagRef chains of 64 blocks in lock step (MqLaneDec above).  Per lane: the decoder and the three context entries in
 // registers.  Both bytes a byte-in might need, and both successor entries of the context's state, are read at the top of the
 // step, so no memory latency sits on the A / C chain.  Lanes whose list has ended decode with Qe = 0, which changes nothing.
+// BITLIST: the context list as two bit strings (t1_lanes.inc's plane kernel: Mag2 members in one, Mag1 in the other, list position
+// = bit position); otherwise one byte per member (round 2's step kernels).
+template <bool BITLIST>
 __global__ __launch_bounds__(64) void t1_dec_magref_lanes_kernel(const BlockJob *__restrict__ jobs, int njobs, const uint8_t *__restrict__ stream,
                                                                  const uint64_t *__restrict__ offs, const uint8_t *__restrict__ numbps,
                                                                  uint8_t *__restrict__ ws, const uint32_t *__restrict__ perm, int k) {
@@ -1482,29 +1485,40 @@ __global__ __launch_bounds__(64) void t1_dec_magref_lanes_kernel(const BlockJob 
     mq.start(stream + offs[live ? jid : 0], st, live, ring, lane);
     __syncthreads();
     const uint4 *const list = reinterpret_cast<const uint4 *>(rec + T1DS_LIST);
+    const uint16_t *const lhi = reinterpret_cast<const uint16_t *>(rec + T1DS_LIST), *const llo = lhi + 256;      // BITLIST: 4096 bits each
     uint16_t *const obits = reinterpret_cast<uint16_t *>(rec + T1DS_BITS);
-    uint4 cur = list[0], nxt = list[nmax > 16 ? 1 : 0];
+    uint4 cur = make_uint4(0, 0, 0, 0), nxt = cur;
+    if (BITLIST) { cur.x = lhi[0]; cur.y = llo[0]; nxt.x = lhi[nmax > 16 ? 1 : 0]; nxt.y = llo[nmax > 16 ? 1 : 0]; }
+    else { cur = list[0]; nxt = list[nmax > 16 ? 1 : 0]; }
     for (uint32_t i0 = 0; i0 < nmax; i0 += 16) {
         uint32_t acc = 0;
         if ((i0 & 16u) == 0) mq.refill();
 #pragma unroll
         for (int s = 0; s < 16; s++) {
             const uint32_t i = i0 + s;
-            const uint32_t wsel = (s >> 2) == 0 ? cur.x : (s >> 2) == 1 ? cur.y : (s >> 2) == 2 ? cur.z : cur.w;
-            const uint32_t code = (wsel >> ((s & 3) * 8)) & 3u;
-            const uint32_t e = code == 2 ? e2 : (code == 1 ? e1 : e0);
+            bool is2, is1;
+            // (the two strings exclude each other below nmr; past it the pieces hold whatever an earlier plane left, and a lane
+            //  whose list has ended must still pick exactly one entry to write back unchanged)
+            if (BITLIST) { is2 = (cur.x >> s) & 1u; is1 = !is2 && ((cur.y >> s) & 1u); }
+            else {
+                const uint32_t wsel = (s >> 2) == 0 ? cur.x : (s >> 2) == 1 ? cur.y : (s >> 2) == 2 ? cur.z : cur.w;
+                const uint32_t code = (wsel >> ((s & 3) * 8)) & 3u;
+                is2 = code == 2; is1 = code == 1;
+            }
+            const uint32_t e = is2 ? e2 : (is1 ? e1 : e0);
             uint32_t b0, b1, e_new;
             mq.peek(b0, b1);
             const uint32_t dec = mq.step(e, mqtab, i < n, b0, b1, e_new);
-            e0 = code == 0 ? e_new : e0;
-            e1 = code == 1 ? e_new : e1;
-            e2 = code == 2 ? e_new : e2;
+            e0 = (is2 || is1) ? e0 : e_new;
+            e1 = is1 ? e_new : e1;
+            e2 = is2 ? e_new : e2;
             acc |= dec << s;
         }
         if (live && i0 < n) obits[i0 >> 4] = (uint16_t)acc;
         cur = nxt;
         const uint32_t nx = (i0 >> 4) + 2;
-        nxt = list[nx < 256 ? nx : 255];
+        if (BITLIST) { nxt.x = lhi[nx < 256 ? nx : 255]; nxt.y = llo[nx < 256 ? nx : 255]; }
+        else nxt = list[nx < 256 ? nx : 255];
     }
     if (live) {
         ent[CtxMag0] = e0; ent[CtxMag1] = e1; ent[CtxMag2] = e2;
@@ -1727,15 +1741,22 @@ hipError_t launch_t1_decode(hipStream_t s, const BlockJob *jobs, int njobs, cons
             for (int k = 0; k <= T1DS_MAXP; k++) {
                 if (sig_lanes) {
                     hipLaunchKernelGGL(t1_dec_sig_lanes_kernel, dim3(ngroups), dim3(64), 0, s, jobs, njobs, stream, offs, lens, numbps, split_ws, masks, perm, k);
-                    hipLaunchKernelGGL(t1_dec_plane_kernel, dim3(njobs), dim3(64), 0, s, jobs, njobs, numbps, decoded, split_ws, masks, slot_of, k);
+                    hipLaunchKernelGGL(t1_dec_plane_kernel, dim3(njobs), dim3(64), 0, s, jobs, njobs, numbps, decoded, split_ws, masks, slot_of,
+                                       reinterpret_cast<uint64_t *>(split_ws + t1_dec_lanes_planes_offset((size_t)njobs)), k);
                 } else {
                     hipLaunchKernelGGL(t1_dec_step_kernel, dim3(njobs), dim3(64), 0, s, jobs, njobs, stream, offs, lens, numbps, decoded, split_ws, k);
                 }
-                if (k < T1DS_MAXP)
-                    hipLaunchKernelGGL(t1_dec_magref_lanes_kernel, dim3(ngroups), dim3(64), 0, s, jobs, njobs, stream, offs, numbps, split_ws,
-                                       sig_lanes ? (const uint32_t *)perm : (const uint32_t *)nullptr, k);
+                if (k < T1DS_MAXP) {
+                    if (sig_lanes) { if (k > 0) hipLaunchKernelGGL(t1_dec_magref_lanes_kernel<true>, dim3(ngroups), dim3(64), 0, s, jobs, njobs, stream, offs, numbps, split_ws, (const uint32_t *)perm, k); }
+                    else hipLaunchKernelGGL(t1_dec_magref_lanes_kernel<false>, dim3(ngroups), dim3(64), 0, s, jobs, njobs, stream, offs, numbps, split_ws, (const uint32_t *)nullptr, k);
+                }
             }
         }
+        if (split_ws && sig_lanes)
+            hipLaunchKernelGGL(t1_dec_assemble_kernel, dim3(njobs), dim3(64), 0, s, jobs, njobs, numbps, decoded,
+                               reinterpret_cast<const uint64_t *>(split_ws + t1_dec_lanes_mask_offset((size_t)njobs)),
+                               reinterpret_cast<const uint32_t *>(split_ws + t1_dec_lanes_perm_offset((size_t)njobs)) + (size_t)((njobs + 63) / 64) * 64,
+                               reinterpret_cast<const uint64_t *>(split_ws + t1_dec_lanes_planes_offset((size_t)njobs)));
         hipLaunchKernelGGL(t1_decode64_kernel, dim3(njobs), dim3(64), 0, s, jobs, njobs, stream, offs, lens, numbps, decoded,
                            split_ws ? T1DS_MAXP + 1 : 0);
         hipError_t e = hipGetLastError();
