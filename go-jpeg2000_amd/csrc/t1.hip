@@ -618,14 +618,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
         }
         // =========== magnitude refinement (t1_fast5.go:252-335): members = significant before this plane ===========
         {
+            // "a significant neighbour" of every sample of a row, for all rows at once (lanes = rows) instead of per row on the scalar
+            // unit: the per-row part of this loop was four more broadcasts and ten 64-bit scalar operations, for every row of
+            // every plane -- the largest single item of this kernel's instruction count
+            uint64_t Up = __shfl_up(Snew, 1), Dn2 = __shfl_down(Snew, 1);
+            if (lane == 0) Up = 0;
+            if (lane == 63) Dn2 = 0;
+            const uint64_t ANY = spread3(Up) | spread3(Dn2) | (Snew << 1) | (Snew >> 1);
             uint64_t rows = __ballot(S != 0);
             while (rows) {
                 const int r = __ffsll((long long)rows) - 1;
                 rows &= rows - 1;
                 T1F_ROOM();
-                const uint64_t M = rl64(S, r), Rf = rl64(REF, r), Bm = rl64(B, r);
-                const uint64_t Su = r > 0 ? rl64(Snew, r - 1) : 0ull, So = rl64(Snew, r), Sd = r < 63 ? rl64(Snew, r + 1) : 0ull;
-                const uint64_t any8 = spread3(Su) | spread3(Sd) | (So << 1) | (So >> 1);
+                const uint64_t M = rl64(S, r), Rf = rl64(REF, r), Bm = rl64(B, r), any8 = rl64(ANY, r);
                 if (bit_at(M, x)) {
                     const uint32_t ctx = bit_at(Rf, x) ? CtxMag2 : (bit_at(any8, x) ? CtxMag1 : CtxMag0);
                     F.sym[nsym + __popcll(M & lt)] = (uint8_t)(ctx | bit_at(Bm, x) << 5);
