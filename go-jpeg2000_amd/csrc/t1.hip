@@ -1348,13 +1348,18 @@ __global__ __launch_bounds__(64) void t1_dec_step_kernel(const BlockJob *__restr
 
 // ---- the MQ decoder of one block per lane (mqc.go:402-497 as a select-only step), shared by the lanes kernels ----
 // Per lane: A, C, CT and the byte position as a 32-bit offset from a 16-byte aligned base below the block's first byte.
-// Compressed bytes come through a per-lane ring of 256 bytes in LDS (lane l at l * 260: lanes start in different banks),
-// filled 256 ahead at the start and looked at every 32 steps: a step can consume at most three bytes (15 shifts), so with
-// more than 128 bytes ahead after every look at least 33 are ahead at the next.  The refill is synchronous (16-byte loads
+// Compressed bytes come through a per-lane ring of T1R_BYTES bytes in LDS (lanes T1R_BYTES + 4 apart: they start in different banks),
+// filled a whole ring ahead at the start and looked at every T1R_PERIOD steps (16 for a ring of 128 bytes): a step can consume at
+// most three bytes (15 shifts), so with more than half a ring ahead after every look at least 17 are ahead at the next.  (The ring
+// is most of these kernels' LDS, and LDS is what limits how many lanes workgroups of twenty frames in flight a CU holds.)  The refill is synchronous (16-byte loads
 // issued together, one wait): values loaded one period ahead and carried in registers were copied at every loop header of the
 // callers' nested loops, which made every step wait for memory.  Lanes without a decision pass act = false (Qe = 0 changes
 // nothing); lanes without a block keep A = 0x8000.
-#define T1R_STRIDE 260
+#ifndef T1R_BYTES
+#define T1R_BYTES 256                    /* ring bytes per lane: 256 (looked at every 32 steps); 128 (every 16) measured 4 % slower at 20 frames in flight */
+#endif
+#define T1R_STRIDE (T1R_BYTES + 4)
+#define T1R_PERIOD (T1R_BYTES / 8)       /* steps between looks: at most 3 bytes each */
 struct MqLaneDec {
     uint32_t A, C, CT, pos, end, filled, d0, rlane, nstep;
     uintptr_t abase;
@@ -1376,7 +1381,7 @@ struct MqLaneDec {
         return make_uint4(pad(v.x, 0), pad(v.y, 4), pad(v.z, 8), pad(v.w, 12));
     }
     __device__ __forceinline__ void st16(uint32_t off, const uint4 v) {
-        uint32_t *q = reinterpret_cast<uint32_t *>(ring + rlane + (off & 255u));
+        uint32_t *q = reinterpret_cast<uint32_t *>(ring + rlane + (off & (T1R_BYTES - 1u)));
         q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
     }
     __device__ __forceinline__ void start(const uint8_t *blk, const T1DecState &st, bool lv, uint8_t *rg, int lane) {
@@ -1387,12 +1392,12 @@ struct MqLaneDec {
         pos = d0 + (uint32_t)(st.bp < 0 ? 0 : st.bp);
         end = d0 + (uint32_t)st.len;
         filled = pos & ~15u;
-        uint4 c[16];
+        uint4 c[T1R_BYTES / 16];
 #pragma unroll
-        for (int q = 0; q < 16; q++) c[q] = ld16(filled + 16 * q);
+        for (int q = 0; q < T1R_BYTES / 16; q++) c[q] = ld16(filled + 16 * q);
 #pragma unroll
-        for (int q = 0; q < 16; q++) st16(filled + 16 * q, c[q]);
-        filled += 256;
+        for (int q = 0; q < T1R_BYTES / 16; q++) st16(filled + 16 * q, c[q]);
+        filled += T1R_BYTES;
     }
     __device__ __forceinline__ void save(T1DecState &st) const {
         st.A = A; st.C = C; st.CT = CT;
@@ -1400,22 +1405,23 @@ struct MqLaneDec {
     }
     // call before every step (wave-uniform): every 32nd looks at the ring
     __device__ __forceinline__ void tick() {
-        if ((nstep++ & 31u) == 0) refill();
+        if ((nstep++ & (T1R_PERIOD - 1u)) == 0) refill();
     }
     __device__ __forceinline__ void refill() {                      // at most 32 steps apart
         const uint32_t ahead = filled - pos;
-        if (!__any(ahead <= 128u)) return;
-        const int nq = ahead <= 128u ? 8 : (ahead <= 192u ? 4 : 0);
-        uint4 c[8];
+        if (!__any(ahead <= T1R_BYTES / 2u)) return;
+        constexpr int NQ = T1R_BYTES / 32;                            // 16-byte pieces in half a ring
+        const int nq = ahead <= T1R_BYTES / 2u ? NQ : (ahead <= 3u * T1R_BYTES / 4u ? NQ / 2 : 0);
+        uint4 c[NQ];
 #pragma unroll
-        for (int q = 0; q < 8; q++) c[q] = q < nq ? ld16(filled + 16 * q) : make_uint4(0, 0, 0, 0);
+        for (int q = 0; q < NQ; q++) c[q] = q < nq ? ld16(filled + 16 * q) : make_uint4(0, 0, 0, 0);
 #pragma unroll
-        for (int q = 0; q < 8; q++) if (q < nq) st16(filled + 16 * q, c[q]);
+        for (int q = 0; q < NQ; q++) if (q < nq) st16(filled + 16 * q, c[q]);
         filled += 16 * nq;
     }
     // the two bytes a byte-in of this step would look at (independent of the step's context: callers read them early)
     __device__ __forceinline__ void peek(uint32_t &b0, uint32_t &b1) const {
-        b0 = ring[rlane + (pos & 255u)]; b1 = ring[rlane + ((pos + 1) & 255u)];
+        b0 = ring[rlane + (pos & (T1R_BYTES - 1u))]; b1 = ring[rlane + ((pos + 1) & (T1R_BYTES - 1u))];
     }
     // one decision with the context's table entry e (qe | nmps << 16 | nlps << 24; MPS = parity of nmps); e_new = its entry after
     __device__ __forceinline__ uint32_t step(uint32_t e, const uint32_t *mqtab, bool act, uint32_t b0, uint32_t b1, uint32_t &e_new) {
@@ -1448,7 +1454,7 @@ struct MqLaneDec {
         };
         round();
         while (__any(nsh > 0)) {
-            b1 = ring[rlane + ((pos + 1) & 255u)];
+            b1 = ring[rlane + ((pos + 1) & (T1R_BYTES - 1u))];
             round();
         }
         return dec;
@@ -1497,7 +1503,7 @@ __global__ __launch_bounds__(64) void t1_dec_magref_lanes_kernel(const BlockJob 
     else { cur = list[0]; nxt = list[nmax > 16 ? 1 : 0]; }
     for (uint32_t i0 = 0; i0 < nmax; i0 += 16) {
         uint32_t acc = 0;
-        if ((i0 & 16u) == 0) mq.refill();
+        if (T1R_PERIOD <= 16 || (i0 & 16u) == 0) mq.refill();
 #pragma unroll
         for (int s = 0; s < 16; s++) {
             const uint32_t i = i0 + s;
