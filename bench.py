@@ -75,6 +75,7 @@ def run(state):
     ap.add_argument("--config", choices=["c2", "c3", "c4", "c5", "c1gpu"], default="c2",
                     help="BASELINE.json configuration: c2 (default, the headline: 4K RGB8 5-3 + HT), c3 (4K RGB 12-bit, 9-7 lossy + MQ), "
                          "c5 (2048x2048 gray16 frames, 5-3 + HT); c4 only with --shard tiles")
+    ap.add_argument("--d2h", action="store_true", help="--shard tiles: copy the finished tile-parts to pinned host memory inside the timed step")
     ap.add_argument("--shard", choices=["frames", "tiles"], default="frames",
                     help="N > 1: every rank codes its own frames (weak scaling, the default) or ONE frame's tiles are sharded over "
                          "the ranks, gathered and assembled into tile-parts on rank 0 (strong scaling, C4 geometry)")
