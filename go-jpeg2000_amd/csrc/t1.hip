@@ -751,6 +751,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
 #define J2K_T1_LANES_PRIO 3
 #endif
 #define T1_LANES_PRIO() __builtin_amdgcn_s_setprio(J2K_T1_LANES_PRIO)
+// Wavefronts per workgroup of the lanes kernels.  Every wavefront works alone (its own 64 blocks, its own LDS, no barrier);
+// putting four of them into one workgroup only makes the dispatcher place them on the four SIMDs of one compute unit, one each,
+// instead of wherever a single-wavefront workgroup happens to land -- with twenty frames' lanes kernels in flight the busiest SIMD
+// decides how long a kernel takes.
+#ifndef T1_LANES_WPW
+#define T1_LANES_WPW 4
+#endif
+__device__ __forceinline__ void t1_wave_sync() {       // LDS written by this wavefront is visible to all its lanes (DS ops of a wave run in order)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // ---- MQ coder, K blocks per wavefront in lock step (mqc.go:224-267, flush t1_fast5.go:878-898) ----
 // t1_encode64_kernel<true> leaves every block's (context, decision) list in memory; here LANE l of workgroup g codes the
@@ -759,15 +771,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
 // symbol falls by K and the kernel runs at the latency of one chain.  All lane-varying state is in registers (A, C, CT,
 // the pending byte) or in a lane-interleaved LDS array (the table entry of each context's current state).  Lanes whose
 // list has ended are fed the no-op symbol (context 31: Qe = 0, never renormalises).
-__global__ __launch_bounds__(64) void t1_mq_lanes_kernel(const BlockJob *__restrict__ jobs, int njobs, int K, const uint8_t *__restrict__ gsym,
+__global__ __launch_bounds__(64 * T1_LANES_WPW) void t1_mq_lanes_kernel(const BlockJob *__restrict__ jobs, int njobs, int K, const uint8_t *__restrict__ gsym,
                                                          size_t sym_stride, const uint32_t *__restrict__ nsyms, uint8_t *__restrict__ slots,
                                                          uint32_t *__restrict__ lens, int *__restrict__ fault, const uint32_t *__restrict__ perm) {
-    __shared__ uint32_t mqtab[96];
-    __shared__ uint32_t ce[32 * 64];
+    __shared__ uint32_t mqtab_w[T1_LANES_WPW][96];
+    __shared__ uint32_t ce_w[T1_LANES_WPW][32 * 64];
     T1_LANES_PRIO();
-    const int lane = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    uint32_t *const mqtab = mqtab_w[wv], *const ce = ce_w[wv];
     // perm: lane order by symbol count (t1_order_kernel), so that the chains of a wavefront end together
-    const long slot = (long)blockIdx.x * K + lane;
+    const long slot = ((long)blockIdx.x * T1_LANES_WPW + wv) * K + lane;
     const uint32_t pj = (lane < K && slot < njobs) ? (perm ? perm[slot] : (uint32_t)slot) : 0xFFFFFFFFu;
     const long jid = (long)pj;
     const bool live = pj != 0xFFFFFFFFu;
@@ -777,7 +790,7 @@ __global__ __launch_bounds__(64) void t1_mq_lanes_kernel(const BlockJob *__restr
         const uint32_t nl = 2 * c_iso_nlps[i] + (c_iso_switch[i] ? 1 - m : m);
         mqtab[s] = (uint32_t)c_iso_qe[i] | nm << 16 | nl << 24;
     }
-    __syncthreads();
+    t1_wave_sync();
     for (int c = 0; c < 32; c++) ce[c * 64 + lane] = c < NumContexts ? mqtab[c == CtxUni ? 92 : 0] : 0u;
     uint32_t n = live ? nsyms[jid] : 0u;
     if (n == T1F_SKIPPED) n = 0;
@@ -1356,7 +1369,7 @@ __global__ __launch_bounds__(64) void t1_dec_step_kernel(const BlockJob *__restr
 // callers' nested loops, which made every step wait for memory.  Lanes without a decision pass act = false (Qe = 0 changes
 // nothing); lanes without a block keep A = 0x8000.
 #ifndef T1R_BYTES
-#define T1R_BYTES 256                    /* ring bytes per lane: 256 (looked at every 32 steps); 128 (every 16) measured 4 % slower at 20 frames in flight */
+#define T1R_BYTES 128                    /* ring bytes per lane (looked at every T1R_BYTES / 8 steps).  With single-wavefront workgroups 256 was 4 % faster at 20 frames in flight; with four wavefronts per workgroup (T1_LANES_WPW) 128 is what lets two such workgroups share a CU: 143.5 -> 133 ms per step */
 #endif
 #define T1R_STRIDE (T1R_BYTES + 4)
 #define T1R_PERIOD (T1R_BYTES / 8)       /* steps between looks: at most 3 bytes each */
@@ -1467,15 +1480,17 @@ struct MqLaneDec {
 // BITLIST: the context list as two bit strings (t1_lanes.inc's plane kernel: Mag2 members in one, Mag1 in the other, list position
 // = bit position); otherwise one byte per member (round 2's step kernels).
 template <bool BITLIST>
-__global__ __launch_bounds__(64) void t1_dec_magref_lanes_kernel(const BlockJob *__restrict__ jobs, int njobs, const uint8_t *__restrict__ stream,
+__global__ __launch_bounds__(64 * T1_LANES_WPW) void t1_dec_magref_lanes_kernel(const BlockJob *__restrict__ jobs, int njobs, const uint8_t *__restrict__ stream,
                                                                  const uint64_t *__restrict__ offs, const uint8_t *__restrict__ numbps,
                                                                  uint8_t *__restrict__ ws, const uint32_t *__restrict__ perm, int k) {
-    __shared__ uint32_t mqtab[96];
-    __shared__ __attribute__((aligned(16))) uint8_t ring[64 * T1R_STRIDE];
+    __shared__ uint32_t mqtab_w[T1_LANES_WPW][96];
+    __shared__ __attribute__((aligned(16))) uint8_t ring_w[T1_LANES_WPW][64 * T1R_STRIDE];
     T1_LANES_PRIO();
-    const int lane = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    uint32_t *const mqtab = mqtab_w[wv];
+    uint8_t *const ring = ring_w[wv];
     // perm: the lane order of t1_lanes.inc (blocks of similar length share a wavefront); slots without a job read as past the end
-    const long slot = (long)blockIdx.x * 64 + lane;
+    const long slot = ((long)blockIdx.x * T1_LANES_WPW + wv) * 64 + lane;
     const uint32_t pj = perm ? perm[slot] : (uint32_t)slot;
     const long jid = pj == 0xFFFFFFFFu ? (long)njobs : (long)pj;
     for (int q = lane; q < 94; q += 64) mqtab[q] = c_mq94.v[q];
@@ -1494,7 +1509,7 @@ __global__ __launch_bounds__(64) void t1_dec_magref_lanes_kernel(const BlockJob 
     uint32_t e0 = ent[CtxMag0], e1 = ent[CtxMag1], e2 = ent[CtxMag2];
     MqLaneDec mq;
     mq.start(stream + offs[live ? jid : 0], st, live, ring, lane);
-    __syncthreads();
+    t1_wave_sync();
     const uint4 *const list = reinterpret_cast<const uint4 *>(rec + T1DS_LIST);
     const uint16_t *const lhi = reinterpret_cast<const uint16_t *>(rec + T1DS_LIST), *const llo = lhi + 256;      // BITLIST: 4096 bits each
     uint16_t *const obits = reinterpret_cast<uint16_t *>(rec + T1DS_BITS);
@@ -1693,7 +1708,7 @@ hipError_t launch_t1_encode(hipStream_t s, const BlockJob *jobs, int njobs, cons
             uint32_t *perm = lane_order ? nsyms + njobs : nullptr;       // njobs + 64 words behind nsyms (t1_workspace in j2k_abi.cpp)
             if (perm) hipLaunchKernelGGL(t1_order_kernel, dim3(1), dim3(1024), 0, s, jobs, njobs, (const uint8_t *)nullptr, (const uint32_t *)nsyms, 1, perm,
                                          (uint32_t *)nullptr, njobs);
-            hipLaunchKernelGGL(t1_mq_lanes_kernel, dim3((njobs + K - 1) / K), dim3(64), 0, s, jobs, njobs, K, sym, sym_stride, nsyms,
+            hipLaunchKernelGGL(t1_mq_lanes_kernel, dim3(((njobs + K - 1) / K + T1_LANES_WPW - 1) / T1_LANES_WPW), dim3(64 * T1_LANES_WPW), 0, s, jobs, njobs, K, sym, sym_stride, nsyms,
                                slots, lens, fault, (const uint32_t *)perm);
             if (planes < 31)
                 hipLaunchKernelGGL(t1_encode64_kernel<false>, dim3(njobs), dim3(64), 0, s, jobs, njobs, coef, slots, lens, numbps, fault,
@@ -1751,15 +1766,15 @@ hipError_t launch_t1_decode(hipStream_t s, const BlockJob *jobs, int njobs, cons
             if (sig_lanes) hipLaunchKernelGGL(t1_order_kernel, dim3(1), dim3(1024), 0, s, jobs, njobs, numbps, lens, 0, perm, slot_of, ngroups * 64);
             for (int k = 0; k <= T1DS_MAXP; k++) {
                 if (sig_lanes) {
-                    hipLaunchKernelGGL(t1_dec_sig_lanes_kernel, dim3(ngroups), dim3(64), 0, s, jobs, njobs, stream, offs, lens, numbps, split_ws, masks, perm, k);
+                    hipLaunchKernelGGL(t1_dec_sig_lanes_kernel, dim3((ngroups + T1_LANES_WPW - 1) / T1_LANES_WPW), dim3(64 * T1_LANES_WPW), 0, s, jobs, njobs, stream, offs, lens, numbps, split_ws, masks, perm, k);
                     hipLaunchKernelGGL(t1_dec_plane_kernel, dim3(njobs), dim3(64), 0, s, jobs, njobs, numbps, decoded, split_ws, masks, slot_of,
                                        reinterpret_cast<uint64_t *>(split_ws + t1_dec_lanes_planes_offset((size_t)njobs)), k);
                 } else {
                     hipLaunchKernelGGL(t1_dec_step_kernel, dim3(njobs), dim3(64), 0, s, jobs, njobs, stream, offs, lens, numbps, decoded, split_ws, k);
                 }
                 if (k < T1DS_MAXP) {
-                    if (sig_lanes) { if (k > 0) hipLaunchKernelGGL(t1_dec_magref_lanes_kernel<true>, dim3(ngroups), dim3(64), 0, s, jobs, njobs, stream, offs, numbps, split_ws, (const uint32_t *)perm, k); }
-                    else hipLaunchKernelGGL(t1_dec_magref_lanes_kernel<false>, dim3(ngroups), dim3(64), 0, s, jobs, njobs, stream, offs, numbps, split_ws, (const uint32_t *)nullptr, k);
+                    if (sig_lanes) { if (k > 0) hipLaunchKernelGGL(t1_dec_magref_lanes_kernel<true>, dim3((ngroups + T1_LANES_WPW - 1) / T1_LANES_WPW), dim3(64 * T1_LANES_WPW), 0, s, jobs, njobs, stream, offs, numbps, split_ws, (const uint32_t *)perm, k); }
+                    else hipLaunchKernelGGL(t1_dec_magref_lanes_kernel<false>, dim3((ngroups + T1_LANES_WPW - 1) / T1_LANES_WPW), dim3(64 * T1_LANES_WPW), 0, s, jobs, njobs, stream, offs, numbps, split_ws, (const uint32_t *)nullptr, k);
                 }
             }
         }
