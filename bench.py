@@ -87,7 +87,7 @@ def run(state):
     # configurations want the opposite: C5's eight frames in flight run at 72-74 Gpixel/s on 4 or 8 queues and at 41 on 16 or 32
     # (eight frames' transforms truly at once evict each other's lines).  Read when the runtime initialises, i.e. before the first
     # torch.cuda call.
-    if args.config == "c3":
+    if args.config in ("c3", "c1gpu"):
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
     import faulthandler
     faulthandler.enable(all_threads=True)   # a native crash in a rank prints every thread's Python stack
