@@ -99,6 +99,8 @@ def run(state):
     if args.config != "c2":
         if "--inflight" not in " ".join(sys.argv):
             args.inflight = 0           # the configuration's own default
+        if args.config == "c1gpu" and "--steps" not in " ".join(sys.argv):
+            args.steps, args.warmup = 10, min(args.warmup, 2)      # a step is 24 frames of 21 serial chains: 0.4 s
         return bench_extra.run_config(args, args.config)
     # CPU baseline first (N = 1 only): nothing has touched the GPU yet, so the worker processes are plain forks / spawns
     cpu_base = None
