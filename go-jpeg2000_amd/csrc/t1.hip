@@ -1477,8 +1477,51 @@ struct MqLaneDec {
 // The MagRef chains of 64 blocks in lock step (MqLaneDec above).  Per lane: the decoder and the three context entries in
 // registers.  Both bytes a byte-in might need, and both successor entries of the context's state, are read at the top of the
 // step, so no memory latency sits on the A / C chain.  Lanes whose list has ended decode with Qe = 0, which changes nothing.
-// BITLIST: the context list as two bit strings (t1_lanes.inc's plane kernel: Mag2 members in one, Mag1 in the other, list position
-// = bit position); otherwise one byte per member (round 2's step kernels).
+// The MagRef chain of one wavefront's 64 blocks (t1.go:1331-1347 as list + chain): lane l decodes the n decisions of its list at
+// `rec` (nmax = the wavefront's largest n), 16 decisions to a 16-bit piece of the decision string.  e0 / e1 / e2: the lane's entries of
+// the contexts Mag0 / Mag1 / Mag2.  BITLIST: the context list as two bit strings (t1_lanes.inc's plane work: Mag2 members in one,
+// Mag1 in the other, list position = bit position); otherwise one byte per member (round 2's step kernels).
+template <bool BITLIST>
+__device__ __forceinline__ void t1_magref_chain(MqLaneDec &mq, const uint32_t *mqtab, uint32_t &e0, uint32_t &e1, uint32_t &e2,
+                                                uint8_t *rec, uint32_t n, uint32_t nmax, bool live) {
+    const uint4 *const list = reinterpret_cast<const uint4 *>(rec + T1DS_LIST);
+    const uint16_t *const lhi = reinterpret_cast<const uint16_t *>(rec + T1DS_LIST), *const llo = lhi + 256;      // BITLIST: 4096 bits each
+    uint16_t *const obits = reinterpret_cast<uint16_t *>(rec + T1DS_BITS);
+    uint4 cur = make_uint4(0, 0, 0, 0), nxt = cur;
+    if (BITLIST) { cur.x = lhi[0]; cur.y = llo[0]; nxt.x = lhi[nmax > 16 ? 1 : 0]; nxt.y = llo[nmax > 16 ? 1 : 0]; }
+    else { cur = list[0]; nxt = list[nmax > 16 ? 1 : 0]; }
+    for (uint32_t i0 = 0; i0 < nmax; i0 += 16) {
+        uint32_t acc = 0;
+        if (T1R_PERIOD <= 16 || (i0 & 16u) == 0) mq.refill();
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+            const uint32_t i = i0 + s;
+            bool is2, is1;
+            // (the two strings exclude each other below n; past it the pieces hold whatever an earlier plane left, and a lane
+            //  whose list has ended must still pick exactly one entry to write back unchanged)
+            if (BITLIST) { is2 = (cur.x >> s) & 1u; is1 = !is2 && ((cur.y >> s) & 1u); }
+            else {
+                const uint32_t wsel = (s >> 2) == 0 ? cur.x : (s >> 2) == 1 ? cur.y : (s >> 2) == 2 ? cur.z : cur.w;
+                const uint32_t code = (wsel >> ((s & 3) * 8)) & 3u;
+                is2 = code == 2; is1 = code == 1;
+            }
+            const uint32_t e = is2 ? e2 : (is1 ? e1 : e0);
+            uint32_t b0, b1, e_new;
+            mq.peek(b0, b1);
+            const uint32_t dec = mq.step(e, mqtab, i < n, b0, b1, e_new);
+            e0 = (is2 || is1) ? e0 : e_new;
+            e1 = is1 ? e_new : e1;
+            e2 = is2 ? e_new : e2;
+            acc |= dec << s;
+        }
+        if (live && i0 < n) obits[i0 >> 4] = (uint16_t)acc;
+        cur = nxt;
+        const uint32_t nx = (i0 >> 4) + 2;
+        if (BITLIST) { nxt.x = lhi[nx < 256 ? nx : 255]; nxt.y = llo[nx < 256 ? nx : 255]; }
+        else nxt = list[nx < 256 ? nx : 255];
+    }
+}
+
 template <bool BITLIST>
 __global__ __launch_bounds__(64 * T1_LANES_WPW) void t1_dec_magref_lanes_kernel(const BlockJob *__restrict__ jobs, int njobs, const uint8_t *__restrict__ stream,
                                                                  const uint64_t *__restrict__ offs, const uint8_t *__restrict__ numbps,
@@ -1510,42 +1553,7 @@ __global__ __launch_bounds__(64 * T1_LANES_WPW) void t1_dec_magref_lanes_kernel(
     MqLaneDec mq;
     mq.start(stream + offs[live ? jid : 0], st, live, ring, lane);
     t1_wave_sync();
-    const uint4 *const list = reinterpret_cast<const uint4 *>(rec + T1DS_LIST);
-    const uint16_t *const lhi = reinterpret_cast<const uint16_t *>(rec + T1DS_LIST), *const llo = lhi + 256;      // BITLIST: 4096 bits each
-    uint16_t *const obits = reinterpret_cast<uint16_t *>(rec + T1DS_BITS);
-    uint4 cur = make_uint4(0, 0, 0, 0), nxt = cur;
-    if (BITLIST) { cur.x = lhi[0]; cur.y = llo[0]; nxt.x = lhi[nmax > 16 ? 1 : 0]; nxt.y = llo[nmax > 16 ? 1 : 0]; }
-    else { cur = list[0]; nxt = list[nmax > 16 ? 1 : 0]; }
-    for (uint32_t i0 = 0; i0 < nmax; i0 += 16) {
-        uint32_t acc = 0;
-        if (T1R_PERIOD <= 16 || (i0 & 16u) == 0) mq.refill();
-#pragma unroll
-        for (int s = 0; s < 16; s++) {
-            const uint32_t i = i0 + s;
-            bool is2, is1;
-            // (the two strings exclude each other below nmr; past it the pieces hold whatever an earlier plane left, and a lane
-            //  whose list has ended must still pick exactly one entry to write back unchanged)
-            if (BITLIST) { is2 = (cur.x >> s) & 1u; is1 = !is2 && ((cur.y >> s) & 1u); }
-            else {
-                const uint32_t wsel = (s >> 2) == 0 ? cur.x : (s >> 2) == 1 ? cur.y : (s >> 2) == 2 ? cur.z : cur.w;
-                const uint32_t code = (wsel >> ((s & 3) * 8)) & 3u;
-                is2 = code == 2; is1 = code == 1;
-            }
-            const uint32_t e = is2 ? e2 : (is1 ? e1 : e0);
-            uint32_t b0, b1, e_new;
-            mq.peek(b0, b1);
-            const uint32_t dec = mq.step(e, mqtab, i < n, b0, b1, e_new);
-            e0 = (is2 || is1) ? e0 : e_new;
-            e1 = is1 ? e_new : e1;
-            e2 = is2 ? e_new : e2;
-            acc |= dec << s;
-        }
-        if (live && i0 < n) obits[i0 >> 4] = (uint16_t)acc;
-        cur = nxt;
-        const uint32_t nx = (i0 >> 4) + 2;
-        if (BITLIST) { nxt.x = lhi[nx < 256 ? nx : 255]; nxt.y = llo[nx < 256 ? nx : 255]; }
-        else nxt = list[nx < 256 ? nx : 255];
-    }
+    t1_magref_chain<BITLIST>(mq, mqtab, e0, e1, e2, rec, n, nmax, live);
     if (live) {
         ent[CtxMag0] = e0; ent[CtxMag1] = e1; ent[CtxMag2] = e2;
         mq.save(st);
