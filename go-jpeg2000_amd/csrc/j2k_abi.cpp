@@ -157,7 +157,7 @@ extern "C" int j2k_ctx_create(int device, j2k_ctx **out) {
     if (const char *e = getenv("J2K_T1_SYM_MB")) { long v = atol(e); if (v >= 0) ctx->t1_sym_mb = v; }
     if (const char *e = getenv("J2K_T1_DEC_GENERAL")) ctx->t1_dec_general = atoi(e) != 0;
     if (const char *e = getenv("J2K_T1_DEC_SPLIT")) { int v = atoi(e); if (v >= -1) ctx->t1_dec_split = v; }
-    if (const char *e = getenv("J2K_T1_DEC_LANES")) ctx->t1_dec_lanes = atoi(e) != 0;
+    if (const char *e = getenv("J2K_T1_DEC_LANES")) { int v = atoi(e); if (v >= 0 && v <= 2) ctx->t1_dec_lanes = v; }
     if (const char *e = getenv("J2K_T1_LANES")) { int v = atoi(e); if (v >= 0 && v <= 64) ctx->t1_lanes = v; }
     if (const char *e = getenv("J2K_CPL0")) { int v = atoi(e); if (v == 2 || v == 4 || v == 8) ctx->cpl0 = v; }
     *out = ctx;

@@ -49,7 +49,7 @@ struct j2k_ctx {
     int t1_split = 1;          // J2K_T1_SPLIT=0: T1 encoder as one kernel (contexts + MQ chain on lane 0) instead of two
     long t1_sym_mb = 8192;     // J2K_T1_SYM_MB: cap of the T1 symbol workspace; blocks with more bit planes than fit take the one-kernel path
     int t1_dec_general = 0;    // J2K_T1_DEC_GENERAL=1: every block on the general T1 decode kernel (A/B against t1_decode64_kernel)
-    int t1_dec_lanes = 1;      // J2K_T1_DEC_LANES=0: the plane-stepped decoder's SigProp / Cleanup as round 2's step kernels (one block per wavefront) instead of t1_lanes.inc
+    int t1_dec_lanes = 2;      // J2K_T1_DEC_LANES: 2 = the plane-stepped decoder as one launch per group of 64 blocks (t1_lanes.inc, PERSIST), 1 = its passes as launches per plane, 0 = the plane-stepped decoder's SigProp / Cleanup as round 2's step kernels (one block per wavefront) instead of t1_lanes.inc
     int t1_dec_split = -1;     // J2K_T1_DEC_SPLIT: MQ decode of frames with at least this many blocks runs plane by plane with the MagRef chains
                                // of 64 blocks per wavefront in lock step (t1.hip); 0: always the one-launch kernels; -1 (default): 512 while
                                // at least two contexts of this process code with the MQ coder (frames in flight: throughput), else 0 (one

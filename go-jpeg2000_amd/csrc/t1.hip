@@ -1767,22 +1767,30 @@ hipError_t launch_t1_decode(hipStream_t s, const BlockJob *jobs, int njobs, cons
     if (!general_only) {
         if (split_ws) {
             // plane-stepped path for blocks of at most 31 planes; the one-launch kernel keeps the deeper ones
-            // sig_lanes (J2K_T1_DEC_LANES): SigProp / Cleanup as lanes kernels (t1_lanes.inc); 0: round 2's step kernels
+            // sig_lanes (J2K_T1_DEC_LANES): 2 = the whole plane-stepped decode of a group of 64 blocks in ONE launch (t1_lanes.inc,
+            // PERSIST); 1 = its passes as separate launches per plane (significance lanes, plane work, MagRef lanes); 0 = round 2's
+            // step kernels (one block per wavefront) + MagRef lanes
             uint64_t *masks = reinterpret_cast<uint64_t *>(split_ws + t1_dec_lanes_mask_offset((size_t)njobs));
+            uint64_t *planes = reinterpret_cast<uint64_t *>(split_ws + t1_dec_lanes_planes_offset((size_t)njobs));
             const int ngroups = (njobs + 63) / 64;
+            const int nwg = (ngroups + T1_LANES_WPW - 1) / T1_LANES_WPW;
             uint32_t *perm = reinterpret_cast<uint32_t *>(split_ws + t1_dec_lanes_perm_offset((size_t)njobs)), *slot_of = perm + (size_t)ngroups * 64;
             if (sig_lanes) hipLaunchKernelGGL(t1_order_kernel, dim3(1), dim3(1024), 0, s, jobs, njobs, numbps, lens, 0, perm, slot_of, ngroups * 64);
+            if (sig_lanes >= 2) {
+                hipLaunchKernelGGL(t1_dec_sig_lanes_kernel<true>, dim3(nwg), dim3(64 * T1_LANES_WPW), 0, s, jobs, njobs, stream, offs, lens, numbps,
+                                   split_ws, masks, (const uint32_t *)perm, planes, 0);
+            } else
             for (int k = 0; k <= T1DS_MAXP; k++) {
                 if (sig_lanes) {
-                    hipLaunchKernelGGL(t1_dec_sig_lanes_kernel, dim3((ngroups + T1_LANES_WPW - 1) / T1_LANES_WPW), dim3(64 * T1_LANES_WPW), 0, s, jobs, njobs, stream, offs, lens, numbps, split_ws, masks, perm, k);
-                    hipLaunchKernelGGL(t1_dec_plane_kernel, dim3(njobs), dim3(64), 0, s, jobs, njobs, numbps, decoded, split_ws, masks, slot_of,
-                                       reinterpret_cast<uint64_t *>(split_ws + t1_dec_lanes_planes_offset((size_t)njobs)), k);
+                    hipLaunchKernelGGL(t1_dec_sig_lanes_kernel<false>, dim3(nwg), dim3(64 * T1_LANES_WPW), 0, s, jobs, njobs, stream, offs, lens, numbps,
+                                       split_ws, masks, (const uint32_t *)perm, planes, k);
+                    hipLaunchKernelGGL(t1_dec_plane_kernel, dim3(njobs), dim3(64), 0, s, jobs, njobs, numbps, decoded, split_ws, masks, slot_of, planes, k);
                 } else {
                     hipLaunchKernelGGL(t1_dec_step_kernel, dim3(njobs), dim3(64), 0, s, jobs, njobs, stream, offs, lens, numbps, decoded, split_ws, k);
                 }
                 if (k < T1DS_MAXP) {
-                    if (sig_lanes) { if (k > 0) hipLaunchKernelGGL(t1_dec_magref_lanes_kernel<true>, dim3((ngroups + T1_LANES_WPW - 1) / T1_LANES_WPW), dim3(64 * T1_LANES_WPW), 0, s, jobs, njobs, stream, offs, numbps, split_ws, (const uint32_t *)perm, k); }
-                    else hipLaunchKernelGGL(t1_dec_magref_lanes_kernel<false>, dim3((ngroups + T1_LANES_WPW - 1) / T1_LANES_WPW), dim3(64 * T1_LANES_WPW), 0, s, jobs, njobs, stream, offs, numbps, split_ws, (const uint32_t *)nullptr, k);
+                    if (sig_lanes) { if (k > 0) hipLaunchKernelGGL(t1_dec_magref_lanes_kernel<true>, dim3(nwg), dim3(64 * T1_LANES_WPW), 0, s, jobs, njobs, stream, offs, numbps, split_ws, (const uint32_t *)perm, k); }
+                    else hipLaunchKernelGGL(t1_dec_magref_lanes_kernel<false>, dim3(nwg), dim3(64 * T1_LANES_WPW), 0, s, jobs, njobs, stream, offs, numbps, split_ws, (const uint32_t *)nullptr, k);
                 }
             }
         }
