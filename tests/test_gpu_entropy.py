@@ -134,10 +134,11 @@ def test_t1_batch_both_decoder_kernels(ent, oracle, general, monkeypatch):
         assert np.array_equal(got[j], wants[j]), (j, blocks[j], general)
 
 
-@pytest.mark.parametrize("lanes", [1, 0])
+@pytest.mark.parametrize("lanes", [2, 1, 0])
 def test_t1_batch_plane_stepped_decoder(ent, oracle, monkeypatch, lanes):
-    """The plane-stepped T1.Decode (J2K_T1_DEC_SPLIT=1; lanes = 1: SigProp / Cleanup one block per lane on row masks, t1_lanes.inc;
-    lanes = 0: round 2's step kernels; MagRef chains in lock step in both) on a batch of mixed block
+    """The plane-stepped T1.Decode (J2K_T1_DEC_SPLIT=1; lanes = 2: the whole decode of 64 blocks per wavefront in one launch, one block
+    per lane on row masks, t1_lanes.inc; lanes = 1: the same passes as launches per plane; lanes = 0: round 2's step kernels; MagRef
+    chains in lock step in all) on a batch of mixed block
     sizes against the oracle: encoder output, arbitrary bytes (streams that end early, 0xFF runs), zero-length streams,
     bit-plane counts from 0 to 40 (above 31 the one-launch kernel takes the block: bit 0 for p >= 32, t1.go:1291) and
     blocks wider than 64 (general kernel) in the same call."""

@@ -128,8 +128,8 @@ def test_lossy_inverse_level0_knobs(W, H, tile, nres, wg, span):
 @pytest.mark.parametrize("W,H,tile,cb,prec,lossless", [(512, 384, (256, 256), (64, 64), 12, False), (200, 150, (0, 0), (32, 32), 8, True),
                                                        (256, 256, (0, 0), (128, 128), 12, False), (96, 80, (0, 0), (64, 16), 16, True)])
 def test_mq_decode_split_knob(W, H, tile, cb, prec, lossless):
-    """MQ block decoder: the plane-stepped paths (J2K_T1_DEC_SPLIT=1: SigProp / Cleanup as lanes kernels, or round 2's step
-    kernels with J2K_T1_DEC_LANES=0; the MagRef chains of 64 blocks in lock step in both) and the one-launch kernels give the
+    """MQ block decoder: the plane-stepped paths (J2K_T1_DEC_SPLIT=1: one launch per frame with a block per lane, the same passes as
+    launches per plane with J2K_T1_DEC_LANES=1, or round 2's step kernels with J2K_T1_DEC_LANES=0) and the one-launch kernels give the
     same decoded blocks -- mixed block sizes, blocks above 64x64 (which keep the general kernel in all), blocks of very
     different bit-plane counts, all-zero blocks"""
     import torch
@@ -139,7 +139,8 @@ def test_mq_decode_split_knob(W, H, tile, cb, prec, lossless):
     frame_h[:, :, : (W * 5) // 8] = 1 << (prec - 1)                       # a flat area: blocks with no bit planes at all
     kw = dict(precision=prec, lossless=lossless, quality=75, num_resolutions=4, cb=cb, tile=tile, coder=0)
     res = []
-    for ctx in (_ctx({"J2K_T1_DEC_SPLIT": 0}), _ctx({"J2K_T1_DEC_SPLIT": 1}), _ctx({"J2K_T1_DEC_SPLIT": 1, "J2K_T1_DEC_LANES": 0})):
+    for ctx in (_ctx({"J2K_T1_DEC_SPLIT": 0}), _ctx({"J2K_T1_DEC_SPLIT": 1}), _ctx({"J2K_T1_DEC_SPLIT": 1, "J2K_T1_DEC_LANES": 0}),
+                _ctx({"J2K_T1_DEC_SPLIT": 1, "J2K_T1_DEC_LANES": 1})):
         plan = FramePlan(W, H, 3, ctx=ctx, **kw)
         coeff = plan.forward(torch.from_numpy(frame_h).to(plan.device))
         stream, offs, lens, nb = plan.encode_stream(coeff)
@@ -150,6 +151,7 @@ def test_mq_decode_split_knob(W, H, tile, cb, prec, lossless):
     assert int(res[0][1].max()) > 8
     assert torch.equal(res[0][0], res[1][0])
     assert torch.equal(res[0][0], res[2][0])
+    assert torch.equal(res[0][0], res[3][0])
 
 
 @pytest.mark.parametrize("W,H,tile,nres,quality", [(1024, 600, (512, 512), 6, 75), (512, 77, (0, 0), 4, 30), (256, 2048, (0, 0), 6, 8000),
