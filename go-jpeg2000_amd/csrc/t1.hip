@@ -1481,6 +1481,9 @@ struct MqLaneDec {
 // `rec` (nmax = the wavefront's largest n), 16 decisions to a 16-bit piece of the decision string.  e0 / e1 / e2: the lane's entries of
 // the contexts Mag0 / Mag1 / Mag2.  BITLIST: the context list as two bit strings (t1_lanes.inc's plane work: Mag2 members in one,
 // Mag1 in the other, list position = bit position); otherwise one byte per member (round 2's step kernels).
+#ifndef T1_MAGREF_UNROLL
+#define T1_MAGREF_UNROLL 8
+#endif
 template <bool BITLIST>
 __device__ __forceinline__ void t1_magref_chain(MqLaneDec &mq, const uint32_t *mqtab, uint32_t &e0, uint32_t &e1, uint32_t &e2,
                                                 uint8_t *rec, uint32_t n, uint32_t nmax, bool live) {
@@ -1493,7 +1496,7 @@ __device__ __forceinline__ void t1_magref_chain(MqLaneDec &mq, const uint32_t *m
     for (uint32_t i0 = 0; i0 < nmax; i0 += 16) {
         uint32_t acc = 0;
         if (T1R_PERIOD <= 16 || (i0 & 16u) == 0) mq.refill();
-#pragma unroll
+#pragma unroll T1_MAGREF_UNROLL
         for (int s = 0; s < 16; s++) {
             const uint32_t i = i0 + s;
             bool is2, is1;
