@@ -392,7 +392,8 @@ struct T1Fast {
     uint32_t ctxent[32];       // per context: the MQ table entry of its current state
     alignas(16) uint8_t sym[T1F_SYM_CAP];  // ctx | decision << 5
 };
-#define T1F_NULL_SYM 31u     /* context 31 is a no-op for the lane-parallel MQ kernel (Qe = 0): pads a chunk to 16 symbols */
+#define T1F_NULL_SYM 19u     /* context 19 (the first unused one) is a no-op for the lane-parallel MQ kernel (Qe = 0): pads a chunk to 16 symbols */
+#define T1F_NCTX 20          /* entries per lane in that kernel's LDS: the 19 contexts and the no-op */
 #define T1F_SKIPPED 0xFFFFFFFFu   /* nsyms[] mark: block over the symbol-plane budget, left to the one-kernel path */
 
 __device__ __forceinline__ uint64_t rl64(uint64_t v, int r) {      // row mask of lane r, broadcast (r wave-uniform)
@@ -775,7 +776,7 @@ __global__ __launch_bounds__(64 * T1_LANES_WPW) void t1_mq_lanes_kernel(const Bl
                                                          size_t sym_stride, const uint32_t *__restrict__ nsyms, uint8_t *__restrict__ slots,
                                                          uint32_t *__restrict__ lens, int *__restrict__ fault, const uint32_t *__restrict__ perm) {
     __shared__ uint32_t mqtab_w[T1_LANES_WPW][96];
-    __shared__ uint32_t ce_w[T1_LANES_WPW][32 * 64];
+    __shared__ uint32_t ce_w[T1_LANES_WPW][T1F_NCTX * 64];
     T1_LANES_PRIO();
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     uint32_t *const mqtab = mqtab_w[wv], *const ce = ce_w[wv];
@@ -791,7 +792,7 @@ __global__ __launch_bounds__(64 * T1_LANES_WPW) void t1_mq_lanes_kernel(const Bl
         mqtab[s] = (uint32_t)c_iso_qe[i] | nm << 16 | nl << 24;
     }
     t1_wave_sync();
-    for (int c = 0; c < 32; c++) ce[c * 64 + lane] = c < NumContexts ? mqtab[c == CtxUni ? 92 : 0] : 0u;
+    for (int c = 0; c < T1F_NCTX; c++) ce[c * 64 + lane] = c < NumContexts ? mqtab[c == CtxUni ? 92 : 0] : 0u;
     uint32_t n = live ? nsyms[jid] : 0u;
     if (n == T1F_SKIPPED) n = 0;
     uint32_t nmax = n;
@@ -821,7 +822,7 @@ __global__ __launch_bounds__(64 * T1_LANES_WPW) void t1_mq_lanes_kernel(const Bl
             CT = ff ? 7u : 8u;
         }
     };
-    const uint4 null16 = make_uint4(0x1F1F1F1Fu, 0x1F1F1F1Fu, 0x1F1F1F1Fu, 0x1F1F1F1Fu);
+    const uint4 null16 = make_uint4(T1F_NULL_SYM * 0x01010101u, T1F_NULL_SYM * 0x01010101u, T1F_NULL_SYM * 0x01010101u, T1F_NULL_SYM * 0x01010101u);
     const uint32_t nclamp = n ? n - 16u : 0u;
     auto fetch = [&](uint32_t i0) -> uint4 {      // unconditional load from a clamped offset, then select (n is a multiple of 16)
         uint4 v;
