@@ -1704,7 +1704,9 @@ extern "C" int j2k_plan_decode_blocks(j2k_plan *P, const uint8_t *d_stream, cons
         for (const j2k_block &b : P->blocks) { wpj = std::max(wpj, t1_flag_bytes(b.w, b.h)); max_dim = std::max(max_dim, std::max(b.w, b.h)); }
         wpj = (wpj + 255) & ~size_t(255);
         // plane-stepped path (t1.hip): frames of at least t1_dec_split blocks, 16-byte aligned stream (its 16-byte loads)
-        const int split_min = ctx->t1_dec_split >= 0 ? ctx->t1_dec_split : (mq_throughput_mode() ? 512 : 0);
+        // (one context alone: the one-launch kernels are a 28-30 ms chain while their 8192 wavefront slots hold the frame, the lanes
+        //  decoder a 45-50 ms one whatever the frame -- an 8K frame of 27 000 blocks: 86 ms against 51, tools/check_big_mq.py)
+        const int split_min = ctx->t1_dec_split >= 0 ? ctx->t1_dec_split : (mq_throughput_mode() ? 512 : 12000);
         const bool split = split_min > 0 && n >= split_min && !ctx->t1_dec_general && !((uintptr_t)d_stream & 15);
         const size_t gen_bytes = (wpj * (size_t)n + 255) & ~size_t(255);
         int r = stage_reserve(ctx, 2, gen_bytes + 256 + (split ? j2k::t1_dec_split_bytes((size_t)n) : 0));
