@@ -26,3 +26,17 @@ for env in ({"J2K_T1_DEC_SPLIT": "0"}, {"J2K_T1_DEC_SPLIT": "1"}):
     res.append(dec.cpu())
     p.close()
 print("equal:", bool(torch.equal(res[0], res[1])))
+# the encoder's MQ lanes kernel at this size: chains per wavefront (J2K_T1_LANES; 0 = the library's choice for a lone context)
+import time
+for K in ("0", "16", "32", "64"):
+    os.environ["J2K_T1_LANES"] = K
+    ctx = Context(0)
+    p = FramePlan(W, H, 3, precision=12, lossless=False, quality=75, num_resolutions=6, cb=(64, 64), tile=(512, 512), coder=0, ctx=ctx)
+    d = torch.from_numpy(fr).to(p.device)
+    co = p.forward(d)
+    p.encode_stream(co); ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(3): p.encode_stream(co)
+    ctx.sync()
+    print("J2K_T1_LANES=%s encode_stream %.1f ms" % (K, (time.perf_counter() - t0) / 3 * 1e3), flush=True)
+    p.close()
