@@ -154,6 +154,31 @@ def test_mq_decode_split_knob(W, H, tile, cb, prec, lossless):
     assert torch.equal(res[0][0], res[3][0])
 
 
+def test_mq_decode_lanes_full_frame():
+    """A C3-sized frame (3840 x 2160, 12 bit, 512^2 tiles, 9-7 + Quality 75: 7005 code-blocks, 110 wavefronts of 64 lanes, every lane
+    order and plane count the real thing) through the one-launch decoder and through the one-launch-per-frame lanes decoder: the same
+    decoded blocks.  (bench.py --config c3 checks the same on its frame 0 after every run.)"""
+    import torch
+    from j2kgfx.codec import FramePlan
+    W, H = 3840, 2160
+    rng = np.random.default_rng(33)
+    yy, xx = np.mgrid[0:H, 0:W]
+    frame_h = np.stack([np.clip(xx * 4095 // W + c * 500 + rng.integers(-300, 301, (H, W)), 0, 4095) for c in range(3)]).astype(np.int32)
+    frame_h[:, :200, :] = 2048                                             # a flat band: blocks without bit planes
+    res = []
+    for ctx in (_ctx({"J2K_T1_DEC_SPLIT": 0}), _ctx({"J2K_T1_DEC_SPLIT": 1})):
+        plan = FramePlan(W, H, 3, ctx=ctx, precision=12, lossless=False, quality=75, num_resolutions=6, cb=(64, 64), tile=(512, 512), coder=0)
+        coeff = plan.forward(torch.from_numpy(frame_h).to(plan.device))
+        stream, offs, lens, nb = plan.encode_stream(coeff)
+        dec = torch.zeros(int(plan.info.decoded_elems), dtype=torch.int32, device=plan.device)
+        plan.decode_blocks(stream, offs, lens, nb, decoded=dec)
+        ctx.sync()
+        res.append(dec.cpu())
+        assert int(plan.info.blocks) == 7005
+        plan.close()
+    assert torch.equal(res[0], res[1])
+
+
 @pytest.mark.parametrize("W,H,tile,nres,quality", [(1024, 600, (512, 512), 6, 75), (512, 77, (0, 0), 4, 30), (256, 2048, (0, 0), 6, 8000),
                                                    (520, 131, (256, 128), 4, 75), (64, 36, (0, 0), 3, 1)])
 def test_lossy_deeper_levels_knob(W, H, tile, nres, quality):
