@@ -12,7 +12,11 @@
   prints : ONE JSON line (rank 0) with the roofline of the dominant kernel (level-0 5-3 DWT, timed with
            HIP events on the library's own stream) and a CPU baseline (the C oracle, 1 thread).
 
-  python bench.py --gpus N --steps K --warmup W        (N>1 via torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+      N > 1 and no WORLD_SIZE in the environment: this process -- before it has touched the GPU -- starts
+      `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` as a CHILD process
+      (one rank per GPU over RCCL), passes rank 0's JSON line through and exits with the child's status.  Under
+      torch.distributed.run (WORLD_SIZE set) it is a rank; WORLD_SIZE != --gpus is an error.
 """
 import argparse
 import json
@@ -54,9 +58,71 @@ def cpu_baseline(budget_s=10.0):
     return bench_extra.cpu_baseline("c2", index=0, budget_s=budget_s)
 
 
+def launch_ranks(n, argv):
+    """--gpus N without a launcher: start the N ranks as a fresh child process tree and relay.  Called before anything in this
+    process has initialised the GPU (no torch.cuda / HIP call yet), and it never replaces this process (no exec): the child
+    inherits stdout, so rank 0's JSON line goes straight through."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"], env["MASTER_PORT"] = "127.0.0.1", str(port)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    sys.stdout.flush(); sys.stderr.flush()
+    return subprocess.call(cmd, env=env)
+
+
+def other_configs_summary(budget_s=75.0):
+    """One driver-visible record for the configurations the headline line does not cover: C3, C5 and C1-on-the-GPU
+    each run as `bench.py --config X` in a FRESH CHILD PROCESS started before this process touches the GPU (C3 / c1gpu need their
+    own GPU_MAX_HW_QUEUES, which the runtime reads when it initialises), short step counts, the CPU baseline's one-thread leg
+    only.  A child that fails or runs out of time is reported as such; the headline line does not depend on any of them."""
+    import subprocess
+    out = {}
+    t_all = time.perf_counter()
+    plan = [("c3", ["--steps", "2", "--warmup", "1"]), ("c5", ["--steps", "20", "--warmup", "3"]), ("c1gpu", ["--steps", "2", "--warmup", "1"])]
+    for name, extra in plan:
+        left = budget_s - (time.perf_counter() - t_all)
+        if left < 10:
+            out[name] = {"error": "skipped: the %.0f s budget of other_configs was used up" % budget_s}
+            continue
+        env = dict(os.environ)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--cpu-baseline-s", "2.5", "--cpu-baseline-1t"] + extra
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=min(left, 45.0))
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines:
+                out[name] = {"error": "exit %d: %s" % (r.returncode, r.stderr.strip()[-300:])}
+                continue
+            d = json.loads(lines[-1])
+            out[name] = {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+                         "frames_in_flight": d["config"].get("frames_in_flight"), "hw_queues": d["config"].get("hw_queues"),
+                         "dtype": d["dtype"], "self_check": d["config"].get("self_check"),
+                         "roofline_kernel": d["roofline"]["kernel"], "roofline_frac": d["roofline"]["frac"],
+                         "roofline_avg_launch_us": d["roofline"]["avg_launch_us"],
+                         "cpu_1_thread": (d.get("cpu_baseline") or {}).get("value_1_thread"), "cpu_unit": "Mpixels/s",
+                         "wall_s": round(time.perf_counter() - t0, 1)}
+            for k in ("single_frame_ms", "kernel_ms"):
+                if k in d["config"]:
+                    out[name][k] = d["config"][k]
+        except subprocess.TimeoutExpired:
+            out[name] = {"error": "timed out after %.0f s" % min(left, 45.0)}
+        except Exception as exc:                            # noqa: BLE001
+            out[name] = {"error": repr(exc)[:300]}
+    return out
+
+
 def run(state):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node; > 1 without a launcher: bench.py starts them itself")
+    ap.add_argument("--no-other-configs", action="store_true", help="default C2 run at N = 1: do not append the short C3 / C5 / c1gpu records")
+    ap.add_argument("--cpu-baseline-s", type=float, default=0.0, help="seconds per leg of the CPU baseline (0: the configuration's default)")
+    ap.add_argument("--cpu-baseline-1t", action="store_true", help="CPU baseline: the one-thread leg only")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -79,7 +145,20 @@ def run(state):
     ap.add_argument("--shard", choices=["frames", "tiles"], default="frames",
                     help="N > 1: every rank codes its own frames (weak scaling, the default) or ONE frame's tiles are sharded over "
                          "the ranks, gathered and assembled into tile-parts on rank 0 (strong scaling, C4 geometry)")
+    state["skip_teardown"] = True                       # until this process is a rank: nothing to tear down before that
     args = ap.parse_args()
+    ws = os.environ.get("WORLD_SIZE")
+    if args.gpus is None:
+        args.gpus = int(ws) if ws else 1
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if ws is not None and int(ws) != args.gpus:
+        print("bench.py: WORLD_SIZE=%s but --gpus %d: launch with --nproc-per-node %d, or drop the launcher and let --gpus start the ranks"
+              % (ws, args.gpus, args.gpus), file=sys.stderr)
+        raise SystemExit(2)
+    if ws is None and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    state["skip_teardown"] = False
     # The HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (4 unless set): with more frames in
     # flight than queues, frames share a queue and their kernels run one after the other.  The MQ coder's kernels run at the
     # latency of their longest chain on a tenth of the device and want every frame on a queue of its own (C3, six frames: 181 ms
@@ -104,8 +183,13 @@ def run(state):
         return bench_extra.run_config(args, args.config)
     # CPU baseline first (N = 1 only): nothing has touched the GPU yet, so the worker processes are plain forks / spawns
     cpu_base = None
-    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline:
-        cpu_base = cpu_baseline()
+    others = None
+    solo = int(os.environ.get("WORLD_SIZE", "1")) == 1
+    plain = solo and not any(os.environ.get(k, "0") not in ("0", "") for k in ("J2K_BENCH_PEER_REHEARSAL", "J2K_BENCH_ROOT_REHEARSAL"))
+    if plain and not args.no_other_configs and not args.no_cpu_baseline and args.io == "rgba8":
+        others = other_configs_summary()
+    if solo and not args.no_cpu_baseline:
+        cpu_base = cpu_baseline(args.cpu_baseline_s or 10.0)
 
     import numpy as np
     import torch
@@ -658,6 +742,8 @@ def run(state):
         }
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
+        if others is not None:
+            out["other_configs"] = others
         print(json.dumps(out))
 
 
@@ -670,7 +756,8 @@ def main():
         run(state)
         ok = True
     finally:
-        bench_extra.teardown(state.get("lanes", []), state.get("multi", False), state.get("helper"), state.get("stop_helper"), ok=ok, comm=state.get("comm"))
+        if not state.get("skip_teardown"):              # (the launcher parent never imported torch: nothing to tear down)
+            bench_extra.teardown(state.get("lanes", []), state.get("multi", False), state.get("helper"), state.get("stop_helper"), ok=ok, comm=state.get("comm"))
         if state.get("probe_abandoned"):                # a probe thread still inside the runtime: do not wait for it at interpreter exit
             sys.stdout.flush(); sys.stderr.flush()
             os._exit(0 if ok else 1)

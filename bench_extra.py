@@ -122,7 +122,7 @@ def _cpu_worker(a):
     return px, n, time.perf_counter() - t0
 
 
-def cpu_baseline(cfgname, index=0, budget_s=10.0, decode=True):
+def cpu_baseline(cfgname, index=0, budget_s=10.0, decode=True, one_thread_only=False):
     """1 thread, then one worker per host core (tiles dealt round-robin), each for `budget_s` seconds."""
     cfg = CONFIGS[cfgname]
     ncores = os.cpu_count() or 1
@@ -144,7 +144,7 @@ def cpu_baseline(cfgname, index=0, budget_s=10.0, decode=True):
     px1, n1, dt1 = _cpu_worker((cfgname, index, budget_s, 0, 1, decode))
     one = px1 / dt1 / 1e6
     allc, nw, nall, dta = one, 1, n1, dt1
-    if ncores > 1:
+    if ncores > 1 and not one_thread_only:
         import multiprocessing as mp
         nw = ncores
         with mp.get_context("spawn").Pool(nw) as pool:      # spawn: the parent has initialised the GPU (no fork after that)
@@ -366,7 +366,8 @@ def run_config(args, cfgname):
             if self_check is not None:
                 out["config"]["self_check"] = self_check
             if world == 1 and not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(cfgname, budget_s=8.0)
+                out["cpu_baseline"] = cpu_baseline(cfgname, budget_s=getattr(args, "cpu_baseline_s", 0) or 8.0,
+                                                   one_thread_only=getattr(args, "cpu_baseline_1t", False))
             print(json.dumps(out))
         ok = True
     finally:

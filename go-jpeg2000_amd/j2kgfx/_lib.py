@@ -62,7 +62,7 @@ SYMBOLS = [
     "j2k_plan_tile_parts_bound", "j2k_plan_assemble_tiles_device",
     "j2k_t2_packet_sequence", "j2k_t2_packet_bound", "j2k_t2_encode_packet", "j2k_t2_decode_packet", "j2k_tagtree_shape", "j2k_tcd_init_tile",
     "j2k_plan_pack_bound", "j2k_plan_pack_stream", "j2k_plan_unpack_stream", "j2k_plan_unpack_streams",
-    "j2k_comm_get_unique_id", "j2k_comm_create", "j2k_comm_destroy", "j2k_comm_last_error", "j2k_comm_stream", "j2k_gather_streams", "j2k_comm_wait",
+    "j2k_comm_load_error", "j2k_comm_get_unique_id", "j2k_comm_create", "j2k_comm_destroy", "j2k_comm_last_error", "j2k_comm_stream", "j2k_gather_streams", "j2k_comm_wait",
 ]
 PIX_GRAY8, PIX_GRAY16, PIX_RGBA8, PIX_RGBA64, PIX_NRGBA8, PIX_NRGBA64 = range(6)
 
@@ -106,6 +106,8 @@ def lib():
         L.j2k_graph_destroy.restype = None
         L.j2k_plan_destroy.argtypes = [C.c_void_p]
         L.j2k_comm_get_unique_id.argtypes = [C.c_void_p]
+        L.j2k_comm_load_error.restype = C.c_char_p
+        L.j2k_comm_load_error.argtypes = []
         L.j2k_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.j2k_comm_destroy.argtypes = [C.c_void_p]
         L.j2k_comm_destroy.restype = None

@@ -14,6 +14,7 @@ from . import _lib
 _live_contexts = weakref.WeakSet()
 _live_plans = weakref.WeakSet()
 _live_graphs = weakref.WeakSet()
+_live_comms = weakref.WeakSet()
 
 
 def register_plan(plan):
@@ -22,7 +23,7 @@ def register_plan(plan):
 
 @atexit.register
 def _close_all():
-    for g in list(_live_graphs):          # graphs first: they hold a pointer to their context
+    for g in list(_live_comms) + list(_live_graphs):          # communicators and graphs first: they hold a pointer to their context
         try:
             g.close()
         except Exception:
@@ -53,6 +54,7 @@ class Context:
         self._capturing = False
         self._ext = None
         self._graphs = weakref.WeakSet()     # closed with the context: a j2k_graph keeps a pointer to its j2k_ctx
+        self._comms = weakref.WeakSet()      # and so does a j2k_comm (dist.Comm)
         _live_contexts.add(self)
 
     def check(self, st):
@@ -102,7 +104,7 @@ class Context:
 
     def close(self):
         if self.h:
-            for g in list(self._graphs):
+            for g in list(self._comms) + list(self._graphs):
                 g.close()
             try:
                 self.L.j2k_ctx_sync(self.h)      # drain the stream before its buffers and the stream itself go away

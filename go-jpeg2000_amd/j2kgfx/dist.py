@@ -158,7 +158,8 @@ class Comm:
             if self.rank == 0:
                 st = L.j2k_comm_get_unique_id(buf)
                 if st != _lib.OK:
-                    raise _lib.J2KError(st, "j2k_comm_get_unique_id: " + L.j2k_status_string(st).decode())
+                    raise _lib.J2KError(st, "j2k_comm_get_unique_id: %s: %s" % (L.j2k_status_string(st).decode(),
+                                                                              L.j2k_comm_load_error().decode()))
             id_bytes = bytes(buf)
             if self.world > 1:
                 import torch.distributed as dist
@@ -169,6 +170,16 @@ class Comm:
         idb = (C.c_uint8 * 128).from_buffer_copy(id_bytes)
         ctx.check(L.j2k_comm_create(ctx.h, idb, self.rank, self.world, C.byref(h)))
         self.h = h
+        # a j2k_comm keeps a pointer to its j2k_ctx (error text): it is closed with -- before -- its context, and first of all
+        # by the atexit hook, exactly like a Graph (context.py)
+        from . import context as _context
+        ctx._comms.add(self)
+        _context._live_comms.add(self)
+
+    def _alive(self):
+        from . import _lib
+        if self.h is None or self.ctx.h is None:
+            raise _lib.J2KError(_lib.ERR_INVALID_ARG, "communicator used after it or its context was closed")
 
     def gather(self, sends, nbytes, recv=None, producers=(), all_bytes=None, self_loop=False):
         """j2k_gather_streams: sends = list of device uint8 tensors, nbytes = their byte counts (host ints), recv = rank 0's
@@ -177,6 +188,7 @@ class Comm:
         recv[offs[r * count + f] : ... + its byte count] on rank 0.  The transfers are queued, not finished: wait()."""
         import ctypes as C
         import numpy as np
+        self._alive()
         k = len(sends)
         VP = C.c_void_p * k
         ptrs = VP(*[int(t.data_ptr()) for t in sends])
@@ -197,12 +209,19 @@ class Comm:
 
     def wait(self, consumer=None):
         """consumer = a Context whose stream must see the gathered bytes (device-side wait), or None: the host waits."""
+        self._alive()
+        if consumer is not None and consumer.h is None:
+            from . import _lib
+            raise _lib.J2KError(_lib.ERR_INVALID_ARG, "consumer context is closed")
         self.ctx.check(self.ctx.L.j2k_comm_wait(self.h, consumer.h if consumer is not None else None))
 
     def close(self):
-        if self.h and self.ctx.h:
+        # j2k_comm_destroy does not dereference the context (it keeps the device number), so a communicator that outlived
+        # its context -- it should not: Context.close() closes its communicators first -- is still destroyed, not leaked
+        if self.h:
             self.ctx.L.j2k_comm_destroy(self.h)
         self.h = None
+        self._keep = None
 
     def __del__(self):
         import sys

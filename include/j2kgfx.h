@@ -263,14 +263,23 @@ int j2k_plan_get_decoded_offsets(const j2k_plan *plan, uint64_t *offs, size_t ca
  *                            streams the send buffers are being produced; the transfers are ordered behind their work so
  *                            far.  On rank 0, stream f of rank r lands at d_recv + recv_offs[r * count + f] (16-byte
  *                            aligned; recv_offs has world * count + 1 entries, host memory, filled on every rank), its own
- *                            streams by a device copy; J2K_ERR_CAPACITY when recv_cap is too small.  Returns once the
- *                            transfers are QUEUED on the communicator's stream.
+ *                            streams by a device copy.  Returns once the transfers are QUEUED on the communicator's
+ *                            stream.  FAILURE IS COLLECTIVE where the call can make it so: J2K_ERR_CAPACITY (recv_cap of
+ *                            rank 0 too small) is returned by EVERY rank when the counts are gathered by the call (rank 0's
+ *                            recv_cap travels with them); with host-provided counts a peer passes rank 0's capacity as its
+ *                            own recv_cap (0 = not known: that peer returns J2K_OK).  Either way nobody is left waiting:
+ *                            the peers always post their sends, and a rank 0 that cannot take the bytes (too small, NULL
+ *                            or misaligned d_recv) receives them into a scratch allocation, drains its stream and then
+ *                            returns the status; the communicator stays usable.  Argument errors that only ONE rank can
+ *                            see (J2K_ERR_INVALID_ARG: a NULL send pointer, all_bytes that disagrees with send_bytes)
+ *                            return before anything is posted on that rank -- the host must agree on them before the call.
  *   j2k_comm_wait            consumer != NULL: that context's stream waits (on the device) for the last gather -- follow with
  *                            j2k_plan_unpack_streams on it; NULL: the host waits.
  * flags: J2K_GATHER_SELF_LOOP (world == 1 only): the lone rank sends to itself through RCCL -- the transfer calls on one GPU. */
 typedef struct j2k_comm j2k_comm;
 #define J2K_COMM_ID_BYTES 128
 #define J2K_GATHER_SELF_LOOP 1
+const char *j2k_comm_load_error(void);   /* why RCCL could not be bound (J2K_ERR_UNSUPPORTED); "" if it was.  J2K_RCCL_LIB names the library */
 int j2k_comm_get_unique_id(uint8_t *id128);
 int j2k_comm_create(j2k_ctx *ctx, const uint8_t *id128, int rank, int world, j2k_comm **out);
 void j2k_comm_destroy(j2k_comm *comm);

@@ -69,3 +69,24 @@ def test_block_bound_is_the_references_buffer_size():
     assert entropy.block_bound(0, 64, 64) == 16384 and entropy.block_bound(0, 16, 16) == 16384
     assert entropy.block_bound(0, 128, 128) == 2 * 128 * 128 + 1024 and entropy.block_bound(0, 256, 256) == 2 * 65536 + 1024
     assert entropy.block_bound(1, 64, 64) == 4096 + 2048 + 4096 + 2 and entropy.block_bound(1, 4, 4) == 32 + 16 + 32 + 2
+
+
+def test_rccl_missing_is_unsupported_not_a_crash(lib):
+    """A host without librccl (forced here with J2K_RCCL_LIB -> a file that does not exist) gets J2K_ERR_UNSUPPORTED and a text from
+    j2k_comm_get_unique_id -- not the strlen(NULL) of a second dlerror() call.  Own process: the binding is per process."""
+    code = (
+        "import ctypes as C, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from j2kgfx import _lib\n"
+        "L = _lib.lib()\n"
+        "buf = (C.c_uint8 * 128)()\n"
+        "st = L.j2k_comm_get_unique_id(buf)\n"
+        "st2 = L.j2k_comm_get_unique_id(buf)\n"
+        "print(st, st2, L.j2k_comm_load_error().decode())\n"
+    ) % os.path.join(ROOT, "go-jpeg2000_amd")
+    env = dict(os.environ, J2K_RCCL_LIB="/nonexistent/librccl-not-here.so")
+    out = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    st, st2, msg = out.stdout.strip().split(" ", 2)
+    assert int(st) == lib.ERR_UNSUPPORTED and int(st2) == lib.ERR_UNSUPPORTED
+    assert msg.startswith("RCCL not found: ") and "librccl-not-here" in msg

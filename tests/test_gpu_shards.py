@@ -160,6 +160,19 @@ def test_bench_two_rank_control_flow_rehearsal():
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["frames_in_flight"] == 2 and d["value"] > 0
+    # the same through bench.py's own launcher: `python bench.py --gpus 2` with no WORLD_SIZE starts the two ranks as a child
+    # (before touching the GPU), relays rank 0's line and the status; n_gpus == --gpus
+    env2 = dict(env)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env2.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
+                          "--inflight", "2"], env=env2, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    # under a launcher, a world size that is not --gpus is refused
+    out = subprocess.run(cmd[:cmd.index("--gpus") + 1] + ["3"] + cmd[cmd.index("--gpus") + 2:], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "WORLD_SIZE=2 but --gpus 3" in out.stderr
 
 
 def _bench_two_ranks(extra):
@@ -245,10 +258,11 @@ def test_c5_full_size_frame_matches_oracle():
 
 
 @pytest.mark.parametrize("W,H,tile,first,count", [(1280, 624, 512, 0, 0), (1280, 624, 512, 2, 3), (200, 96, 64, 1, 4), (512, 512, 0, 0, 0), (3840, 2160, 512, 17, 9)])
-def test_device_tile_part_assembly_equals_host(W, H, tile, first, count):
-    """j2k_plan_assemble_tiles_device: the tile-parts of a shard built on the device are byte for byte what the host call
-    (j2k_assemble_tiles = encoder.createTileHeader per tile, checked against the oracle in test_codestream_tiles.py) builds
-    from the same stream, and the reference's tile-part parser reads them back"""
+def test_device_tile_part_assembly_equals_host(W, H, tile, first, count, oracle):
+    """j2k_plan_assemble_tiles_device: the tile-parts of a shard built on the device are byte for byte (a) the ORACLE's
+    encoder.createTileHeader (orc_create_tile_header, encoder.go:746-760) applied tile by tile to the ORACLE's block bytes of that
+    tile, and (b) what the host call (j2k_assemble_tiles) builds from the same stream; the reference's tile-part parser reads
+    them back"""
     import torch
     from j2kgfx import codestream
     from j2kgfx.codec import FramePlan
@@ -268,6 +282,23 @@ def test_device_tile_part_assembly_equals_host(W, H, tile, first, count):
     want = codestream.assemble_tiles(stream[:int(o_h[n])].cpu().numpy(), t_offs, tile_first=first)
     got = out[:int(out_len[0].item())].cpu().numpy().tobytes()
     assert got == want
+    # straight against the oracle, no product code on the expected side: per tile of the shard, preprocess -> block bytes ->
+    # createTileHeader
+    tw = tile or W
+    tx_n = (W + tw - 1) // tw
+    th = tile or H
+    pos = 0
+    for t in range(first, first + len(starts) - 1):
+        tx, ty = t % tx_n, t // tx_n
+        x0, y0 = tx * tw, ty * th
+        w_t, h_t = min(tw, W - x0), min(th, H - y0)
+        comps = [np.ascontiguousarray(frame_h[c, y0:y0 + h_t, x0:x0 + w_t]) for c in range(3)]
+        coeff = oracle.preprocess(comps, w_t, h_t, 8, True, 4)
+        tile_bytes, _, _ = oracle.encode_tile_blocks(coeff, w_t, h_t, 4, 32, 32, 1)
+        part = oracle.create_tile_header(t, bytes(tile_bytes))
+        assert got[pos:pos + len(part)] == part, "tile-part %d differs from the oracle" % t
+        pos += len(part)
+    assert pos == len(got)
     parts = codestream.parse_tile_parts(got)
     assert [p.TileIndex for p, _ in parts] == list(range(first, first + len(starts) - 1))
 
@@ -315,8 +346,25 @@ def test_c_abi_gather_streams_self_loop():
             tot = int(o0[n].item())
             assert torch.equal(o1[:n + 1], o0[:n + 1]) and torch.equal(l1[:n], l0[:n]) and torch.equal(b1[:n], b0[:n])
             assert torch.equal(s1[:tot], s0[:tot])
-    # a receive buffer that is too small is refused before anything is posted
-    from j2kgfx import J2KError
+    # a receive buffer that is too small is refused -- collectively: the sends are still posted and rank 0 drains them into a
+    # scratch buffer (here the lone rank's own), so nobody is left waiting and the communicator stays usable
+    from j2kgfx import J2KError, _lib as jl
+    for given in (True, False):
+        with pytest.raises(J2KError) as ei:
+            comm.gather(packs, nbytes, recv=recv[:1024], producers=ctxs, all_bytes=[nbytes] if given else None, self_loop=True)
+        assert ei.value.status == jl.ERR_CAPACITY
+        comm.wait()                                              # the host-side wait returns: nothing is stuck on the stream
+    recv.fill_(0xEE)
+    offs = comm.gather(packs, nbytes, recv=recv, producers=ctxs, all_bytes=None, self_loop=True)
+    comm.wait()
+    for f in range(3):
+        assert torch.equal(recv[int(offs[f]):int(offs[f]) + nbytes[f]], packs[f][:nbytes[f]])
+    # lifetime: a communicator is closed with (before) its context and refuses use afterwards
+    root_plan.close()
+    root_ctx.close()
+    assert comm.h is None
     with pytest.raises(J2KError):
-        comm.gather(packs, nbytes, recv=recv[:1024], producers=ctxs, all_bytes=[nbytes], self_loop=True)
+        comm.gather(packs, nbytes, recv=recv, producers=ctxs, self_loop=True)
+    with pytest.raises(J2KError):
+        comm.wait()
     comm.close()
