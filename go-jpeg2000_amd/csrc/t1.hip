@@ -1142,7 +1142,7 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(const BlockJob *__restric
     if (jid >= njobs) return;
     const int lane = threadIdx.x;
     const BlockJob J = jobs[jid];
-    if (skip_small && J.w <= 64 && J.h <= 64) return;             // t1_decode64_kernel takes these
+    if (skip_small && J.w <= skip_small && J.h <= skip_small) return;   // skip_small = 64 / 256: t1_decode64_kernel (and t1_decode_big_kernel) take these
     const int w = J.w, h = J.h, stride = T1D_STRIDE(w);
     const size_t n = (size_t)w * h;
     T1Tables &T = *reinterpret_cast<T1Tables *>(smem);
@@ -1237,6 +1237,8 @@ __global__ __launch_bounds__(64) void t1_decode64_kernel(const BlockJob *__restr
         out[i] = (int32_t)(0u - (uint32_t)v);
     }
 }
+
+#include "t1_bigdec.inc"
 
 // ---- plane-stepped decoder for blocks up to 64x64 -----------------------------------------------------------------
 // A frame at 12 bits and Quality 75 has 18 bit planes per block and ~78 % of its MQ decisions are magnitude refinements
@@ -1808,6 +1810,16 @@ hipError_t launch_t1_decode(hipStream_t s, const BlockJob *jobs, int njobs, cons
         hipError_t e = hipGetLastError();
         if (e != hipSuccess || max_dim <= 64) return e;
     }
+    // blocks above 64 x 64, up to 256 x 256 (the reference's default size): the wave-uniform decoder (t1_bigdec.inc)
+    int big_dec = 1;                   // J2K_T1_BIG_DEC=0: A/B against the general kernel (read per call: only frames with such blocks get here)
+    { const char *en = getenv("J2K_T1_BIG_DEC"); if (en) big_dec = atoi(en); }
+    const bool use_big = big_dec && !general_only;
+    if (use_big) {
+        hipLaunchKernelGGL(t1_decode_big_kernel, dim3(njobs), dim3(64), sizeof(T1BigDec), s, jobs, njobs, stream, offs, lens, numbps, decoded);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess || max_dim <= 256) return e;
+    }
+    const int skip = general_only ? 0 : (use_big ? 256 : 64);
     const int wb = lds_for(work_per_job, T1_LDS_BIG_LIMIT);     // work_per_job = flag bytes of the largest block
     const size_t lds = ((sizeof(T1Tables) + 15) & ~size_t(15)) + (size_t)wb;
     if (lds > 64 * 1024) {
@@ -1819,9 +1831,9 @@ hipError_t launch_t1_decode(hipStream_t s, const BlockJob *jobs, int njobs, cons
         }
     }
     if (wb) hipLaunchKernelGGL(t1_decode_kernel<true>, dim3(njobs), dim3(64), lds, s, jobs, njobs, stream, offs, lens, numbps, decoded,
-                               work, work_per_job, wb, general_only ? 0 : 1);
+                               work, work_per_job, wb, skip);
     else hipLaunchKernelGGL(t1_decode_kernel<false>, dim3(njobs), dim3(64), lds, s, jobs, njobs, stream, offs, lens, numbps, decoded,
-                            work, work_per_job, wb, general_only ? 0 : 1);
+                            work, work_per_job, wb, skip);
     return hipGetLastError();
 }
 

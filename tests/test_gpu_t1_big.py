@@ -1,0 +1,78 @@
+"""GPU parity: T1 (MQ) for code-blocks above 64 x 64 up to 256 x 256 -- the reference's DEFAULT block size (encoder.go:606-607:
+1 << (6 + 2)) -- through the C ABI against the C oracle: EncodeFast5's bytes (t1_fast5.go:10-899) from t1_encode_big_kernel and
+T1.Decode's coefficients (t1.go:1261-1410) from the wave-uniform t1_decode_big_kernel, on encoder output and on arbitrary bytes
+(FuzzT1Decode's domain), every band, ragged shapes (rows / columns that are not multiples of 4 / 64), 0 ... 40 bit planes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+BIG_SHAPES = [(256, 256), (65, 64), (64, 65), (128, 128), (200, 77), (256, 3), (70, 256), (129, 130), (255, 255), (192, 66)]
+
+
+@pytest.fixture(scope="module")
+def ent():
+    from j2kgfx import entropy
+    return entropy
+
+
+def _contents(rng, w, h):
+    i = np.arange(w * h, dtype=np.int64)
+    ref = (i * 17) % 512
+    ref[i % 7 == 0] *= -1                                            # the reference's own test input (t1_test.go)
+    yield ref.astype(np.int32).reshape(h, w)
+    yield rng.integers(-2000, 2001, (h, w)).astype(np.int32)         # noise: every sample coded in the first planes
+    sp = np.zeros((h, w), np.int32)                                  # sparse: long run-length stretches, isolated samples
+    idx = rng.integers(0, w * h, max(3, w * h // 300))
+    sp.reshape(-1)[idx] = rng.integers(-(1 << 20), 1 << 20, idx.size)
+    yield sp
+    yy, xx = np.mgrid[0:h, 0:w]
+    yield ((xx * 3 + yy * 5) % 97 - 48).astype(np.int32) * (((xx // 7 + yy // 5) % 3) - 1)    # smooth texture with sign flips and zero patches
+
+
+@pytest.mark.parametrize("w,h", BIG_SHAPES)
+def test_big_block_encode_bytes_and_decode(ent, oracle, w, h):
+    rng = np.random.default_rng(w * 1000 + h)
+    for k, x in enumerate(_contents(rng, w, h)):
+        band = (k + w) % 4
+        t1 = ent.NewT1(w, h)
+        t1.SetData(x)
+        got = t1.Encode(band)
+        want, nb = oracle.t1_encode(x, w, h, band)
+        assert got == bytes(want) and t1.numBPS == nb, (w, h, k)
+        back = ent.NewT1(w, h).Decode(got, nb, band)
+        assert np.array_equal(back.reshape(h, w), oracle.t1_decode(want, nb, band, w, h)), (w, h, k)
+        assert np.array_equal(back.reshape(h, w), x), (w, h, k)
+
+
+@pytest.mark.parametrize("w,h", [(256, 256), (65, 64), (64, 200), (130, 131), (256, 5)])
+def test_big_block_decode_arbitrary_bytes(ent, oracle, w, h):
+    """streams that are not encoder output: random bytes, 0xFF-rich bytes, empty and one-byte streams, more bit planes than an int32 has"""
+    rng = np.random.default_rng(w * 7 + h)
+    cases = []
+    for nb in (1, 2, 5, 12):
+        cases.append((rng.integers(0, 256, int(rng.integers(0, 6000))).astype(np.uint8), nb))
+    ff = rng.integers(0, 256, 3000).astype(np.uint8)
+    ff[rng.integers(0, 3000, 900)] = 0xFF                            # markers and stuffing all over
+    cases += [(ff, 6), (np.zeros(0, np.uint8), 3), (np.array([0x80], np.uint8), 4), (np.full(700, 0xFF, np.uint8), 3),
+              (rng.integers(0, 256, 20000).astype(np.uint8), 33), (rng.integers(0, 256, 400).astype(np.uint8), 40), (np.zeros(50, np.uint8), 9)]
+    for k, (g, nb) in enumerate(cases):
+        band = k % 4
+        got = ent.NewT1(w, h).Decode(bytes(g), nb, band)
+        assert np.array_equal(got.reshape(h, w), oracle.t1_decode(g, nb, band, w, h)), (w, h, k, nb)
+
+
+def test_big_block_decoder_knob_matches_general_kernel(ent, oracle, monkeypatch):
+    """J2K_T1_BIG_DEC=0 (the round-2 general kernel: byte flags, decisions on lane 0) and the default (wave-uniform kernel on row
+    masks) decode the same bytes to the same block"""
+    rng = np.random.default_rng(5)
+    x = rng.integers(-500, 501, (96, 160)).astype(np.int32)
+    want, nb = oracle.t1_encode(x, 160, 96, 1)
+    g = rng.integers(0, 256, 900).astype(np.uint8)
+    res = {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("J2K_T1_BIG_DEC", knob)
+        res[knob] = (ent.NewT1(160, 96).Decode(bytes(want), nb, 1), ent.NewT1(160, 96).Decode(bytes(g), 7, 2))
+    assert np.array_equal(res["1"][0].reshape(96, 160), x) and np.array_equal(res["0"][0], res["1"][0])
+    assert np.array_equal(res["0"][1], res["1"][1])
+    assert np.array_equal(res["1"][1].reshape(96, 160), oracle.t1_decode(g, 7, 2, 160, 96))
