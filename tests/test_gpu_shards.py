@@ -67,7 +67,7 @@ def test_full_size_lossless_roundtrip(W, H, Cn, tile, prec):
     assert int(o2[n].item()) == tot and torch.equal(st2[:tot], a)
 
 
-def _sample_tile_parity(W, H, tile, prec, lossless, quality, coder, sample_tiles, frame, ncomp=3):
+def _sample_tile_parity(W, H, tile, prec, lossless, quality, coder, sample_tiles, frame, ncomp=3, ctx=None):
     """GPU frame pipeline at full size vs the oracle's per-tile pipeline (encoder.preprocess + encodeTile body,
     encoder.go:198-281, 616-688) on a few sampled tiles: coefficients, block bytes, lengths, numBPS, and the block
     decoders' output for those blocks."""
@@ -75,7 +75,7 @@ def _sample_tile_parity(W, H, tile, prec, lossless, quality, coder, sample_tiles
     import oracle as orc
     from j2kgfx.codec import FramePlan
     plan = FramePlan(W, H, ncomp, precision=prec, lossless=lossless, quality=quality, num_resolutions=6, cb=(64, 64),
-                     tile=(tile, tile), coder=coder)
+                     tile=(tile, tile), coder=coder, ctx=ctx)
     tile = tile or max(W, H)
     d = torch.from_numpy(frame).to(plan.device)
     torch.cuda.synchronize()
@@ -138,6 +138,31 @@ def test_c3_full_size_sampled_tiles_match_oracle():
     import bench
     frame = (bench.synth_frame(np, 1).astype(np.int64) * 4095 // 255).astype(np.int32)
     _sample_tile_parity(3840, 2160, 512, 12, False, 75, 0, [0, 39], frame)
+
+
+def test_c3_full_size_sampled_tiles_match_oracle_throughput_kernels(monkeypatch):
+    """The same C3 frame through the kernels `bench.py --config c3` TIMES: with a second MQ-coder context alive
+    the library is in its throughput setting -- the encoder's MQ lanes kernel with 64 sorted chains per wavefront -- and
+    J2K_T1_DEC_SPLIT=1 sends every block to the one-launch-per-frame lanes decoder (t1_dec_sig_lanes_kernel<true>, a block per lane).
+    Coefficients, block bytes, lengths, bit-plane counts and sampled decoded blocks of tiles 0 and 39 against the oracle."""
+    import os, sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    import bench
+    from j2kgfx import Context
+    from j2kgfx.codec import FramePlan
+    monkeypatch.setenv("J2K_T1_DEC_SPLIT", "1")
+    monkeypatch.setenv("J2K_T1_DEC_LANES", "2")
+    other = Context(0)                                                   # a second context that codes with the MQ coder: throughput mode
+    op = FramePlan(128, 128, 3, precision=12, lossless=False, quality=75, num_resolutions=3, cb=(64, 64), coder=0, ctx=other)
+    x = torch.zeros((3, 128, 128), dtype=torch.int32, device=op.device)
+    op.encode_stream(op.forward(x)); other.sync()
+    main = Context(0)
+    try:
+        frame = (bench.synth_frame(np, 1).astype(np.int64) * 4095 // 255).astype(np.int32)
+        _sample_tile_parity(3840, 2160, 512, 12, False, 75, 0, [0, 39], frame, ctx=main)
+    finally:
+        op.close(); other.close(); main.close()
 
 
 def test_bench_two_rank_control_flow_rehearsal():
