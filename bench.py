@@ -39,10 +39,17 @@ MIN_TIMED_S = 0.1              # floor of the timed region, whatever --steps say
 DECODED_SHA256 = "76eab55b1f63e2eb3644d138c6d655d4b16975c46310378f3f9f1bc509de7d5e"
 # HBM traffic of one level-0 launch from the rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KiB -> bytes);
 # cannot be collected from inside this process, so it is the committed measurement (see profiles/)
-TRAFFIC = {   # frame_io -> (bytes per level-0 forward launch, source)
-    "planes": (207044198, "profiles/r01_bench_v3_inflight1_pmc_{FETCH,WRITE}_SIZE.csv: (2 x 52495.8 + 97200.0) KiB"),
-    "rgba8": (133236070, "profiles/r03_bench_inflight1_pmc_summary.txt: (2 x 16430.8 + 97251.9) KiB"),
+def _traffic(fetch_kib, write_kib, src):
+    """(bytes, text) from the two per-launch PMC averages of the committed summary: ONE pair of numbers, the text is made from them
+    (gfx950: FETCH_SIZE counts 64 B per 128-B request of a wide coalesced read -> doubled; MI355X_MICROARCH.md)"""
+    return int(round((2 * fetch_kib + write_kib) * 1024)), "%s: (2 x %.1f + %.1f) KiB" % (src, fetch_kib, write_kib)
+
+
+TRAFFIC = {   # frame_io -> (bytes per level-0 forward launch, source); tests/test_bench_traffic_constant.py re-reads the summary
+    "planes": _traffic(52495.8, 97200.0, "profiles/r01_bench_v3_inflight1_pmc_{FETCH,WRITE}_SIZE.csv"),
+    "rgba8": _traffic(16432.3, 97269.9, "profiles/r03_bench_inflight1_pmc_summary.txt"),
 }
+COPY_PEAK_GUIDE_GBS = 6290.0   # MI355X_MICROARCH.md: the float4 device-to-device copy the guide measured (what a pure copy reaches)
 
 
 def synth_frame(np, index):
@@ -624,25 +631,6 @@ def run(state):
         tags = [ctx.profile_read_tag(t) for t in range(4)]   # forward level 0 / deeper levels, inverse level 0 / deeper levels
         iso_launches, iso_ms = ctx.profile_read()
         ctx.profile_enable(False)
-    # ---- practical HBM roofline of this box ("measure a device-to-device copy ... and report both"):
-    #      int32 copy at the level-0 footprint cycled over 8 buffer pairs so the Infinity Cache cannot serve it ----
-    copy_gbs = None
-    if rank == 0:
-        nel = int(info.dwt_level0_bytes // 8)            # elements read = elements written = one planar level-0 launch
-        srcs = [torch.empty(nel, dtype=torch.int32, device=plan.device).fill_(i) for i in range(8)]
-        dsts = [torch.empty_like(srcs[0]) for _ in range(8)]
-        for i in range(8):
-            dsts[i].copy_(srcs[i])
-        torch.cuda.synchronize()
-        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        c0.record()
-        for _ in range(3):
-            for i in range(8):
-                dsts[i].copy_(srcs[i])
-        c1.record()
-        c1.synchronize()
-        copy_gbs = 24 * 2 * nel * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
-        del srcs, dsts
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=plan.device if os.environ.get("J2K_BENCH_BACKEND", "nccl") == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -737,8 +725,8 @@ def run(state):
                                      "(sum of algorithmic bytes / sum of kernel durations)",
                          "avg_launch_us_in_timed_region": round(k_conc_s * 1e6, 2), "launches_in_timed_region": int(launches),
                          "traffic_source": TRAFFIC[args.io][1],
-                         "copy_gbs_measured": round(copy_gbs, 1) if copy_gbs else None,
-                         "frac_of_measured_copy": round(achieved / copy_gbs, 4) if copy_gbs else None},
+                         "copy_peak_guide_gbs": COPY_PEAK_GUIDE_GBS,
+                         "frac_of_guide_copy_peak": round(achieved / COPY_PEAK_GUIDE_GBS, 4)},
         }
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base

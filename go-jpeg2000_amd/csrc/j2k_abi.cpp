@@ -1707,9 +1707,13 @@ extern "C" int j2k_plan_decode_blocks(j2k_plan *P, const uint8_t *d_stream, cons
         // (one context alone: the one-launch kernels are a 28-30 ms chain while their 8192 wavefront slots hold the frame, the lanes
         //  decoder a 45-50 ms one whatever the frame -- an 8K frame of 27 000 blocks: 86 ms against 51, tools/check_big_mq.py)
         const int split_min = ctx->t1_dec_split >= 0 ? ctx->t1_dec_split : (mq_throughput_mode() ? 512 : 12000);
-        const bool split = split_min > 0 && n >= split_min && !ctx->t1_dec_general && !((uintptr_t)d_stream & 15);
+        bool split = split_min > 0 && n >= split_min && !ctx->t1_dec_general && !((uintptr_t)d_stream & 15);
         const size_t gen_bytes = (wpj * (size_t)n + 255) & ~size_t(255);
+        // The lanes decoder's workspace is T1DS_STRIDE + 3.5 KB of row masks + 16 KB of plane words per block (0.55 GB for an 8K frame of
+        // 27 000 blocks); if the device cannot give it, the one-launch kernels decode the frame with gen_bytes alone
+        // rather than the call failing.
         int r = stage_reserve(ctx, 2, gen_bytes + 256 + (split ? j2k::t1_dec_split_bytes((size_t)n) : 0));
+        if (r != J2K_OK && split) { (void)hipGetLastError(); split = false; r = stage_reserve(ctx, 2, gen_bytes + 256); }
         if (r != J2K_OK) return r;
         HIPCHK(ctx, launch_t1_decode(ctx->stream, P->d_djobs, n, d_stream, d_offs, d_lens, d_numbps, d_decoded,
                                      (uint8_t *)ctx->stage[2], wpj, max_dim, ctx->t1_dec_general,
@@ -1952,9 +1956,13 @@ extern "C" int j2k_decode_blocks(j2k_ctx *ctx, int coder, const uint8_t *bytes, 
         TRY(hipMalloc(&d_work, ht_decode_scratch_words((int)nblocks) * 4 + 256));
         TRY(launch_ht_decode(ctx->stream, (BlockJob *)d_jobs, (int)nblocks, (uint8_t *)d_bytes, (uint64_t *)d_offs, (uint32_t *)d_lens, (int32_t *)d_dec, (uint32_t *)d_work));
     } else {
-        const bool split = ctx->t1_dec_split > 0 && (int)nblocks >= ctx->t1_dec_split && !ctx->t1_dec_general;     // host unit call: only when asked for
+        // the same choice of decoder as j2k_plan_decode_blocks (the two entry points used to differ), and the same fall-back
+        // to the one-launch kernels when the lanes decoder's workspace cannot be had
+        const int split_min = ctx->t1_dec_split >= 0 ? ctx->t1_dec_split : (mq_throughput_mode() ? 512 : 12000);
+        bool split = split_min > 0 && (int)nblocks >= split_min && !ctx->t1_dec_general;
         const size_t gen_bytes = (wpj * nblocks + 255) & ~size_t(255);
-        TRY(hipMalloc(&d_work, gen_bytes + 256 + (split ? j2k::t1_dec_split_bytes(nblocks) : 0)));
+        if (split && hipMalloc(&d_work, gen_bytes + 256 + j2k::t1_dec_split_bytes(nblocks)) != hipSuccess) { (void)hipGetLastError(); d_work = nullptr; split = false; }
+        if (!split) TRY(hipMalloc(&d_work, gen_bytes + 256));
         int max_dim = 0;
         for (size_t j = 0; j < nblocks; j++) max_dim = std::max(max_dim, std::max(bj[j].w, bj[j].h));
         TRY(launch_t1_decode(ctx->stream, (BlockJob *)d_jobs, (int)nblocks, (uint8_t *)d_bytes, (uint64_t *)d_offs, (uint32_t *)d_lens, (uint8_t *)d_nb,
