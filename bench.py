@@ -174,6 +174,11 @@ def run(state):
     # (eight frames' transforms truly at once evict each other's lines).  Read when the runtime initialises, i.e. before the first
     # torch.cuda call.
     if args.config in ("c3", "c1gpu"):
+        if "GPU_MAX_HW_QUEUES" not in os.environ and any("rocprof" in os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")):
+            # a profiler's preloaded library has initialised the runtime before this line: the variable set here is not read
+            print("bench.py: GPU_MAX_HW_QUEUES was not in the environment when the HIP runtime initialised (profiler preload): this run "
+                  "uses the runtime's 4 hardware queues -- export GPU_MAX_HW_QUEUES=32 in the shell instead", file=sys.stderr)
+            os.environ["J2K_BENCH_HWQ_LATE"] = "1"
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
     import faulthandler
     faulthandler.enable(all_threads=True)   # a native crash in a rank prints every thread's Python stack

@@ -354,7 +354,7 @@ def run_config(args, cfgname):
                               "decode halves are checked separately)",
                               "tiles": int(info.tiles), "code_blocks": ln0["n"], "compressed_bytes_per_frame": total_bytes,
                               "achieved_compression_ratio": round(W * H * C * ((cfg["prec"] + 7) // 8) / max(total_bytes, 1), 2),
-                              "frames_in_flight": F, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "hip_graph_per_frame": bool(use_graph), "frame_io": cfg["io"], "parallelism": "frames/rank" if world > 1 else "single GPU"},
+                              "frames_in_flight": F, "hw_queues": 4 if os.environ.get("J2K_BENCH_HWQ_LATE") else int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "hip_graph_per_frame": bool(use_graph), "frame_io": cfg["io"], "parallelism": "frames/rank" if world > 1 else "single GPU"},
                    "roofline": {"bound": "hbm", "kernel": kern, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg,
                                 "avg_launch_us": round(k_s * 1e6, 2), "launches_timed": int(iso_n),

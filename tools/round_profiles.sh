@@ -18,6 +18,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c3lanes -- pyth
 unset J2K_T1_DEC_SPLIT
 tail -7 $O/stats_c3lanes.log
 python $R/tools/t1_trace.py $O/stats_c3lanes > $O/c3lanes_per_launch.txt 2>&1; cat $O/c3lanes_per_launch.txt | cut -c1-200
+export GPU_MAX_HW_QUEUES=32     # c3 / c1gpu want a hardware queue per frame in flight; under rocprofv3 the profiler's preload initialises the runtime before
+                                # bench.py can set it, so it is set HERE; unset again before the C5 line
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c3bench -- python $R/bench.py --config c3 --steps 3 --warmup 1 --no-cpu-baseline > $O/stats_c3bench.log 2>&1
 tail -1 $O/stats_c3bench.log | cut -c1-200
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -25,5 +27,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c1gpu -- python $R/bench.py --config c1gpu --steps 3 --warmup 1 --no-cpu-baseline > $O/stats_c1gpu.log 2>&1
 tail -1 $O/stats_c1gpu.log | cut -c1-200
+unset GPU_MAX_HW_QUEUES
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c5 -- python $R/bench.py --config c5 --steps 20 --warmup 3 --no-cpu-baseline > $O/stats_c5.log 2>&1
 tail -1 $O/stats_c5.log | cut -c1-200
