@@ -1026,13 +1026,15 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void dwt53_tail_fwd_kernel(const T
 // lds_fwd_level: a wave takes PER pair-rows at a time and requests all their rows first (low-pass rows q .. q+PER, high-pass
 // rows q-1 .. q+PER), then runs the vertical steps (dwt.go:132-146 down the columns) and the horizontal inverse of each row.
 template <int PER>
-__device__ __forceinline__ void lds_inv_level(const int32_t *prev, const int32_t *gcoef, int32_t *dst, int w, int h, int n_next,
+__device__ __forceinline__ void lds_inv_level(const int32_t *prev, const int32_t *gcoef, const int32_t *gcoef_hi, int32_t *dst, int w, int h, int n_next,
                                               int wave, int lane, bool coef_lds, bool dst_lds, int qlo, int qhi) {
     const int halfW = (w + 1) >> 1, halfH = (h + 1) >> 1, nhigh = h - halfH;
     const int c = 2 * lane;
     const bool owned = c < w;
     const int lL = (lane < halfW) ? lane : 0, lH = (lane < w - halfW) ? lane : 0;      // clamped: valid addresses for every lane
     auto ld1 = [&](int idx) { return (idx < n_next) ? ld_lds(prev + idx) : (coef_lds ? ld_lds(gcoef + idx) : ld_glb(gcoef + idx)); };
+    // the high-pass rows through their own base: a caller that staged the coefficients as two compact runs of rows (dwt53_deep.inc)
+    auto ld1h = [&](int idx) { return coef_lds ? ld_lds(gcoef_hi + idx) : ld_glb(gcoef_hi + idx); };
     auto finish = [&](int ro, int lo, int hi) {
         int l1[1] = {lo}, h1[1] = {hi}, x[2];
         hinv<2>(l1, h1, c, w, x);
@@ -1050,7 +1052,7 @@ __device__ __forceinline__ void lds_inv_level(const int32_t *prev, const int32_t
 #pragma unroll
         for (int k = 0; k < PER + 2; k++) {
             const int row = (halfH + min(max(qa - 1 + k, 0), max(nhigh - 1, 0))) * w;
-            dl[k] = (nhigh > 0) ? ld1(row + lL) : 0; dh[k] = (nhigh > 0) ? ld1(row + halfW + lH) : 0;
+            dl[k] = (nhigh > 0) ? ld1h(row + lL) : 0; dh[k] = (nhigh > 0) ? ld1h(row + halfW + lH) : 0;
         }
         if (lane >= halfW) {
 #pragma unroll
@@ -1090,13 +1092,14 @@ __device__ __forceinline__ void lds_inv_level(const int32_t *prev, const int32_t
 }
 // The fast shapes (see lds_fwd_level_fast): lane = column pair, several bands per wave, 8-byte stores of the finished rows.
 template <int PER>
-__device__ __forceinline__ void lds_inv_level_fast(const int32_t *prev, const int32_t *gcoef, int32_t *dst, int w, int h, int n_next,
+__device__ __forceinline__ void lds_inv_level_fast(const int32_t *prev, const int32_t *gcoef, const int32_t *gcoef_hi, int32_t *dst, int w, int h, int n_next,
                                                    int wave, int lane, bool coef_lds, bool dst_lds, int qlo, int qhi) {
     const int HW = w >> 1, halfH = (h + 1) >> 1, nhigh = h - halfH;       // h >= 2: nhigh >= 1
     const int R = 64 / HW;
     const int cp = lane & (HW - 1), g = lane / HW;
     const bool first = cp == 0, last = cp == HW - 1;
     auto ld1 = [&](int idx) { return (idx < n_next) ? ld_lds(prev + idx) : (coef_lds ? ld_lds(gcoef + idx) : ld_glb(gcoef + idx)); };
+    auto ld1h = [&](int idx) { return coef_lds ? ld_lds(gcoef_hi + idx) : ld_glb(gcoef_hi + idx); };      // high-pass rows (never below n_next)
     auto finish = [&](int ro, int lo, int hi) {
         int dl = from_left(hi);
         if (first) dl = hi;
@@ -1121,7 +1124,7 @@ __device__ __forceinline__ void lds_inv_level_fast(const int32_t *prev, const in
 #pragma unroll
         for (int k = 0; k < PER + 2; k++) {
             const int row = (halfH + min(max(qa - 1 + k, 0), min(nhigh - 1, qhi))) * w + cp;
-            dl[k] = ld1(row); dh[k] = ld1(row + HW);
+            dl[k] = ld1h(row); dh[k] = ld1h(row + HW);
         }
         int el[PER + 1], eh[PER + 1];
 #pragma unroll
@@ -1149,24 +1152,24 @@ __device__ __forceinline__ void lds_inv_level_fast(const int32_t *prev, const in
     }
 }
 // pair-rows [qlo, qhi) of the level (the whole level: 0, ceil(h / 2)): output rows 2 qlo .. 2 qhi - 1
-__device__ __forceinline__ void tail_inv_level(const int32_t *prev, const int32_t *gcoef, int32_t *dst, int w, int h, int n_next,
+__device__ __forceinline__ void tail_inv_level(const int32_t *prev, const int32_t *gcoef, const int32_t *gcoef_hi, int32_t *dst, int w, int h, int n_next,
                                                int wave, int lane, bool coef_lds, bool dst_lds, int qlo, int qhi) {
     const int nq = qhi - qlo;
     if (nq <= 0) return;
     if (tail_level_fast_shape(w, h)) {
         const int per_band = (nq + TAIL_WAVES * (128 / w) - 1) / (TAIL_WAVES * (128 / w));
-        if (per_band > 2) lds_inv_level_fast<4>(prev, gcoef, dst, w, h, n_next, wave, lane, coef_lds, dst_lds, qlo, qhi);
-        else if (per_band > 1) lds_inv_level_fast<2>(prev, gcoef, dst, w, h, n_next, wave, lane, coef_lds, dst_lds, qlo, qhi);
-        else lds_inv_level_fast<1>(prev, gcoef, dst, w, h, n_next, wave, lane, coef_lds, dst_lds, qlo, qhi);
+        if (per_band > 2) lds_inv_level_fast<4>(prev, gcoef, gcoef_hi, dst, w, h, n_next, wave, lane, coef_lds, dst_lds, qlo, qhi);
+        else if (per_band > 1) lds_inv_level_fast<2>(prev, gcoef, gcoef_hi, dst, w, h, n_next, wave, lane, coef_lds, dst_lds, qlo, qhi);
+        else lds_inv_level_fast<1>(prev, gcoef, gcoef_hi, dst, w, h, n_next, wave, lane, coef_lds, dst_lds, qlo, qhi);
         return;
     }
-    if (nq > 2 * TAIL_WAVES) lds_inv_level<4>(prev, gcoef, dst, w, h, n_next, wave, lane, coef_lds, dst_lds, qlo, qhi);
-    else if (nq > TAIL_WAVES) lds_inv_level<2>(prev, gcoef, dst, w, h, n_next, wave, lane, coef_lds, dst_lds, qlo, qhi);
-    else lds_inv_level<1>(prev, gcoef, dst, w, h, n_next, wave, lane, coef_lds, dst_lds, qlo, qhi);
+    if (nq > 2 * TAIL_WAVES) lds_inv_level<4>(prev, gcoef, gcoef_hi, dst, w, h, n_next, wave, lane, coef_lds, dst_lds, qlo, qhi);
+    else if (nq > TAIL_WAVES) lds_inv_level<2>(prev, gcoef, gcoef_hi, dst, w, h, n_next, wave, lane, coef_lds, dst_lds, qlo, qhi);
+    else lds_inv_level<1>(prev, gcoef, gcoef_hi, dst, w, h, n_next, wave, lane, coef_lds, dst_lds, qlo, qhi);
 }
 __device__ __forceinline__ void tail_inv_level(const int32_t *prev, const int32_t *gcoef, int32_t *dst, int w, int h, int n_next,
                                                int wave, int lane, bool coef_lds, bool dst_lds) {
-    tail_inv_level(prev, gcoef, dst, w, h, n_next, wave, lane, coef_lds, dst_lds, 0, (h + 1) >> 1);
+    tail_inv_level(prev, gcoef, gcoef, dst, w, h, n_next, wave, lane, coef_lds, dst_lds, 0, (h + 1) >> 1);
 }
 
 __global__ __launch_bounds__(64 * TAIL_WAVES) void dwt53_tail_inv_kernel(const TailPlane *__restrict__ planes, const int32_t *__restrict__ coef,

@@ -486,8 +486,20 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
             const size_t n1a = (a_ints + 3) & ~size_t(3), n2a = (size_t)((w2 * h2 + 3) & ~3), nc = (size_t)((w1 * h1 + 3) & ~3), slots = 16 * 64 * 4;   // (ints)
             lds_f = std::max(lds_f, (std::max(2 * slots, n2a) + n1a + 8) * 4);          // forward: slotE, slotD (later bufB) | bufA
             const size_t n1i = (has_mid && ctx->deep_mid_inv) ? n1a : nc;                 // (the inverse takes the split only on request)
+            // inverse, deep + mid + flat (J2K_DEEP_MID_INV=1, the default since round 4): the staged coefficients as compact runs in the
+            // places that are free when they are needed (dwt53_deep_inv_body, DEEP_COMPACT) -- bufA | X = bufB + the low-pass rows beyond
+            // |X_{l0+2}| (mid: its low-pass rows) | RB = the high-pass rows: 69 KB for a 256 x 256 plane instead of 113, two workgroups per CU
+            const size_t nn1 = (L - l0 > 2) ? (size_t)w2 * h2 : 0;
+            const bool compact = has_mid && ctx->deep_mid_inv == 1 && (w1 % 4) == 0 && (nn1 % 4) == 0;
+            if (compact) {
+                const size_t lowtail = (size_t)std::max<int64_t>((int64_t)std::min(T1 + 2, T) * w1 - (int64_t)nn1, 0), lowmid = (size_t)(T - T1) * w1;
+                const size_t xsize = (std::max(std::max(n2a + lowtail, lowmid), slots) + 3) & ~size_t(3);
+                const size_t rb = (size_t)std::max(std::min(T + T1 + 2, h1) - T, h1 - (T + T1 - 1)) * w1;
+                lds = std::max(lds, (n1a + xsize + rb + 8) * 4);
+            } else
             lds = std::max(lds, (n1i + n2a + std::max(nc, slots) + 8) * 4);             // inverse: bufA | bufB | bufC (= slotE later)
             const int flag = has_mid ? 0x10000 : 0;
+            const int cflag = compact ? 0x20000 : 0;
             for (int k = 0; k < g.nc; k++) {
                 const int64_t so = ((l0 & 1) ? g.scrA_off : g.scrB_off)[k];
                 if ((so % 4) || (g.coef_off[k] % 4)) ok = false;
@@ -510,8 +522,8 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                     deep_i.push_back(DwtJob{pi, 1 | fa << 8, 0, T1 | flag});
                     deep_i.push_back(DwtJob{pi, 3 | (nf - fa) << 8 | fa << 16, T1, (T - T1) | flag});
                 } else if (mid_inv == 1) {
-                    deep_i.push_back(DwtJob{pi, 1, 0, T1 | flag});
-                    deep_i.push_back(DwtJob{pi, 3, T1, (T - T1) | flag});
+                    deep_i.push_back(DwtJob{pi, 1, 0, T1 | flag | cflag});
+                    deep_i.push_back(DwtJob{pi, 3, T1, (T - T1) | flag | cflag});
                 } else deep_i.push_back(DwtJob{pi, 1, 0, T});
                 for (int q = T; q < halfH; q += 64) {
                     flat_f.push_back(DwtJob{pi, 0, q, std::min(64, halfH - q)});

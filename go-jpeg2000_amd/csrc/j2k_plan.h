@@ -39,7 +39,7 @@ struct j2k_ctx {
                                // (dwt53_mega_*_kernel); 0 (default) = level 0 as one launch + the deep launch; 1 / 2 = job order (deep, bands, flat / deep, flat, bands).
                                // Measured (C2, one frame in flight): forward 14.3 + 23.9 us against 22.2 + 15.6, inverse 29.5 + 16.3 against 16.0 + 25.0 -- the launch's
                                // LDS size is that of its largest role (112-144 KB), so the level-0 bands run one 16-wave workgroup per CU and lose what the overlap gains
-    int deep_mid_inv = 0;      // J2K_DEEP_MID_INV: the same split in the inverse launch (0 off: measured no gain; 1 = deep + mid + flat; 2 = deep + mid, flat rows inside them)
+    int deep_mid_inv = 1;      // J2K_DEEP_MID_INV: the same split in the inverse launch (1 = deep + mid + flat with the compact LDS layout: two workgroups per CU, the default since round 4; 0 = deep + flat; 2 = deep + mid, flat rows inside them)
     int deep_min_planes = 12;  // J2K_DEEP_MIN_PLANES: fewer tile-components than this keep the per-level launches
     int deep_mid = 1;          // J2K_DEEP_MID=0: the deep workgroup keeps the whole top half of its plane (no mid workgroup beside it)
     int use_deep = 1;          // J2K_DEEP=0: level tail_l0 - 1 as its own launch + the LDS tail (round 2) instead of ONE launch for every level below 0 (dwt53_deep.inc)

@@ -42,7 +42,7 @@ def test_deep_levels_single_component(oracle, W, H, tile, nres):
     small = rng.integers(0, 65536, (1, H, W)).astype(np.int32)
     outs = {}
     for deep in (0, 1, 2, 3, 4):                    # 0: per-level launches; 1: default; 2-4: the mid-job variants of both directions
-        env = {0: dict(J2K_DEEP=0), 1: dict(J2K_DEEP=1), 2: dict(J2K_DEEP_MID=0), 3: dict(J2K_DEEP_MID_INV=1), 4: dict(J2K_DEEP_MID_INV=2)}[deep]
+        env = {0: dict(J2K_DEEP=0), 1: dict(J2K_DEEP=1), 2: dict(J2K_DEEP_MID=0), 3: dict(J2K_DEEP_MID_INV=0), 4: dict(J2K_DEEP_MID_INV=2)}[deep]
         env["J2K_DEEP_MIN_PLANES"] = 1              # (by default a frame of fewer than 12 tile-components keeps the per-level launches)
         plan = FramePlan(W, H, 1, precision=16, lossless=True, num_resolutions=nres, cb=(64, 64), tile=(tile, tile), coder=1,
                          ctx=_ctx(**env))
