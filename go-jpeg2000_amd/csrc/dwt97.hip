@@ -519,13 +519,19 @@ hipError_t launch_dwt97_fwd(hipStream_t s, const LevelLaunch &L, const void *src
         if (L.wg_waves == 16) return fwd97_wg_go<16>(s, L, src, out_i32, out_f64, nxt, dc_shift, quant, step);
         return hipErrorInvalidValue;
     }
-    if (L.pwaves == 8 && L.pnjobs > 0 && L.ncomp == 1 && src_is_f64 && quant != Q_NONE_) {   // a deeper level, single planes, workgroup form
-        const double *pf = reinterpret_cast<const double *>(src);
+    if (L.pwaves == 8 && L.pnjobs > 0 && L.ncomp == 1) {   // single planes in workgroup form: a deeper level (float64 in), level 0 of one int32 component, the float64 unit calls
         const double rstep = 1.0 / step;
-#define J2K_PWG97(Q) hipExtLaunchKernelGGL((dwt97_fwd_rgb_wg_kernel<8, Q, 7, 1>), dim3(L.pnjobs), dim3(512), 0, s, L.ev_start, L.ev_stop, 0, \
-                                            L.pjobs, L.pnjobs, L.planes, (const int32_t *)nullptr, pf, out_i32, out_f64, nxt, dc_shift, step, rstep)
-        if (quant == Q_ENCODER_) J2K_PWG97(Q_ENCODER_);
-        else J2K_PWG97(Q_TCD_);
+#define J2K_PWG97(Q, SRC) hipExtLaunchKernelGGL((dwt97_fwd_rgb_wg_kernel<8, Q, 7, SRC>), dim3(L.pnjobs), dim3(512), 0, s, L.ev_start, L.ev_stop, 0, \
+                                                 L.pjobs, L.pnjobs, L.planes, reinterpret_cast<const int32_t *>(src), reinterpret_cast<const double *>(src), out_i32, out_f64, nxt, dc_shift, step, rstep)
+        if (src_is_f64) {
+            if (quant == Q_ENCODER_) J2K_PWG97(Q_ENCODER_, 1);
+            else if (quant == Q_TCD_) J2K_PWG97(Q_TCD_, 1);
+            else J2K_PWG97(Q_NONE_, 1);
+        } else {
+            if (quant == Q_ENCODER_) J2K_PWG97(Q_ENCODER_, 2);
+            else if (quant == Q_TCD_) J2K_PWG97(Q_TCD_, 2);
+            else J2K_PWG97(Q_NONE_, 2);
+        }
 #undef J2K_PWG97
         return hipGetLastError();
     }
@@ -557,9 +563,12 @@ hipError_t launch_dwt97_inv(hipStream_t s, const LevelLaunch &L, const void *coe
 #undef J2K_WG97I
         return hipGetLastError();
     }
-    if (L.pwaves == 8 && L.pnjobs > 0 && L.ncomp == 1 && !coef_is_f64 && dst_mode == DST_F64_SCRATCH) {   // a deeper level, workgroup form
-        hipLaunchKernelGGL((dwt97_inv_plane_wg_kernel<8, 6>), dim3(L.pnjobs), dim3(512), 0, s, L.pjobs, L.pnjobs, L.planes,
-                           reinterpret_cast<const int32_t *>(coef), prev, reinterpret_cast<double *>(dst));
+    if (L.pwaves == 8 && L.pnjobs > 0 && L.ncomp == 1) {   // single planes in workgroup form: a deeper level, level 0 of one int32 component, the float64 unit calls
+#define J2K_PWG97I(CF, DI) hipLaunchKernelGGL((dwt97_inv_plane_wg_kernel<8, 6, CF, DI>), dim3(L.pnjobs), dim3(512), 0, s, L.pjobs, L.pnjobs, L.planes, \
+                                               coef, prev, dst, dc_shift, dst_mode == DST_F64_FRAME ? 1 : 0)
+        if (dst_mode == DST_I32_FRAME) { if (coef_is_f64) J2K_PWG97I(true, true); else J2K_PWG97I(false, true); }
+        else { if (coef_is_f64) J2K_PWG97I(true, false); else J2K_PWG97I(false, false); }
+#undef J2K_PWG97I
         return hipGetLastError();
     }
     const int blocks = (L.njobs + 3) / 4;

@@ -714,14 +714,17 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                         if (r != J2K_OK) { j2k_plan_destroy(P); return r; }
                     }
                 }
-                if (S.wavelet == W97 && cls == 0 && l >= 1 && ctx->plane_wg97 > 0 && S.quant != Q_NONE && !S.frame_is_f64) {
-                    // the deeper 9-7 levels in workgroup form (dwt97_l0wg.inc SRC = 1, dwt97_l0wg_inv.inc: single float64 planes,
-                    // int32 coefficients): one job per (plane, band of NW - 3 pair-rows)
+                if (S.wavelet == W97 && cls == 0 && ctx->plane_wg97 > 0) {
+                    // single planes of the 9-7 transform in workgroup form (dwt97_l0wg.inc SRC = 1 / 2, dwt97_l0wg_inv.inc): the deeper
+                    // levels (float64 scratch in, int32 coefficients), and since round 4 level 0 of one int32 component (gray frames,
+                    // frames without the colour transform) and the float64 unit calls (dwt.go:432-473, 551-573): one job per (plane,
+                    // band of NW - 3 pair-rows)
                     bool ok = true;
                     for (size_t i = 0; i < planes.size() && ok; i++) {
                         const DwtPlane &D = planes[i];
                         if (pw[i] < 16 || pw[i] > 512 || (pw[i] % 8) || ph[i] < 2) ok = false;
                         if ((D.src_off[0] % 4) || (D.out_off[0] % 4) || (D.nxt_off[0] % 4)) ok = false;
+                        if (l == 0 && ((D.src_stride % 4) || (D.out_stride % 4))) ok = false;      // a frame's rows: 16-byte row accesses
                     }
                     if (ok) {
                         std::vector<DwtJob> pj;

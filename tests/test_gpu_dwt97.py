@@ -82,7 +82,10 @@ def test_tcd_apply_dwt_irreversible(oracle, w, h, levels):
 
 
 FRAMES = [(64, 64, 3, (0, 0), 3, 8, 75), (100, 75, 3, (0, 0), 6, 12, 75), (96, 80, 1, (32, 32), 4, 8, 0),
-          (640, 368, 3, (512, 512), 6, 12, 75), (333, 217, 4, (128, 64), 5, 10, 30), (512, 512, 3, (0, 0), 6, 12, 100)]
+          (640, 368, 3, (512, 512), 6, 12, 75), (333, 217, 4, (128, 64), 5, 10, 30), (512, 512, 3, (0, 0), 6, 12, 100),
+          # single components whose level 0 takes the workgroup kernels (16 <= w <= 512, w % 8 == 0; dwt97_l0wg.inc SRC = 2): a gray
+          # frame in one tile, gray 512-tiles with a ragged last column of 256, four components (no colour transform), odd heights
+          (512, 256, 1, (0, 0), 4, 12, 50), (1280, 131, 1, (512, 512), 6, 8, 75), (256, 67, 4, (128, 128), 3, 16, 8191), (64, 2, 1, (0, 0), 2, 8, 1)]
 
 
 @pytest.mark.parametrize("W,H,Cn,tile,nres,prec,quality", FRAMES)
