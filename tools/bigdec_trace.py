@@ -1,5 +1,7 @@
+"""dev tool (GPU box): the (context, decision) trace of t1_decode_big_kernel against the Python restatement's, first divergence with the
+neighbourhood the reference sees.  bash tools/variant.sh trace t1.hip -DJ2K_TBD_TRACE ; J2K_LIB=.../libj2kgfx_trace.so python tools/bigdec_trace.py W H numBPS band seed"""
 import sys, os
-sys.path.insert(0, "go-jpeg2000_amd"); sys.path.insert(0, "oracle")
+import os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [os.path.join(R, "go-jpeg2000_amd"), os.path.join(R, "oracle")]
 import numpy as np
 import pyref
 from j2kgfx import entropy as ent
