@@ -95,7 +95,7 @@ def other_configs_summary(budget_s=90.0):
     except ImportError:
         pass
     t_all = time.perf_counter()
-    plan = [("c3", ["--steps", "10", "--warmup", "2"]), ("c5", ["--steps", "20", "--warmup", "3"]), ("c1gpu", ["--steps", "3", "--warmup", "1"])]
+    plan = [("c3", ["--steps", "10", "--warmup", "2"]), ("c5", ["--steps", "20", "--warmup", "3"]), ("c1gpu", ["--steps", "4", "--warmup", "1"])]
     for name, extra in plan:
         left = budget_s - (time.perf_counter() - t_all)
         if left < 10:
@@ -197,7 +197,7 @@ def run(state):
         if "--inflight" not in " ".join(sys.argv):
             args.inflight = 0           # the configuration's own default
         if args.config == "c1gpu" and "--steps" not in " ".join(sys.argv):
-            args.steps, args.warmup = 10, min(args.warmup, 2)      # a step is 24 frames of 21 serial chains: 0.4 s
+            args.steps, args.warmup = 10, min(args.warmup, 2)      # a step is 22 frames of 21 serial chains: 0.2 s
         return bench_extra.run_config(args, args.config)
     # CPU baseline first (N = 1 only): nothing has touched the GPU yet, so the worker processes are plain forks / spawns
     cpu_base = None

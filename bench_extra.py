@@ -31,11 +31,12 @@ CONFIGS = {
     # BASELINE configs[0] ("pure-Go CPU path, plumbing") on the GPU: the reference's DEFAULT code-block size, 1 << (6 + 2) = 256
     # (encoder.go:606-607), i.e. the blocks above 64 x 64 that take the general T1 kernels; 21 blocks per frame (9 of 256 x 256,
     # 12 of 128 x 128): a handful of serial MQ chains, not a throughput configuration
-    "c1gpu": dict(W=512, H=512, C=3, prec=8, lossless=True, quality=0, tile=0, nres=3, cb=256, coder=0, io="planes", inflight=24, content="c1",
+    "c1gpu": dict(W=512, H=512, C=3, prec=8, lossless=True, quality=0, tile=0, nres=3, cb=256, coder=0, io="planes", inflight=22, content="c1",
                   metric="Mpixels/s encode+decode (512x512 sRGB, 5-3 lossless, 256x256 code-blocks, MQ coder)",
                   workload="512x512 sRGB 8-bit, single tile, 5-3 lossless, NumResolutions 3, CodeBlockSize{6,6} = 256x256 code-blocks (the "
                            "reference's default, encoder.go:606-607), MQ block coder (BASELINE configs[0] run on the GPU); even frames = the "
-                           "reference's benchmark gradient (jpeg2000_test.go:340-352), odd frames = uniform random bytes"),
+                           "reference's benchmark gradient (jpeg2000_test.go:340-352), odd frames = uniform random bytes; stream f codes frame f on "
+                           "even steps and frame f^1 on odd steps (the same frames every step)"),
     "c5": dict(W=2048, H=2048, C=1, prec=16, lossless=True, quality=0, tile=0, nres=6, cb=64, coder=1, io="gray16", inflight=8,
                metric="Mpixels/s encode+decode (2048x2048 16-bit gray frames, 5-3 lossless)",
                workload="independent 2048x2048 16-bit gray frames (BASELINE configs[4]: a batch of 256, frame f -> rank f mod N), "
@@ -208,11 +209,20 @@ def run_config(args, cfgname):
             if cfg["io"] == "gray16":                          # image.Gray16.Pix: two bytes per pixel, high byte first
                 ln["pix"] = torch.from_numpy(np.ascontiguousarray(fr[0].astype(">u2")).view(np.uint8).reshape(H, W * 2)).to(p.device)
                 ln["bpix"] = torch.zeros((H, W * 2), dtype=torch.uint8, device=p.device)
+            if cfg.get("content") == "c1":
+                # a noise frame takes 1.6x the coding time of the gradient (twice the symbols on the same serial chains): the step
+                # codes the same F frames every time, but stream f takes frame f on even steps and frame f ^ 1 on odd ones, so that
+                # no stream is left waiting for the streams that hold the slow frames (steps are not separated by a barrier)
+                ln["frames"] = [ln["frame"], torch.from_numpy(synth_frame(np, cfg, rank * F + (f ^ 1))).to(p.device)]
+                ln["k"] = 0
             lanes.append(ln)
         torch.cuda.synchronize()
 
         def code(ln):
             p = ln["p"]
+            if "frames" in ln:
+                ln["frame"] = ln["frames"][ln["k"] & 1]
+                ln["k"] += 1
             if cfg["io"] == "gray16":
                 p.forward_pixels(1, ln["pix"], ln["coeff"])
             else:
@@ -236,6 +246,7 @@ def run_config(args, cfgname):
             for ln in lanes:
                 code(ln)
         use_graph = cfg.get("graph", 0) if getattr(args, "graph", -1) < 0 else bool(args.graph)
+        use_graph = use_graph and cfg.get("content") != "c1"      # (those streams alternate between two frames)
         if use_graph:
             # one HIP graph per frame in flight: its plan calls recorded once (after the warm-up sized every workspace) and
             # replayed with one launch per step -- same kernels, same buffers, no per-kernel launch from the host

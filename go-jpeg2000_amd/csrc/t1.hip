@@ -1743,7 +1743,9 @@ hipError_t launch_t1_encode(hipStream_t s, const BlockJob *jobs, int njobs, cons
                 if (e != hipSuccess) return e;
                 raised = true;
             }
-            hipLaunchKernelGGL(t1_encode_big_kernel, dim3(njobs), dim3(256), sizeof(T1Big), s, jobs, njobs, coef, slots, lens, numbps, fault);
+            int rot = 1;               // J2K_T1_BIG_ROT=0: the chain stays on wave 0 (A/B)
+            { const char *en = getenv("J2K_T1_BIG_ROT"); if (en) rot = atoi(en); }
+            hipLaunchKernelGGL(t1_encode_big_kernel, dim3(njobs), dim3(256), sizeof(T1Big), s, jobs, njobs, coef, slots, lens, numbps, fault, rot);
             e = hipGetLastError();
             if (e != hipSuccess || max_dim <= 256) return e;
         }
@@ -1815,7 +1817,9 @@ hipError_t launch_t1_decode(hipStream_t s, const BlockJob *jobs, int njobs, cons
     { const char *en = getenv("J2K_T1_BIG_DEC"); if (en) big_dec = atoi(en); }
     const bool use_big = big_dec && !general_only;
     if (use_big) {
-        hipLaunchKernelGGL(t1_decode_big_kernel, dim3(njobs), dim3(64), sizeof(T1BigDec), s, jobs, njobs, stream, offs, lens, numbps, decoded);
+        int rot = 1;                   // J2K_T1_BIG_ROT=0: one wave per block, wherever the dispatcher puts it (A/B)
+        { const char *en = getenv("J2K_T1_BIG_ROT"); if (en) rot = atoi(en); }
+        hipLaunchKernelGGL(t1_decode_big_kernel, dim3(njobs), dim3(rot ? 256 : 64), sizeof(T1BigDec), s, jobs, njobs, stream, offs, lens, numbps, decoded, rot);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess || max_dim <= 256) return e;
     }

@@ -78,6 +78,21 @@ def test_big_block_decoder_knob_matches_general_kernel(ent, oracle, monkeypatch)
     assert np.array_equal(res["1"][1].reshape(96, 160), oracle.t1_decode(g, 7, 2, 160, 96))
 
 
+def test_big_block_chain_placement_knob(ent, oracle, monkeypatch):
+    """J2K_T1_BIG_ROT: which wave of the workgroup runs the MQ chain (the one on the SIMD the CU's counter names, or wave 0 / the
+    single wave) changes where the chain runs, not one byte of what it produces"""
+    rng = np.random.default_rng(11)
+    x = (rng.integers(-3000, 3001, (200, 256)) * (rng.random((200, 256)) < 0.4)).astype(np.int32)
+    want, nb = oracle.t1_encode(x, 256, 200, 3)
+    for knob in ("1", "0", "1"):
+        monkeypatch.setenv("J2K_T1_BIG_ROT", knob)
+        for _ in range(3):                                   # (the counter moves on with every block)
+            t1 = ent.NewT1(256, 200)
+            t1.SetData(x)
+            assert t1.Encode(3) == bytes(want) and t1.numBPS == nb, knob
+            assert np.array_equal(ent.NewT1(256, 200).Decode(bytes(want), nb, 3).reshape(200, 256), x), knob
+
+
 def test_big_block_fuzz_slice(ent, oracle):
     """A seeded slice of random geometry x content x band for the two big-block kernels: 65 ... 256 columns or rows (one side may be
     small), magnitudes from 1 to 30 bits, densities from a few isolated samples to full noise, arbitrary byte strings of random length
