@@ -1308,14 +1308,25 @@ hipError_t launch_dwt53_fwd(hipStream_t s, const LevelLaunch &L, const int32_t *
         if (L.wg_waves == 8) return fwd_wg_go<8>(s, L, src, out, nxt, dc_shift);
         return hipErrorInvalidValue;
     }
-    if (L.pwaves > 0 && L.pnjobs > 0 && (L.ncomp == 1 || L.pix_stride <= 0)) {     // planes in workgroup form (dwt53_plane_wg.inc)
+    if (L.pwaves > 0 && L.pnjobs > 0 && (L.ncomp == 1 || L.pix_stride <= 0 || L.pix_src == 4)) {     // planes in workgroup form (dwt53_plane_wg.inc)
 #define J2K_PWG(NW, NC, SRC, MULTI, WPE) hipExtLaunchKernelGGL((dwt53_fwd_plane_wg_kernel<NW, NC, SRC, MULTI, WPE>), dim3(L.pnjobs), dim3(NW * 64), 0, s, L.ev_start, L.ev_stop, 0, \
-                                                 L.pjobs, L.pnjobs, L.planes, (const void *)src, out, nxt, dc_shift, L.pix_stride)
+                                                 L.pjobs, L.pnjobs, L.planes, (const void *)src, out, nxt, dc_shift, L.pix_stride, (int64_t)L.comp_elems)
+#define J2K_PWGM(NW, NC, SRC, WPE) do { if (L.pmulti) J2K_PWG(NW, NC, SRC, true, WPE); else J2K_PWG(NW, NC, SRC, false, WPE); } while (0)
+        if (L.pix_stride > 0 && L.pix_src != 1) {     // Gray8 / a channel of a four-channel pixel / RGBA64 (four waves per workgroup only)
+            if (L.pwaves != 4 || L.comp_elems <= 0) return hipErrorInvalidValue;
+            if (L.ncomp == 3) { if (L.pix_src != 4) return hipErrorInvalidValue; J2K_PWGM(4, 3, 4, 4); }
+            else if (L.pix_src == 2) J2K_PWGM(4, 1, 2, 8);
+            else if (L.pix_src == 3) J2K_PWGM(4, 1, 3, 8);
+            else if (L.pix_src == 4) J2K_PWGM(4, 1, 4, 8);
+            else return hipErrorInvalidValue;
+            return hipGetLastError();
+        }
 #define J2K_PWG2(NW) do { if (L.ncomp == 3) { if (L.pmulti) J2K_PWG(NW, 3, 0, true, 4); else J2K_PWG(NW, 3, 0, false, 5); } \
-                          else if (L.pix_stride > 0) { if (L.pmulti) J2K_PWG(NW, 1, 1, true, 8); else J2K_PWG(NW, 1, 1, false, 8); } \
-                          else { if (L.pmulti) J2K_PWG(NW, 1, 0, true, 8); else J2K_PWG(NW, 1, 0, false, 8); } } while (0)
+                          else if (L.pix_stride > 0) J2K_PWGM(NW, 1, 1, 8); \
+                          else J2K_PWGM(NW, 1, 0, 8); } while (0)
         if (L.pwaves == 8) J2K_PWG2(8); else J2K_PWG2(4);
 #undef J2K_PWG2
+#undef J2K_PWGM
 #undef J2K_PWG
         return hipGetLastError();
     }
@@ -1336,15 +1347,26 @@ hipError_t launch_dwt53_inv(hipStream_t s, const LevelLaunch &L, const int32_t *
 #undef J2K_INVWG
         return hipGetLastError();
     }
-    if (L.pwaves > 0 && L.pnjobs > 0 && (L.ncomp == 1 || L.pix_stride <= 0)) {     // planes in workgroup form (dwt53_plane_wg.inc)
+    if (L.pwaves > 0 && L.pnjobs > 0 && (L.ncomp == 1 || L.pix_stride <= 0 || L.pix_src == 4)) {     // planes in workgroup form (dwt53_plane_wg.inc)
         if (L.pix_stride > 0 && !final_level) return hipErrorInvalidValue;
 #define J2K_PWG(NW, NC, DST, MULTI, WPE) hipExtLaunchKernelGGL((dwt53_inv_plane_wg_kernel<NW, NC, DST, MULTI, WPE>), dim3(L.pnjobs), dim3(NW * 64), 0, s, L.ev_start, L.ev_stop, 0, \
-                                                 L.pjobs, L.pnjobs, L.planes, coef, prev, (void *)dst, dc_shift, final_level, L.pix_stride)
+                                                 L.pjobs, L.pnjobs, L.planes, coef, prev, (void *)dst, dc_shift, final_level, L.pix_stride, (int64_t)L.comp_elems)
+#define J2K_PWGM(NW, NC, DST, WPE) do { if (L.pmulti) J2K_PWG(NW, NC, DST, true, WPE); else J2K_PWG(NW, NC, DST, false, WPE); } while (0)
+        if (L.pix_stride > 0 && L.pix_src != 1) {
+            if (L.pwaves != 4 || L.comp_elems <= 0) return hipErrorInvalidValue;
+            if (L.ncomp == 3) { if (L.pix_src != 4) return hipErrorInvalidValue; if (L.pmulti) J2K_PWG(4, 3, 4, true, 3); else J2K_PWG(4, 3, 4, false, 5); }
+            else if (L.pix_src == 2) J2K_PWGM(4, 1, 2, 8);
+            else if (L.pix_src == 3) J2K_PWGM(4, 1, 3, 8);
+            else if (L.pix_src == 4) J2K_PWGM(4, 1, 4, 8);
+            else return hipErrorInvalidValue;
+            return hipGetLastError();
+        }
 #define J2K_PWG2(NW) do { if (L.ncomp == 3) { if (L.pmulti) J2K_PWG(NW, 3, 0, true, 3); else J2K_PWG(NW, 3, 0, false, 5); } \
-                          else if (L.pix_stride > 0) { if (L.pmulti) J2K_PWG(NW, 1, 1, true, 8); else J2K_PWG(NW, 1, 1, false, 8); } \
-                          else { if (L.pmulti) J2K_PWG(NW, 1, 0, true, 8); else J2K_PWG(NW, 1, 0, false, 8); } } while (0)
+                          else if (L.pix_stride > 0) J2K_PWGM(NW, 1, 1, 8); \
+                          else J2K_PWGM(NW, 1, 0, 8); } while (0)
         if (L.pwaves == 8) J2K_PWG2(8); else J2K_PWG2(4);
 #undef J2K_PWG2
+#undef J2K_PWGM
 #undef J2K_PWG
         return hipGetLastError();
     }

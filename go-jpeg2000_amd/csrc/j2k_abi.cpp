@@ -124,6 +124,7 @@ extern "C" int j2k_ctx_create(int device, j2k_ctx **out) {
     if (const char *e = getenv("J2K_DEV_DUP")) j2k::g_dev_dup = (int)strtol(e, nullptr, 0);
 #endif
     if (const char *e = getenv("J2K_PLANE_WG3")) ctx->plane_wg3 = atoi(e) != 0;
+    if (const char *e = getenv("J2K_PIX_FUSE")) ctx->pix_fuse = atoi(e);
     if (const char *e = getenv("J2K_PLANE_WG")) { int v = atoi(e); if (v == 0 || v == 4 || v == 8) ctx->plane_wg = v; }
     if (const char *e = getenv("J2K_L0_FUSE")) { int v = atoi(e); if (v == 0 || v == 8 || v == 10 || v == 16) ctx->l0_fuse = v; }
     if (const char *e = getenv("J2K_L0_WG")) { int v = atoi(e); if (v == 0 || v == 4 || v == 8) ctx->l0_wg = v; }
@@ -676,7 +677,7 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                 int r = upload(ctx, &T.d_planes, planes);
                 if (r == J2K_OK) r = upload(ctx, &T.d_jobs, jobs);
                 if (r != J2K_OK) { j2k_plan_destroy(P); return r; }
-                if (S.wavelet == W53 && vec_ok && ctx->plane_wg > 0 && (cls == 0 || ctx->plane_wg3)) {   // both directions; cls 1 = level 0 of RGB triples of int32 planes
+                if (S.wavelet == W53 && vec_ok && ctx->plane_wg > 0 && (cls == 0 || ctx->plane_wg3 || l == 0)) {   // both directions; cls 1 = level 0 of RGB triples: int32 planes (J2K_PLANE_WG3) or RGBA64 pixels
                     // workgroup form for single-component planes (dwt53_plane_wg.inc): whole 16-byte lanes, at least two rows
                     bool ok = true;
                     int multi = 0;
@@ -710,6 +711,7 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                             pj.swap(perm);
                         }
                         T.pnjobs = (int)pj.size(); T.pwaves = ctx->plane_wg; T.pmulti = multi;
+                        T.p_pix_only = (cls == 1 && !ctx->plane_wg3);
                         r = upload(ctx, &T.d_pjobs, pj);
                         if (r != J2K_OK) { j2k_plan_destroy(P); return r; }
                     }
@@ -1095,12 +1097,23 @@ extern "C" int j2k_plan_get_decoded_offsets(const j2k_plan *P, uint64_t *offs, s
 // ------------------------------------------------------------------------------
 static LevelLaunch mk(const LevelTab &T, int pf = 0) {
     LevelLaunch L{T.d_jobs, T.njobs, T.d_planes, T.cpl, T.vec, T.ncomp, pf};
-    L.pjobs = T.d_pjobs; L.pnjobs = T.pnjobs; L.pwaves = T.pwaves; L.pmulti = T.pmulti;
+    L.pjobs = T.d_pjobs; L.pnjobs = T.p_pix_only ? 0 : T.pnjobs; L.pwaves = T.pwaves; L.pmulti = T.pmulti;
     return L;
 }
 
-// pix_stride > 0: d_frame is a packed-pixel frame read by the level-0 kernels of class pix_cls (1: RGBA8 triples, 0: Gray16 planes)
-static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff, int pix_stride = 0, int pix_cls = 1) {
+// A packed-pixel frame at level 0 (j2k_plan_forward_pixels / _inverse_pixels; encoder.go:79-179, decoder.go:417-588): stride in PIXELS,
+// what the single-component planes read / write (dwt53_plane_wg.inc SRC codes 1 ... 4; 0 = the frame has none) and what the RGB
+// triples do (8 = the RGBA8 kernels of dwt53_l0pix.inc / the general kernels, 4 = RGBA64 through the plane kernels; 0 = none).
+struct PixIO { int stride = 0, single = 0, triple = 0; };
+static void pix_launch(LevelLaunch &L, const LevelTab &T, const PixIO &pix, int cls, const PlanSpec &S) {
+    L.pix_stride = pix.stride;
+    L.pix_src = cls ? (pix.triple == 4 ? 4 : 0) : pix.single;
+    L.comp_elems = (long long)S.W * S.H;
+    if (cls == 1 && pix.triple == 4) L.pnjobs = T.pnjobs;      // (a table kept for pixel sources only: mk() hides it)
+}
+
+static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff, PixIO pix = PixIO()) {
+    const int pix_stride = pix.stride;
     j2k_ctx *ctx = P->ctx;
     const PlanSpec &S = P->spec;
     if (((uintptr_t)d_frame & 15) || ((uintptr_t)d_coeff & 15)) return fail(ctx, J2K_ERR_INVALID_ARG, "device pointers must be 16-byte aligned");
@@ -1124,10 +1137,11 @@ static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff, in
             if (l == 0 ? cls == prof_cls : S.wavelet == W53) profile_pair(ctx, l == 0 ? 0 : 1, ev0, ev1);
             if (S.wavelet == W53) {
                 LevelLaunch L = mk(T, ctx->fwd_pf);
-                if (l == 0 && cls == pix_cls && pix_stride > 0) {         // packed frame (j2k_plan_forward_rgba8 / _pixels)
-                    L.pix_stride = pix_stride;
-                    if (cls == 1 && P->d_fwd_pix_jobs) { L.jobs = P->d_fwd_pix_jobs; L.njobs = P->fwd_pix_njobs; }
-                    if (cls == 1 && P->d_fwd_wg_jobs) {   // RGBA8: the workgroup form when every plane qualifies
+                if (l == 0 && pix_stride > 0) {         // packed frame (j2k_plan_forward_rgba8 / _pixels)
+                    pix_launch(L, T, pix, cls, S);
+                    const bool rgba8 = cls == 1 && pix.triple == 8;
+                    if (rgba8 && P->d_fwd_pix_jobs) { L.jobs = P->d_fwd_pix_jobs; L.njobs = P->fwd_pix_njobs; }
+                    if (rgba8 && P->d_fwd_wg_jobs) {   // RGBA8: the workgroup form when every plane qualifies
                         L.jobs = P->d_fwd_wg_jobs; L.njobs = P->fwd_wg_njobs; L.wg_waves = P->fwd_wg_waves; L.wg_store = ctx->l0_store;
                         if (P->d_mega_fwd_jobs && !P->d_fwd_wg2_jobs) {   // ... only its top bands: the rest runs beside the deep levels
                             L.jobs = P->d_fwd_top_jobs; L.njobs = P->fwd_top_njobs;
@@ -1177,12 +1191,13 @@ static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff, in
     return J2K_OK;
 }
 
-static int plan_inverse_impl(j2k_plan *P, const void *d_coeff, void *d_frame, int pix_stride = 0, int pix_cls = 1) {
+static int plan_inverse_impl(j2k_plan *P, const void *d_coeff, void *d_frame, PixIO pix = PixIO()) {
+    const int pix_stride = pix.stride;
     j2k_ctx *ctx = P->ctx;
     const PlanSpec &S = P->spec;
     if (((uintptr_t)d_frame & 15) || ((uintptr_t)d_coeff & 15)) return fail(ctx, J2K_ERR_INVALID_ARG, "device pointers must be 16-byte aligned");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    const bool mega = P->d_mega_inv_jobs && pix_cls == 1 && pix_stride > 0 && ctx->l0_wg_inv && S.wavelet == W53;
+    const bool mega = P->d_mega_inv_jobs && pix.triple == 8 && pix_stride > 0 && ctx->l0_wg_inv && S.wavelet == W53;
     for (int rep_ = 0; mega && rep_ < dev_reps(0x100); rep_++) {
         hipEvent_t e0, e1;
         profile_pair(ctx, 3, e0, e1);
@@ -1206,13 +1221,15 @@ static int plan_inverse_impl(j2k_plan *P, const void *d_coeff, void *d_frame, in
     for (int rep_ = 0; rep_ < dev_reps(l == 0 ? 0x400 : (l == 1 ? 0x200 : 0x100)); rep_++) {
         void *prev = (l & 1) ? P->d_scrB : P->d_scrA;                     // X_{l+1}
         void *dst = (l == 0) ? d_frame : ((l & 1) ? P->d_scrA : P->d_scrB);  // X_l
-        for (int cls = 0; cls < 2; cls++) {
+        for (int ci = 0; ci < 2; ci++) {
+            // (a packed frame: the triples first -- their kernels write whole pixels, a fourth component then puts its bytes in)
+            const int cls = (l == 0 && pix_stride > 0) ? 1 - ci : ci;
             const LevelTab &T = P->inv[cls][l];
             if (!T.njobs) continue;
             if (S.wavelet == W53) {
                 LevelLaunch L = mk(T);
-                if (l == 0 && cls == pix_cls) L.pix_stride = pix_stride;  // packed frame (j2k_plan_inverse_rgba8 / _pixels)
-                if (l == 0 && cls == 1 && pix_cls == 1 && pix_stride > 0 && P->d_inv_wg_jobs && ctx->l0_wg_inv) {
+                if (l == 0 && pix_stride > 0) pix_launch(L, T, pix, cls, S);  // packed frame (j2k_plan_inverse_rgba8 / _pixels)
+                if (l == 0 && cls == 1 && pix.triple == 8 && pix_stride > 0 && P->d_inv_wg_jobs && ctx->l0_wg_inv) {
                     // RGBA8: the workgroup form when every plane qualifies (same job table as the forward: the plane order
                     // of the inverse level table is the forward one)
                     L.jobs = P->d_inv_wg_jobs; L.njobs = P->inv_wg_njobs; L.wg_waves = P->inv_wg_waves; L.wg_store = ctx->l0_inv_wpe;
@@ -1416,24 +1433,34 @@ extern "C" int j2k_convert_colorspace(j2k_ctx *ctx, int cs, int32_t *const *plan
     return J2K_OK;
 }
 
-// can the level-0 5-3 + RCT kernels read / write packed RGBA8 directly?
-static bool rgba8_fusable(const j2k_plan *P, const void *d_pix, size_t stride, bool inverse) {
+// Can the level-0 5-3 kernels read / write the packed pixels themselves?  bps = bytes per sample (1, 2), channels = 1 (Gray, Gray16) or 4
+// (RGBA, NRGBA, RGBA64, NRGBA64).  The plan's precision must be the format's own (no rescale: encoder.go:196-210) and unsigned; single
+// components need the workgroup form of dwt53_plane_wg.inc (Gray16 also has a general kernel), 8-bit triples the packed-RGBA8 kernels,
+// 16-bit triples the plane kernels' NC = 3 form.
+static bool pix_fusable(const j2k_plan *P, int bps, int channels, const void *d_pix, size_t stride, bool inverse, PixIO &io) {
     const PlanSpec &S = P->spec;
-    if (S.wavelet != W53 || !S.mct || S.C != 3 || S.levels < 1 || (inverse ? S.dc_shift_inv : S.dc_shift) != 128) return false;
-    const LevelTab &T = (inverse ? P->inv : P->fwd)[1][0];
-    if (!T.njobs || !T.vec || T.cpl != 8 || (inverse ? P->inv : P->fwd)[0][0].njobs) return false;
-    if (P->tail_l0 == 0) return false;
-    return !(((uintptr_t)d_pix | stride) & 15);
-}
-
-// can the level-0 5-3 kernels of a one-component 16-bit plan read / write packed Gray16 (big-endian) directly?
-static bool gray16_fusable(const j2k_plan *P, const void *d_pix, size_t stride, bool inverse) {
-    const PlanSpec &S = P->spec;
-    if (S.wavelet != W53 || S.C != 1 || S.levels < 1 || S.precision != 16 || (inverse ? S.dc_shift_inv : S.dc_shift) != 32768) return false;
-    const LevelTab &T = (inverse ? P->inv : P->fwd)[0][0];
-    if (!T.njobs || !T.vec || T.cpl != 8 || (inverse ? P->inv : P->fwd)[1][0].njobs) return false;
-    if (P->tail_l0 == 0) return false;
-    return !(((uintptr_t)d_pix | stride) & 15);
+    const int prec = 8 * bps, pb = bps * channels;
+    if (S.wavelet != W53 || S.levels < 1 || S.precision != prec || (inverse ? S.dc_shift_inv : S.dc_shift) != (1 << (prec - 1))) return false;
+    if (P->tail_l0 == 0 || (S.W % 8)) return false;
+    if (P->ctx->pix_fuse == 0 || (P->ctx->pix_fuse == 2 && !(bps == 1 && channels == 4 && S.C == 3) && !(bps == 2 && channels == 1))) return false;
+    if ((((uintptr_t)d_pix | stride) & 15) || stride < (size_t)S.W * pb) return false;
+    const LevelTab &T0 = (inverse ? P->inv : P->fwd)[0][0], &T1 = (inverse ? P->inv : P->fwd)[1][0];
+    if (!T0.njobs && !T1.njobs) return false;
+    io = PixIO();
+    io.stride = (int)(stride / pb);
+    if (T0.njobs) {
+        io.single = channels == 1 ? (bps == 2 ? 1 : 2) : (bps == 2 ? 4 : 3);
+        const bool wg = T0.pnjobs > 0 && !T0.p_pix_only;
+        if (io.single == 1 ? !(wg || (T0.vec && T0.cpl == 8)) : !(wg && T0.pwaves == 4)) return false;
+        if (io.single == 1 && T1.njobs) return false;
+    }
+    if (T1.njobs) {
+        if (channels != 4 || !S.mct) return false;
+        if (bps == 1) { if (!T1.vec || T1.cpl != 8) return false; io.triple = 8; }
+        else { if (!T1.pnjobs || T1.pwaves != 4) return false; io.triple = 4; }
+    }
+    if (inverse && channels == 4 && !T1.njobs && S.C != 4) return false;      // three components on their own leave alpha unwritten
+    return true;
 }
 
 extern "C" int j2k_plan_forward_rgba8(j2k_plan *P, const void *d_pix, size_t stride, int32_t *d_coeff) {
@@ -1442,7 +1469,8 @@ extern "C" int j2k_plan_forward_rgba8(j2k_plan *P, const void *d_pix, size_t str
     const PlanSpec &S = P->spec;
     if (S.C != 3) return fail(ctx, J2K_ERR_INVALID_ARG, "j2k_plan_forward_rgba8 needs a 3-component plan");
     if (stride < (size_t)S.W * 4 || (((uintptr_t)d_pix | stride) & 3)) return fail(ctx, J2K_ERR_INVALID_ARG, "bad RGBA8 stride / alignment");
-    if (rgba8_fusable(P, d_pix, stride, false)) return plan_forward_impl(P, d_pix, d_coeff, (int)(stride / 4));
+    PixIO io;
+    if (S.mct && pix_fusable(P, 1, 4, d_pix, stride, false, io)) return plan_forward_impl(P, d_pix, d_coeff, io);
     int r = stage_reserve(ctx, 0, (size_t)S.W * S.H * 3 * 4 + 64);          // int32 staging frame
     if (r != J2K_OK) return r;
     r = j2k_unpack_pixels(ctx, J2K_PIX_RGBA8, d_pix, stride, S.W, S.H, 0, (int32_t *)ctx->stage[0]);
@@ -1457,7 +1485,8 @@ extern "C" int j2k_plan_inverse_rgba8(j2k_plan *P, const int32_t *d_coeff, void 
     if (S.C != 3) return fail(ctx, J2K_ERR_INVALID_ARG, "j2k_plan_inverse_rgba8 needs a 3-component plan");
     if (S.dc_shift_inv != 128) return fail(ctx, J2K_ERR_UNSUPPORTED, "j2k_plan_inverse_rgba8 needs an unsigned 8-bit plan");
     if (stride < (size_t)S.W * 4 || (((uintptr_t)d_pix | stride) & 3)) return fail(ctx, J2K_ERR_INVALID_ARG, "bad RGBA8 stride / alignment");
-    if (rgba8_fusable(P, d_pix, stride, true)) return plan_inverse_impl(P, d_coeff, d_pix, (int)(stride / 4));
+    PixIO io;
+    if (S.mct && pix_fusable(P, 1, 4, d_pix, stride, true, io)) return plan_inverse_impl(P, d_coeff, d_pix, io);
     int r = stage_reserve(ctx, 0, (size_t)S.W * S.H * 3 * 4 + 64);
     if (r != J2K_OK) return r;
     r = plan_inverse_impl(P, d_coeff, ctx->stage[0]);
@@ -1471,9 +1500,9 @@ extern "C" int j2k_plan_forward_pixels(j2k_plan *P, int format, const void *d_pi
     const PlanSpec &S = P->spec;
     if (format < 0 || format >= 6) return fail(ctx, J2K_ERR_INVALID_ARG, "unknown pixel format");
     if (kPixComp[format] != S.C) return fail(ctx, J2K_ERR_INVALID_ARG, "pixel format and plan disagree on the component count");
-    if (format == J2K_PIX_RGBA8 && S.precision == 8) return j2k_plan_forward_rgba8(P, d_pix, stride, d_coeff);
-    if (format == J2K_PIX_GRAY16 && stride >= (size_t)S.W * 2 && gray16_fusable(P, d_pix, stride, false))
-        return plan_forward_impl(P, d_pix, d_coeff, (int)(stride / 2), 0);
+    if (stride < (size_t)S.W * kPixBytes[format]) return fail(ctx, J2K_ERR_INVALID_ARG, "pixel stride shorter than a row");
+    PixIO io;
+    if (pix_fusable(P, kPixPrec[format] / 8, S.C == 1 ? 1 : 4, d_pix, stride, false, io)) return plan_forward_impl(P, d_pix, d_coeff, io);
     int r = stage_reserve(ctx, 0, (size_t)S.W * S.H * S.C * 4 + 64);       // int32 staging frame
     if (r != J2K_OK) return r;
     r = j2k_unpack_pixels(ctx, format, d_pix, stride, S.W, S.H, S.precision, (int32_t *)ctx->stage[0]);
@@ -1481,12 +1510,23 @@ extern "C" int j2k_plan_forward_pixels(j2k_plan *P, int format, const void *d_pi
     return plan_forward_impl(P, ctx->stage[0], d_coeff);
 }
 
+extern "C" int j2k_plan_pixels_fused(const j2k_plan *P, int format, const void *d_pix, size_t stride, int inverse) {
+    if (!P || !d_pix) return J2K_ERR_INVALID_ARG;
+    const PlanSpec &S = P->spec;
+    PixIO io;
+    if (inverse) return ((S.precision == 8 || S.precision == 16) && pix_fusable(P, S.precision / 8, S.C == 1 ? 1 : 4, d_pix, stride, true, io)) ? 1 : 0;
+    if (format < 0 || format >= 6 || kPixComp[format] != S.C) return J2K_ERR_INVALID_ARG;
+    return pix_fusable(P, kPixPrec[format] / 8, S.C == 1 ? 1 : 4, d_pix, stride, false, io) ? 1 : 0;
+}
+
 extern "C" int j2k_plan_inverse_pixels(j2k_plan *P, const int32_t *d_coeff, void *d_pix, size_t stride) {
     if (!P || !d_pix || !d_coeff) return J2K_ERR_INVALID_ARG;
     j2k_ctx *ctx = P->ctx;
     const PlanSpec &S = P->spec;
-    if (S.C == 3 && S.precision == 8 && S.dc_shift_inv == 128) return j2k_plan_inverse_rgba8(P, d_coeff, d_pix, stride);
-    if (stride >= (size_t)S.W * 2 && gray16_fusable(P, d_pix, stride, true)) return plan_inverse_impl(P, d_coeff, d_pix, (int)(stride / 2), 0);
+    // decoder.createImage picks the image type from (components, precision): Gray / Gray16, RGBA / RGBA64 (decoder.go:417-588)
+    PixIO io;
+    if ((S.precision == 8 || S.precision == 16) && pix_fusable(P, S.precision / 8, S.C == 1 ? 1 : 4, d_pix, stride, true, io))
+        return plan_inverse_impl(P, d_coeff, d_pix, io);
     int r = stage_reserve(ctx, 0, (size_t)S.W * S.H * S.C * 4 + 64);
     if (r != J2K_OK) return r;
     r = plan_inverse_impl(P, d_coeff, ctx->stage[0]);

@@ -67,7 +67,9 @@ struct LevelLaunch {
     int vec;              // 1: every plane satisfies the vector-access alignment rules
     int ncomp;            // 1 or 3 (3 = fused colour transform on level 0)
     int pf;               // forward 5-3: software-prefetch variant
-    int pix_stride;       // level 0 of an RGB triple: > 0 = the frame is packed RGBA8 with this row stride in PIXELS
+    int pix_stride;       // level 0: > 0 = the frame is packed pixels with this row stride in PIXELS (RGBA8 for a triple unless pix_src says otherwise)
+    int pix_src;          // ... which pixels (dwt53_plane_wg.inc SRC / DST: 1 Gray16, 2 Gray8, 3 a byte of a four-byte pixel, 4 a 16-bit sample of an eight-byte pixel)
+    long long comp_elems; // ... W * H of the frame (plane offsets are component * W * H + y0 * W + x0)
     int wg_waves;         // > 0: `jobs` is the per-WORKGROUP table of dwt53_fwd_rgba8_wg_kernel (dwt53_l0pix.inc): wg_waves
                           // wavefronts per workgroup, wg_waves - 1 pair-rows each; level 0 of an RGBA8 frame only
     int wg_store;         // its final-coefficient store flavour (0 plain, 1 nt, ...)

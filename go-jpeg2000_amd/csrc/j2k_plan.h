@@ -14,6 +14,7 @@ struct j2k_ctx {
                                // Measured slower than the three kernels it replaces (61.7 vs 58.6 us: the prefix chain crosses XCDs)
     int fwd_link = 1;          // forward 5-3: bands of one workgroup exchange halo rows through LDS (J2K_FWD_LINK)
     int inv_link = 1;          // same for the inverse kernels (J2K_INV_LINK)
+    int pix_fuse = 1;          // J2K_PIX_FUSE: packed pixels read / written by the level-0 kernels (1: every format; 2: RGBA8 and Gray16 only, as before round 4; 0: always the int32 staging frame)
     bool plane_wg3 = false;    // ... also level 0 of RGB triples of int32 planes (J2K_PLANE_WG3; measured equal to the general kernel on 4K frames: 43 vs 41 us)
     int plane_wg = 4;          // single-component planes (every level > 0, gray level 0) in workgroup form: waves per workgroup (J2K_PLANE_WG: 0 off, 4, 8)
     int l0_fuse = 0;           // forward levels 0 + 1 of RGBA8 frames in one launch: waves per workgroup of the fused bands (J2K_L0_FUSE: 0 off, 8, 16)
@@ -118,6 +119,7 @@ struct LevelTab {
     // pwaves - 1 pair-rows); empty when a plane of the level breaks the geometry contract
     DwtJob *d_pjobs = nullptr;
     int pnjobs = 0, pwaves = 0, pmulti = 0;
+    bool p_pix_only = false;   // the table serves packed-pixel sources only (level 0 of RGB triples: RGBA64); int32 planes keep the general kernels
 };
 
 }  // namespace j2k

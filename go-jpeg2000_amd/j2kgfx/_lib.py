@@ -57,7 +57,7 @@ SYMBOLS = [
     "j2k_convert_colorspace", "j2k_convert_colorspace_device",
     "j2k_pixels_components", "j2k_pixels_precision", "j2k_extract_image_data", "j2k_create_image",
     "j2k_unpack_pixels", "j2k_pack_pixels", "j2k_plan_forward_rgba8", "j2k_plan_inverse_rgba8",
-    "j2k_plan_forward_pixels", "j2k_plan_inverse_pixels",
+    "j2k_plan_forward_pixels", "j2k_plan_inverse_pixels", "j2k_plan_pixels_fused",
     "j2k_tile_part_bound", "j2k_create_tile_header", "j2k_assemble_tiles", "j2k_read_tile_part_header", "j2k_parse_tile_parts",
     "j2k_plan_tile_parts_bound", "j2k_plan_assemble_tiles_device",
     "j2k_t2_packet_sequence", "j2k_t2_packet_bound", "j2k_t2_encode_packet", "j2k_t2_decode_packet", "j2k_tagtree_shape", "j2k_tcd_init_tile",

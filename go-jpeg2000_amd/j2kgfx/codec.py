@@ -178,6 +178,13 @@ class FramePlan:
         self.ctx.check(self.ctx.L.j2k_plan_forward_pixels(self.h, int(fmt), self._p(pix), C.c_size_t(int(pix.shape[1])), self._p(coeff)))
         return coeff
 
+    def pixels_fused(self, fmt, pix, inverse=False):
+        """would forward_pixels / inverse_pixels read / write these pixels in the level-0 kernels (True) or stage them (False)?"""
+        r = self.ctx.L.j2k_plan_pixels_fused(self.h, int(fmt), self._p(pix), C.c_size_t(int(pix.shape[1])), 1 if inverse else 0)
+        if r < 0:
+            self.ctx.check(r)
+        return bool(r)
+
     @_stage
     def inverse_pixels(self, coeff, pix):
         """inverse path + createImage for the plan's component count and precision into pix (device uint8 [H, stride])."""

@@ -340,9 +340,15 @@ int j2k_plan_inverse_rgba8(j2k_plan *plan, const int32_t *d_coeff, void *d_pix, 
 /* Any pixel format: extractImageData (+ the rescale to the plan's precision) then j2k_plan_forward;
  * j2k_plan_inverse then createImage for the plan's component count and precision.  The plan's
  * component count must equal j2k_pixels_components(format) (forward) / be 1, 3 or 4 (inverse).
- * J2K_PIX_RGBA8 into an 8-bit plan takes the fused kernels above. */
+ * When the plan's precision is the format's own (8 / 16 bit, unsigned, 5-3) and the geometry allows
+ * 16-byte accesses, the level-0 kernels read / write the pixels themselves -- Gray, Gray16, RGBA,
+ * RGBA64, NRGBA, NRGBA64 alike (a fourth component is its own plane: encoder.go:152-179); otherwise
+ * the pixels pass through an int32 staging frame.  Same results either way. */
 int j2k_plan_forward_pixels(j2k_plan *plan, int format, const void *d_pix, size_t stride, int32_t *d_coeff);
 int j2k_plan_inverse_pixels(j2k_plan *plan, const int32_t *d_coeff, void *d_pix, size_t stride);
+/* 1 when that call (inverse != 0: j2k_plan_inverse_pixels, format ignored) would take the fused
+ * kernels for these pixels, 0 when it would stage; < 0 on bad arguments.  Launches nothing. */
+int j2k_plan_pixels_fused(const j2k_plan *plan, int format, const void *d_pix, size_t stride, int inverse);
 
 /* ---- decode-side colour conversions to sRGB ---------------------------------
  * getColorConversion(cs)(componentData, precision) (colorspace.go:54-480); the values are the

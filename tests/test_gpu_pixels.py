@@ -186,6 +186,51 @@ def test_plan_forward_inverse_pixels_all_formats(oracle, fmt, prec):
         assert np.array_equal(out.cpu().numpy(), oracle.create_image([p for p in back.cpu().numpy()], prec))
 
 
+@pytest.mark.parametrize("fmt", range(6))
+@pytest.mark.parametrize("W,H,tile,pad,fused", [(1024, 130, 0, 0, True),      # one plane of two 512-column strips, odd pair count
+                                                 (1536, 77, 512, 32, True),    # three tiles across, odd height, padded rows
+                                                 (512, 1000, 512, 16, True),   # two tiles down, the lower one 488 rows
+                                                 (520, 64, 0, 0, True),        # a second strip of eight columns
+                                                 (256, 64, 0, 8, False),       # rows not 16-byte aligned: staged
+                                                 (100, 75, 64, 16, False)])    # planes that are not whole 16-byte lanes: staged
+def test_plan_pixels_fused_every_format(oracle, fmt, W, H, tile, pad, fused):
+    """VERDICT r3 missing #6: Gray, RGBA64, NRGBA and NRGBA64 pixels (and Gray16 / RGBA as before) are read and written by the
+    level-0 kernels themselves where the geometry allows -- one component as a byte / a 16-bit sample per pixel, a fourth component
+    (NRGBA's alpha, encoder.go:152-179) as its own plane out of the same pixels, RGBA64 triples with the colour transform.  Coefficients
+    equal extractImageData + preprocess of the oracle's planes, pixels equal createImage of the inverse path (decoder.go:417-588: alpha
+    255 / 65535 for three components, component 3 for four; the int32 wrap of v * 65535 / 65535)."""
+    import torch
+    from j2kgfx import pixels
+    from j2kgfx.codec import FramePlan
+    nc, prec = pixels.components(fmt), (16 if fmt in (1, 3, 5) else 8)
+    rng = np.random.default_rng(fmt * 100 + W + H)
+    stride = (W * BPP[fmt] + 15) // 16 * 16 + pad
+    pix = rng.integers(0, 256, (H, stride)).astype(np.uint8)
+    pix[rng.integers(0, H, 40), rng.integers(0, stride, 40)] = 255                # extremes in both byte positions
+    pix[rng.integers(0, H, 40), rng.integers(0, stride, 40)] = 0
+    plan = FramePlan(W, H, nc, precision=prec, lossless=True, num_resolutions=4, cb=(64, 64), tile=(tile, tile), coder=1)
+    dpix = torch.from_numpy(pix).to(plan.device)
+    assert plan.pixels_fused(fmt, dpix) == fused
+    planes = oracle.extract_image_data(pix, fmt, W, H, prec)
+    frame = torch.from_numpy(np.stack(planes)).to(plan.device)
+    torch.cuda.synchronize()
+    want = plan.forward(frame)
+    got = plan.forward_pixels(fmt, dpix)
+    plan.ctx.sync()
+    assert torch.equal(got, want)
+    back = plan.inverse(got)
+    bpp = (1 if nc == 1 else 4) * (prec // 8)
+    ostride = (W * bpp + 15) // 16 * 16 + pad
+    out = torch.full((H, ostride), 0x5A, dtype=torch.uint8, device=plan.device)
+    assert plan.pixels_fused(fmt, out, inverse=True) == fused
+    plan.inverse_pixels(got, out)
+    plan.ctx.sync()
+    o = out.cpu().numpy()
+    assert np.array_equal(o[:, :W * bpp], oracle.create_image([p for p in back.cpu().numpy()], prec))
+    assert (o[:, W * bpp:] == 0x5A).all()                                          # row padding is not touched
+    assert np.array_equal(back.cpu().numpy().reshape(nc, H, W), np.stack(planes))  # and the transform is lossless
+
+
 @pytest.mark.parametrize("cs", range(-1, 18))
 @pytest.mark.parametrize("prec", [8, 12, 16])
 def test_colorspace_conversions(oracle, cs, prec):
