@@ -1085,6 +1085,60 @@ extern "C" int j2k_plan_get_planes(const j2k_plan *P, int64_t *desc7, size_t cap
     memcpy(desc7, P->plane_desc.data(), P->plane_desc.size() * sizeof(int64_t));
     return J2K_OK;
 }
+// ---- Tier-2 packets on device buffers (t2dev.hip) -------------------------------------------------------------------
+extern "C" int j2k_t2_encode_packets_device(j2k_ctx *ctx, const j2k_t2_dev_packet *d_packets, size_t npackets, const j2k_t2_dev_cb *d_cbs, size_t ncbs,
+                                            const uint8_t *d_data, int sop, int eph, uint8_t *bio_delay, uint8_t *d_out, size_t cap,
+                                            uint64_t *d_offs, size_t *total) {
+    if (!ctx || !bio_delay || !d_offs || !total || (npackets && !d_packets) || (ncbs && !d_cbs) || (cap && !d_out)) return J2K_ERR_INVALID_ARG;
+    if (ctx->capturing) return fail(ctx, J2K_ERR_INVALID_ARG, "a synchronising call while the context captures a graph");
+    if (npackets > ((size_t)1 << 31)) return fail(ctx, J2K_ERR_INVALID_ARG, "too many packets");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t ws = j2k::t2_dev_workspace((long)npackets);
+    int r = stage_reserve(ctx, 1, ws + 64);
+    if (r != J2K_OK) return r;
+    uint64_t *d_res = reinterpret_cast<uint64_t *>((uint8_t *)ctx->stage[1] + ((ws + 15) & ~size_t(15)));
+    HIPCHK(ctx, hipMemsetAsync(d_res, 0, 3 * sizeof(uint64_t), ctx->stream));
+    HIPCHK(ctx, j2k::launch_t2_encode_packets(ctx->stream, d_packets, (long)npackets, d_cbs, (uint64_t)ncbs, d_data, sop, eph, *bio_delay ? 1 : 0, d_out, (uint64_t)cap,
+                                              d_offs, ctx->stage[1], d_res));
+    uint64_t res[3] = {0, 0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(res, d_res, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (res[2]) return fail(ctx, J2K_ERR_GO_PANIC, "packet coder: a tag tree of width 0 (the reference divides by it, t2.go:328,348), or a packet whose code-blocks lie outside the table");
+    *total = (size_t)res[0];
+    if (res[0] > cap) return fail(ctx, J2K_ERR_CAPACITY, "packet coder: the output buffer is smaller than the packets");
+    *bio_delay = res[1] ? 1 : 0;
+    return J2K_OK;
+}
+
+// one packet per (tile-component, resolution): a new one where the plane changes or the band index falls back (LL -> HL, HH -> HL)
+extern "C" int j2k_plan_t2_packets(const j2k_plan *P, int layer, j2k_t2_dev_packet *packets, size_t cap, size_t *count) {
+    if (!P || !count || (cap && !packets)) return J2K_ERR_INVALID_ARG;
+    std::vector<j2k_t2_dev_packet> out;
+    const size_t n = P->blocks.size();
+    for (size_t j = 0; j < n; j++) {
+        const j2k_block &b = P->blocks[j];
+        const bool fresh = j == 0 || b.plane != P->blocks[j - 1].plane || b.band < P->blocks[j - 1].band || (P->blocks[j - 1].band == J2K_BAND_LL && b.band != J2K_BAND_LL);
+        if (fresh) {
+            int cols = 0;                                      // block columns of the precinct's first band
+            for (size_t k = j; k < n && P->blocks[k].plane == b.plane && P->blocks[k].band == b.band && P->blocks[k].y0 == b.y0; k++) cols++;
+            out.push_back(j2k_t2_dev_packet{layer, cols, cols, 0, (int64_t)j, 0});
+        }
+        out.back().ncb++;
+    }
+    *count = out.size();
+    if (cap < out.size()) return J2K_ERR_CAPACITY;
+    if (!out.empty()) memcpy(packets, out.data(), out.size() * sizeof(j2k_t2_dev_packet));
+    return J2K_OK;
+}
+
+extern "C" int j2k_plan_t2_fill_cbs(j2k_plan *P, int mb, const uint64_t *d_offs, const uint32_t *d_lens, const uint8_t *d_numbps, j2k_t2_dev_cb *d_cbs) {
+    if (!P || !d_offs || !d_lens || !d_numbps || !d_cbs) return J2K_ERR_INVALID_ARG;
+    j2k_ctx *ctx = P->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, j2k::launch_t2_fill_cbs(ctx->stream, (long)P->blocks.size(), d_offs, d_lens, d_numbps, mb, P->spec.coder == J2K_CODER_HT ? 1 : 0, d_cbs));
+    return J2K_OK;
+}
+
 extern "C" int j2k_plan_get_decoded_offsets(const j2k_plan *P, uint64_t *offs, size_t cap) {
     if (!P || !offs) return J2K_ERR_INVALID_ARG;
     if (cap < P->dec_off.size()) return J2K_ERR_CAPACITY;

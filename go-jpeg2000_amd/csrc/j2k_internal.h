@@ -112,6 +112,12 @@ hipError_t launch_unpack_pixels(hipStream_t s, const uint8_t *pix, size_t stride
 hipError_t launch_colorspace(hipStream_t s, int cs, int32_t *planes, int ncomp, size_t n, int precision);
 hipError_t launch_pack_pixels(hipStream_t s, const int32_t *planes, int ncomp, int precision, int w, int h, uint8_t *pix, size_t stride);
 
+// Tier-2 packets on device buffers (t2dev.hip)
+hipError_t launch_t2_fill_cbs(hipStream_t s, long n, const uint64_t *offs, const uint32_t *lens, const uint8_t *numbps, int mb, int ht, j2k_t2_dev_cb *cbs);
+size_t t2_dev_workspace(long npackets);
+hipError_t launch_t2_encode_packets(hipStream_t s, const j2k_t2_dev_packet *packets, long npackets, const j2k_t2_dev_cb *cbs, uint64_t ncbs, const uint8_t *data,
+                                    int sop, int eph, int delay_in, uint8_t *out, uint64_t cap, uint64_t *offs, void *ws, uint64_t *result);
+
 // DEV BUILDS ONLY (make CXXFLAGS+=-DJ2K_DEV; env J2K_DEV_SKIP = bit mask): launches left out to measure what each kernel
 // costs with several frames in flight (`J2K_DEV_SKIP=<mask> bash tools/ab.sh ...` on a -DJ2K_DEV build).  Results are wrong with any bit set, so the shipped library
 // does not have the switch at all: g_dev_skip is the constant 0 and every test of it folds away.

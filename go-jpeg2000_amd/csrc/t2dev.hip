@@ -1,0 +1,287 @@
+// t2dev.hip -- Tier-2 packet ENCODING on device buffers: PacketEncoder.EncodePacket (internal/tcd/t2.go:250-438)
+// for a whole run of packets, over code-block bytes that never leave HBM.  csrc/t2.cpp is the same coder on host buffers, one packet
+// per call; this is the batch form for the end of the encode pipeline (block coder -> compaction -> packets).
+//
+// What is serial in the reference and what is not:
+//   * a packet's header is a bit string through bio.ByteStuffingWriter (bio.go:157-226: after a 0xFF byte the next byte holds seven
+//     bits), flushed at its end: bit-serial, but independent of every other packet EXCEPT for one flag -- whether the last header byte
+//     the encoder wrote was 0xFF, which the writer keeps across packets (the Flush leaves it).  So every packet is sized for both
+//     values of the flag (t2_size_kernel, a wavefront per packet: the lanes form the code-blocks' header fields, two lanes string them
+//     together for the two entry states), a scan composes the packets' flag -> flag maps and sums the lengths (t2_scan_kernel, one
+//     workgroup), and the packets are then written in parallel, each at its final offset with its flag known (t2_header_kernel, a
+//     wavefront per packet; t2_body_kernel, eight wavefronts per packet copy the code-blocks' bytes);
+//   * the "tag tree" values are unary (t2.go:368-377) -- a run of zeros is added in bulk, so a large value costs its bytes, not its bits;
+//     everything else goes into the writer a field at a time, not a bit at a time.
+// The reference's quirks stay (include/j2kgfx.h, "Tier-2"): inclusion is written for every block of layer 0 whether or not it is
+// included, the length-of-length field has three bits and wraps, a tree width of 0 is Go's divide panic.
+#include "j2k_internal.h"
+
+namespace j2k {
+
+// bio.ByteStuffingWriter, fed several bits at a time; out == nullptr: count only.  A byte holds 8 bits, or 7 behind a 0xFF byte (and a
+// 7-bit byte is never 0xFF itself).
+struct T2Sink {
+    uint8_t *out;
+    uint64_t n;
+    uint64_t acc;         // the low `have` bits are pending, oldest on top
+    unsigned have;        // < 8 between calls
+    bool after_ff;
+    __device__ __forceinline__ void drain() {
+        for (;;) {
+            const unsigned room = after_ff ? 7u : 8u;
+            if (have < room) break;
+            const unsigned b = (unsigned)(acc >> (have - room)) & ((1u << room) - 1u);
+            if (out) out[n] = (uint8_t)b;
+            n++;
+            have -= room;
+            after_ff = b == 0xFF;
+        }
+    }
+    __device__ __forceinline__ void put(uint32_t v, unsigned count) {       // count <= 32, MSB first (bio.go:196-205)
+        if (!count) return;
+        acc = (acc << count) | (uint64_t)(count < 32 ? v & ((1u << count) - 1u) : v);
+        have += count;
+        drain();
+    }
+    __device__ void zeros(int64_t z) {                      // a unary value's run (t2.go:368-377): in bulk once a byte boundary is reached
+        while (z > 0) {
+            if (have == 0 && !after_ff && z >= 8) {
+                const int64_t whole = z >> 3;               // whole zero bytes: eight bits each, none of them 0xFF
+                if (out) for (int64_t i = 0; i < whole; i++) out[n + i] = 0;
+                n += (uint64_t)whole;
+                z &= 7;
+            } else {
+                const unsigned room = (after_ff ? 7u : 8u) - have;
+                const unsigned c = (unsigned)(z < (int64_t)room ? z : (int64_t)room);
+                put(0, c);
+                z -= c;
+            }
+        }
+    }
+    __device__ void flush() {                               // bio.go:211-221: pad the byte in progress with zeros
+        if (have) put(0, (after_ff ? 7u : 8u) - have);
+    }
+};
+
+__device__ __forceinline__ bool t2_contributes(const j2k_t2_dev_cb &cb, int layer) { return cb.included_in_layers <= layer && cb.data_len > 0; }
+
+// One code-block's share of a packet header (t2.go:320-364) as two unary runs and two bit strings: zeros z1, bits b1 (n1), zeros z2,
+// bits b2 (n2 <= 52: the closing one of the zero-bit-plane value, the pass code of t2.go:379-406, the bit length of the length in a
+// 3-bit field -- it wraps -- and the length in all its bits, t2.go:408-437).
+struct T2Fields { uint32_t z1, z2, b1, n1, n2, pad_; uint64_t b2; };
+__device__ __forceinline__ T2Fields t2_fields(const j2k_t2_dev_cb &cb, int layer) {
+    T2Fields F{0, 0, 0, 0, 0, 0, 0};
+    const bool inc = t2_contributes(cb, layer);
+    if (layer == 0) { F.z1 = cb.included_in_layers > 0 ? (uint32_t)cb.included_in_layers : 0u; F.b1 = 1; F.n1 = 1; }   // written whether or not the block is included
+    else { F.b1 = inc ? 1u : 0u; F.n1 = 1; }
+    if (!inc) return F;
+    uint64_t b = 0;
+    unsigned n = 0;
+    auto add = [&](uint32_t v, unsigned c) { b = (b << c) | ((uint64_t)v & ((1ull << c) - 1ull)); n += c; };
+    if (cb.included_in_layers == layer) { F.z2 = cb.zero_bit_planes > 0 ? (uint32_t)cb.zero_bit_planes : 0u; add(1, 1); }
+    const int np = cb.num_passes;
+    if (np == 1) add(0, 1);
+    else if (np == 2) add(2, 2);
+    else if (np <= 5) { add(3, 2); add((uint32_t)(np - 3), 2); }
+    else if (np <= 36) { add(15, 4); add((uint32_t)(np - 6), 5); }
+    else { add(0x1FF, 9); add((uint32_t)(np - 37), 7); }
+    unsigned nb = 0;
+    for (uint32_t t = cb.data_len; t; t >>= 1) nb++;
+    add(nb, 3);
+    if (nb) add(cb.data_len, nb);
+    F.b2 = b; F.n2 = n;
+    return F;
+}
+
+// encodePacketHeader (t2.go:293-366) by one wavefront: 64 code-blocks at a time, every lane forms the fields of one, then the lanes
+// below `nsinks` string them together, each into its own sink (the size pass runs the two entry states of the writer side by side).
+// Returns false on the reference's divide panic (a tree of width 0 that the coder consults) or a table out of range.
+__device__ bool t2_header_wave(T2Sink &w, int nsinks, const j2k_t2_dev_packet &P, const j2k_t2_dev_cb *__restrict__ cbs, T2Fields *fld, int lane) {
+    const int layer = P.layer;
+    bool any = false, need_imsb = false;
+    for (int64_t i0 = 0; i0 < P.ncb; i0 += 64) {
+        const int64_t i = i0 + lane;
+        bool c = false, m = false;
+        if (i < P.ncb) { const j2k_t2_dev_cb cb = cbs[i]; c = t2_contributes(cb, layer); m = c && cb.included_in_layers == layer; }
+        any |= __any(c) != 0;
+        need_imsb |= __any(m) != 0;
+    }
+    if (any && ((layer == 0 && P.incl_tree_w == 0) || (need_imsb && P.imsb_tree_w == 0))) return false;
+    const bool mine = lane < nsinks;
+    if (!any) {
+        if (mine) w.put(0, 1);
+    } else {
+        if (mine) w.put(1, 1);
+        for (int64_t i0 = 0; i0 < P.ncb; i0 += 64) {
+            const int64_t i = i0 + lane;
+            __syncthreads();                                // (one wavefront: orders the LDS traffic of the two phases)
+            if (i < P.ncb) fld[lane] = t2_fields(cbs[i], layer);
+            __syncthreads();
+            const int cnt = (int)(P.ncb - i0 < 64 ? P.ncb - i0 : 64);
+            if (mine)
+                for (int j = 0; j < cnt; j++) {
+                    const T2Fields F = fld[j];
+                    w.zeros(F.z1); w.put(F.b1, F.n1);
+                    w.zeros(F.z2);
+                    if (F.n2 > 32) { w.put((uint32_t)(F.b2 >> 32), F.n2 - 32); w.put((uint32_t)F.b2, 32); } else w.put((uint32_t)F.b2, F.n2);
+                }
+        }
+    }
+    if (mine) w.flush();
+    return true;
+}
+
+// per packet: header bytes for the writer's flag clear / set on entry, the flag on exit, the body bytes
+struct T2Size { uint64_t hlen[2]; uint64_t body; uint32_t ff_out; uint32_t pad_; };
+
+__global__ __launch_bounds__(64) void t2_size_kernel(const j2k_t2_dev_packet *__restrict__ packets, long npackets, const j2k_t2_dev_cb *__restrict__ cbs,
+                                                     uint64_t ncbs, T2Size *__restrict__ sizes, uint64_t *__restrict__ result) {
+    __shared__ T2Fields fld[64];
+    const long p = blockIdx.x;
+    const int lane = threadIdx.x;
+    const j2k_t2_dev_packet P = packets[p];
+    T2Sink w{nullptr, 0, 0, 0, lane == 1};
+    if (P.ncb < 0 || P.cb0 < 0 || (uint64_t)P.cb0 + (uint64_t)P.ncb > ncbs || !t2_header_wave(w, 2, P, cbs + P.cb0, fld, lane)) {
+        if (lane == 0) { atomicMax((unsigned long long *)&result[2], 1ull); sizes[p] = T2Size{}; }
+        return;
+    }
+    uint64_t body = 0;
+    for (int64_t i = lane; i < P.ncb; i += 64) { const j2k_t2_dev_cb cb = cbs[P.cb0 + i]; if (t2_contributes(cb, P.layer)) body += cb.data_len; }
+    for (int d = 32; d > 0; d >>= 1) body += __shfl_xor(body, d);
+    const uint64_t h1 = __shfl(w.n, 1);
+    const uint32_t f1 = __shfl((uint32_t)w.after_ff, 1);
+    if (lane == 0) {
+        T2Size S{};
+        S.hlen[0] = w.n; S.hlen[1] = h1; S.body = body;
+        S.ff_out = (w.after_ff ? 1u : 0u) | f1 << 1;
+        sizes[p] = S;
+    }
+}
+
+// offs[p] = where packet p starts, var[p] = the writer's flag on entry; result = {total bytes, flag after the last packet, fault}
+__global__ __launch_bounds__(256) void t2_scan_kernel(const T2Size *__restrict__ sizes, long npackets, int fixed, int delay_in, uint64_t *__restrict__ offs,
+                                                      uint8_t *__restrict__ var, uint64_t *__restrict__ result) {
+    __shared__ uint64_t len_s[256][2], base_s[256];
+    __shared__ uint8_t st_s[256][2], in_s[256];
+    const int t = threadIdx.x;
+    const long chunk = (npackets + 255) / 256, p0 = (long)t * chunk < npackets ? (long)t * chunk : npackets, p1 = p0 + chunk < npackets ? p0 + chunk : npackets;
+    for (int s = 0; s < 2; s++) {
+        uint64_t len = 0;
+        int st = s;
+        for (long p = p0; p < p1; p++) { const T2Size S = sizes[p]; len += (uint64_t)fixed + S.hlen[st] + S.body; st = (S.ff_out >> st) & 1; }
+        len_s[t][s] = len; st_s[t][s] = (uint8_t)st;
+    }
+    __syncthreads();
+    if (t == 0) {
+        uint64_t base = 0;
+        int st = delay_in ? 1 : 0;
+        for (int c = 0; c < 256; c++) { base_s[c] = base; in_s[c] = (uint8_t)st; base += len_s[c][st]; st = st_s[c][st]; }
+        result[0] = base; result[1] = (uint64_t)st;
+        offs[npackets] = base;
+    }
+    __syncthreads();
+    uint64_t off = base_s[t];
+    int st = in_s[t];
+    for (long p = p0; p < p1; p++) {
+        const T2Size S = sizes[p];
+        offs[p] = off; var[p] = (uint8_t)st;
+        off += (uint64_t)fixed + S.hlen[st] + S.body;
+        st = (S.ff_out >> st) & 1;
+    }
+}
+
+// markers + header of packet p at its final place, the writer's entry state known (t2.go:257-276)
+__global__ __launch_bounds__(64) void t2_header_kernel(const j2k_t2_dev_packet *__restrict__ packets, long npackets, const j2k_t2_dev_cb *__restrict__ cbs,
+                                                       const T2Size *__restrict__ sizes, const uint64_t *__restrict__ offs, const uint8_t *__restrict__ var,
+                                                       int sop, int eph, uint8_t *__restrict__ out, uint64_t cap, const uint64_t *__restrict__ result) {
+    __shared__ T2Fields fld[64];
+    const long p = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (result[2] != 0 || offs[npackets] > cap) return;      // (a fault or too little room: nothing is written, the host reports it)
+    const j2k_t2_dev_packet P = packets[p];
+    const int v = var[p];
+    uint8_t *o = out + offs[p];
+    if (lane == 0 && sop) { o[0] = 0xFF; o[1] = 0x91; o[2] = 0x00; o[3] = 0x04; o[4] = (uint8_t)((unsigned)P.layer >> 8); o[5] = (uint8_t)P.layer; }
+    T2Sink w{o + (sop ? 6 : 0), 0, 0, 0, v != 0};
+    (void)t2_header_wave(w, 1, P, cbs + P.cb0, fld, lane);
+    if (lane == 0 && eph) { uint8_t *e = o + (sop ? 6 : 0) + sizes[p].hlen[v]; e[0] = 0xFF; e[1] = 0x92; }
+}
+
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+#define T2_BODY_SLICES 8
+// The bodies in block order behind the header (t2.go:279-287).  Wavefront (p, s) copies the code-blocks j = s mod T2_BODY_SLICES of
+// packet p; every wavefront sizes all of them (64 at a time, a scan over the lanes) to know where its own go.
+__global__ __launch_bounds__(64) void t2_body_kernel(const j2k_t2_dev_packet *__restrict__ packets, long npackets, const j2k_t2_dev_cb *__restrict__ cbs,
+                                                     const uint8_t *__restrict__ data, const T2Size *__restrict__ sizes, const uint64_t *__restrict__ offs,
+                                                     const uint8_t *__restrict__ var, int fixed, uint8_t *__restrict__ out, uint64_t cap,
+                                                     const uint64_t *__restrict__ result) {
+    const long p = blockIdx.x;
+    const int slice = blockIdx.y, lane = threadIdx.x;
+    if (result[2] != 0 || offs[npackets] > cap) return;
+    const j2k_t2_dev_packet P = packets[p];
+    uint8_t *o = out + offs[p];
+    uint64_t pos = (uint64_t)fixed + sizes[p].hlen[var[p]];
+    for (int64_t i0 = 0; i0 < P.ncb; i0 += 64) {
+        const int64_t i = i0 + lane;
+        j2k_t2_dev_cb cb{};
+        if (i < P.ncb) cb = cbs[P.cb0 + i];
+        const uint32_t mylen = (i < P.ncb && t2_contributes(cb, P.layer)) ? cb.data_len : 0u;
+        uint64_t incl = mylen;
+        for (int d = 1; d < 64; d <<= 1) { const uint64_t u = __shfl_up(incl, d); if (lane >= d) incl += u; }
+        const uint64_t myoff = pos + incl - mylen;
+        const int cnt = (int)(P.ncb - i0 < 64 ? P.ncb - i0 : 64);
+        for (int j = slice; j < cnt; j += T2_BODY_SLICES) {
+            const uint32_t len = __shfl(mylen, j);
+            if (!len) continue;
+            const uint64_t dof = __shfl(myoff, j), sof = __shfl(cb.data_off, j);
+            const uint8_t *s = data + sof;
+            uint8_t *d = o + dof;
+            const uint32_t words = len >> 2;
+            for (uint32_t k = lane; k < words; k += 64) *reinterpret_cast<u32_unaligned *>(d + 4 * k) = *reinterpret_cast<const u32_unaligned *>(s + 4 * k);
+            if (lane < (int)(len & 3)) d[4 * words + lane] = s[4 * words + lane];
+        }
+        pos += __shfl(incl, 63);
+    }
+}
+
+// The block coder's outputs as packet tables: code-block j of a plan (its job order is component, resolution, band, block row,
+// block column: encoder.go:616-673) with the bytes lens[j] at offs[j] of the compacted stream.  IncludedInLayers 0, Passes = the
+// 3 * numBPS - 2 coding passes EncodeFast5 ran (t1_fast5.go:66-70; HT: one), ZeroBitPlanes = max(mb - numBPS, 0).
+__global__ __launch_bounds__(256) void t2_fill_cbs_kernel(long n, const uint64_t *__restrict__ offs, const uint32_t *__restrict__ lens,
+                                                          const uint8_t *__restrict__ numbps, int mb, int ht, j2k_t2_dev_cb *__restrict__ cbs) {
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const int nb = numbps[j];
+    j2k_t2_dev_cb cb{};
+    cb.included_in_layers = 0;
+    cb.zero_bit_planes = mb > nb ? mb - nb : 0;
+    cb.num_passes = nb == 0 ? 0 : (ht ? 1 : 3 * nb - 2);
+    cb.data_len = lens[j];
+    cb.data_off = offs[j];
+    cbs[j] = cb;
+}
+
+hipError_t launch_t2_fill_cbs(hipStream_t s, long n, const uint64_t *offs, const uint32_t *lens, const uint8_t *numbps, int mb, int ht, j2k_t2_dev_cb *cbs) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(t2_fill_cbs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, offs, lens, numbps, mb, ht, cbs);
+    return hipGetLastError();
+}
+
+size_t t2_dev_workspace(long npackets) { return (size_t)npackets * sizeof(T2Size) + (size_t)npackets + 64; }
+
+// ws: t2_dev_workspace(npackets) bytes; result: 3 x uint64 {total, flag out, fault}, zeroed by the caller on this stream
+hipError_t launch_t2_encode_packets(hipStream_t s, const j2k_t2_dev_packet *packets, long npackets, const j2k_t2_dev_cb *cbs, uint64_t ncbs, const uint8_t *data,
+                                    int sop, int eph, int delay_in, uint8_t *out, uint64_t cap, uint64_t *offs, void *ws, uint64_t *result) {
+    T2Size *sizes = reinterpret_cast<T2Size *>(ws);
+    uint8_t *var = reinterpret_cast<uint8_t *>(sizes + npackets);
+    const int fixed = (sop ? 6 : 0) + (eph ? 2 : 0);
+    if (npackets > 0) hipLaunchKernelGGL(t2_size_kernel, dim3((unsigned)npackets), dim3(64), 0, s, packets, npackets, cbs, ncbs, sizes, result);
+    hipLaunchKernelGGL(t2_scan_kernel, dim3(1), dim3(256), 0, s, sizes, npackets, fixed, delay_in, offs, var, result);
+    if (npackets > 0) {
+        hipLaunchKernelGGL(t2_header_kernel, dim3((unsigned)npackets), dim3(64), 0, s, packets, npackets, cbs, sizes, offs, var, sop, eph, out, cap, result);
+        hipLaunchKernelGGL(t2_body_kernel, dim3((unsigned)npackets, T2_BODY_SLICES), dim3(64), 0, s, packets, npackets, cbs, data, sizes, offs, var, fixed, out, cap, result);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace j2k

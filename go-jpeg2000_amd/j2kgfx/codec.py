@@ -204,6 +204,25 @@ class FramePlan:
                                                          self._p(numbps)))
         return stream, offs, lens, numbps
 
+    def t2_packets(self, layer=0):
+        """one packet per (tile-component, resolution) of the plan in job order: numpy table (t2.DEV_PACKET_DTYPE)"""
+        from . import t2
+        n = C.c_size_t(0)
+        st = self.ctx.L.j2k_plan_t2_packets(self.h, int(layer), None, C.c_size_t(0), C.byref(n))
+        if st not in (0, -4):
+            self.ctx.check(st)
+        out = np.zeros(n.value, t2.DEV_PACKET_DTYPE)
+        self.ctx.check(self.ctx.L.j2k_plan_t2_packets(self.h, int(layer), out.ctypes.data_as(C.c_void_p), C.c_size_t(n.value), C.byref(n)))
+        return out
+
+    @_stage
+    def t2_fill_cbs(self, mb, offs, lens, numbps, cbs=None):
+        """the block coder's outputs as the packet coder's code-block table (device uint8 [blocks * 24])"""
+        t = _torch()
+        cbs = cbs if cbs is not None else self.empty(int(self.info.blocks) * 24, t.uint8)
+        self.ctx.check(self.ctx.L.j2k_plan_t2_fill_cbs(self.h, int(mb), self._p(offs), self._p(lens), self._p(numbps), self._p(cbs)))
+        return cbs
+
     def pack_bound(self):
         return int(self.ctx.L.j2k_plan_pack_bound(self.h))
 

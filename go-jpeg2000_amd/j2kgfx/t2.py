@@ -156,6 +156,55 @@ class PacketEncoder:
         self.buf += out[:n.value].tobytes()
 
 
+class _DevCb(C.Structure):
+    _fields_ = [("included_in_layers", C.c_int32), ("zero_bit_planes", C.c_int32), ("num_passes", C.c_int32), ("data_len", C.c_uint32),
+                ("data_off", C.c_uint64)]
+
+
+class _DevPacket(C.Structure):
+    _fields_ = [("layer", C.c_int32), ("incl_tree_w", C.c_int32), ("imsb_tree_w", C.c_int32), ("pad_", C.c_int32), ("cb0", C.c_int64),
+                ("ncb", C.c_int64)]
+
+
+DEV_CB_DTYPE = np.dtype([("included_in_layers", "<i4"), ("zero_bit_planes", "<i4"), ("num_passes", "<i4"), ("data_len", "<u4"), ("data_off", "<u8")])
+DEV_PACKET_DTYPE = np.dtype([("layer", "<i4"), ("incl_tree_w", "<i4"), ("imsb_tree_w", "<i4"), ("pad_", "<i4"), ("cb0", "<i8"), ("ncb", "<i8")])
+
+
+class DevicePacketEncoder:
+    """One tcd.PacketEncoder whose EncodePacket calls are made a RUN at a time on device buffers (csrc/t2dev.hip,
+    j2k_t2_encode_packets_device): the byte-stuffing writer's state carries from run to run as it does from packet to packet."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self._delay = C.c_uint8(0)
+
+    def tables(self, runs):
+        """numpy tables for a run given as [(Precinct, layer), ...]: (packets, cbs, data) with every block's bytes appended to data"""
+        packets = np.zeros(len(runs), DEV_PACKET_DTYPE)
+        cbs, data = [], bytearray()
+        for i, (pr, layer) in enumerate(runs):
+            flat = [cb for band in pr.CodeBlocks for cb in band]
+            packets[i] = (int(layer), pr.InclusionTree.width, pr.IMSBTree.width, 0, len(cbs), len(flat))
+            for cb in flat:
+                d = cb.Data or b""
+                cbs.append((cb.IncludedInLayers, cb.ZeroBitPlanes, cb.Passes, len(d), len(data)))
+                data += d
+        return packets, np.array(cbs, DEV_CB_DTYPE) if cbs else np.zeros(0, DEV_CB_DTYPE), np.frombuffer(bytes(data), np.uint8)
+
+    def encode(self, d_packets, npackets, d_cbs, d_data, enableSOP, enableEPH, d_out, d_offs):
+        """device tensors in (uint8 views of the tables), packets out into d_out at d_offs (int64 / uint64 [npackets + 1]); returns the total"""
+        L = self.ctx.L
+        total = C.c_size_t(0)
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None and t.numel() else None      # noqa: E731
+        st = L.j2k_t2_encode_packets_device(self.ctx.h, ptr(d_packets), C.c_size_t(int(npackets)), ptr(d_cbs),
+                                            C.c_size_t(int(d_cbs.numel()) // 24 if d_cbs is not None else 0), ptr(d_data), int(bool(enableSOP)),
+                                            int(bool(enableEPH)), C.byref(self._delay), ptr(d_out), C.c_size_t(int(d_out.numel()) if d_out is not None else 0),
+                                            ptr(d_offs), C.byref(total))
+        self.total = total.value
+        self.ctx.check(st)
+        return total.value
+
+
 class PacketDecoder:
     """tcd.NewPacketDecoder(data)"""
 

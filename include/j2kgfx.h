@@ -453,6 +453,28 @@ int j2k_t2_encode_packet(const j2k_t2_precinct *p, int layer, int sop, int eph, 
  * the reference's error return: J2K_ERR_INVALID_ARG. */
 typedef struct j2k_t2_dec_state { uint64_t pos, rpos; uint8_t buf, cnt, saw_ff, pad_[5]; } j2k_t2_dec_state;
 int j2k_t2_decode_packet(const uint8_t *data, size_t len, j2k_t2_dec_state *st, j2k_t2_precinct *p, int layer, int sop, int eph);
+/* PacketEncoder.EncodePacket for a RUN of packets on DEVICE buffers (csrc/t2dev.hip): packet i is coded by the same encoder
+ * right after packet i - 1, so the writer's "last byte was 0xFF" flag runs through the run (*bio_delay in and out, as above).
+ * A packet = its layer, the widths of its two tag trees (divisors only) and ncb code-blocks from d_cbs[cb0] (a table of ncbs) in coding order
+ * (band after band: the band structure changes nothing in the bytes, t2.go:320-364); a code-block's bytes are data_len bytes
+ * at d_data + data_off (e.g. the compacted stream of j2k_plan_encode_stream).  Packet i lands at d_out + d_offs[i]
+ * (d_offs: npackets + 1 entries, the last = *total).  J2K_ERR_CAPACITY (with *total set, nothing written) when cap is
+ * smaller; J2K_ERR_GO_PANIC for a tree width of 0 that the coder divides by.  Synchronises the context's stream. */
+typedef struct j2k_t2_dev_cb { int32_t included_in_layers, zero_bit_planes, num_passes; uint32_t data_len; uint64_t data_off; } j2k_t2_dev_cb;
+typedef struct j2k_t2_dev_packet { int32_t layer, incl_tree_w, imsb_tree_w, pad_; int64_t cb0, ncb; } j2k_t2_dev_packet;
+int j2k_t2_encode_packets_device(j2k_ctx *ctx, const j2k_t2_dev_packet *d_packets, size_t npackets, const j2k_t2_dev_cb *d_cbs, size_t ncbs,
+                                 const uint8_t *d_data, int sop, int eph, uint8_t *bio_delay, uint8_t *d_out, size_t cap,
+                                 uint64_t *d_offs, size_t *total);
+/* The block coder's outputs as those tables.  j2k_plan_t2_packets (host table out): one packet per (tile, component,
+ * resolution) of the plan in job order (encoder.go:616-673: tile, component, resolution, band, block row, block column), its
+ * code-blocks = the plan's jobs of that resolution, tree widths = block columns of its first band; layer as given.
+ * j2k_plan_t2_fill_cbs (device, asynchronous): code-block j from d_offs / d_lens / d_numbps of j2k_plan_encode_stream:
+ * IncludedInLayers 0, len(Passes) = 3 * numBPS - 2 (the passes EncodeFast5 runs, t1_fast5.go:66-70; HT blocks: 1; empty
+ * blocks: 0), ZeroBitPlanes = max(mb - numBPS, 0) -- the reference never fills these fields from real blocks (only its
+ * tests build precincts, t2_test.go), so this mapping is this library's. */
+int j2k_plan_t2_packets(const j2k_plan *plan, int layer, j2k_t2_dev_packet *packets, size_t cap, size_t *count);
+int j2k_plan_t2_fill_cbs(j2k_plan *plan, int mb, const uint64_t *d_offs, const uint32_t *d_lens, const uint8_t *d_numbps,
+                         j2k_t2_dev_cb *d_cbs);
 /* NewTagTree(width, height) (tcd.go:168-197): number of levels and nodes per level (the coder never walks the tree) */
 int j2k_tagtree_shape(int width, int height, int32_t *levels, int64_t *level_sizes, size_t cap);
 
