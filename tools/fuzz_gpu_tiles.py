@@ -19,12 +19,12 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 t0 = time.time()
-n = npanic = npix = 0
+n = npanic = npix = nfused = 0
 t_say = t0
 while time.time() - t0 < budget:
     if time.time() - t_say > 60:                          # (a run that prints nothing for minutes is taken to be hung)
         t_say = time.time(); print("... %d frames, %.0f s" % (n, t_say - t0), flush=True)
-    Cn = int(rng.choice([1, 3]))
+    Cn = int(rng.choice([1, 3, 3, 4]))
     tile = int(rng.choice([32, 64, 128, 256, 512]))
     W = int(rng.choice([tile, tile + 8, 2 * tile, 2 * tile + 24, 3 * tile - 16, 100, 264, 520, 1032]))
     H = int(rng.choice([tile, tile + 3, 2 * tile - 5, 33, 64, 130]))
@@ -111,26 +111,37 @@ while time.time() - t0 < budget:
                 want_d = orc.ht_decode(chunk, bw, bh) if coder == 1 else orc.t1_decode(chunk, int(wn[k]), band, bw, bh)
                 assert np.array_equal(hd[int(doffs[j]):int(doffs[j]) + bw * bh].reshape(bh, bw), want_d), ("decoded", desc, tl, k)
             j0 += nj
-    # packed pixels in and out (8-bit RGB -> RGBA8, 16-bit gray -> Gray16) against the planar entry points
-    if lossless and ((Cn == 3 and prec == 8) or (Cn == 1 and prec == 16)):
+    # packed pixels in and out -- image.Gray / Gray16 / RGBA / RGBA64 / NRGBA / NRGBA64 by component count and precision -- against the
+    # planar entry points and decoder.createImage (row strides with and without the 16-byte alignment the fused kernels need)
+    if lossless and prec in (8, 16):
+        fmt = {1: 0, 3: 2, 4: 4}[Cn] + (1 if prec == 16 else 0)
+        ch, sb = (1 if Cn == 1 else 4), prec // 8
+        samp = np.zeros((H, W, ch), np.int64)
+        samp[..., :Cn] = frame.transpose(1, 2, 0)
         if Cn == 3:
-            pix = np.concatenate([frame.transpose(1, 2, 0), np.full((H, W, 1), 255, np.int32)], axis=2).astype(np.uint8).reshape(H, W * 4)
-            dp = torch.from_numpy(np.ascontiguousarray(pix)).to(plan.device)
-            c2 = plan.forward_rgba8(dp)
-            out = plan.inverse_rgba8(c2)
-        else:
-            be = frame[0].astype(">u2").view(np.uint8).reshape(H, W * 2)
-            pix = np.ascontiguousarray(be)
-            dp = torch.from_numpy(pix).to(plan.device)
-            c2 = plan.forward_pixels(1, dp)
-            out = torch.zeros((H, W * 2), dtype=torch.uint8, device=plan.device)
-            plan.inverse_pixels(c2, out)
+            samp[..., 3] = rng.integers(0, top + 1, (H, W))                 # alpha of an RGBA source: ignored (encoder.go:108-138)
+        row = (samp.astype(">u2").view(np.uint8) if sb == 2 else samp.astype(np.uint8)).reshape(H, W * ch * sb)
+        stride = (row.shape[1] + 15) // 16 * 16 + int(rng.choice([0, 0, 16, 8, 3 if ch * sb == 1 else 24])) if rng.random() < 0.8 else row.shape[1]
+        pix = rng.integers(0, 256, (H, stride)).astype(np.uint8)
+        pix[:, :row.shape[1]] = row
+        dp = torch.from_numpy(pix).to(plan.device)
+        nfused += int(plan.pixels_fused(fmt, dp))
+        c2 = plan.forward_pixels(fmt, dp)
+        out = torch.full((H, stride), 0x5A, dtype=torch.uint8, device=plan.device)
+        plan.inverse_pixels(c2, out)
+        if Cn == 3 and prec == 8 and stride % 4 == 0:                        # the RGBA8 entry points of round 2
+            c3 = plan.forward_rgba8(dp)
+            plan.ctx.sync()
+            assert torch.equal(c3, coeff), ("rgba8 forward", desc)
         plan.ctx.sync()
-        assert torch.equal(c2, coeff), ("pixel forward", desc)
-        # decoder.createImage: 8-bit RGBA returns the pixels; 16-bit gray goes through the reference's wrapping v * 65535 / 65535
-        want_pix = pix if Cn == 3 else orc.create_image([frame[0]], 16)
-        assert np.array_equal(out.cpu().numpy(), want_pix), ("pixel inverse", desc)
+        assert torch.equal(c2, coeff), ("pixel forward", desc, fmt, stride)
+        # decoder.createImage: alpha 255 / 65535 for three components, component 3 for four; 16 bit goes through the reference's
+        # wrapping v * 65535 / 65535
+        want_pix = orc.create_image([frame[c] for c in range(Cn)], prec)
+        o = out.cpu().numpy()
+        assert np.array_equal(o[:, :row.shape[1]], want_pix), ("pixel inverse", desc, fmt, stride)
+        assert (o[:, row.shape[1]:] == 0x5A).all(), ("pixel inverse: row padding written", desc, fmt, stride)
         npix += 1
     plan.close()
     n += 1
-print("fuzz (tiles) ok: %d frames (%d in the Go-panic domain, %d through the pixel entry points) in %.0f s (seed %d)" % (n, npanic, npix, time.time() - t0, seed))
+print("fuzz (tiles) ok: %d frames (%d in the Go-panic domain, %d through the pixel entry points, %d of those read by the level-0 kernels themselves) in %.0f s (seed %d)" % (n, npanic, npix, nfused, time.time() - t0, seed))
