@@ -96,9 +96,11 @@ __device__ __forceinline__ T2Fields t2_fields(const j2k_t2_dev_cb &cb, int layer
 // encodePacketHeader (t2.go:293-366) by one wavefront: 64 code-blocks at a time, every lane forms the fields of one, then the lanes
 // below `nsinks` string them together, each into its own sink (the size pass runs the two entry states of the writer side by side).
 // Returns false on the reference's divide panic (a tree of width 0 that the coder consults) or a table out of range.
-__device__ bool t2_header_wave(T2Sink &w, int nsinks, const j2k_t2_dev_packet &P, const j2k_t2_dev_cb *__restrict__ cbs, T2Fields *fld, int lane) {
+// does the packet hold data (t2.go:295-309), and does its header divide by a tree width of 0 (false)?
+__device__ bool t2_header_checks(const j2k_t2_dev_packet &P, const j2k_t2_dev_cb *__restrict__ cbs, int lane, bool &any) {
     const int layer = P.layer;
-    bool any = false, need_imsb = false;
+    bool need_imsb = false;
+    any = false;
     for (int64_t i0 = 0; i0 < P.ncb; i0 += 64) {
         const int64_t i = i0 + lane;
         bool c = false, m = false;
@@ -106,7 +108,12 @@ __device__ bool t2_header_wave(T2Sink &w, int nsinks, const j2k_t2_dev_packet &P
         any |= __any(c) != 0;
         need_imsb |= __any(m) != 0;
     }
-    if (any && ((layer == 0 && P.incl_tree_w == 0) || (need_imsb && P.imsb_tree_w == 0))) return false;
+    return !(any && ((layer == 0 && P.incl_tree_w == 0) || (need_imsb && P.imsb_tree_w == 0)));
+}
+__device__ bool t2_header_wave(T2Sink &w, int nsinks, const j2k_t2_dev_packet &P, const j2k_t2_dev_cb *__restrict__ cbs, T2Fields *fld, int lane) {
+    const int layer = P.layer;
+    bool any = false;
+    if (!t2_header_checks(P, cbs, lane, any)) return false;
     const bool mine = lane < nsinks;
     if (!any) {
         if (mine) w.put(0, 1);
@@ -131,17 +138,106 @@ __device__ bool t2_header_wave(T2Sink &w, int nsinks, const j2k_t2_dev_packet &P
     return true;
 }
 
+// Headers of up to 16 384 bits in parallel: without the stuffing a header is just its fields end to end.  The wavefront lays the
+// fields of all code-blocks out in an LDS bit buffer (bit offsets by a scan over the lanes, the bits OR-ed in; most significant bit first)
+// and returns the number of bits -- or 0 when the header does not fit the buffer and the serial writer has to take it.
+#define T2_FAST_WORDS 512
+__device__ __forceinline__ void t2_or_bits(uint32_t *bits, uint64_t pos, uint32_t v, unsigned n) {      // n <= 32
+    if (!n) return;
+    const uint32_t w = (uint32_t)(pos >> 5), sh = (uint32_t)pos & 31u;
+    if (n < 32) v &= (1u << n) - 1u;
+    if (sh + n <= 32) atomicOr(&bits[w], v << (32 - sh - n));
+    else { const unsigned lo = sh + n - 32; atomicOr(&bits[w], v >> lo); atomicOr(&bits[w + 1], v << (32 - lo)); }
+}
+__device__ uint64_t t2_fast_build(const j2k_t2_dev_packet &P, const j2k_t2_dev_cb *__restrict__ cbs, bool any, uint32_t *bits, int lane) {
+    for (int i = lane; i < T2_FAST_WORDS + 2; i += 64) bits[i] = 0;
+    __syncthreads();
+    if (!any) return 1;                                     // the presence bit, 0
+    if (lane == 0) bits[0] = 0x80000000u;                   // the presence bit, 1
+    uint64_t base = 1;
+    for (int64_t i0 = 0; i0 < P.ncb; i0 += 64) {
+        const int64_t i = i0 + lane;
+        T2Fields F{0, 0, 0, 0, 0, 0, 0};
+        if (i < P.ncb) F = t2_fields(cbs[i], P.layer);
+        const uint64_t tb = (uint64_t)F.z1 + F.n1 + F.z2 + F.n2;
+        uint64_t incl = tb;
+        for (int d = 1; d < 64; d <<= 1) { const uint64_t u = __shfl_up(incl, d); if (lane >= d) incl += u; }
+        const uint64_t tot = __shfl(incl, 63);
+        if (base + tot > (uint64_t)T2_FAST_WORDS * 32) return 0;
+        const uint64_t off = base + incl - tb;
+        t2_or_bits(bits, off + F.z1, F.b1, F.n1);
+        const uint64_t p2 = off + F.z1 + F.n1 + F.z2;
+        if (F.n2 > 32) { t2_or_bits(bits, p2, (uint32_t)(F.b2 >> 32), F.n2 - 32); t2_or_bits(bits, p2 + F.n2 - 32, (uint32_t)F.b2, 32); }
+        else t2_or_bits(bits, p2, (uint32_t)F.b2, F.n2);
+        base += tot;
+    }
+    __syncthreads();
+    return base;
+}
+// The byte-stuffing writer over that bit buffer, by the whole wavefront: as long as no byte is 0xFF the bytes are the bits cut every
+// eight (the first one every seven when the writer enters behind a 0xFF), so the lanes cut 64 bytes at a time and look for the first
+// 0xFF; everything up to it stands, the byte behind it holds seven bits, and the cutting starts again from there -- one round per 0xFF
+// byte in the header.  out == nullptr: count only.  Returns the bytes; ff = the writer's state afterwards.
+__device__ uint64_t t2_fast_emit(const uint32_t *bits, uint64_t total, int s, uint8_t *out, int lane, bool &ff) {
+    uint64_t pos = 0, nout = 0;
+    bool after_ff = s != 0;
+    while (pos < total) {
+        const unsigned first_nb = after_ff ? 7u : 8u;
+        const uint64_t rest = total - pos;
+        const uint64_t nby = rest <= first_nb ? 1 : 1 + (rest - first_nb + 7) / 8;
+        int64_t found = -1;
+        for (uint64_t k0 = 0; k0 < nby && found < 0; k0 += 64) {
+            const uint64_t k = k0 + lane;
+            uint32_t v = 0;
+            if (k < nby) {
+                const uint64_t bp = pos + (k ? first_nb + 8 * (k - 1) : 0);
+                const unsigned nb = k ? 8u : first_nb;
+                const uint32_t w = (uint32_t)(bp >> 5), sh = (uint32_t)bp & 31u;
+                const uint64_t two = (uint64_t)bits[w] << 32 | bits[w + 1];
+                v = (uint32_t)(two >> (64 - sh - nb)) & ((1u << nb) - 1u);
+            }
+            const uint64_t m = __ballot(k < nby && v == 0xFF);
+            const int first = m ? __builtin_ctzll(m) : 64;
+            if (out && k < nby && lane <= first) out[nout + k] = (uint8_t)v;
+            if (m) found = (int64_t)k0 + first;
+        }
+        if (found < 0) { nout += nby; after_ff = false; break; }
+        nout += (uint64_t)found + 1;
+        pos += first_nb + 8 * (uint64_t)found;
+        after_ff = true;
+    }
+    ff = after_ff;
+    return nout;
+}
+
 // per packet: header bytes for the writer's flag clear / set on entry, the flag on exit, the body bytes
 struct T2Size { uint64_t hlen[2]; uint64_t body; uint32_t ff_out; uint32_t pad_; };
 
 __global__ __launch_bounds__(64) void t2_size_kernel(const j2k_t2_dev_packet *__restrict__ packets, long npackets, const j2k_t2_dev_cb *__restrict__ cbs,
                                                      uint64_t ncbs, T2Size *__restrict__ sizes, uint64_t *__restrict__ result) {
     __shared__ T2Fields fld[64];
+    __shared__ uint32_t bits[T2_FAST_WORDS + 2];
     const long p = blockIdx.x;
     const int lane = threadIdx.x;
     const j2k_t2_dev_packet P = packets[p];
     T2Sink w{nullptr, 0, 0, 0, lane == 1};
-    if (P.ncb < 0 || P.cb0 < 0 || (uint64_t)P.cb0 + (uint64_t)P.ncb > ncbs || !t2_header_wave(w, 2, P, cbs + P.cb0, fld, lane)) {
+    bool bad = P.ncb < 0 || P.cb0 < 0 || (uint64_t)P.cb0 + (uint64_t)P.ncb > ncbs;
+    bool fast = false;
+    if (!bad) {
+        bool any = false;
+        bad = !t2_header_checks(P, cbs + P.cb0, lane, any);
+        if (!bad) {
+            const uint64_t total = t2_fast_build(P, cbs + P.cb0, any, bits, lane);
+            if (total) {
+                bool f0, f1;
+                const uint64_t n0 = t2_fast_emit(bits, total, 0, nullptr, lane, f0), n1 = t2_fast_emit(bits, total, 1, nullptr, lane, f1);
+                fast = true;
+                w.n = lane == 1 ? n1 : n0;                              // (lanes 0 and 1 carry the two entry states, as below)
+                w.after_ff = lane == 1 ? f1 : f0;
+            }
+        }
+    }
+    if (bad || (!fast && !t2_header_wave(w, 2, P, cbs + P.cb0, fld, lane))) {
         if (lane == 0) { atomicMax((unsigned long long *)&result[2], 1ull); sizes[p] = T2Size{}; }
         return;
     }
@@ -172,12 +268,25 @@ __global__ __launch_bounds__(256) void t2_scan_kernel(const T2Size *__restrict__
         len_s[t][s] = len; st_s[t][s] = (uint8_t)st;
     }
     __syncthreads();
-    if (t == 0) {
-        uint64_t base = 0;
-        int st = delay_in ? 1 : 0;
-        for (int c = 0; c < 256; c++) { base_s[c] = base; in_s[c] = (uint8_t)st; base += len_s[c][st]; st = st_s[c][st]; }
-        result[0] = base; result[1] = (uint64_t)st;
-        offs[npackets] = base;
+    // inclusive scan of the chunks' maps (entry state -> bytes, exit state) under composition, Hillis-Steele over the 256 threads
+    for (int d = 1; d < 256; d <<= 1) {
+        uint64_t l0 = 0, l1 = 0;
+        uint8_t s0 = 0, s1 = 1;
+        const bool on = t >= d;
+        if (on) {                                            // (chunk t - d ... first, then mine)
+            const uint8_t a0 = st_s[t - d][0], a1 = st_s[t - d][1];
+            l0 = len_s[t - d][0] + len_s[t][a0]; s0 = st_s[t][a0];
+            l1 = len_s[t - d][1] + len_s[t][a1]; s1 = st_s[t][a1];
+        }
+        __syncthreads();
+        if (on) { len_s[t][0] = l0; len_s[t][1] = l1; st_s[t][0] = s0; st_s[t][1] = s1; }
+        __syncthreads();
+    }
+    {
+        const int s = delay_in ? 1 : 0;
+        base_s[t] = t ? len_s[t - 1][s] : 0;
+        in_s[t] = t ? st_s[t - 1][s] : (uint8_t)s;
+        if (t == 255) { result[0] = len_s[255][s]; result[1] = (uint64_t)st_s[255][s]; offs[npackets] = len_s[255][s]; }
     }
     __syncthreads();
     uint64_t off = base_s[t];
@@ -195,6 +304,7 @@ __global__ __launch_bounds__(64) void t2_header_kernel(const j2k_t2_dev_packet *
                                                        const T2Size *__restrict__ sizes, const uint64_t *__restrict__ offs, const uint8_t *__restrict__ var,
                                                        int sop, int eph, uint8_t *__restrict__ out, uint64_t cap, const uint64_t *__restrict__ result) {
     __shared__ T2Fields fld[64];
+    __shared__ uint32_t bits[T2_FAST_WORDS + 2];
     const long p = blockIdx.x;
     const int lane = threadIdx.x;
     if (result[2] != 0 || offs[npackets] > cap) return;      // (a fault or too little room: nothing is written, the host reports it)
@@ -202,8 +312,18 @@ __global__ __launch_bounds__(64) void t2_header_kernel(const j2k_t2_dev_packet *
     const int v = var[p];
     uint8_t *o = out + offs[p];
     if (lane == 0 && sop) { o[0] = 0xFF; o[1] = 0x91; o[2] = 0x00; o[3] = 0x04; o[4] = (uint8_t)((unsigned)P.layer >> 8); o[5] = (uint8_t)P.layer; }
-    T2Sink w{o + (sop ? 6 : 0), 0, 0, 0, v != 0};
-    (void)t2_header_wave(w, 1, P, cbs + P.cb0, fld, lane);
+    {
+        bool any = false;
+        (void)t2_header_checks(P, cbs + P.cb0, lane, any);
+        const uint64_t total = t2_fast_build(P, cbs + P.cb0, any, bits, lane);
+        if (total) {
+            bool f;
+            (void)t2_fast_emit(bits, total, v, o + (sop ? 6 : 0), lane, f);
+        } else {
+            T2Sink w{o + (sop ? 6 : 0), 0, 0, 0, v != 0};
+            (void)t2_header_wave(w, 1, P, cbs + P.cb0, fld, lane);
+        }
+    }
     if (lane == 0 && eph) { uint8_t *e = o + (sop ? 6 : 0) + sizes[p].hlen[v]; e[0] = 0xFF; e[1] = 0x92; }
 }
 
