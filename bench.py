@@ -81,7 +81,7 @@ def launch_ranks(n, argv):
     return subprocess.call(cmd, env=env)
 
 
-def other_configs_summary(budget_s=90.0):
+def other_configs_summary(budget_s=120.0):
     """One driver-visible record for the configurations the headline line does not cover: C3, C5 and C1-on-the-GPU
     each run as `bench.py --config X` in a FRESH CHILD PROCESS started before this process touches the GPU (C3 / c1gpu need their
     own GPU_MAX_HW_QUEUES, which the runtime reads when it initialises), short step counts, the CPU baseline's one-thread leg
@@ -95,7 +95,7 @@ def other_configs_summary(budget_s=90.0):
     except ImportError:
         pass
     t_all = time.perf_counter()
-    plan = [("c3", ["--steps", "10", "--warmup", "2"]), ("c5", ["--steps", "20", "--warmup", "3"]), ("c1gpu", ["--steps", "4", "--warmup", "1"])]
+    plan = [("c3", ["--steps", "10", "--warmup", "2"]), ("c5", ["--steps", "20", "--warmup", "3"]), ("c1gpu", ["--steps", "3", "--warmup", "1"])]
     for name, extra in plan:
         left = budget_s - (time.perf_counter() - t_all)
         if left < 10:
@@ -154,6 +154,7 @@ def run(state):
     ap.add_argument("--config", choices=["c2", "c3", "c4", "c5", "c1gpu"], default="c2",
                     help="BASELINE.json configuration: c2 (default, the headline: 4K RGB8 5-3 + HT), c3 (4K RGB 12-bit, 9-7 lossy + MQ), "
                          "c5 (2048x2048 gray16 frames, 5-3 + HT); c4 only with --shard tiles")
+    ap.add_argument("--batch", type=int, default=0, help="--config c1gpu: frames per context and call, coded as the tiles of one plan (0: the configuration's default)")
     ap.add_argument("--d2h", action="store_true", help="--shard tiles: copy the finished tile-parts to pinned host memory inside the timed step")
     ap.add_argument("--shard", choices=["frames", "tiles"], default="frames",
                     help="N > 1: every rank codes its own frames (weak scaling, the default) or ONE frame's tiles are sharded over "
@@ -197,7 +198,7 @@ def run(state):
         if "--inflight" not in " ".join(sys.argv):
             args.inflight = 0           # the configuration's own default
         if args.config == "c1gpu" and "--steps" not in " ".join(sys.argv):
-            args.steps, args.warmup = 10, min(args.warmup, 2)      # a step is 22 frames of 21 serial chains: 0.2 s
+            args.steps, args.warmup = 5, min(args.warmup, 1)       # a step is 22 x 8 frames of 21 serial chains: 0.7 s
         return bench_extra.run_config(args, args.config)
     # CPU baseline first (N = 1 only): nothing has touched the GPU yet, so the worker processes are plain forks / spawns
     cpu_base = None

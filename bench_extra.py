@@ -31,12 +31,13 @@ CONFIGS = {
     # BASELINE configs[0] ("pure-Go CPU path, plumbing") on the GPU: the reference's DEFAULT code-block size, 1 << (6 + 2) = 256
     # (encoder.go:606-607), i.e. the blocks above 64 x 64 that take the general T1 kernels; 21 blocks per frame (9 of 256 x 256,
     # 12 of 128 x 128): a handful of serial MQ chains, not a throughput configuration
-    "c1gpu": dict(W=512, H=512, C=3, prec=8, lossless=True, quality=0, tile=0, nres=3, cb=256, coder=0, io="planes", inflight=22, content="c1",
+    "c1gpu": dict(W=512, H=512, C=3, prec=8, lossless=True, quality=0, tile=0, nres=3, cb=256, coder=0, io="planes", inflight=22, batch=8, content="c1",
                   metric="Mpixels/s encode+decode (512x512 sRGB, 5-3 lossless, 256x256 code-blocks, MQ coder)",
                   workload="512x512 sRGB 8-bit, single tile, 5-3 lossless, NumResolutions 3, CodeBlockSize{6,6} = 256x256 code-blocks (the "
                            "reference's default, encoder.go:606-607), MQ block coder (BASELINE configs[0] run on the GPU); even frames = the "
                            "reference's benchmark gradient (jpeg2000_test.go:340-352), odd frames = uniform random bytes; stream f codes frame f on "
-                           "even steps and frame f^1 on odd steps (the same frames every step)"),
+                           "even steps and frame f^1 on odd steps when a context holds one frame (the same frames every step); by default a context "
+                           "holds a batch of frames, coded as the tiles of one plan (one launch carries the code-blocks of all of them)"),
     "c5": dict(W=2048, H=2048, C=1, prec=16, lossless=True, quality=0, tile=0, nres=6, cb=64, coder=1, io="gray16", inflight=8,
                metric="Mpixels/s encode+decode (2048x2048 16-bit gray frames, 5-3 lossless)",
                workload="independent 2048x2048 16-bit gray frames (BASELINE configs[4]: a batch of 256, frame f -> rank f mod N), "
@@ -194,26 +195,35 @@ def run_config(args, cfgname):
             dist.init_process_group(backend, rank=rank, world_size=world)
     W, H, C = cfg["W"], cfg["H"], cfg["C"]
     F = args.inflight if args.inflight > 0 else cfg["inflight"]
+    # --batch B (c1gpu): every context codes B frames per call, as the B tiles of ONE plan (W x B*H, tiles of W x H: a tile IS the
+    # reference's pipeline on that frame alone) -- one launch then carries B frames' code-blocks
+    B = max(1, int(getattr(args, "batch", 0) or cfg.get("batch", 1)))
+    frame_h, tile_wh = H, (cfg["tile"], cfg["tile"])
+    if B > 1:
+        assert cfg["tile"] == 0, "--batch stacks untiled frames"
+        tile_wh = (max(W, H), max(W, H))
+        assert tile_wh[1] == H, "--batch needs frames no wider than high"
+        H = H * B
     lanes = []
     ok = False
     try:
         for f in range(F):
             ctx = Context(local)
             p = FramePlan(W, H, C, precision=cfg["prec"], lossless=cfg["lossless"], quality=cfg["quality"], num_resolutions=cfg["nres"],
-                          cb=(cfg["cb"], cfg["cb"]), tile=(cfg["tile"], cfg["tile"]), coder=cfg["coder"], ctx=ctx, track_streams=False)
+                          cb=(cfg["cb"], cfg["cb"]), tile=tile_wh, coder=cfg["coder"], ctx=ctx, track_streams=False)
             i = p.info; n = int(i.blocks)
-            fr = synth_frame(np, cfg, rank * F + f)           # every frame in flight is a different frame
+            fr = np.concatenate([synth_frame(np, cfg, (rank * F + f) * B + b) for b in range(B)], axis=1)   # every frame in flight is a different frame
             ln = dict(ctx=ctx, p=p, n=n, frame=torch.from_numpy(fr).to(p.device), coeff=p.alloc_coeff(), stream=p.empty(i.bytes_cap, torch.uint8),
                       lens=p.empty(n, torch.int32), nb=p.empty(n, torch.uint8), offs=p.empty(n + 1, torch.int64),
                       decoded=p.empty(i.decoded_elems, torch.int32), back=p.alloc_frame())
             if cfg["io"] == "gray16":                          # image.Gray16.Pix: two bytes per pixel, high byte first
                 ln["pix"] = torch.from_numpy(np.ascontiguousarray(fr[0].astype(">u2")).view(np.uint8).reshape(H, W * 2)).to(p.device)
                 ln["bpix"] = torch.zeros((H, W * 2), dtype=torch.uint8, device=p.device)
-            if cfg.get("content") == "c1":
+            if cfg.get("content") == "c1" and B % 2 == 1:   # (an even batch holds as many frames of either kind already)
                 # a noise frame takes 1.6x the coding time of the gradient (twice the symbols on the same serial chains): the step
                 # codes the same F frames every time, but stream f takes frame f on even steps and frame f ^ 1 on odd ones, so that
                 # no stream is left waiting for the streams that hold the slow frames (steps are not separated by a barrier)
-                ln["frames"] = [ln["frame"], torch.from_numpy(synth_frame(np, cfg, rank * F + (f ^ 1))).to(p.device)]
+                ln["frames"] = [ln["frame"], torch.from_numpy(np.concatenate([synth_frame(np, cfg, (rank * F + (f ^ 1)) * B + b) for b in range(B)], axis=1)).to(p.device)]
                 ln["k"] = 0
             lanes.append(ln)
         torch.cuda.synchronize()
@@ -321,7 +331,7 @@ def run_config(args, cfgname):
                     else:
                         os.environ[k] = v
             cp = FramePlan(W, H, C, precision=cfg["prec"], lossless=cfg["lossless"], quality=cfg["quality"], num_resolutions=cfg["nres"],
-                           cb=(cfg["cb"], cfg["cb"]), tile=(cfg["tile"], cfg["tile"]), coder=cfg["coder"], ctx=cctx, track_streams=False)
+                           cb=(cfg["cb"], cfg["cb"]), tile=tile_wh, coder=cfg["coder"], ctx=cctx, track_streams=False)
             ln0["ctx"].sync(); torch.cuda.synchronize()
             ln0["decoded"].zero_(); torch.cuda.synchronize()
             ln0["p"].decode_blocks(ln0["stream"], ln0["offs"], ln0["lens"], ln0["nb"], ln0["decoded"])
@@ -363,9 +373,9 @@ def run_config(args, cfgname):
                               "a step = forward transform + block coding + stream compaction, then block decode of that stream + inverse "
                               "transform of the encoder's coefficients (the reference has no packet->plane placement to mirror: the two "
                               "decode halves are checked separately)",
-                              "tiles": int(info.tiles), "code_blocks": ln0["n"], "compressed_bytes_per_frame": total_bytes,
+                              "tiles": int(info.tiles), "code_blocks": ln0["n"], "compressed_bytes_per_frame": total_bytes // B,
                               "achieved_compression_ratio": round(W * H * C * ((cfg["prec"] + 7) // 8) / max(total_bytes, 1), 2),
-                              "frames_in_flight": F, "hw_queues": 4 if os.environ.get("J2K_BENCH_HWQ_LATE") else int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "hip_graph_per_frame": bool(use_graph), "frame_io": cfg["io"], "parallelism": "frames/rank" if world > 1 else "single GPU"},
+                              "frames_in_flight": F * B, "contexts": F, "frames_per_context": B, "hw_queues": 4 if os.environ.get("J2K_BENCH_HWQ_LATE") else int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "hip_graph_per_frame": bool(use_graph), "frame_io": cfg["io"], "parallelism": "frames/rank" if world > 1 else "single GPU"},
                    "roofline": {"bound": "hbm", "kernel": kern, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg,
                                 "avg_launch_us": round(k_s * 1e6, 2), "launches_timed": int(iso_n),

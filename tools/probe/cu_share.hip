@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void k(int mode, int kind, int iters, Rec *rec
   if (threadIdx.x == 0) { slot = mode ? atomicAdd(&g_rot[(xcc << 8 | ((hw >> 8) & 255u)) & 4095u], 1u) & 3u : 99u; lds[0] = hw; }
   __syncthreads();
   int mine = 0;
-  for (int i = 3; i >= 0; i--) if (wsimd[i] == slot) mine = i;
+  for (int i = (int)(blockDim.x >> 6) - 1; i >= 0; i--) if (wsimd[i] == slot) mine = i;
   if (wv != __builtin_amdgcn_readfirstlane(mine)) return;
   uint32_t s = __builtin_amdgcn_readfirstlane(iters * 977 + 13), v = threadIdx.x * 977 + 13;
   const long long t0 = wall_clock64();
@@ -35,6 +35,7 @@ __global__ __launch_bounds__(256) void k(int mode, int kind, int iters, Rec *rec
 }
 int main(int argc, char **argv) {
   const int K = argc > 1 ? atoi(argv[1]) : 24, G = argc > 2 ? atoi(argv[2]) : 21, lds = argc > 3 ? atoi(argv[3]) : 60000, iters = argc > 4 ? atoi(argv[4]) : 200000;
+  const int threads = argc > 5 ? atoi(argv[5]) : 256;     // 64: one wave per workgroup (no choice of SIMD: mode 1 = mode 0)
   Rec *rec; uint32_t *sink;
   (void)hipMalloc(&rec, sizeof(Rec) * K * G); (void)hipMalloc(&sink, 4 * K * G);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
@@ -43,7 +44,7 @@ int main(int argc, char **argv) {
   for (int kind = 0; kind < (getenv("CU_SHARE_GRIDS") ? 1 : 2); kind++)
     for (int mode = 0; mode < 2; mode++) {
       for (int rep = 0; rep < 2; rep++) {
-        for (int i = 0; i < K; i++) hipLaunchKernelGGL(k, dim3(G), dim3(256), lds, st[i], mode, kind, iters, rec + i * G, sink + i * G);
+        for (int i = 0; i < K; i++) hipLaunchKernelGGL(k, dim3(G), dim3(threads), lds, st[i], threads == 64 ? 0 : mode, kind, iters, rec + i * G, sink + i * G);
         (void)hipDeviceSynchronize();
       }
       std::vector<Rec> h(K * G);
