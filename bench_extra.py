@@ -38,10 +38,11 @@ CONFIGS = {
                            "reference's benchmark gradient (jpeg2000_test.go:340-352), odd frames = uniform random bytes; stream f codes frame f on "
                            "even steps and frame f^1 on odd steps when a context holds one frame (the same frames every step); by default a context "
                            "holds a batch of frames, coded as the tiles of one plan (one launch carries the code-blocks of all of them)"),
-    "c5": dict(W=2048, H=2048, C=1, prec=16, lossless=True, quality=0, tile=0, nres=6, cb=64, coder=1, io="gray16", inflight=8,
+    "c5": dict(W=2048, H=2048, C=1, prec=16, lossless=True, quality=0, tile=0, nres=6, cb=64, coder=1, io="gray16", inflight=3, batch=4,
                metric="Mpixels/s encode+decode (2048x2048 16-bit gray frames, 5-3 lossless)",
                workload="independent 2048x2048 16-bit gray frames (BASELINE configs[4]: a batch of 256, frame f -> rank f mod N), "
-                        "untiled, 5-3 lossless + HT block coder, 64x64 code-blocks, 6 resolutions"),
+                        "untiled, 5-3 lossless + HT block coder, 64x64 code-blocks, 6 resolutions; a context codes a batch of frames per call, as the "
+                        "tiles of one plan (frames_per_context)"),
 }
 
 
@@ -312,6 +313,14 @@ def run_config(args, cfgname):
         for ln in lanes:
             if cfg["lossless"] and cfg["io"] == "planes":
                 assert torch.equal(ln["back"], ln["frame"]), "lossless round trip failed"
+            if cfg["lossless"] and cfg["io"] == "gray16":
+                # decoder.createImage at 16 bit (decoder.go:434-451): v * 65535 / 65535 in int32 -- it wraps for v >= 32769, so those
+                # pixels do not come back as they went in, here exactly as in the reference
+                v = (ln["pix"][:, 0::2].to(torch.int64) << 8) | ln["pix"][:, 1::2].to(torch.int64)
+                t = ((v * 65535 + 2 ** 31) % 2 ** 32) - 2 ** 31
+                q = torch.div(t, 65535, rounding_mode="trunc") & 0xFFFF
+                want = torch.stack([(q >> 8), (q & 255)], dim=2).reshape(ln["pix"].shape).to(torch.uint8)
+                assert torch.equal(ln["bpix"], want), "Gray16 pixels out differ from createImage of the pixels in"
         ln0 = lanes[0]
         info = ln0["p"].info
         total_bytes = int(ln0["offs"][ln0["n"]].item())
