@@ -1,0 +1,61 @@
+"""GPU: a batch of frames as the tiles of one plan ("Batches of frames"; bench.py --batch) gives what the frames give one
+by one: coefficients, block bytes / lengths / bit-plane counts, decoded blocks and pixels."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "go-jpeg2000_amd"))
+
+
+@pytest.mark.parametrize("W,H,C,prec,coder,cb,nres,B", [(512, 512, 3, 8, 0, 256, 3, 3),      # bench --config c1gpu's frames
+                                                       (256, 192, 1, 16, 1, 64, 5, 4),      # gray16 frames, HT (C5's kind)
+                                                       (320, 256, 3, 12, 0, 64, 4, 2),      # lossy is per tile as well
+                                                       (200, 136, 4, 8, 1, 32, 3, 5)])
+def test_batch_of_frames_equals_frames_one_by_one(W, H, C, prec, coder, cb, nres, B):
+    import torch
+    from j2kgfx.codec import FramePlan
+    lossless = prec != 12
+    rng = np.random.default_rng(W + B)
+    top = (1 << prec) - 1
+    frames = [rng.integers(0, top + 1, (C, H, W)).astype(np.int32) if b % 2 else
+              np.clip(np.stack([np.add.outer(np.arange(H) * (c + 1), np.arange(W)) % (top + 1) for c in range(C)]) + rng.integers(-3, 4, (C, H, W)), 0, top).astype(np.int32)
+              for b in range(B)]
+    kw = dict(precision=prec, lossless=lossless, quality=0 if lossless else 75, num_resolutions=nres, cb=(cb, cb), coder=coder)
+    batch = FramePlan(W, H * B, C, tile=(W, H), **kw)
+    assert int(batch.info.tiles) == B
+    stacked = torch.from_numpy(np.concatenate(frames, axis=1)).to(batch.device)
+    co = batch.forward(stacked)
+    stream, offs, lens, nb = batch.encode_stream(co)
+    dec = batch.decode_blocks(stream, offs, lens, nb)
+    back = batch.inverse(co)
+    batch.ctx.sync()
+    n1 = int(batch.info.blocks) // B
+    doffs = batch.decoded_offsets()
+    h_co, h_s, h_o, h_l, h_n, h_d, h_b = (t.cpu().numpy() for t in (co, stream, offs, lens, nb, dec, back))
+    pos_co = 0
+    for b, fr in enumerate(frames):
+        one = FramePlan(W, H, C, tile=(0, 0), **kw)
+        assert int(one.info.blocks) == n1
+        c1 = one.forward(torch.from_numpy(fr).to(one.device))
+        s1, o1, l1, b1 = one.encode_stream(c1)
+        d1 = one.decode_blocks(s1, o1, l1, b1)
+        k1 = one.inverse(c1)
+        one.ctx.sync()
+        ne = int(one.info.coeff_elems)
+        assert np.array_equal(h_co[pos_co:pos_co + ne], c1.cpu().numpy()[:ne]), ("coefficients", b)
+        pos_co += ne
+        j0 = b * n1
+        assert np.array_equal(h_l[j0:j0 + n1], l1.cpu().numpy()[:n1]) and np.array_equal(h_n[j0:j0 + n1], b1.cpu().numpy()[:n1]), ("lengths", b)
+        tot = int(o1.cpu().numpy()[n1])
+        assert np.array_equal(h_s[int(h_o[j0]):int(h_o[j0]) + tot], s1.cpu().numpy()[:tot]), ("block bytes", b)
+        d0, dn = int(doffs[j0]), int(one.info.decoded_elems)
+        assert np.array_equal(h_d[d0:d0 + dn], d1.cpu().numpy()[:dn]), ("decoded blocks", b)
+        assert np.array_equal(h_b.reshape(C, H * B, W)[:, b * H:(b + 1) * H], k1.cpu().numpy().reshape(C, H, W)), ("pixels back", b)
+        if lossless:
+            assert np.array_equal(k1.cpu().numpy().reshape(C, H, W), fr)
+        one.close()
+    batch.close()
