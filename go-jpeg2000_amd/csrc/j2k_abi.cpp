@@ -36,7 +36,8 @@ hipError_t launch_ht_encode_stream(hipStream_t s, const BlockJob *jobs, int njob
 int ht_fast_max_samples();
 hipError_t launch_t1_encode(hipStream_t s, const BlockJob *jobs, int njobs, const int32_t *coef, uint8_t *slots,
                             uint32_t *lens, uint8_t *numbps, uint8_t *work, size_t work_per_job, int *fault, int max_dim,
-                            uint8_t *sym, size_t sym_stride, uint32_t *nsyms, int lanes);
+                            uint8_t *sym, size_t sym_stride, uint32_t *nsyms, int lanes, uint8_t *bigsym = nullptr, const uint64_t *bigsym_off = nullptr,
+                            uint32_t *bignsyms = nullptr);
 size_t t1_sym_stride(int planes);
 hipError_t launch_t1_decode(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs,
                             const uint32_t *lens, const uint8_t *numbps, int32_t *decoded, uint8_t *work,
@@ -171,7 +172,7 @@ extern "C" void j2k_ctx_destroy(j2k_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (j2k_plan *p : ctx->cache) j2k_plan_destroy(p);
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 5; i++)
         if (ctx->stage[i]) (void)hipFree(ctx->stage[i]);
     for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
@@ -1019,6 +1020,7 @@ extern "C" void j2k_plan_destroy(j2k_plan *P) {
     if (P->ctx) { (void)hipSetDevice(P->ctx->device); (void)hipStreamSynchronize(P->ctx->stream); }
     for (int cls = 0; cls < 2; cls++) {
         for (auto &T : P->fwd[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); if (T.d_pjobs) (void)hipFree(T.d_pjobs); }
+        if (cls == 0 && P->d_bigsym_off) { (void)hipFree(P->d_bigsym_off); P->d_bigsym_off = nullptr; }
         for (auto &T : P->inv[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); if (T.d_pjobs) (void)hipFree(T.d_pjobs); }
     }
     void *ptrs[] = {P->d_deep_jobs_inv, P->d_mega_fwd_jobs, P->d_mega_inv_jobs, P->d_fwd_top_jobs, P->d_inv_top_jobs, P->d_inv_wg_jobs, P->d_deep_planes, P->d_deep_jobs, P->d_tile_job0, P->d_scrA, P->d_scrB, P->d_tail, P->d_bjobs, P->d_djobs, P->d_frame, P->d_coeff, P->d_slots, P->d_stream, P->d_lens, P->d_numbps, P->d_offs, P->d_status, P->d_fwd_pix_jobs, P->d_fwd_wg2_jobs, P->d_fwd_wg_rest_jobs, P->d_fwd_wg_jobs, P->d_fwd97_wg_jobs, P->d_inv97_wg_jobs, P->d_ht_ujobs, P->d_ht_alias_next, P->d_bjobs_alias, P->d_maglens, P->d_mels, P->d_toffs};
@@ -1635,9 +1637,34 @@ extern "C" int j2k_plan_encode_blocks(j2k_plan *P, const int32_t *d_coeff, uint8
         r = stage_reserve(ctx, 2, W.total);
         if (r != J2K_OK) return r;
         uint8_t *ws = (uint8_t *)ctx->stage[2];
+        // blocks of 65 ... 256 columns or rows: symbol lists for the two-kernel form (t1_big.inc) -- 16 symbols of room per sample
+        // (a 256 x 256 block of 8-bit noise makes 10; a block that needs more takes the fused kernel), n words of counts in front
+        uint8_t *bigsym = nullptr;
+        uint32_t *bignsyms = nullptr;
+        // (one MQ context alone = one frame at a time: the fused kernel's latency is 7 % shorter; several = throughput: the lists)
+        if (max_dim > 64 && (mq_throughput_mode() || getenv("J2K_T1_BIG_SPLIT"))) {
+            if (!P->d_bigsym_off) {
+                std::vector<uint64_t> off((size_t)n + 1, 0);
+                uint64_t room = 16;                                   // J2K_T1_BIG_SYM_ROOM: symbols of room per sample (testing the fall-back)
+                if (const char *en = getenv("J2K_T1_BIG_SYM_ROOM")) { const long v = atol(en); if (v >= 1 && v <= 64) room = (uint64_t)v; }
+                for (int j = 0; j < n; j++) {
+                    const j2k_block &b = P->blocks[(size_t)j];
+                    const bool big = (b.w > 64 || b.h > 64) && b.w <= 256 && b.h <= 256;
+                    off[(size_t)j + 1] = off[(size_t)j] + (big ? ((room * b.w * b.h + 255) & ~uint64_t(255)) : 0);
+                }
+                r = upload(ctx, &P->d_bigsym_off, off);
+                if (r != J2K_OK) return r;
+                P->bigsym_total = (size_t)off[(size_t)n];
+            }
+            const size_t head = ((size_t)n * 4 + 255) & ~size_t(255);
+            if (P->bigsym_total && stage_reserve(ctx, 4, head + P->bigsym_total + 256) == J2K_OK) {      // (no room: the fused kernel)
+                bignsyms = (uint32_t *)ctx->stage[4];
+                bigsym = (uint8_t *)ctx->stage[4] + head;
+            }
+        }
         HIPCHK(ctx, launch_t1_encode(ctx->stream, P->d_bjobs, n, d_coeff, d_slots, d_lens, d_numbps, ws, wpj, d_fault, max_dim,
                                      W.stride ? ws + W.off_sym : nullptr, W.stride, (uint32_t *)(ws + W.off_nsyms),
-                                     ctx->t1_lanes > 0 ? ctx->t1_lanes : (mq_throughput_mode() ? -1 : 0)));
+                                     ctx->t1_lanes > 0 ? ctx->t1_lanes : (mq_throughput_mode() ? -1 : 0), bigsym, P->d_bigsym_off, bignsyms));
     }
     return J2K_OK;
 }

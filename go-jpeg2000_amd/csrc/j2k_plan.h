@@ -62,9 +62,9 @@ struct j2k_ctx {
     // cached single-plane plans for the host (unit) calls
     std::vector<j2k_plan *> cache;
     // host-call staging buffers (device)
-    void *stage[4] = {nullptr, nullptr, nullptr, nullptr};
+    void *stage[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};    // 0 / 1 staging, 2 T1 workspace, 3 fault word + results, 4 symbol lists of the big-block encoder
     bool fault_armed = false;  // a block-encode launch may have written the sticky fault word (stage[3]) since the last check
-    size_t stage_bytes[4] = {0, 0, 0, 0};
+    size_t stage_bytes[5] = {0, 0, 0, 0, 0};
     // level-0 kernel timing (j2k_ctx_profile_*)
     int profile = 0;
     std::vector<hipEvent_t> ev;     // pool of event pairs
@@ -190,5 +190,7 @@ struct j2k_plan {
     uint64_t *d_status = nullptr;
     uint32_t epoch = 0;
     bool all_blocks_fast = false;           // every job on the parallel HT path
+    uint64_t *d_bigsym_off = nullptr;       // MQ plans with blocks above 64 x 64: where each job's symbol list starts (bytes; n + 1 entries), built at the first encode
+    size_t bigsym_total = 0;
     bool dec_coded_rows_only = false;       // j2k_plan_set_decode_coded_rows_only: HT decode leaves the rows the reference's decoder never writes alone
 };

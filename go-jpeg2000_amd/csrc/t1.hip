@@ -203,18 +203,22 @@ __host__ __device__ inline size_t t1_mqbuf_bytes(size_t n) { return n * 2 + 1024
 
 // LDSW: the flag / magnitude workspace is in LDS (every block fits) or in `work`; a template parameter so that the
 // accesses compile to ds_* / global_* instead of flat_* (a pointer chosen at run time is a flat pointer).
+#define T1B_OVERFLOW 0xFFFFFFFFu
 template <bool LDSW>
 __global__ __launch_bounds__(64) void t1_encode_kernel(const BlockJob *__restrict__ jobs, int njobs, const int32_t *__restrict__ coef,
                                                        uint8_t *__restrict__ slots, uint32_t *__restrict__ lens,
                                                        uint8_t *__restrict__ numbps, uint8_t *__restrict__ work, size_t work_per_job,
-                                                       int lds_work_bytes, int *__restrict__ fault, int skip_small) {
+                                                       int lds_work_bytes, int *__restrict__ fault, int skip_small,
+                                                       const uint32_t *__restrict__ marked) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int jid = blockIdx.x;                  // (vector loop control as in t1_decode64_kernel is slower here: 87 -> 118 ms)
     if (jid >= njobs) return;
     const int lane = threadIdx.x;
     const BlockJob J = jobs[jid];
     const int w = J.w, h = J.h, stride = w + 2;
-    if (skip_small && w <= skip_small && h <= skip_small) return;   // skip_small = 64 / 256: t1_encode64_kernel (and t1_encode_big_kernel) take these
+    // skip_small = 64 / 256: t1_encode64_kernel (and t1_encode_big_kernel) take these -- unless the two-kernel form of t1_big.inc marked
+    // the block as one whose symbols did not fit its list
+    if (skip_small && w <= skip_small && h <= skip_small && !(marked && marked[jid] == T1B_OVERFLOW)) return;
     const size_t n = (size_t)w * h;
     T1Tables &T = *reinterpret_cast<T1Tables *>(smem);
     const size_t flag_bytes = ((size_t)(w + 2) * (h + 2) + 15) & ~size_t(15);
@@ -1697,7 +1701,7 @@ size_t t1_sym_stride(int planes) { return ((size_t)(planes + 2) * 4096 + 1024 + 
 // nsyms = njobs words); blocks with more bit planes than the stride allows fall back to the one-kernel path.
 hipError_t launch_t1_encode(hipStream_t s, const BlockJob *jobs, int njobs, const int32_t *coef, uint8_t *slots,
                             uint32_t *lens, uint8_t *numbps, uint8_t *work, size_t work_per_job, int *fault, int max_dim,
-                            uint8_t *sym, size_t sym_stride, uint32_t *nsyms, int lanes) {
+                            uint8_t *sym, size_t sym_stride, uint32_t *nsyms, int lanes, uint8_t *bigsym, const uint64_t *bigsym_off, uint32_t *bignsyms) {
     if (njobs <= 0) return hipSuccess;
     static int serial_only = -1;   // J2K_T1_SERIAL=1: A/B against the serial kernel
     if (serial_only < 0) { const char *en = getenv("J2K_T1_SERIAL"); serial_only = en ? atoi(en) : 0; }
@@ -1734,36 +1738,49 @@ hipError_t launch_t1_encode(hipStream_t s, const BlockJob *jobs, int njobs, cons
         hipError_t e = hipGetLastError();
         if (e != hipSuccess || max_dim <= 64) return e;
         // blocks above 64 x 64, up to 256 x 256 (the reference's default size): wave-parallel context formation (t1_big.inc)
+        const uint32_t *marked = nullptr;      // the two-kernel form's overflow marks: those blocks take the serial kernel below (its workspace is global memory: no LDS to wait for)
         static int big_on = -1;        // J2K_T1_BIG=0: A/B against the serial kernel
         if (big_on < 0) { const char *en = getenv("J2K_T1_BIG"); big_on = en ? atoi(en) : 1; }
         if (big_on) {
             static bool raised = false;
             if (!raised) {
-                e = hipFuncSetAttribute(reinterpret_cast<const void *>(t1_encode_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(T1Big));
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(t1_encode_big_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(T1Big));
+                if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(t1_encode_big_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(T1Big));
                 if (e != hipSuccess) return e;
                 raised = true;
             }
             int rot = 1;               // J2K_T1_BIG_ROT=0: the chain stays on wave 0 (A/B)
             { const char *en = getenv("J2K_T1_BIG_ROT"); if (en) rot = atoi(en); }
-            hipLaunchKernelGGL(t1_encode_big_kernel, dim3(njobs), dim3(256), sizeof(T1Big), s, jobs, njobs, coef, slots, lens, numbps, fault, rot);
+            int split = 1;             // J2K_T1_BIG_SPLIT=0: context formation and MQ chain in one kernel (round 3's form; A/B)
+            { const char *en = getenv("J2K_T1_BIG_SPLIT"); if (en) split = atoi(en); }
+            if (split && bigsym && bigsym_off && bignsyms) {
+                // two kernels through symbol lists in global memory, so that a block holds its LDS and four waves for the milliseconds of
+                // context formation only and its chain -- one wave, no LDS -- is resident beside thousands of others; a block whose
+                // symbols do not fit its list (16 per sample) is marked and takes the serial kernel afterwards
+                hipLaunchKernelGGL(t1_encode_big_kernel<true>, dim3(njobs), dim3(256), sizeof(T1Big), s, jobs, njobs, coef, slots, lens, numbps, fault, rot, bigsym, bigsym_off, bignsyms);
+                hipLaunchKernelGGL(t1_mq_big_kernel, dim3(njobs), dim3(rot ? 256 : 64), 0, s, jobs, njobs, slots, lens, fault, rot, (const uint8_t *)bigsym, bigsym_off, (const uint32_t *)bignsyms);
+                marked = bignsyms;
+            } else {
+                hipLaunchKernelGGL(t1_encode_big_kernel<false>, dim3(njobs), dim3(256), sizeof(T1Big), s, jobs, njobs, coef, slots, lens, numbps, fault, rot, (uint8_t *)nullptr, (const uint64_t *)nullptr, (uint32_t *)nullptr);
+            }
             e = hipGetLastError();
-            if (e != hipSuccess || max_dim <= 256) return e;
+            if (e != hipSuccess || (max_dim <= 256 && !marked)) return e;
         }
         const int skip = big_on ? 256 : 64;
         const int wb = lds_for(work_per_job);
         const size_t lds = ((sizeof(T1Tables) + 15) & ~size_t(15)) + (size_t)wb;
         if (wb) hipLaunchKernelGGL(t1_encode_kernel<true>, dim3(njobs), dim3(64), lds, s, jobs, njobs, coef, slots, lens, numbps, work,
-                                   work_per_job, wb, fault, skip);
+                                   work_per_job, wb, fault, skip, marked);
         else hipLaunchKernelGGL(t1_encode_kernel<false>, dim3(njobs), dim3(64), lds, s, jobs, njobs, coef, slots, lens, numbps, work,
-                                work_per_job, wb, fault, skip);
+                                work_per_job, wb, fault, skip, marked);
         return hipGetLastError();
     }
     const int wb = lds_for(work_per_job);
     const size_t lds = ((sizeof(T1Tables) + 15) & ~size_t(15)) + (size_t)wb;
     if (wb) hipLaunchKernelGGL(t1_encode_kernel<true>, dim3(njobs), dim3(64), lds, s, jobs, njobs, coef, slots, lens, numbps, work,
-                               work_per_job, wb, fault, 0);
+                               work_per_job, wb, fault, 0, (const uint32_t *)nullptr);
     else hipLaunchKernelGGL(t1_encode_kernel<false>, dim3(njobs), dim3(64), lds, s, jobs, njobs, coef, slots, lens, numbps, work,
-                            work_per_job, wb, fault, 0);
+                            work_per_job, wb, fault, 0, (const uint32_t *)nullptr);
     return hipGetLastError();
 }
 

@@ -137,3 +137,53 @@ def test_big_block_fuzz_slice(ent, oracle):
         nbp = int(rng.integers(1, 35))
         dec = ent.NewT1(w, h).Decode(bytes(g), nbp, band)
         assert np.array_equal(dec.reshape(h, w), oracle.t1_decode(g, nbp, band, w, h)), (case, w, h, band, nbp, n)
+
+
+@pytest.mark.parametrize("W,H,C,prec,nres,cb,kind", [(512, 512, 3, 8, 3, 256, "noise"),      # bench --config c1gpu's frame
+                                                      (512, 512, 3, 8, 3, 256, "gradient"),
+                                                      (300, 260, 1, 12, 2, 256, "noise"),
+                                                      (384, 200, 3, 12, 3, 128, "mixed"),
+                                                      (200, 330, 4, 8, 2, 256, "mixed")])
+def test_plan_big_blocks_match_oracle(oracle, W, H, C, prec, nres, cb, kind):
+    """The PLAN path for code-blocks above 64 x 64 (j2k_plan_encode_stream / j2k_plan_decode_blocks): context formation and MQ chain
+    as two kernels through symbol lists in global memory (t1_encode_big_kernel<true> + t1_mq_big_kernel; a block whose symbols do not
+    fit its list falls back to the fused kernel) -- bytes, lengths, bit-plane counts and decoded blocks against the oracle's
+    encodeTile job loop (encoder.go:616-688), and the same with J2K_T1_BIG_SPLIT=0."""
+    import os
+    import torch
+    from j2kgfx.codec import FramePlan
+    rng = np.random.default_rng(W * 3 + H + prec)
+    top = (1 << prec) - 1
+    yy, xx = np.mgrid[0:H, 0:W]
+    if kind == "noise":
+        frame = rng.integers(0, top + 1, (C, H, W))
+    elif kind == "gradient":
+        frame = np.stack([(xx * top // W + c * yy * top // H) % (top + 1) for c in range(C)])
+    else:
+        frame = np.clip(np.stack([(xx * top // W + yy + c * 5) for c in range(C)]) + rng.integers(-40, 41, (C, H, W)) * (rng.random((C, H, W)) < 0.3), 0, top)
+    frame = frame.astype(np.int32)
+    want_c = oracle.preprocess([np.ascontiguousarray(frame[c]) for c in range(C)], W, H, prec, True, nres, 0)
+    data, wl, wn = oracle.encode_tile_blocks(want_c, W, H, nres, cb, cb, 0)
+    for knob in ("1", "0", "room"):
+        # "room": lists of 3 symbols per sample -- most blocks overflow theirs and take the fused kernel afterwards, the others stay split
+        os.environ.update({"J2K_T1_BIG_SPLIT": "1", "J2K_T1_BIG_SYM_ROOM": "3"} if knob == "room" else {"J2K_T1_BIG_SPLIT": knob})
+        try:
+            plan = FramePlan(W, H, C, precision=prec, lossless=True, num_resolutions=nres, cb=(cb, cb), tile=(0, 0), coder=0)
+            coeff = plan.forward(torch.from_numpy(frame).to(plan.device))
+            stream, offs, lens, nb = plan.encode_stream(coeff)
+            dec = plan.decode_blocks(stream, offs, lens, nb)
+            plan.ctx.sync()
+        finally:
+            os.environ.pop("J2K_T1_BIG_SPLIT", None)
+            os.environ.pop("J2K_T1_BIG_SYM_ROOM", None)
+        n = int(plan.info.blocks)
+        blocks, doffs = plan.blocks(), plan.decoded_offsets()
+        assert any(max(int(b["w"]), int(b["h"])) > 64 for b in blocks)
+        hl, hn, ho, hs, hd = lens.cpu().numpy()[:n], nb.cpu().numpy()[:n], offs.cpu().numpy(), stream.cpu().numpy(), dec.cpu().numpy()
+        assert np.array_equal(hl, wl.astype(hl.dtype)) and np.array_equal(hn, wn), knob
+        assert np.array_equal(hs[:int(ho[n])], data), knob
+        for j in range(n):
+            bw, bh, band = int(blocks[j]["w"]), int(blocks[j]["h"]), int(blocks[j]["band"])
+            chunk = data[int(ho[j]):int(ho[j]) + int(wl[j])]
+            assert np.array_equal(hd[int(doffs[j]):int(doffs[j]) + bw * bh].reshape(bh, bw), oracle.t1_decode(chunk, int(wn[j]), band, bw, bh)), (knob, j)
+        plan.close()
