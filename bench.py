@@ -198,7 +198,7 @@ def run(state):
         if "--inflight" not in " ".join(sys.argv):
             args.inflight = 0           # the configuration's own default
         if args.config == "c1gpu" and "--steps" not in " ".join(sys.argv):
-            args.steps, args.warmup = 5, min(args.warmup, 1)       # a step is 22 x 8 frames of 21 serial chains: 0.7 s
+            args.steps, args.warmup = 5, min(args.warmup, 1)       # a step is 22 x 16 frames of 21 serial chains: 0.7 s
         return bench_extra.run_config(args, args.config)
     # CPU baseline first (N = 1 only): nothing has touched the GPU yet, so the worker processes are plain forks / spawns
     cpu_base = None

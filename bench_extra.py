@@ -31,7 +31,7 @@ CONFIGS = {
     # BASELINE configs[0] ("pure-Go CPU path, plumbing") on the GPU: the reference's DEFAULT code-block size, 1 << (6 + 2) = 256
     # (encoder.go:606-607), i.e. the blocks above 64 x 64 that take the general T1 kernels; 21 blocks per frame (9 of 256 x 256,
     # 12 of 128 x 128): a handful of serial MQ chains, not a throughput configuration
-    "c1gpu": dict(W=512, H=512, C=3, prec=8, lossless=True, quality=0, tile=0, nres=3, cb=256, coder=0, io="planes", inflight=22, batch=8, content="c1",
+    "c1gpu": dict(W=512, H=512, C=3, prec=8, lossless=True, quality=0, tile=0, nres=3, cb=256, coder=0, io="planes", inflight=22, batch=16, content="c1",
                   metric="Mpixels/s encode+decode (512x512 sRGB, 5-3 lossless, 256x256 code-blocks, MQ coder)",
                   workload="512x512 sRGB 8-bit, single tile, 5-3 lossless, NumResolutions 3, CodeBlockSize{6,6} = 256x256 code-blocks (the "
                            "reference's default, encoder.go:606-607), MQ block coder (BASELINE configs[0] run on the GPU); even frames = the "

@@ -41,7 +41,7 @@ hipError_t launch_t1_encode(hipStream_t s, const BlockJob *jobs, int njobs, cons
 size_t t1_sym_stride(int planes);
 hipError_t launch_t1_decode(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs,
                             const uint32_t *lens, const uint8_t *numbps, int32_t *decoded, uint8_t *work,
-                            size_t work_per_job, int max_dim, int general_only, uint8_t *split_ws, int sig_lanes);
+                            size_t work_per_job, int max_dim, int general_only, uint8_t *split_ws, int sig_lanes, int throughput = 0);
 size_t t1_dec_split_bytes(size_t njobs);
 hipError_t launch_mq_encode(hipStream_t s, const uint8_t *ctxs, const uint8_t *decs, size_t n, uint8_t *out, size_t cap, uint32_t *out_len, int *fault);
 hipError_t launch_mq_decode(hipStream_t s, const uint8_t *data, size_t len, const uint8_t *ctxs, size_t n, uint8_t *decs, int *fault);
@@ -1853,7 +1853,7 @@ extern "C" int j2k_plan_decode_blocks(j2k_plan *P, const uint8_t *d_stream, cons
         if (r != J2K_OK) return r;
         HIPCHK(ctx, launch_t1_decode(ctx->stream, P->d_djobs, n, d_stream, d_offs, d_lens, d_numbps, d_decoded,
                                      (uint8_t *)ctx->stage[2], wpj, max_dim, ctx->t1_dec_general,
-                                     split ? (uint8_t *)ctx->stage[2] + gen_bytes : nullptr, ctx->t1_dec_lanes));
+                                     split ? (uint8_t *)ctx->stage[2] + gen_bytes : nullptr, ctx->t1_dec_lanes, mq_throughput_mode() ? 1 : 0));
     }
     return J2K_OK;
 }

@@ -1787,7 +1787,7 @@ hipError_t launch_t1_encode(hipStream_t s, const BlockJob *jobs, int njobs, cons
 // general_only: every block on the general kernel (A/B knob); otherwise blocks up to 64x64 take t1_decode64_kernel
 hipError_t launch_t1_decode(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs,
                             const uint32_t *lens, const uint8_t *numbps, int32_t *decoded, uint8_t *work, size_t work_per_job,
-                            int max_dim, int general_only, uint8_t *split_ws, int sig_lanes) {
+                            int max_dim, int general_only, uint8_t *split_ws, int sig_lanes, int throughput) {
     if (njobs <= 0) return hipSuccess;
     if (!general_only) {
         if (split_ws) {
@@ -1836,7 +1836,14 @@ hipError_t launch_t1_decode(hipStream_t s, const BlockJob *jobs, int njobs, cons
     if (use_big) {
         int rot = 1;                   // J2K_T1_BIG_ROT=0: one wave per block, wherever the dispatcher puts it (A/B)
         { const char *en = getenv("J2K_T1_BIG_ROT"); if (en) rot = atoi(en); }
-        hipLaunchKernelGGL(t1_decode_big_kernel, dim3(njobs), dim3(rot ? 256 : 64), sizeof(T1BigDec), s, jobs, njobs, stream, offs, lens, numbps, decoded, rot);
+        // two sizes of block state (t1_bigdec.inc): each launch takes the blocks of its size
+        // throughput (several MQ contexts: frames in flight): two launches, so that the small blocks hold 10 KB of LDS instead of 41 --
+        // one after the other on this stream, beside the other streams' launches; one context alone: one launch with the large state
+        // for every block (the blocks of a frame decode side by side: latency)
+        int classes = throughput;
+        { const char *en = getenv("J2K_T1_BIG_DEC_CLASSES"); if (en) classes = atoi(en); }
+        hipLaunchKernelGGL((t1_decode_big_kernel<4, 258>), dim3(njobs), dim3(rot ? 256 : 64), sizeof(T1BigDec<4, 258>), s, jobs, njobs, stream, offs, lens, numbps, decoded, rot, classes ? 0 : 1);
+        if (classes) hipLaunchKernelGGL((t1_decode_big_kernel<2, 130>), dim3(njobs), dim3(rot ? 256 : 64), sizeof(T1BigDec<2, 130>), s, jobs, njobs, stream, offs, lens, numbps, decoded, rot, 0);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess || max_dim <= 256) return e;
     }
