@@ -164,9 +164,11 @@ def test_plan_big_blocks_match_oracle(oracle, W, H, C, prec, nres, cb, kind):
     frame = frame.astype(np.int32)
     want_c = oracle.preprocess([np.ascontiguousarray(frame[c]) for c in range(C)], W, H, prec, True, nres, 0)
     data, wl, wn = oracle.encode_tile_blocks(want_c, W, H, nres, cb, cb, 0)
-    for knob in ("1", "0", "room"):
-        # "room": lists of 3 symbols per sample -- most blocks overflow theirs and take the fused kernel afterwards, the others stay split
-        os.environ.update({"J2K_T1_BIG_SPLIT": "1", "J2K_T1_BIG_SYM_ROOM": "3"} if knob == "room" else {"J2K_T1_BIG_SPLIT": knob})
+    for knob in ("1", "0", "room", "classes"):
+        # "room": lists of 3 symbols per sample -- most blocks overflow theirs and take the serial kernel afterwards, the others stay split;
+        # "classes": the decoder's two sizes of block state as two launches (what several contexts in flight get)
+        os.environ.update({"J2K_T1_BIG_SPLIT": "1", "J2K_T1_BIG_SYM_ROOM": "3"} if knob == "room" else
+                          {"J2K_T1_BIG_SPLIT": "1", "J2K_T1_BIG_DEC_CLASSES": "1"} if knob == "classes" else {"J2K_T1_BIG_SPLIT": knob, "J2K_T1_BIG_DEC_CLASSES": "0"})
         try:
             plan = FramePlan(W, H, C, precision=prec, lossless=True, num_resolutions=nres, cb=(cb, cb), tile=(0, 0), coder=0)
             coeff = plan.forward(torch.from_numpy(frame).to(plan.device))
@@ -176,6 +178,7 @@ def test_plan_big_blocks_match_oracle(oracle, W, H, C, prec, nres, cb, kind):
         finally:
             os.environ.pop("J2K_T1_BIG_SPLIT", None)
             os.environ.pop("J2K_T1_BIG_SYM_ROOM", None)
+            os.environ.pop("J2K_T1_BIG_DEC_CLASSES", None)
         n = int(plan.info.blocks)
         blocks, doffs = plan.blocks(), plan.decoded_offsets()
         assert any(max(int(b["w"]), int(b["h"])) > 64 for b in blocks)
