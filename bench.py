@@ -47,7 +47,7 @@ def _traffic(fetch_kib, write_kib, src):
 
 TRAFFIC = {   # frame_io -> (bytes per level-0 forward launch, source); tests/test_bench_traffic_constant.py re-reads the summary
     "planes": _traffic(52495.8, 97200.0, "profiles/r01_bench_v3_inflight1_pmc_{FETCH,WRITE}_SIZE.csv"),
-    "rgba8": _traffic(16436.0, 97248.3, "profiles/r04_bench_inflight1_pmc_summary.txt"),
+    "rgba8": _traffic(16431.7, 97269.2, "profiles/r04_bench_inflight1_pmc_summary.txt"),
 }
 COPY_PEAK_GUIDE_GBS = 6290.0   # MI355X_MICROARCH.md: the float4 device-to-device copy the guide measured (what a pure copy reaches)
 

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 HBM_PEAK_GBS = 8000.0
 # HBM bytes of one launch of the configuration's roofline kernel from the PMC counters (cannot be collected from inside this
 # process: the committed measurement, checked against its source by tests/test_bench_traffic_constant.py)
-TRAFFIC = {"c3": (int(round((2 * 49694.0 + 121500.2) * 1024)), "profiles/r04_c3_pmc_summary.txt: dwt97_fwd_rgb_wg_kernel<8, 1, 7, 0>, (2 x 49694.0 + 121500.2) KiB")}
+TRAFFIC = {"c3": (int(round((2 * 49692.0 + 121500.5) * 1024)), "profiles/r04_c3_pmc_summary.txt: dwt97_fwd_rgb_wg_kernel<8, 1, 7, 0>, (2 x 49692.0 + 121500.5) KiB")}
 SEED = 0x4A324B30              # "J2K0" 
 
 # coder: 0 = MQ (T1.EncodeFast5 / T1.Decode), 1 = HT.  io: frame format at the boundary.
