@@ -95,7 +95,7 @@ def other_configs_summary(budget_s=120.0):
     except ImportError:
         pass
     t_all = time.perf_counter()
-    plan = [("c3", ["--steps", "10", "--warmup", "2"]), ("c5", ["--steps", "20", "--warmup", "3"]), ("c1gpu", ["--steps", "3", "--warmup", "1"])]
+    plan = [("c3", ["--steps", "5", "--warmup", "1"]), ("c5", ["--steps", "20", "--warmup", "3"]), ("c1gpu", ["--steps", "3", "--warmup", "1"])]
     for name, extra in plan:
         left = budget_s - (time.perf_counter() - t_all)
         if left < 10:

@@ -19,7 +19,7 @@ CONFIGS = {
                metric="Mpixels/s encode+decode (4K sRGB, 5-3 lossless)",
                workload="3840x2160 sRGB 8-bit, 512x512 tiles, 5-3 lossless + HT block coder, 64x64 code-blocks, 6 resolutions "
                         "(BASELINE configs[1])"),
-    "c3": dict(W=3840, H=2160, C=3, prec=12, lossless=False, quality=75, tile=512, nres=6, cb=64, coder=0, io="planes", inflight=20,
+    "c3": dict(W=3840, H=2160, C=3, prec=12, lossless=False, quality=75, tile=512, nres=6, cb=64, coder=0, io="planes", inflight=20, batch=4,
                metric="Mpixels/s encode+decode (4K sRGB 12-bit, 9-7 lossy)",
                workload="3840x2160 sRGB rescaled to 12 bit (v*4095/255, encoder.go:198-210), 512x512 tiles, ICT + 9-7 + quantisation "
                         "(Quality 75; the reference ignores CompressionRatio) + MQ block coder (T1.EncodeFast5 / T1.Decode), 64x64 "
@@ -195,25 +195,29 @@ def run_config(args, cfgname):
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     W, H, C = cfg["W"], cfg["H"], cfg["C"]
+    if os.environ.get("J2K_BENCH_H"):          # dev: another frame height (e.g. a whole number of tile rows, to try --batch on a tiled configuration)
+        cfg = dict(cfg, H=int(os.environ["J2K_BENCH_H"])); H = cfg["H"]
     F = args.inflight if args.inflight > 0 else cfg["inflight"]
-    # --batch B (c1gpu): every context codes B frames per call, as the B tiles of ONE plan (W x B*H, tiles of W x H: a tile IS the
-    # reference's pipeline on that frame alone) -- one launch then carries B frames' code-blocks
+    # --batch B: every context codes B frames per call -- ONE plan over the frames stacked vertically whose tile grid starts again at
+    # every frame (j2k_params.frame_rows), so that a frame is coded exactly as it would be alone and one launch carries B frames' work
     B = max(1, int(getattr(args, "batch", 0) or cfg.get("batch", 1)))
     frame_h, tile_wh = H, (cfg["tile"], cfg["tile"])
-    if B > 1:
-        assert cfg["tile"] == 0, "--batch stacks untiled frames"
-        tile_wh = (max(W, H), max(W, H))
-        assert tile_wh[1] == H, "--batch needs frames no wider than high"
-        H = H * B
+    H = H * B
     lanes = []
     ok = False
     try:
         for f in range(F):
             ctx = Context(local)
             p = FramePlan(W, H, C, precision=cfg["prec"], lossless=cfg["lossless"], quality=cfg["quality"], num_resolutions=cfg["nres"],
-                          cb=(cfg["cb"], cfg["cb"]), tile=tile_wh, coder=cfg["coder"], ctx=ctx, track_streams=False)
+                          cb=(cfg["cb"], cfg["cb"]), tile=tile_wh, coder=cfg["coder"], ctx=ctx, track_streams=False, frame_rows=frame_h if B > 1 else 0)
             i = p.info; n = int(i.blocks)
-            fr = np.concatenate([synth_frame(np, cfg, (rank * F + f) * B + b) for b in range(B)], axis=1)   # every frame in flight is a different frame
+            # every frame in flight is a different frame (large frames: frame b > 0 of a batch is frame 0 of its context shifted by
+            # (41 b, 97 b) samples with wrap-around -- other tile contents, a fraction of the time it takes to synthesise another one)
+            if B > 1 and W * frame_h >= (1 << 22):
+                base = synth_frame(np, cfg, rank * F + f)
+                fr = np.concatenate([base if b == 0 else np.roll(base, (41 * b, 97 * b), axis=(1, 2)) for b in range(B)], axis=1)
+            else:
+                fr = np.concatenate([synth_frame(np, cfg, (rank * F + f) * B + b) for b in range(B)], axis=1)
             ln = dict(ctx=ctx, p=p, n=n, frame=torch.from_numpy(fr).to(p.device), coeff=p.alloc_coeff(), stream=p.empty(i.bytes_cap, torch.uint8),
                       lens=p.empty(n, torch.int32), nb=p.empty(n, torch.uint8), offs=p.empty(n + 1, torch.int64),
                       decoded=p.empty(i.decoded_elems, torch.int32), back=p.alloc_frame())
@@ -340,7 +344,7 @@ def run_config(args, cfgname):
                     else:
                         os.environ[k] = v
             cp = FramePlan(W, H, C, precision=cfg["prec"], lossless=cfg["lossless"], quality=cfg["quality"], num_resolutions=cfg["nres"],
-                           cb=(cfg["cb"], cfg["cb"]), tile=tile_wh, coder=cfg["coder"], ctx=cctx, track_streams=False)
+                           cb=(cfg["cb"], cfg["cb"]), tile=tile_wh, coder=cfg["coder"], ctx=cctx, track_streams=False, frame_rows=frame_h if B > 1 else 0)
             ln0["ctx"].sync(); torch.cuda.synchronize()
             ln0["decoded"].zero_(); torch.cuda.synchronize()
             ln0["p"].decode_blocks(ln0["stream"], ln0["offs"], ln0["lens"], ln0["nb"], ln0["decoded"])
@@ -378,7 +382,9 @@ def run_config(args, cfgname):
             out = {"metric": cfg["metric"], "value": round(world * F * W * H / (dt / args.steps) / 1e6, 1), "unit": "Mpixels/s", "n_gpus": world,
                    "steps": args.steps, "steps_requested": steps_requested, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
                    "scaling": "weak", "vs_baseline": None, "dtype": "int32" if cfg["lossless"] else "f64", "data": "synthetic",
-                   "config": {"workload": cfg["workload"] + "; frames_in_flight independent frames per rank per step, each on its own HIP stream; "
+                   "config": {"workload": cfg["workload"] + "; frames_in_flight independent frames per rank per step: `contexts` HIP streams, each coding a batch of "
+                              "frames_per_context frames per call (one plan over the stacked frames whose tile grid starts again at every frame, "
+                              "j2k_params.frame_rows: every frame is coded as it would be alone); "
                               "a step = forward transform + block coding + stream compaction, then block decode of that stream + inverse "
                               "transform of the encoder's coefficients (the reference has no packet->plane placement to mirror: the two "
                               "decode halves are checked separately)",

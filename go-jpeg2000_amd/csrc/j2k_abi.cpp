@@ -337,7 +337,7 @@ static int stage_reserve(j2k_ctx *ctx, int slot, size_t bytes) {
 // ------------------------------------------------------------------------------
 bool PlanSpec::operator==(const PlanSpec &o) const {
     return W == o.W && H == o.H && C == o.C && tile_w == o.tile_w && tile_h == o.tile_h && levels == o.levels &&
-           wavelet == o.wavelet && precision == o.precision && dc_shift == o.dc_shift && dc_shift_inv == o.dc_shift_inv && mct == o.mct && quant == o.quant && quality == o.quality &&
+           frame_h == o.frame_h && wavelet == o.wavelet && precision == o.precision && dc_shift == o.dc_shift && dc_shift_inv == o.dc_shift_inv && mct == o.mct && quant == o.quant && quality == o.quality &&
            num_res_jobs == o.num_res_jobs && cb_w == o.cb_w && cb_h == o.cb_h && coder == o.coder &&
            tile_first == o.tile_first && tile_count == o.tile_count && frame_is_f64 == o.frame_is_f64;
 }
@@ -385,9 +385,12 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
     j2k_plan *P = new j2k_plan();
     P->ctx = ctx;
     P->spec = S;
-    const int tw = S.tile_w > 0 ? S.tile_w : S.W, th = S.tile_h > 0 ? S.tile_h : S.H;
+    // a batch (j2k_params.frame_rows): S.H / fh frames stacked vertically, the tile grid starts again at every frame
+    const int fh = S.frame_h > 0 ? S.frame_h : S.H;
+    const int tw = S.tile_w > 0 ? S.tile_w : S.W, th = S.tile_h > 0 ? S.tile_h : fh;
+    const int tiles_y_frame = (fh + th - 1) / th;
     P->tiles_x = (S.W + tw - 1) / tw;
-    P->tiles_y = (S.H + th - 1) / th;
+    P->tiles_y = tiles_y_frame * (S.H / fh);
     const int ntiles_all = P->tiles_x * P->tiles_y;
     P->tile_first = std::min(std::max(S.tile_first, 0), ntiles_all);
     P->tile_count = S.tile_count > 0 ? std::min(S.tile_count, ntiles_all - P->tile_first) : ntiles_all - P->tile_first;
@@ -400,8 +403,8 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
     for (int tl = 0; tl < P->tile_count; tl++) {
         const int t = P->tile_first + tl;
         const int tx = t % P->tiles_x, ty = t / P->tiles_x;
-        const int x0 = tx * tw, y0 = ty * th;
-        const int w = std::min(tw, S.W - x0), h = std::min(th, S.H - y0);
+        const int x0 = tx * tw, y0 = (ty / tiles_y_frame) * fh + (ty % tiles_y_frame) * th;
+        const int w = std::min(tw, S.W - x0), h = std::min(th, fh - (ty % tiles_y_frame) * th);
         const int w1 = (w + 1) / 2, h1 = (h + 1) / 2, w2 = (w1 + 1) / 2, h2 = (h1 + 1) / 2;
         int c = 0;
         while (c < S.C) {
@@ -1032,6 +1035,8 @@ static int spec_from_params(j2k_ctx *ctx, const j2k_params *p, PlanSpec &S) {
     if (!p) return fail(ctx, J2K_ERR_INVALID_ARG, "params == NULL");
     if (p->precision < 1 || p->precision > 31) return fail(ctx, J2K_ERR_INVALID_ARG, "precision out of range");
     S.W = p->width; S.H = p->height; S.C = p->ncomp;
+    S.frame_h = p->frame_rows > 0 ? p->frame_rows : p->height;
+    if (S.frame_h > 0 && p->height % S.frame_h) return fail(ctx, J2K_ERR_INVALID_ARG, "height is not a whole number of frames (frame_rows)");
     S.tile_w = p->tile_w; S.tile_h = p->tile_h;
     S.levels = p->num_resolutions - 1;
     if (S.levels <= 0) S.levels = 5;                                  // encoder.go:249-252

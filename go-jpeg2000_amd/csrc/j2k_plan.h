@@ -96,6 +96,7 @@ struct PlanSpec {
     int num_res_jobs = 6;      // resolutions for the encodeTile job enumeration
     int cb_w = 64, cb_h = 64;
     int coder = J2K_CODER_MQ;
+    int frame_h = 0;           // rows of one frame of a batch (j2k_params.frame_rows; = H for a single frame)
     int tile_first = 0, tile_count = 0;
     bool frame_is_f64 = false; // unit 9-7 calls: source/destination "frame" is f64
     bool operator==(const PlanSpec &o) const;

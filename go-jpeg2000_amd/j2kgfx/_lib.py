@@ -28,7 +28,7 @@ class Block(C.Structure):
 class Params(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "width", "height", "ncomp", "precision", "is_signed", "lossless", "quality", "num_resolutions",
-        "cb_w", "cb_h", "tile_w", "tile_h", "coder", "tile_first", "tile_count")]
+        "cb_w", "cb_h", "tile_w", "tile_h", "coder", "tile_first", "tile_count", "frame_rows")]
 
 
 class PlanInfo(C.Structure):

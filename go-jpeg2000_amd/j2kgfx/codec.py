@@ -45,7 +45,7 @@ def _stage(fn):
 class FramePlan:
     def __init__(self, width, height, ncomp, precision=8, lossless=True, quality=0, num_resolutions=6,
                  cb=(64, 64), tile=(0, 0), coder=_lib.CODER_MQ, is_signed=False, tile_first=0, tile_count=0,
-                 ctx=None, track_streams=True):
+                 ctx=None, track_streams=True, frame_rows=0):
         self.ctx = ctx or default_context()
         self.track_streams = bool(track_streams)
         self._ext_stream = None
@@ -53,7 +53,8 @@ class FramePlan:
         self.params = _lib.Params(width=width, height=height, ncomp=ncomp, precision=precision,
                                   is_signed=int(bool(is_signed)), lossless=int(bool(lossless)), quality=quality,
                                   num_resolutions=num_resolutions, cb_w=cb[0], cb_h=cb[1], tile_w=tile[0],
-                                  tile_h=tile[1], coder=coder, tile_first=tile_first, tile_count=tile_count)
+                                  tile_h=tile[1], coder=coder, tile_first=tile_first, tile_count=tile_count,
+                                  frame_rows=frame_rows)    # frame_rows > 0: a batch of height / frame_rows frames stacked vertically
         h = C.c_void_p()
         self.ctx.check(L.j2k_plan_create(self.ctx.h, C.byref(self.params), C.byref(h)))
         self.h = h

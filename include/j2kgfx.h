@@ -161,6 +161,11 @@ typedef struct {
                                    pipeline run on the cropped sub-image          */
     int32_t coder;              /* J2K_CODER_MQ | J2K_CODER_HT                                */
     int32_t tile_first, tile_count; /* shard: tiles [first, first+count); count<=0 -> all     */
+    int32_t frame_rows;         /* > 0: a BATCH -- height / frame_rows frames of `width` x frame_rows stacked
+                                   vertically (planes [C][height][W], pixels height rows): the tile grid starts
+                                   again at every frame, so every frame is coded exactly as it would be alone,
+                                   and one call carries all of them in its launches (tiles are numbered frame
+                                   after frame).  0: one frame of `height` rows.  height % frame_rows must be 0 */
 } j2k_params;
 
 typedef struct {

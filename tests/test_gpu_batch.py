@@ -1,5 +1,6 @@
-"""GPU: a batch of frames as the tiles of one plan ("Batches of frames"; bench.py --batch) gives what the frames give one
-by one: coefficients, block bytes / lengths / bit-plane counts, decoded blocks and pixels."""
+"""GPU: a batch of frames in one plan (j2k_params.frame_rows: frames stacked vertically, the tile grid starting again at every frame;
+INTEGRATION.md, "Batches of frames"; bench.py --batch) gives what the frames give one by one: coefficients, block bytes / lengths /
+bit-plane counts, decoded blocks and pixels."""
 import os
 import sys
 
@@ -11,11 +12,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "go-jpeg2000_amd"))
 
 
-@pytest.mark.parametrize("W,H,C,prec,coder,cb,nres,B", [(512, 512, 3, 8, 0, 256, 3, 3),      # bench --config c1gpu's frames
-                                                       (256, 192, 1, 16, 1, 64, 5, 4),      # gray16 frames, HT (C5's kind)
-                                                       (320, 256, 3, 12, 0, 64, 4, 2),      # lossy is per tile as well
-                                                       (200, 136, 4, 8, 1, 32, 3, 5)])
-def test_batch_of_frames_equals_frames_one_by_one(W, H, C, prec, coder, cb, nres, B):
+@pytest.mark.parametrize("W,H,C,prec,coder,cb,nres,B,tile", [(512, 512, 3, 8, 0, 256, 3, 3, 0),      # bench --config c1gpu's frames
+                                                            (256, 192, 1, 16, 1, 64, 5, 4, 0),      # gray16 frames, HT (C5's kind)
+                                                            (320, 256, 3, 12, 0, 64, 4, 2, 0),      # lossy is per tile as well
+                                                            (200, 136, 4, 8, 1, 32, 3, 5, 0),
+                                                            (640, 300, 3, 12, 0, 64, 4, 3, 128),    # tiled frames (C3's kind): 300 = 2 x 128 + 44 rows
+                                                            (520, 200, 3, 8, 1, 64, 3, 2, 256)])    # ragged tiles both ways
+def test_batch_of_frames_equals_frames_one_by_one(W, H, C, prec, coder, cb, nres, B, tile):
     import torch
     from j2kgfx.codec import FramePlan
     lossless = prec != 12
@@ -25,8 +28,9 @@ def test_batch_of_frames_equals_frames_one_by_one(W, H, C, prec, coder, cb, nres
               np.clip(np.stack([np.add.outer(np.arange(H) * (c + 1), np.arange(W)) % (top + 1) for c in range(C)]) + rng.integers(-3, 4, (C, H, W)), 0, top).astype(np.int32)
               for b in range(B)]
     kw = dict(precision=prec, lossless=lossless, quality=0 if lossless else 75, num_resolutions=nres, cb=(cb, cb), coder=coder)
-    batch = FramePlan(W, H * B, C, tile=(W, H), **kw)
-    assert int(batch.info.tiles) == B
+    batch = FramePlan(W, H * B, C, tile=(tile, tile), frame_rows=H, **kw)        # j2k_params.frame_rows: the tile grid starts again at every frame
+    tiles1 = (1 if tile == 0 else -(-W // tile) * -(-H // tile))
+    assert int(batch.info.tiles) == B * tiles1
     stacked = torch.from_numpy(np.concatenate(frames, axis=1)).to(batch.device)
     co = batch.forward(stacked)
     stream, offs, lens, nb = batch.encode_stream(co)
@@ -38,7 +42,7 @@ def test_batch_of_frames_equals_frames_one_by_one(W, H, C, prec, coder, cb, nres
     h_co, h_s, h_o, h_l, h_n, h_d, h_b = (t.cpu().numpy() for t in (co, stream, offs, lens, nb, dec, back))
     pos_co = 0
     for b, fr in enumerate(frames):
-        one = FramePlan(W, H, C, tile=(0, 0), **kw)
+        one = FramePlan(W, H, C, tile=(tile, tile), **kw)
         assert int(one.info.blocks) == n1
         c1 = one.forward(torch.from_numpy(fr).to(one.device))
         s1, o1, l1, b1 = one.encode_stream(c1)
