@@ -63,3 +63,40 @@ def test_batch_of_frames_equals_frames_one_by_one(W, H, C, prec, coder, cb, nres
             assert np.array_equal(k1.cpu().numpy().reshape(C, H, W), fr)
         one.close()
     batch.close()
+
+
+def test_batch_shards_by_tile_index_across_frames():
+    """tile_first / tile_count index the tiles of a batch frame after frame: a shard that straddles two frames codes the same coefficients and
+    bytes as the whole batch does for those tiles (the multi-GPU partition of SURVEY 8e applies to batches unchanged)"""
+    import torch
+    from j2kgfx.codec import FramePlan
+    W, H, C, B, T = 384, 200, 3, 3, 128                    # 3 x 2 tiles per frame (the lower row 72 high), 18 in the batch
+    rng = np.random.default_rng(5)
+    frame = rng.integers(0, 256, (C, H * B, W)).astype(np.int32)
+    kw = dict(precision=8, lossless=True, num_resolutions=4, cb=(32, 32), coder=1, tile=(T, T), frame_rows=H)
+    full = FramePlan(W, H * B, C, **kw)
+    assert int(full.info.tiles) == 18
+    d = torch.from_numpy(frame).to(full.device)
+    co = full.forward(d)
+    s, o, l, nb = full.encode_stream(co)
+    full.ctx.sync()
+    planes_full, blocks_full = full.planes(), full.blocks()
+    shard = FramePlan(W, H * B, C, tile_first=4, tile_count=5, **kw)       # tiles 4, 5 of frame 0 and 0, 1, 2 of frame 1
+    assert int(shard.info.tiles) == 5
+    c2 = shard.forward(d)
+    s2, o2, l2, n2 = shard.encode_stream(c2)
+    shard.ctx.sync()
+    p2 = shard.planes()
+    assert [int(r[0]) for r in p2[::C]] == [4, 5, 6, 7, 8]
+    ys = sorted({int(r[3]) for r in p2})
+    assert ys == [128, 200]                                 # the lower tile row of frame 0 (72 rows from y = 128) and the upper one of frame 1
+    # the same planes in the whole batch
+    first = 4 * C
+    e0 = int(planes_full[first][6]); e1 = e0 + int(shard.info.coeff_elems)
+    assert np.array_equal(co.cpu().numpy()[e0:e1], c2.cpu().numpy()[:int(shard.info.coeff_elems)])
+    nblk = int(shard.info.blocks)
+    j0 = next(j for j in range(len(blocks_full)) if int(blocks_full[j]["plane"]) == first)
+    assert np.array_equal(l.cpu().numpy()[j0:j0 + nblk], l2.cpu().numpy()[:nblk])
+    a, b = int(o.cpu().numpy()[j0]), int(o.cpu().numpy()[j0 + nblk])
+    assert np.array_equal(s.cpu().numpy()[a:b], s2.cpu().numpy()[:b - a])
+    full.close(); shard.close()
