@@ -1647,7 +1647,8 @@ extern "C" int j2k_plan_encode_blocks(j2k_plan *P, const int32_t *d_coeff, uint8
         uint8_t *bigsym = nullptr;
         uint32_t *bignsyms = nullptr;
         // (one MQ context alone = one frame at a time: the fused kernel's latency is 7 % shorter; several = throughput: the lists)
-        if (max_dim > 64 && (mq_throughput_mode() || getenv("J2K_T1_BIG_SPLIT"))) {
+        // (while a graph is being captured nothing may be allocated or copied: the lists need their table from an earlier call)
+        if (max_dim > 64 && (mq_throughput_mode() || getenv("J2K_T1_BIG_SPLIT")) && !(ctx->capturing && !P->d_bigsym_off)) {
             if (!P->d_bigsym_off) {
                 std::vector<uint64_t> off((size_t)n + 1, 0);
                 uint64_t room = 16;                                   // J2K_T1_BIG_SYM_ROOM: symbols of room per sample (testing the fall-back)
