@@ -114,7 +114,8 @@ def other_configs_summary(budget_s=120.0):
                 continue
             d = json.loads(lines[-1])
             out[name] = {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
-                         "frames_in_flight": d["config"].get("frames_in_flight"), "hw_queues": d["config"].get("hw_queues"),
+                         "frames_in_flight": d["config"].get("frames_in_flight"), "contexts": d["config"].get("contexts"),
+                         "frames_per_context": d["config"].get("frames_per_context"), "hw_queues": d["config"].get("hw_queues"),
                          "dtype": d["dtype"], "self_check": d["config"].get("self_check"),
                          "roofline_kernel": d["roofline"]["kernel"], "roofline_frac": d["roofline"]["frac"],
                          "roofline_avg_launch_us": d["roofline"]["avg_launch_us"],
