@@ -100,3 +100,17 @@ def test_batch_shards_by_tile_index_across_frames():
     a, b = int(o.cpu().numpy()[j0]), int(o.cpu().numpy()[j0 + nblk])
     assert np.array_equal(s.cpu().numpy()[a:b], s2.cpu().numpy()[:b - a])
     full.close(); shard.close()
+
+
+@pytest.mark.parametrize("cfg,extra", [("c5", ["--batch", "2", "--inflight", "2"]), ("c1gpu", ["--batch", "2", "--inflight", "3"])])
+def test_bench_batch_paths_run_and_check_themselves(cfg, extra):
+    """bench.py --config c5|c1gpu --batch B: the line is produced, says how its frames in flight are made up, and its own checks (lossless
+    round trip / createImage of the pixels in, the MQ kernels' self-check) have passed -- they are asserts inside the run"""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", cfg, "--steps", "2", "--warmup", "1", "--no-cpu-baseline"] + extra,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    c = d["config"]
+    assert c["frames_per_context"] == 2 and c["frames_in_flight"] == c["contexts"] * 2 and d["value"] > 0
