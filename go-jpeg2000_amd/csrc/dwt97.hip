@@ -498,7 +498,13 @@ static hipError_t fwd97_wg_go(hipStream_t s, const LevelLaunch &L, const void *s
     const int32_t *p = reinterpret_cast<const int32_t *>(src);
     const double rstep = 1.0 / step;          // RN(1 / step): the reciprocal of the Markstein division (dwt97_l0wg.inc)
 #define J2K_WG97(Q) hipExtLaunchKernelGGL((dwt97_fwd_rgb_wg_kernel<NW, Q, J2K_WG97F_WPE, 0>), dim3(L.njobs), dim3(NW * 64), 0, s, L.ev_start, L.ev_stop, 0, \
-                                           L.jobs, L.njobs, L.planes, p, (const double *)nullptr, out_i32, out_f64, nxt, dc_shift, step, rstep)
+                                           L.jobs, L.njobs, L.planes, p, (const double *)nullptr, out_i32, out_f64, nxt, dc_shift, step, rstep, 0)
+    if (L.pix_stride > 0) {      // packed RGBA8 pixels (j2k_plan_forward_pixels on a lossy plan): eight waves, the encoder's quantiser
+        if (NW != 8 || quant != Q_ENCODER_) return hipErrorInvalidValue;
+        hipExtLaunchKernelGGL((dwt97_fwd_rgb_wg_kernel<8, Q_ENCODER_, J2K_WG97F_WPE, 3>), dim3(L.njobs), dim3(512), 0, s, L.ev_start, L.ev_stop, 0,
+                              L.jobs, L.njobs, L.planes, p, (const double *)nullptr, out_i32, out_f64, nxt, dc_shift, step, rstep, L.pix_stride);
+        return hipGetLastError();
+    }
     if (quant == Q_ENCODER_) J2K_WG97(Q_ENCODER_);
     else if (quant == Q_TCD_) J2K_WG97(Q_TCD_);
     else J2K_WG97(Q_NONE_);
@@ -522,7 +528,7 @@ hipError_t launch_dwt97_fwd(hipStream_t s, const LevelLaunch &L, const void *src
     if (L.pwaves == 8 && L.pnjobs > 0 && L.ncomp == 1) {   // single planes in workgroup form: a deeper level (float64 in), level 0 of one int32 component, the float64 unit calls
         const double rstep = 1.0 / step;
 #define J2K_PWG97(Q, SRC) hipExtLaunchKernelGGL((dwt97_fwd_rgb_wg_kernel<8, Q, 7, SRC>), dim3(L.pnjobs), dim3(512), 0, s, L.ev_start, L.ev_stop, 0, \
-                                                 L.pjobs, L.pnjobs, L.planes, reinterpret_cast<const int32_t *>(src), reinterpret_cast<const double *>(src), out_i32, out_f64, nxt, dc_shift, step, rstep)
+                                                 L.pjobs, L.pnjobs, L.planes, reinterpret_cast<const int32_t *>(src), reinterpret_cast<const double *>(src), out_i32, out_f64, nxt, dc_shift, step, rstep, 0)
         if (src_is_f64) {
             if (quant == Q_ENCODER_) J2K_PWG97(Q_ENCODER_, 1);
             else if (quant == Q_TCD_) J2K_PWG97(Q_TCD_, 1);
@@ -552,9 +558,15 @@ hipError_t launch_dwt97_inv(hipStream_t s, const LevelLaunch &L, const void *coe
     if (L.njobs <= 0) return hipSuccess;
     if (L.wg_waves > 0) {      // level 0 of an RGB triple, int32 coefficients -> int32 frame with inverse ICT (dwt97_l0wg_inv.inc)
         if (L.ncomp != 3 || coef_is_f64 || !mct || dst_mode != DST_I32_FRAME) return hipErrorInvalidValue;
-#define J2K_WG97I(NW) hipExtLaunchKernelGGL((dwt97_inv_rgb_wg_kernel<NW, J2K_WG97I_WPE>), dim3(L.njobs), dim3(NW * 64), 0, s, L.ev_start, L.ev_stop, 0, \
+#define J2K_WG97I(NW) hipExtLaunchKernelGGL((dwt97_inv_rgb_wg_kernel<NW, J2K_WG97I_WPE, false>), dim3(L.njobs), dim3(NW * 64), 0, s, L.ev_start, L.ev_stop, 0, \
                                              L.jobs, L.njobs, L.planes, reinterpret_cast<const int32_t *>(coef), prev,                       \
-                                             reinterpret_cast<int32_t *>(dst), dc_shift)
+                                             reinterpret_cast<int32_t *>(dst), dc_shift, 0)
+        if (L.pix_stride > 0) {  // straight to packed RGBA8 pixels (j2k_plan_inverse_pixels on a lossy 8-bit plan): eight waves
+            if (L.wg_waves != 8) return hipErrorInvalidValue;
+            hipExtLaunchKernelGGL((dwt97_inv_rgb_wg_kernel<8, J2K_WG97I_WPE, true>), dim3(L.njobs), dim3(512), 0, s, L.ev_start, L.ev_stop, 0,
+                                  L.jobs, L.njobs, L.planes, reinterpret_cast<const int32_t *>(coef), prev, reinterpret_cast<int32_t *>(dst), dc_shift, L.pix_stride);
+            return hipGetLastError();
+        }
         if (L.wg_waves == 6) J2K_WG97I(6);
         else if (L.wg_waves == 8) J2K_WG97I(8);
         else if (L.wg_waves == 10) J2K_WG97I(10);

@@ -1224,6 +1224,7 @@ static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff, Pi
                 if (l == 0 && cls == prof_cls && ev1) { L97.ev_start = ev0; L97.ev_stop = ev1; }
                 if (l == 0 && cls == 1 && !src_f64 && P->d_fwd97_wg_jobs) {      // the workgroup form when every plane qualifies
                     L97.jobs = P->d_fwd97_wg_jobs; L97.njobs = P->fwd97_wg_njobs; L97.wg_waves = P->fwd97_wg_waves;
+                    if (pix.triple == 97) L97.pix_stride = pix.stride;           // packed RGBA8 frame (j2k_plan_forward_pixels)
                 }
                 HIPCHK(ctx, launch_dwt97_fwd(ctx->stream, L97, in, src_f64, (int32_t *)d_coeff, (double *)d_coeff, (double *)nx,
                                              l == 0 ? S.dc_shift : 0, S.quant, step, (cls == 1) ? 1 : 0));
@@ -1305,6 +1306,7 @@ static int plan_inverse_impl(j2k_plan *P, const void *d_coeff, void *d_frame, Pi
                 LevelLaunch L97 = mk(T);
                 if (l == 0 && cls == 1 && dst_mode == 2 && P->d_inv97_wg_jobs) {   // the workgroup form when every plane qualifies
                     L97.jobs = P->d_inv97_wg_jobs; L97.njobs = P->inv97_wg_njobs; L97.wg_waves = P->inv97_wg_waves;
+                    if (pix.triple == 97) L97.pix_stride = pix.stride;           // packed RGBA8 frame (j2k_plan_inverse_pixels)
                 }
                 HIPCHK(ctx, launch_dwt97_inv(ctx->stream, L97, d_coeff, S.quant == Q_NONE ? 1 : 0, (const double *)prev, dst,
                                              l == 0 ? S.dc_shift_inv : 0, l == 0, dst_mode, (cls == 1) ? 1 : 0));
@@ -1501,6 +1503,19 @@ extern "C" int j2k_convert_colorspace(j2k_ctx *ctx, int cs, int32_t *const *plan
 static bool pix_fusable(const j2k_plan *P, int bps, int channels, const void *d_pix, size_t stride, bool inverse, PixIO &io) {
     const PlanSpec &S = P->spec;
     const int prec = 8 * bps, pb = bps * channels;
+    if (S.wavelet == W97) {
+        // the lossy path -- the reference's default (jpeg2000.go:305-316) -- for image.RGBA at 8 bit: the workgroup kernels of level 0 read /
+        // write the pixels (dwt97_l0wg.inc SRC 3, dwt97_l0wg_inv.inc PIX)
+        if (P->ctx->pix_fuse != 1 || bps != 1 || channels != 4 || S.C != 3 || !S.mct || S.frame_is_f64 || S.precision != 8 || S.quant != Q_ENCODER) return false;
+        if ((inverse ? S.dc_shift_inv : S.dc_shift) != 128 || S.levels < 1 || (S.W % 8)) return false;
+        if ((((uintptr_t)d_pix | stride) & 15) || stride < (size_t)S.W * 4) return false;
+        if (inverse ? !(P->d_inv97_wg_jobs && P->inv97_wg_waves == 8) : !(P->d_fwd97_wg_jobs && P->fwd97_wg_waves == 8)) return false;
+        if ((inverse ? P->inv : P->fwd)[0][0].njobs) return false;
+        io = PixIO();
+        io.stride = (int)(stride / 4);
+        io.triple = 97;
+        return true;
+    }
     if (S.wavelet != W53 || S.levels < 1 || S.precision != prec || (inverse ? S.dc_shift_inv : S.dc_shift) != (1 << (prec - 1))) return false;
     if (P->tail_l0 == 0 || (S.W % 8)) return false;
     if (P->ctx->pix_fuse == 0 || (P->ctx->pix_fuse == 2 && !(bps == 1 && channels == 4 && S.C == 3) && !(bps == 2 && channels == 1))) return false;

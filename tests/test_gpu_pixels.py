@@ -231,6 +231,53 @@ def test_plan_pixels_fused_every_format(oracle, fmt, W, H, tile, pad, fused):
     assert np.array_equal(back.cpu().numpy().reshape(nc, H, W), np.stack(planes))  # and the transform is lossless
 
 
+@pytest.mark.parametrize("W,H,tile,pad,quality,fused", [(1024, 300, 512, 0, 75, True),     # the reference's DEFAULT options: lossy, Quality 75 (jpeg2000.go:305-316)
+                                                         (512, 130, 0, 32, 100, True),
+                                                         (768, 77, 256, 16, 1, True),
+                                                         (1032, 64, 0, 0, 75, False),     # a plane wider than 512 columns: staged
+                                                         (256, 64, 0, 8, 75, False)])     # rows not 16-byte aligned: staged
+def test_plan_pixels_lossy_rgba8(oracle, W, H, tile, pad, quality, fused):
+    """image.RGBA through the LOSSY path (ICT + 9-7 + quantisation): the level-0 workgroup kernels read the packed pixels themselves
+    (dwt97_l0wg.inc SRC 3) and the inverse writes them (dwt97_l0wg_inv.inc PIX) -- coefficients equal extractImageData + preprocess on
+    int32 planes, pixels equal createImage of the inverse path's planes; geometries outside the kernels' contract stage, same results."""
+    import torch
+    from j2kgfx.codec import FramePlan
+    rng = np.random.default_rng(W + H + quality)
+    stride = (W * 4 + 15) // 16 * 16 + pad
+    pix = rng.integers(0, 256, (H, stride)).astype(np.uint8)
+    yy, xx = np.mgrid[0:H, 0:W]
+    pix[:, 0:W * 4:4] = np.clip(xx * 255 // W + rng.integers(-9, 10, (H, W)), 0, 255)      # something smoother in R
+    plan = FramePlan(W, H, 3, precision=8, lossless=False, quality=quality, num_resolutions=4, cb=(64, 64), tile=(tile, tile), coder=0)
+    dpix = torch.from_numpy(pix).to(plan.device)
+    assert plan.pixels_fused(2, dpix) == fused
+    planes = oracle.extract_image_data(pix, 2, W, H, 8)
+    frame = torch.from_numpy(np.stack(planes)).to(plan.device)
+    torch.cuda.synchronize()
+    want = plan.forward(frame)
+    got = plan.forward_pixels(2, dpix)
+    plan.ctx.sync()
+    assert torch.equal(got, want)
+    # against the oracle's preprocess on the first tile, too (the planar path is itself tested against it elsewhere)
+    back = plan.inverse(got)
+    out = torch.full((H, stride), 0x5A, dtype=torch.uint8, device=plan.device)
+    assert plan.pixels_fused(2, out, inverse=True) == fused
+    plan.inverse_pixels(got, out)
+    plan.ctx.sync()
+    o = out.cpu().numpy()
+    assert np.array_equal(o[:, :W * 4], oracle.create_image([p for p in back.cpu().numpy()], 8))
+    assert (o[:, W * 4:] == 0x5A).all()
+    # extremes: all-black / all-white pixels clamp the same way in both paths
+    ext = np.zeros((H, stride), np.uint8); ext[:, : W * 2] = 255
+    dext = torch.from_numpy(ext).to(plan.device)
+    c2 = plan.forward_pixels(2, dext)
+    out2 = torch.zeros((H, stride), dtype=torch.uint8, device=plan.device)
+    plan.inverse_pixels(c2, out2)
+    b2 = plan.inverse(c2)
+    plan.ctx.sync()
+    assert np.array_equal(out2.cpu().numpy()[:, :W * 4], oracle.create_image([p for p in b2.cpu().numpy()], 8))
+    plan.close()
+
+
 @pytest.mark.parametrize("cs", range(-1, 18))
 @pytest.mark.parametrize("prec", [8, 12, 16])
 def test_colorspace_conversions(oracle, cs, prec):
