@@ -113,7 +113,7 @@ while time.time() - t0 < budget:
             j0 += nj
     # packed pixels in and out -- image.Gray / Gray16 / RGBA / RGBA64 / NRGBA / NRGBA64 by component count and precision -- against the
     # planar entry points and decoder.createImage (row strides with and without the 16-byte alignment the fused kernels need)
-    if lossless and prec in (8, 16):
+    if prec in (8, 16) and (lossless or (Cn == 3 and prec == 8)):         # (lossy: image.RGBA at 8 bit, the reference's default path)
         fmt = {1: 0, 3: 2, 4: 4}[Cn] + (1 if prec == 16 else 0)
         ch, sb = (1 if Cn == 1 else 4), prec // 8
         samp = np.zeros((H, W, ch), np.int64)
@@ -137,7 +137,7 @@ while time.time() - t0 < budget:
         assert torch.equal(c2, coeff), ("pixel forward", desc, fmt, stride)
         # decoder.createImage: alpha 255 / 65535 for three components, component 3 for four; 16 bit goes through the reference's
         # wrapping v * 65535 / 65535
-        want_pix = orc.create_image([frame[c] for c in range(Cn)], prec)
+        want_pix = orc.create_image([frame[c] for c in range(Cn)], prec) if lossless else orc.create_image([p_ for p_ in back.cpu().numpy().reshape(Cn, H, W)], prec)
         o = out.cpu().numpy()
         assert np.array_equal(o[:, :row.shape[1]], want_pix), ("pixel inverse", desc, fmt, stride)
         assert (o[:, row.shape[1]:] == 0x5A).all(), ("pixel inverse: row padding written", desc, fmt, stride)
