@@ -143,7 +143,8 @@ def test_big_block_fuzz_slice(ent, oracle):
                                                       (512, 512, 3, 8, 3, 256, "gradient"),
                                                       (300, 260, 1, 12, 2, 256, "noise"),
                                                       (384, 200, 3, 12, 3, 128, "mixed"),
-                                                      (200, 330, 4, 8, 2, 256, "mixed")])
+                                                      (200, 330, 4, 8, 2, 256, "mixed"),
+                                                      (512, 384, 3, 8, 6, 256, "default")])   # DefaultOptions(): lossy, Quality 75, six resolutions, 256 x 256 blocks
 def test_plan_big_blocks_match_oracle(oracle, W, H, C, prec, nres, cb, kind):
     """The PLAN path for code-blocks above 64 x 64 (j2k_plan_encode_stream / j2k_plan_decode_blocks): context formation and MQ chain
     as two kernels through symbol lists in global memory (t1_encode_big_kernel<true> + t1_mq_big_kernel; a block whose symbols do not
@@ -162,7 +163,8 @@ def test_plan_big_blocks_match_oracle(oracle, W, H, C, prec, nres, cb, kind):
     else:
         frame = np.clip(np.stack([(xx * top // W + yy + c * 5) for c in range(C)]) + rng.integers(-40, 41, (C, H, W)) * (rng.random((C, H, W)) < 0.3), 0, top)
     frame = frame.astype(np.int32)
-    want_c = oracle.preprocess([np.ascontiguousarray(frame[c]) for c in range(C)], W, H, prec, True, nres, 0)
+    lossless, quality = kind != "default", (0 if kind != "default" else 75)
+    want_c = oracle.preprocess([np.ascontiguousarray(frame[c]) for c in range(C)], W, H, prec, lossless, nres, quality)
     data, wl, wn = oracle.encode_tile_blocks(want_c, W, H, nres, cb, cb, 0)
     for knob in ("1", "0", "room", "classes"):
         # "room": lists of 3 symbols per sample -- most blocks overflow theirs and take the serial kernel afterwards, the others stay split;
@@ -170,7 +172,7 @@ def test_plan_big_blocks_match_oracle(oracle, W, H, C, prec, nres, cb, kind):
         os.environ.update({"J2K_T1_BIG_SPLIT": "1", "J2K_T1_BIG_SYM_ROOM": "3"} if knob == "room" else
                           {"J2K_T1_BIG_SPLIT": "1", "J2K_T1_BIG_DEC_CLASSES": "1"} if knob == "classes" else {"J2K_T1_BIG_SPLIT": knob, "J2K_T1_BIG_DEC_CLASSES": "0"})
         try:
-            plan = FramePlan(W, H, C, precision=prec, lossless=True, num_resolutions=nres, cb=(cb, cb), tile=(0, 0), coder=0)
+            plan = FramePlan(W, H, C, precision=prec, lossless=lossless, quality=quality, num_resolutions=nres, cb=(cb, cb), tile=(0, 0), coder=0)
             coeff = plan.forward(torch.from_numpy(frame).to(plan.device))
             stream, offs, lens, nb = plan.encode_stream(coeff)
             dec = plan.decode_blocks(stream, offs, lens, nb)
