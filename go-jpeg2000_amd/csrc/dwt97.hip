@@ -528,7 +528,7 @@ hipError_t launch_dwt97_fwd(hipStream_t s, const LevelLaunch &L, const void *src
     if (L.pwaves == 8 && L.pnjobs > 0 && L.ncomp == 1) {   // single planes in workgroup form: a deeper level (float64 in), level 0 of one int32 component, the float64 unit calls
         const double rstep = 1.0 / step;
 #define J2K_PWG97(Q, SRC) hipExtLaunchKernelGGL((dwt97_fwd_rgb_wg_kernel<8, Q, 7, SRC>), dim3(L.pnjobs), dim3(512), 0, s, L.ev_start, L.ev_stop, 0, \
-                                                 L.pjobs, L.pnjobs, L.planes, reinterpret_cast<const int32_t *>(src), reinterpret_cast<const double *>(src), out_i32, out_f64, nxt, dc_shift, step, rstep, 0)
+                                                 L.pjobs, L.pnjobs, L.planes, reinterpret_cast<const int32_t *>(src), reinterpret_cast<const double *>(src), out_i32, out_f64, nxt, dc_shift, step, rstep, src_is_f64 ? 0 : L.pix_stride)
         if (src_is_f64) {
             if (quant == Q_ENCODER_) J2K_PWG97(Q_ENCODER_, 1);
             else if (quant == Q_TCD_) J2K_PWG97(Q_TCD_, 1);
@@ -577,7 +577,7 @@ hipError_t launch_dwt97_inv(hipStream_t s, const LevelLaunch &L, const void *coe
     }
     if (L.pwaves == 8 && L.pnjobs > 0 && L.ncomp == 1) {   // single planes in workgroup form: a deeper level, level 0 of one int32 component, the float64 unit calls
 #define J2K_PWG97I(CF, DI) hipLaunchKernelGGL((dwt97_inv_plane_wg_kernel<8, 6, CF, DI>), dim3(L.pnjobs), dim3(512), 0, s, L.pjobs, L.pnjobs, L.planes, \
-                                               coef, prev, dst, dc_shift, dst_mode == DST_F64_FRAME ? 1 : 0)
+                                               coef, prev, dst, dc_shift, dst_mode == DST_F64_FRAME ? 1 : 0, dst_mode == DST_I32_FRAME ? L.pix_stride : 0)
         if (dst_mode == DST_I32_FRAME) { if (coef_is_f64) J2K_PWG97I(true, true); else J2K_PWG97I(false, true); }
         else { if (coef_is_f64) J2K_PWG97I(true, false); else J2K_PWG97I(false, false); }
 #undef J2K_PWG97I

@@ -1221,6 +1221,7 @@ static int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff, Pi
             } else {
                 const int src_f64 = (l > 0) || S.frame_is_f64;
                 LevelLaunch L97 = mk(T);
+                if (l == 0 && cls == 0 && pix.single == 97) L97.pix_stride = pix.stride;      // image.Gray pixels (j2k_plan_forward_pixels)
                 if (l == 0 && cls == prof_cls && ev1) { L97.ev_start = ev0; L97.ev_stop = ev1; }
                 if (l == 0 && cls == 1 && !src_f64 && P->d_fwd97_wg_jobs) {      // the workgroup form when every plane qualifies
                     L97.jobs = P->d_fwd97_wg_jobs; L97.njobs = P->fwd97_wg_njobs; L97.wg_waves = P->fwd97_wg_waves;
@@ -1304,6 +1305,7 @@ static int plan_inverse_impl(j2k_plan *P, const void *d_coeff, void *d_frame, Pi
                 // dst_mode: 0 = f64 scratch (l>0), 1 = f64 frame (unit calls), 2 = int32 frame via int32(v+0.5) (tcd.go:433-435)
                 const int dst_mode = (l > 0) ? 0 : (S.frame_is_f64 ? 1 : 2);
                 LevelLaunch L97 = mk(T);
+                if (l == 0 && cls == 0 && pix.single == 97) L97.pix_stride = pix.stride;      // image.Gray pixels (j2k_plan_inverse_pixels)
                 if (l == 0 && cls == 1 && dst_mode == 2 && P->d_inv97_wg_jobs) {   // the workgroup form when every plane qualifies
                     L97.jobs = P->d_inv97_wg_jobs; L97.njobs = P->inv97_wg_njobs; L97.wg_waves = P->inv97_wg_waves;
                     if (pix.triple == 97) L97.pix_stride = pix.stride;           // packed RGBA8 frame (j2k_plan_inverse_pixels)
@@ -1506,11 +1508,20 @@ static bool pix_fusable(const j2k_plan *P, int bps, int channels, const void *d_
     if (S.wavelet == W97) {
         // the lossy path -- the reference's default (jpeg2000.go:305-316) -- for image.RGBA at 8 bit: the workgroup kernels of level 0 read /
         // write the pixels (dwt97_l0wg.inc SRC 3, dwt97_l0wg_inv.inc PIX)
-        if (P->ctx->pix_fuse != 1 || bps != 1 || channels != 4 || S.C != 3 || !S.mct || S.frame_is_f64 || S.precision != 8 || S.quant != Q_ENCODER) return false;
+        if (P->ctx->pix_fuse != 1 || bps != 1 || S.frame_is_f64 || S.precision != 8 || S.quant != Q_ENCODER) return false;
         if ((inverse ? S.dc_shift_inv : S.dc_shift) != 128 || S.levels < 1 || (S.W % 8)) return false;
-        if ((((uintptr_t)d_pix | stride) & 15) || stride < (size_t)S.W * 4) return false;
+        if ((((uintptr_t)d_pix | stride) & 15) || stride < (size_t)S.W * (size_t)channels) return false;
+        const LevelTab &T0 = (inverse ? P->inv : P->fwd)[0][0], &T1 = (inverse ? P->inv : P->fwd)[1][0];
+        if (channels == 1 && S.C == 1) {                 // image.Gray: the single-plane workgroup kernels (SRC 2 / DSTI32 with a pixel stride)
+            if (!T0.njobs || T1.njobs || !(T0.pnjobs > 0 && T0.pwaves == 8)) return false;
+            io = PixIO();
+            io.stride = (int)stride;
+            io.single = 97;
+            return true;
+        }
+        if (channels != 4 || S.C != 3 || !S.mct) return false;
         if (inverse ? !(P->d_inv97_wg_jobs && P->inv97_wg_waves == 8) : !(P->d_fwd97_wg_jobs && P->fwd97_wg_waves == 8)) return false;
-        if ((inverse ? P->inv : P->fwd)[0][0].njobs) return false;
+        if (T0.njobs) return false;
         io = PixIO();
         io.stride = (int)(stride / 4);
         io.triple = 97;

@@ -348,7 +348,7 @@ int j2k_plan_inverse_rgba8(j2k_plan *plan, const int32_t *d_coeff, void *d_pix, 
  * When the plan's precision is the format's own (8 / 16 bit, unsigned, 5-3) and the geometry allows
  * 16-byte accesses, the level-0 kernels read / write the pixels themselves -- Gray, Gray16, RGBA,
  * RGBA64, NRGBA, NRGBA64 alike (a fourth component is its own plane: encoder.go:152-179), and so do the
- * 9-7 level-0 kernels for image.RGBA on a lossy 8-bit plan (the reference's DefaultOptions); otherwise
+ * 9-7 level-0 kernels for image.RGBA and image.Gray on a lossy 8-bit plan (the reference's DefaultOptions); otherwise
  * the pixels pass through an int32 staging frame.  Same results either way. */
 int j2k_plan_forward_pixels(j2k_plan *plan, int format, const void *d_pix, size_t stride, int32_t *d_coeff);
 int j2k_plan_inverse_pixels(j2k_plan *plan, const int32_t *d_coeff, void *d_pix, size_t stride);

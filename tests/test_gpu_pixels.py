@@ -278,6 +278,38 @@ def test_plan_pixels_lossy_rgba8(oracle, W, H, tile, pad, quality, fused):
     plan.close()
 
 
+@pytest.mark.parametrize("W,H,tile,pad,fused", [(1024, 200, 512, 0, True), (512, 77, 0, 16, True), (384, 64, 128, 32, True),
+                                                 (520, 64, 0, 8, False), (1024, 64, 0, 0, False)])
+def test_plan_pixels_lossy_gray8(oracle, W, H, tile, pad, fused):
+    """image.Gray through the lossy path: the single-plane 9-7 workgroup kernels read / write a byte per pixel (dwt97_l0wg.inc SRC 2 and
+    dwt97_inv_plane_wg_kernel with a pixel stride); planes wider than 512 columns or unaligned rows stage."""
+    import torch
+    from j2kgfx.codec import FramePlan
+    rng = np.random.default_rng(W * 7 + H)
+    stride = (W + 15) // 16 * 16 + pad
+    pix = rng.integers(0, 256, (H, stride)).astype(np.uint8)
+    pix[::3, :W] = np.clip(np.arange(W) * 255 // W + rng.integers(-5, 6, (pix[::3].shape[0], W)), 0, 255)
+    plan = FramePlan(W, H, 1, precision=8, lossless=False, quality=75, num_resolutions=4, cb=(64, 64), tile=(tile, tile), coder=1)
+    dpix = torch.from_numpy(pix).to(plan.device)
+    assert plan.pixels_fused(0, dpix) == fused
+    planes = oracle.extract_image_data(pix, 0, W, H, 8)
+    frame = torch.from_numpy(np.stack(planes)).to(plan.device)
+    torch.cuda.synchronize()
+    want = plan.forward(frame)
+    got = plan.forward_pixels(0, dpix)
+    plan.ctx.sync()
+    assert torch.equal(got, want)
+    back = plan.inverse(got)
+    out = torch.full((H, stride), 0x5A, dtype=torch.uint8, device=plan.device)
+    assert plan.pixels_fused(0, out, inverse=True) == fused
+    plan.inverse_pixels(got, out)
+    plan.ctx.sync()
+    o = out.cpu().numpy()
+    assert np.array_equal(o[:, :W], oracle.create_image([p for p in back.cpu().numpy()], 8))
+    assert (o[:, W:] == 0x5A).all()
+    plan.close()
+
+
 @pytest.mark.parametrize("cs", range(-1, 18))
 @pytest.mark.parametrize("prec", [8, 12, 16])
 def test_colorspace_conversions(oracle, cs, prec):

@@ -113,7 +113,7 @@ while time.time() - t0 < budget:
             j0 += nj
     # packed pixels in and out -- image.Gray / Gray16 / RGBA / RGBA64 / NRGBA / NRGBA64 by component count and precision -- against the
     # planar entry points and decoder.createImage (row strides with and without the 16-byte alignment the fused kernels need)
-    if prec in (8, 16) and (lossless or (Cn == 3 and prec == 8)):         # (lossy: image.RGBA at 8 bit, the reference's default path)
+    if prec in (8, 16) and (lossless or (Cn in (1, 3) and prec == 8)):    # (lossy: image.RGBA / image.Gray at 8 bit, the reference's default path)
         fmt = {1: 0, 3: 2, 4: 4}[Cn] + (1 if prec == 16 else 0)
         ch, sb = (1 if Cn == 1 else 4), prec // 8
         samp = np.zeros((H, W, ch), np.int64)
