@@ -99,6 +99,7 @@ struct PlanSpec {
     int frame_h = 0;           // rows of one frame of a batch (j2k_params.frame_rows; = H for a single frame)
     int tile_first = 0, tile_count = 0;
     bool frame_is_f64 = false; // unit 9-7 calls: source/destination "frame" is f64
+    bool closed_loop = false;  // j2k_params.closed_loop: code-block windows = the Mallat rectangles of the plane (they partition it)
     bool operator==(const PlanSpec &o) const;
 };
 
@@ -156,6 +157,22 @@ struct j2k_plan {
     // code-block jobs
     std::vector<j2k_block> blocks;          // plane = shard-local tile-component index
     std::vector<int32_t> block_tile;        // tile of each job
+    std::vector<int32_t> block_res;         // resolution of each job (a packet = the jobs of one tile-component and resolution)
+    // closed-loop frame codec (j2k_plan_encode_tile_parts / j2k_plan_decode_tile_parts): tables and workspaces, made at first use
+    j2k_t2_dev_packet *d_t2_packets = nullptr;   // one packet per (tile, component, resolution) with blocks, J2K_T2_* flags set
+    int *d_tile_packet0 = nullptr;               // first packet of every tile of the shard (+ the packet count)
+    int t2_npackets = 0;
+    j2k_t2_dev_cb *d_t2_cbs = nullptr;           // code-block table of the packet coder / decoder (one entry per job)
+    uint64_t *d_t2_poffs = nullptr;              // encode: where each packet starts in d_t2_stream (+ the total)
+    uint8_t *d_t2_stream = nullptr;              // encode: the packets end to end, before the tile-part headers go in between
+    size_t t2_stream_cap = 0;
+    void *d_t2_ws = nullptr;                     // encode: the packet coder's workspace + its 3-word result
+    void *d_t2_chains = nullptr;                 // decode: one chain per tile
+    uint64_t *d_t2_body_base = nullptr;          // decode: where each packet's bodies start
+    int *d_frame_status = nullptr;               // sticky status word of the asynchronous frame calls (j2k_plan_frame_status)
+    int32_t *d_cl_decoded = nullptr, *d_cl_coeff = nullptr;   // j2k_plan_*_frame_pixels: decoded blocks, coefficient planes
+    uint8_t *d_cl_stream = nullptr, *d_cl_numbps = nullptr; uint64_t *d_cl_offs = nullptr; uint32_t *d_cl_lens = nullptr;
+    int max_block_h = 0;
     int *d_tile_job0 = nullptr;             // first job of each tile of the shard (+ the job count): j2k_plan_assemble_tiles_device
     uint64_t max_tile_bytes = 0;            // slot bytes of the largest tile (an upper bound of its stream bytes)
     std::vector<uint64_t> slot_off;         // byte offset of each job's worst-case slot

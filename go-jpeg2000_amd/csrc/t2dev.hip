@@ -66,10 +66,10 @@ struct T2Sink {
 __device__ __forceinline__ bool t2_contributes(const j2k_t2_dev_cb &cb, int layer) { return cb.included_in_layers <= layer && cb.data_len > 0; }
 
 // One code-block's share of a packet header (t2.go:320-364) as two unary runs and two bit strings: zeros z1, bits b1 (n1), zeros z2,
-// bits b2 (n2 <= 52: the closing one of the zero-bit-plane value, the pass code of t2.go:379-406, the bit length of the length in a
-// 3-bit field -- it wraps -- and the length in all its bits, t2.go:408-437).
+// bits b2 (n2 <= 54: the closing one of the zero-bit-plane value, the pass code of t2.go:379-406, the bit length of the length in a
+// 3-bit field -- it wraps; five bits with J2K_T2_WIDE_LEN -- and the length in all its bits, t2.go:408-437).
 struct T2Fields { uint32_t z1, z2, b1, n1, n2, pad_; uint64_t b2; };
-__device__ __forceinline__ T2Fields t2_fields(const j2k_t2_dev_cb &cb, int layer) {
+__device__ __forceinline__ T2Fields t2_fields(const j2k_t2_dev_cb &cb, int layer, int flags) {
     T2Fields F{0, 0, 0, 0, 0, 0, 0};
     const bool inc = t2_contributes(cb, layer);
     if (layer == 0) { F.z1 = cb.included_in_layers > 0 ? (uint32_t)cb.included_in_layers : 0u; F.b1 = 1; F.n1 = 1; }   // written whether or not the block is included
@@ -87,7 +87,7 @@ __device__ __forceinline__ T2Fields t2_fields(const j2k_t2_dev_cb &cb, int layer
     else { add(0x1FF, 9); add((uint32_t)(np - 37), 7); }
     unsigned nb = 0;
     for (uint32_t t = cb.data_len; t; t >>= 1) nb++;
-    add(nb, 3);
+    add(nb, (flags & J2K_T2_WIDE_LEN) ? 5 : 3);            // (closed-loop mode: five bits, so that the field holds every length's bit count)
     if (nb) add(cb.data_len, nb);
     F.b2 = b; F.n2 = n;
     return F;
@@ -122,7 +122,7 @@ __device__ bool t2_header_wave(T2Sink &w, int nsinks, const j2k_t2_dev_packet &P
         for (int64_t i0 = 0; i0 < P.ncb; i0 += 64) {
             const int64_t i = i0 + lane;
             __syncthreads();                                // (one wavefront: orders the LDS traffic of the two phases)
-            if (i < P.ncb) fld[lane] = t2_fields(cbs[i], layer);
+            if (i < P.ncb) fld[lane] = t2_fields(cbs[i], layer, P.flags);
             __syncthreads();
             const int cnt = (int)(P.ncb - i0 < 64 ? P.ncb - i0 : 64);
             if (mine)
@@ -158,7 +158,7 @@ __device__ uint64_t t2_fast_build(const j2k_t2_dev_packet &P, const j2k_t2_dev_c
     for (int64_t i0 = 0; i0 < P.ncb; i0 += 64) {
         const int64_t i = i0 + lane;
         T2Fields F{0, 0, 0, 0, 0, 0, 0};
-        if (i < P.ncb) F = t2_fields(cbs[i], P.layer);
+        if (i < P.ncb) F = t2_fields(cbs[i], P.layer, P.flags);
         const uint64_t tb = (uint64_t)F.z1 + F.n1 + F.z2 + F.n2;
         uint64_t incl = tb;
         for (int d = 1; d < 64; d <<= 1) { const uint64_t u = __shfl_up(incl, d); if (lane >= d) incl += u; }
@@ -250,6 +250,7 @@ __global__ __launch_bounds__(64) void t2_size_kernel(const j2k_t2_dev_packet *__
         T2Size S{};
         S.hlen[0] = w.n; S.hlen[1] = h1; S.body = body;
         S.ff_out = (w.after_ff ? 1u : 0u) | f1 << 1;
+        if (P.flags & J2K_T2_FRESH) { S.hlen[1] = S.hlen[0]; S.ff_out = (S.ff_out & 1u) * 3u; }     // a new encoder object: whatever came before, its writer starts clear
         sizes[p] = S;
     }
 }
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(64) void t2_header_kernel(const j2k_t2_dev_packet *
     const int lane = threadIdx.x;
     if (result[2] != 0 || offs[npackets] > cap) return;      // (a fault or too little room: nothing is written, the host reports it)
     const j2k_t2_dev_packet P = packets[p];
-    const int v = var[p];
+    const int v = (P.flags & J2K_T2_FRESH) ? 0 : var[p];
     uint8_t *o = out + offs[p];
     if (lane == 0 && sop) { o[0] = 0xFF; o[1] = 0x91; o[2] = 0x00; o[3] = 0x04; o[4] = (uint8_t)((unsigned)P.layer >> 8); o[5] = (uint8_t)P.layer; }
     {
@@ -373,9 +374,9 @@ __global__ __launch_bounds__(256) void t2_fill_cbs_kernel(long n, const uint64_t
     if (j >= n) return;
     const int nb = numbps[j];
     j2k_t2_dev_cb cb{};
-    cb.included_in_layers = 0;
+    cb.included_in_layers = ((ht & 2) && lens[j] == 0) ? 1 : 0;     // closed-loop mode (bit 1): a block without data is in no layer, and says so
     cb.zero_bit_planes = mb > nb ? mb - nb : 0;
-    cb.num_passes = nb == 0 ? 0 : (ht ? 1 : 3 * nb - 2);
+    cb.num_passes = nb == 0 ? 0 : ((ht & 1) ? 1 : 3 * nb - 2);
     cb.data_len = lens[j];
     cb.data_off = offs[j];
     cbs[j] = cb;

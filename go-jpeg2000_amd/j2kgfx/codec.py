@@ -45,7 +45,7 @@ def _stage(fn):
 class FramePlan:
     def __init__(self, width, height, ncomp, precision=8, lossless=True, quality=0, num_resolutions=6,
                  cb=(64, 64), tile=(0, 0), coder=_lib.CODER_MQ, is_signed=False, tile_first=0, tile_count=0,
-                 ctx=None, track_streams=True, frame_rows=0):
+                 ctx=None, track_streams=True, frame_rows=0, closed_loop=False):
         self.ctx = ctx or default_context()
         self.track_streams = bool(track_streams)
         self._ext_stream = None
@@ -54,7 +54,8 @@ class FramePlan:
                                   is_signed=int(bool(is_signed)), lossless=int(bool(lossless)), quality=quality,
                                   num_resolutions=num_resolutions, cb_w=cb[0], cb_h=cb[1], tile_w=tile[0],
                                   tile_h=tile[1], coder=coder, tile_first=tile_first, tile_count=tile_count,
-                                  frame_rows=frame_rows)    # frame_rows > 0: a batch of height / frame_rows frames stacked vertically
+                                  frame_rows=frame_rows,    # frame_rows > 0: a batch of height / frame_rows frames stacked vertically
+                                  closed_loop=int(bool(closed_loop)))   # this library's closed-loop mode (not the reference): windows that partition the plane, readable packets
         h = C.c_void_p()
         self.ctx.check(L.j2k_plan_create(self.ctx.h, C.byref(self.params), C.byref(h)))
         self.h = h
@@ -223,6 +224,61 @@ class FramePlan:
         cbs = cbs if cbs is not None else self.empty(int(self.info.blocks) * 24, t.uint8)
         self.ctx.check(self.ctx.L.j2k_plan_t2_fill_cbs(self.h, int(mb), self._p(offs), self._p(lens), self._p(numbps), self._p(cbs)))
         return cbs
+
+    # ---- the closed-loop frame codec (plans made with closed_loop=True) ----------------------------------------------
+    def frame_bound(self):
+        self.ctx.L.j2k_plan_frame_bound.restype = C.c_size_t
+        return int(self.ctx.L.j2k_plan_frame_bound(self.h))
+
+    @_stage
+    def encode_tile_parts(self, stream, offs, lens, numbps, sop=False, eph=False, out=None, tile_offs=None):
+        """the block coder's outputs -> SOT | SOD | packets per tile, end to end: (out uint8, tile_offs int64[tiles + 1])"""
+        t = _torch()
+        out = out if out is not None else self.empty(self.frame_bound(), t.uint8)
+        tile_offs = tile_offs if tile_offs is not None else self.empty(int(self.info.tiles) + 1, t.int64)
+        self.ctx.check(self.ctx.L.j2k_plan_encode_tile_parts(self.h, self._p(stream), self._p(offs), self._p(lens), self._p(numbps), int(bool(sop)),
+                                                             int(bool(eph)), self._p(out), C.c_size_t(int(out.numel())), self._p(tile_offs)))
+        return out, tile_offs
+
+    @_stage
+    def decode_tile_parts(self, cs, length, tile_offs=None, sop=False, eph=False, offs=None, lens=None, numbps=None):
+        """tile-parts cs[:length] -> (offs, lens, numbps) as decode_blocks takes them (offsets into cs)"""
+        t = _torch()
+        n = int(self.info.blocks)
+        offs = offs if offs is not None else self.empty(n + 1, t.int64)
+        lens = lens if lens is not None else self.empty(n, t.int32)
+        numbps = numbps if numbps is not None else self.empty(n, t.uint8)
+        self.ctx.check(self.ctx.L.j2k_plan_decode_tile_parts(self.h, self._p(cs), C.c_size_t(int(length)), self._p(tile_offs) if tile_offs is not None else None,
+                                                             int(bool(sop)), int(bool(eph)), self._p(offs), self._p(lens), self._p(numbps)))
+        return offs, lens, numbps
+
+    @_stage
+    def place_blocks(self, decoded, coeff=None):
+        coeff = coeff if coeff is not None else self.alloc_coeff()
+        self.ctx.check(self.ctx.L.j2k_plan_place_blocks(self.h, self._p(decoded), self._p(coeff)))
+        return coeff
+
+    def frame_status(self):
+        """synchronises; raises what the asynchronous frame calls found since the last call (capacity, malformed input)"""
+        self.ctx.check(self.ctx.L.j2k_plan_frame_status(self.h))
+        self.ctx.sync()
+
+    @_stage
+    def encode_frame_pixels(self, fmt, pix, sop=False, eph=False, out=None, tile_offs=None):
+        """pixels (a Go Pix layout, device uint8 [H, stride]) -> tile-parts: (out uint8, tile_offs int64[tiles + 1])"""
+        t = _torch()
+        out = out if out is not None else self.empty(self.frame_bound(), t.uint8)
+        tile_offs = tile_offs if tile_offs is not None else self.empty(int(self.info.tiles) + 1, t.int64)
+        self.ctx.check(self.ctx.L.j2k_plan_encode_frame_pixels(self.h, int(fmt), self._p(pix), C.c_size_t(int(pix.shape[1])), int(bool(sop)), int(bool(eph)),
+                                                               self._p(out), C.c_size_t(int(out.numel())), self._p(tile_offs)))
+        return out, tile_offs
+
+    @_stage
+    def decode_frame_pixels(self, cs, length, pix, tile_offs=None, sop=False, eph=False):
+        """tile-parts cs[:length] -> pixels into pix (device uint8 [H, stride])"""
+        self.ctx.check(self.ctx.L.j2k_plan_decode_frame_pixels(self.h, self._p(cs), C.c_size_t(int(length)), self._p(tile_offs) if tile_offs is not None else None,
+                                                               int(bool(sop)), int(bool(eph)), self._p(pix), C.c_size_t(int(pix.shape[1]))))
+        return pix
 
     def pack_bound(self):
         return int(self.ctx.L.j2k_plan_pack_bound(self.h))

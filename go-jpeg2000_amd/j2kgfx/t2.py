@@ -162,12 +162,12 @@ class _DevCb(C.Structure):
 
 
 class _DevPacket(C.Structure):
-    _fields_ = [("layer", C.c_int32), ("incl_tree_w", C.c_int32), ("imsb_tree_w", C.c_int32), ("pad_", C.c_int32), ("cb0", C.c_int64),
+    _fields_ = [("layer", C.c_int32), ("incl_tree_w", C.c_int32), ("imsb_tree_w", C.c_int32), ("flags", C.c_int32), ("cb0", C.c_int64),
                 ("ncb", C.c_int64)]
 
 
 DEV_CB_DTYPE = np.dtype([("included_in_layers", "<i4"), ("zero_bit_planes", "<i4"), ("num_passes", "<i4"), ("data_len", "<u4"), ("data_off", "<u8")])
-DEV_PACKET_DTYPE = np.dtype([("layer", "<i4"), ("incl_tree_w", "<i4"), ("imsb_tree_w", "<i4"), ("pad_", "<i4"), ("cb0", "<i8"), ("ncb", "<i8")])
+DEV_PACKET_DTYPE = np.dtype([("layer", "<i4"), ("incl_tree_w", "<i4"), ("imsb_tree_w", "<i4"), ("flags", "<i4"), ("cb0", "<i8"), ("ncb", "<i8")])
 
 
 class DevicePacketEncoder:
@@ -178,13 +178,14 @@ class DevicePacketEncoder:
         self.ctx = ctx
         self._delay = C.c_uint8(0)
 
-    def tables(self, runs):
-        """numpy tables for a run given as [(Precinct, layer), ...]: (packets, cbs, data) with every block's bytes appended to data"""
+    def tables(self, runs, flags=0):
+        """numpy tables for a run given as [(Precinct, layer), ...]: (packets, cbs, data) with every block's bytes appended to data.
+        flags: J2K_T2_* of the closed-loop mode for every packet (an int, or one per packet)"""
         packets = np.zeros(len(runs), DEV_PACKET_DTYPE)
         cbs, data = [], bytearray()
         for i, (pr, layer) in enumerate(runs):
             flat = [cb for band in pr.CodeBlocks for cb in band]
-            packets[i] = (int(layer), pr.InclusionTree.width, pr.IMSBTree.width, 0, len(cbs), len(flat))
+            packets[i] = (int(layer), pr.InclusionTree.width, pr.IMSBTree.width, int(flags if np.isscalar(flags) else flags[i]), len(cbs), len(flat))
             for cb in flat:
                 d = cb.Data or b""
                 cbs.append((cb.IncludedInLayers, cb.ZeroBitPlanes, cb.Passes, len(d), len(data)))
@@ -203,6 +204,33 @@ class DevicePacketEncoder:
         self.total = total.value
         self.ctx.check(st)
         return total.value
+
+
+class DevicePacketDecoder:
+    """One tcd.PacketDecoder whose DecodePacket calls are made a RUN at a time on a device buffer (csrc/t2dec.hip,
+    j2k_t2_decode_packets_device): the decoder's state (Position(), the header bit reader) carries from run to run."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self._st = _DecState()
+        self.done = 0
+
+    def decode(self, d_packets, npackets, d_cbs, d_data, sopEnabled, ephEnabled):
+        """device tensors (uint8 views of the packet table, the code-block table -- read and written -- and the buffer the
+        decoder was made on); returns the packets decoded; raises the first failing packet's J2KError after setting .done"""
+        L = self.ctx.L
+        done = C.c_size_t(0)
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None and t.numel() else None      # noqa: E731
+        st = L.j2k_t2_decode_packets_device(self.ctx.h, ptr(d_packets), C.c_size_t(int(npackets)), ptr(d_cbs),
+                                            C.c_size_t(int(d_cbs.numel()) // 24 if d_cbs is not None else 0), ptr(d_data),
+                                            C.c_size_t(int(d_data.numel()) if d_data is not None else 0), int(bool(sopEnabled)),
+                                            int(bool(ephEnabled)), C.byref(self._st), C.byref(done))
+        self.done = done.value
+        self.ctx.check(st)
+        return done.value
+
+    def Position(self):
+        return int(self._st.pos)
 
 
 class PacketDecoder:

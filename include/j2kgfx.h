@@ -166,6 +166,19 @@ typedef struct {
                                    again at every frame, so every frame is coded exactly as it would be alone,
                                    and one call carries all of them in its launches (tiles are numbered frame
                                    after frame).  0: one frame of `height` rows.  height % frame_rows must be 0 */
+    int32_t closed_loop;        /* 0 (default): the reference's behaviour, byte for byte -- code-block windows cut from the
+                                   top left of the plane for every band (encoder.go:763-795: they overlap, most of the
+                                   plane is never coded) and Tier-2 packets that the reference's own decoder cannot read.
+                                   1: THIS LIBRARY'S closed-loop mode, outside reference parity (SURVEY 8f rank 3 asks for
+                                   "proper sub-band addressing and a real decode body"): band b of resolution r is the
+                                   Mallat rectangle of decomposition level l = numRes-1-r of the tile-component
+                                   (w_0 = w, w_{l+1} = ceil(w_l/2); LL = [0,w_L) x [0,h_L), HL = [w_{l+1},w_l) x [0,h_{l+1}),
+                                   LH = [0,w_{l+1}) x [h_{l+1},h_l), HH the rest), cut into cb_w x cb_h blocks from the
+                                   band's origin: the windows PARTITION the plane, job order stays comp -> res -> band ->
+                                   row -> column, and j2k_plan_encode_tile_parts / j2k_plan_decode_tile_parts write and
+                                   read packets with the J2K_T2_* flags below, so that pixels -> tile-parts -> pixels is
+                                   a bit-exact round trip with the MQ coder.  Transform, block coders and every byte of
+                                   a code-block are the reference's in both modes */
 } j2k_params;
 
 typedef struct {
@@ -467,10 +480,63 @@ int j2k_t2_decode_packet(const uint8_t *data, size_t len, j2k_t2_dec_state *st, 
  * (d_offs: npackets + 1 entries, the last = *total).  J2K_ERR_CAPACITY (with *total set, nothing written) when cap is
  * smaller; J2K_ERR_GO_PANIC for a tree width of 0 that the coder divides by.  Synchronises the context's stream. */
 typedef struct j2k_t2_dev_cb { int32_t included_in_layers, zero_bit_planes, num_passes; uint32_t data_len; uint64_t data_off; } j2k_t2_dev_cb;
-typedef struct j2k_t2_dev_packet { int32_t layer, incl_tree_w, imsb_tree_w, pad_; int64_t cb0, ncb; } j2k_t2_dev_packet;
+/* flags: 0 = the reference's coder.  The closed-loop mode (j2k_params.closed_loop; NOT the reference) sets
+ *   J2K_T2_FRESH     this packet is the first of a new PacketEncoder / PacketDecoder object (one per tile): the byte-stuffing
+ *                    writer's / reader's "last byte was 0xFF" flag starts clear
+ *   J2K_T2_WIDE_LEN  the length-of-length field has 5 bits (the reference's 3 wrap for blocks of 128 bytes or more, t2.go:408-437)
+ *   J2K_T2_SEATED    decoder only: the header is read from Position() and Position() moves past it (the reference's header
+ *                    reader runs over the buffer on its own and Position() only moves over markers and bodies, t2.go:463-503) */
+#define J2K_T2_FRESH 1
+#define J2K_T2_WIDE_LEN 2
+#define J2K_T2_SEATED 4
+typedef struct j2k_t2_dev_packet { int32_t layer, incl_tree_w, imsb_tree_w, flags; int64_t cb0, ncb; } j2k_t2_dev_packet;
 int j2k_t2_encode_packets_device(j2k_ctx *ctx, const j2k_t2_dev_packet *d_packets, size_t npackets, const j2k_t2_dev_cb *d_cbs, size_t ncbs,
                                  const uint8_t *d_data, int sop, int eph, uint8_t *bio_delay, uint8_t *d_out, size_t cap,
                                  uint64_t *d_offs, size_t *total);
+/* PacketDecoder.DecodePacket (t2.go:463-652) for a RUN of packets by ONE decoder object on a DEVICE buffer d_data[0, len)
+ * (csrc/t2dec.hip): packet i is decoded right after packet i - 1 with the object's state -- *st in and out, as
+ * j2k_t2_decode_packet's (a zeroed struct is NewPacketDecoder).  d_cbs is read AND written (IncludedInLayers persists from
+ * layer to layer): a block the packet includes gets IncludedInLayers, ZeroBitPlanes, len(Passes), len(Data) = data_len and
+ * data_off = where its body lies in d_data (nothing is copied).  *packets_done = packets decoded before the first error;
+ * the status is that packet's: J2K_ERR_INVALID_ARG for the reference's error returns (out of header bits, a body past the
+ * end), J2K_ERR_GO_PANIC for a tree of width 0 it divides by.  Synchronises the context's stream. */
+int j2k_t2_decode_packets_device(j2k_ctx *ctx, const j2k_t2_dev_packet *d_packets, size_t npackets, j2k_t2_dev_cb *d_cbs, size_t ncbs,
+                                 const uint8_t *d_data, size_t len, int sop, int eph, j2k_t2_dec_state *st, size_t *packets_done);
+
+/* ---- the closed-loop frame codec (j2k_params.closed_loop = 1): tile-parts of packets out, pixels back -------
+ * The reference has the pieces -- PacketEncoder / PacketDecoder (t2.go), createTileHeader (encoder.go:746-760),
+ * DecodeCodeBlock and ApplyInverseDWT (tcd.go:393-437) -- but no decode body (decoder.decodeTile is a placeholder,
+ * decoder.go:375-411).  These calls are that body on device buffers, asynchronous on the context's stream:
+ *   j2k_plan_encode_tile_parts  the block coder's outputs (j2k_plan_encode_stream) -> for every tile of the shard
+ *                               SOT | SOD | one packet per (component, resolution) in job order, tile-parts end to end in
+ *                               d_out (j2k_plan_frame_bound bytes at most); d_tile_offs[t] (tiles + 1, device) = where
+ *                               tile-part t starts, the last entry the total.  Code-block fields as j2k_plan_t2_fill_cbs
+ *                               with mb = 31, an empty block IncludedInLayers 1; a new PacketEncoder per tile.
+ *                               cap < the bytes needed: nothing is written and d_tile_offs[tiles] holds the need
+ *                               (J2K_ERR_CAPACITY from the next j2k_plan_frame_status).
+ *   j2k_plan_decode_tile_parts  the inverse: d_cs[0, len) -> d_offs / d_lens / d_numbps as j2k_plan_decode_blocks takes
+ *                               them (a block's bytes stay where they are in d_cs: d_offs points into it).  d_tile_offs
+ *                               (device, tiles + 1) where the caller knows the tile-parts' positions (the Go-side parser
+ *                               has read the SOT segments, parser.go:894-983; or the encode call's own table), else NULL:
+ *                               the call walks the SOT segments itself (Psot), one after the other.
+ *   j2k_plan_place_blocks       decoded blocks (j2k_plan_decode_blocks) -> each at its window of the coefficient planes
+ *   j2k_plan_frame_status       synchronises and reports what the asynchronous calls above found since the last call:
+ *                               J2K_OK, J2K_ERR_CAPACITY, or J2K_ERR_INVALID_ARG for a malformed tile-part / packet
+ *   j2k_plan_encode_frame_pixels / j2k_plan_decode_frame_pixels   the whole chain with the plan's own workspaces:
+ *                               pixels (any format, as j2k_plan_forward_pixels) -> tile-parts, and tile-parts -> pixels
+ * All of them return J2K_ERR_UNSUPPORTED on a plan without closed_loop. */
+size_t j2k_plan_frame_bound(const j2k_plan *plan);
+int j2k_plan_encode_tile_parts(j2k_plan *plan, const uint8_t *d_stream, const uint64_t *d_offs, const uint32_t *d_lens, const uint8_t *d_numbps,
+                               int sop, int eph, uint8_t *d_out, size_t cap, uint64_t *d_tile_offs);
+int j2k_plan_decode_tile_parts(j2k_plan *plan, const uint8_t *d_cs, size_t len, const uint64_t *d_tile_offs, int sop, int eph,
+                               uint64_t *d_offs, uint32_t *d_lens, uint8_t *d_numbps);
+int j2k_plan_place_blocks(j2k_plan *plan, const int32_t *d_decoded, int32_t *d_coeff);
+int j2k_plan_frame_status(j2k_plan *plan);
+int j2k_plan_encode_frame_pixels(j2k_plan *plan, int format, const void *d_pix, size_t stride, int sop, int eph,
+                                 uint8_t *d_out, size_t cap, uint64_t *d_tile_offs);
+int j2k_plan_decode_frame_pixels(j2k_plan *plan, const uint8_t *d_cs, size_t len, const uint64_t *d_tile_offs, int sop, int eph,
+                                 void *d_pix, size_t stride);
+
 /* The block coder's outputs as those tables.  j2k_plan_t2_packets (host table out): one packet per (tile, component,
  * resolution) of the plan in job order (encoder.go:616-673: tile, component, resolution, band, block row, block column), its
  * code-blocks = the plan's jobs of that resolution, tree widths = block columns of its first band; layer as given.

@@ -1533,8 +1533,14 @@ int orc_ht_decode(const uint8_t *bytes, size_t nbytes, int num_bitplanes, int ba
 /* encoder.encodeTile job list + sequential body                             */
 /* ======================================================================== */
 
-size_t orc_enumerate_blocks(int ncomp, int w, int h, int num_resolutions,
-                            int cb_w, int cb_h, orc_block *out, size_t cap) { /* encoder.go:597-673 */
+/* The job list in two window modes.  windows == 0: the reference's (encoder.go:597-673: every band's blocks are cut from the
+ * TOP LEFT of the plane, so windows overlap and most of the plane is never coded).  windows == 1: this library's closed-loop
+ * mode (NOT the reference): the same comp -> res -> band -> cby -> cbx order, but band b of resolution r is the Mallat
+ * rectangle of decomposition level l = numRes-1-r of the plane (w_0 = w, w_{l+1} = ceil(w_l / 2); LL = [0,w_L) x [0,h_L);
+ * HL = [w_{l+1},w_l) x [0,h_{l+1}); LH = [0,w_{l+1}) x [h_{l+1},h_l); HH = the rest), cut into cb_w x cb_h blocks from the
+ * band's own origin -- the rectangles partition the plane, so that a decoder can put every sample back. */
+size_t orc_enumerate_blocks2(int ncomp, int w, int h, int num_resolutions,
+                             int cb_w, int cb_h, int windows, orc_block *out, size_t cap) { /* encoder.go:597-673 */
     int numRes = num_resolutions;
     if (numRes <= 0) numRes = 6;
     if (cb_w <= 0) cb_w = 64;
@@ -1545,9 +1551,21 @@ size_t orc_enumerate_blocks(int ncomp, int w, int h, int num_resolutions,
             int numBands = r == 0 ? 1 : 3;
             for (int b = 0; b < numBands; b++) {
                 int band = r == 0 ? BandLL : (b == 0 ? BandHL : (b == 1 ? BandLH : BandHH));
-                long scale = 1L << (numRes - 1 - r);
-                int bw = (int)(((long)w + scale - 1) / scale), bh = (int)(((long)h + scale - 1) / scale);
-                if (r > 0) { bw = (bw + 1) / 2; bh = (bh + 1) / 2; }
+                int bx0 = 0, by0 = 0, bw, bh;
+                if (!windows) {
+                    long scale = 1L << (numRes - 1 - r);
+                    bw = (int)(((long)w + scale - 1) / scale); bh = (int)(((long)h + scale - 1) / scale);
+                    if (r > 0) { bw = (bw + 1) / 2; bh = (bh + 1) / 2; }
+                } else {
+                    int lv = r == 0 ? numRes - 1 : numRes - 1 - r;   /* dims of level lv, and of the next one */
+                    int wl = w, hl = h;
+                    for (int i = 0; i < lv; i++) { wl = (wl + 1) / 2; hl = (hl + 1) / 2; }
+                    int wn = (wl + 1) / 2, hn = (hl + 1) / 2;
+                    if (r == 0) { bw = wl; bh = hl; }
+                    else if (band == BandHL) { bx0 = wn; bw = wl - wn; bh = hn; }
+                    else if (band == BandLH) { by0 = hn; bw = wn; bh = hl - hn; }
+                    else { bx0 = wn; by0 = hn; bw = wl - wn; bh = hl - hn; }
+                }
                 for (int cby = 0; cby * cb_h < bh; cby++)
                     for (int cbx = 0; cbx * cb_w < bw; cbx++) {
                         int aw = cb_w, ah = cb_h, sx = cbx * cb_w, sy = cby * cb_h;
@@ -1555,13 +1573,17 @@ size_t orc_enumerate_blocks(int ncomp, int w, int h, int num_resolutions,
                         if (sy + ah > bh) ah = bh - sy;
                         if (k < cap) {
                             out[k].comp = c; out[k].res = r; out[k].band = band;
-                            out[k].x0 = sx; out[k].y0 = sy; out[k].w = aw; out[k].h = ah;
+                            out[k].x0 = bx0 + sx; out[k].y0 = by0 + sy; out[k].w = aw; out[k].h = ah;
                         }
                         k++;
                     }
             }
         }
     return k;
+}
+size_t orc_enumerate_blocks(int ncomp, int w, int h, int num_resolutions,
+                            int cb_w, int cb_h, orc_block *out, size_t cap) {
+    return orc_enumerate_blocks2(ncomp, w, h, num_resolutions, cb_w, cb_h, 0, out, cap);
 }
 
 void orc_extract_block(const int32_t *plane, int plane_w, int plane_h,
@@ -1573,12 +1595,12 @@ void orc_extract_block(const int32_t *plane, int plane_w, int plane_h,
         }
 }
 
-long orc_encode_tile_blocks(int32_t *const *planes, int ncomp, int w, int h,
-                            int num_resolutions, int cb_w, int cb_h, int coder,
-                            uint8_t *out, size_t cap, uint32_t *lens, uint8_t *numbps) { /* encoder.go:677-688 */
-    size_t nj = orc_enumerate_blocks(ncomp, w, h, num_resolutions, cb_w, cb_h, NULL, 0);
+long orc_encode_tile_blocks2(int32_t *const *planes, int ncomp, int w, int h,
+                             int num_resolutions, int cb_w, int cb_h, int coder, int windows,
+                             uint8_t *out, size_t cap, uint32_t *lens, uint8_t *numbps) { /* encoder.go:677-688 */
+    size_t nj = orc_enumerate_blocks2(ncomp, w, h, num_resolutions, cb_w, cb_h, windows, NULL, 0);
     orc_block *jobs = (orc_block *)malloc((nj ? nj : 1) * sizeof(orc_block));
-    orc_enumerate_blocks(ncomp, w, h, num_resolutions, cb_w, cb_h, jobs, nj);
+    orc_enumerate_blocks2(ncomp, w, h, num_resolutions, cb_w, cb_h, windows, jobs, nj);
     size_t total = 0;
     long status = 0;
     for (size_t j = 0; j < nj && status >= 0; j++) {
@@ -1608,6 +1630,43 @@ long orc_encode_tile_blocks(int32_t *const *planes, int ncomp, int w, int h,
     }
     free(jobs);
     return status < 0 ? status : (long)total;
+}
+long orc_encode_tile_blocks(int32_t *const *planes, int ncomp, int w, int h,
+                            int num_resolutions, int cb_w, int cb_h, int coder,
+                            uint8_t *out, size_t cap, uint32_t *lens, uint8_t *numbps) {
+    return orc_encode_tile_blocks2(planes, ncomp, w, h, num_resolutions, cb_w, cb_h, coder, 0, out, cap, lens, numbps);
+}
+
+/* The decode body the reference leaves as a placeholder (decoder.go:375-411), composed from the functions it does have:
+ * TileDecoder.DecodeCodeBlock (tcd.go:393-413: NewT1(w, h).Decode(data, numBPS, band) / a fresh HT decoder; a block without
+ * data is skipped and its samples stay 0) for every job of the list, each decoded block put at its window of the (zeroed)
+ * component plane.  With windows == 1 every sample is written exactly once; with the reference's overlapping windows a later
+ * job overwrites an earlier one.  bytes = the jobs' data end to end in job order. */
+int orc_decode_tile_blocks(const uint8_t *bytes, const uint32_t *lens, const uint8_t *numbps, int ncomp, int w, int h,
+                           int num_resolutions, int cb_w, int cb_h, int coder, int windows, int32_t *const *planes) {
+    size_t nj = orc_enumerate_blocks2(ncomp, w, h, num_resolutions, cb_w, cb_h, windows, NULL, 0);
+    orc_block *jobs = (orc_block *)malloc((nj ? nj : 1) * sizeof(orc_block));
+    orc_enumerate_blocks2(ncomp, w, h, num_resolutions, cb_w, cb_h, windows, jobs, nj);
+    for (int c = 0; c < ncomp; c++) memset(planes[c], 0, (size_t)w * h * sizeof(int32_t));
+    size_t pos = 0;
+    int status = 0;
+    for (size_t j = 0; j < nj; j++) {
+        const orc_block *b = &jobs[j];
+        size_t bn = (size_t)b->w * (size_t)b->h;
+        if (lens[j] == 0) continue;                                  /* tcd.go:394-396 */
+        int32_t *blk = (int32_t *)calloc(bn ? bn : 1, sizeof(int32_t));
+        if (coder == 0) orc_t1_decode(bytes + pos, lens[j], numbps[j], b->band, b->w, b->h, blk);
+        else if (orc_ht_decode(bytes + pos, lens[j], numbps[j], b->band, b->w, b->h, blk) != 0) status = -2;
+        pos += lens[j];
+        for (int y = 0; y < b->h; y++)
+            for (int x = 0; x < b->w; x++) {
+                int sx = b->x0 + x, sy = b->y0 + y;
+                if (sx < w && sy < h) planes[b->comp][(size_t)sy * w + sx] = blk[(size_t)y * b->w + x];
+            }
+        free(blk);
+    }
+    free(jobs);
+    return status;
 }
 
 /* ======================================================================== */

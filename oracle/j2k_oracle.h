@@ -128,6 +128,18 @@ long orc_encode_tile_blocks(int32_t *const *planes, int ncomp, int w, int h,
                             int num_resolutions, int cb_w, int cb_h, int coder,
                             uint8_t *out, size_t cap, uint32_t *lens, uint8_t *numbps);
 
+/* The same with a window mode: 0 = the reference's top-left windows (the functions above); 1 = this library's CLOSED-LOOP
+ * mode, not the reference: the bands are the Mallat rectangles of the plane, which partition it (see j2k_oracle.c). */
+size_t orc_enumerate_blocks2(int ncomp, int w, int h, int num_resolutions,
+                             int cb_w, int cb_h, int windows, orc_block *out, size_t cap);
+long orc_encode_tile_blocks2(int32_t *const *planes, int ncomp, int w, int h,
+                             int num_resolutions, int cb_w, int cb_h, int coder, int windows,
+                             uint8_t *out, size_t cap, uint32_t *lens, uint8_t *numbps);
+/* DecodeCodeBlock (tcd.go:393-413) for every job + each block put back at its window of the zeroed planes: the decode body
+ * decoder.decodeTile leaves out (decoder.go:375-411).  Returns 0, or -2 where the Go HT decoder would panic. */
+int orc_decode_tile_blocks(const uint8_t *bytes, const uint32_t *lens, const uint8_t *numbps, int ncomp, int w, int h,
+                           int num_resolutions, int cb_w, int cb_h, int coder, int windows, int32_t *const *planes);
+
 /* encoder.createTileHeader(tileIdx, tileData) (encoder.go:746-760): writes 14 + len bytes to out, returns that count */
 size_t orc_create_tile_header(int tile_idx, const uint8_t *tile_data, size_t len, uint8_t *out);
 

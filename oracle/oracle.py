@@ -32,6 +32,8 @@ def lib():
         _LIB.orc_ht_bound.argtypes = [C.c_int, C.c_int]
         _LIB.orc_enumerate_blocks.restype = C.c_size_t
         _LIB.orc_encode_tile_blocks.restype = C.c_long
+        _LIB.orc_enumerate_blocks2.restype = C.c_size_t
+        _LIB.orc_encode_tile_blocks2.restype = C.c_long
     return _LIB
 
 
@@ -275,31 +277,48 @@ BLOCK_DTYPE = np.dtype([("comp", "<i4"), ("res", "<i4"), ("band", "<i4"),
                         ("x0", "<i4"), ("y0", "<i4"), ("w", "<i4"), ("h", "<i4")])
 
 
-def enumerate_blocks(ncomp, w, h, num_resolutions, cb_w, cb_h):
-    n = lib().orc_enumerate_blocks(int(ncomp), int(w), int(h), int(num_resolutions), int(cb_w), int(cb_h),
-                                   None, C.c_size_t(0))
+def enumerate_blocks(ncomp, w, h, num_resolutions, cb_w, cb_h, windows=0):
+    """windows = 0: the reference's top-left windows (encoder.go:597-673); 1: the closed-loop mode's Mallat rectangles
+    (this library's, not the reference's -- see orc_enumerate_blocks2)."""
+    n = lib().orc_enumerate_blocks2(int(ncomp), int(w), int(h), int(num_resolutions), int(cb_w), int(cb_h), int(windows),
+                                    None, C.c_size_t(0))
     out = np.zeros(n, dtype=BLOCK_DTYPE)
-    lib().orc_enumerate_blocks(int(ncomp), int(w), int(h), int(num_resolutions), int(cb_w), int(cb_h),
-                               out.ctypes.data_as(C.POINTER(Block)), C.c_size_t(n))
+    lib().orc_enumerate_blocks2(int(ncomp), int(w), int(h), int(num_resolutions), int(cb_w), int(cb_h), int(windows),
+                                out.ctypes.data_as(C.POINTER(Block)), C.c_size_t(n))
     return out
 
 
-def encode_tile_blocks(planes, w, h, num_resolutions, cb_w, cb_h, coder):
+def encode_tile_blocks(planes, w, h, num_resolutions, cb_w, cb_h, coder, windows=0):
     """Sequential encodeTile body. Returns (bytes, lens[u32], numbps[u8])."""
     planes = [_own_i32(p).reshape(-1) for p in planes]
-    nj = len(enumerate_blocks(len(planes), w, h, num_resolutions, cb_w, cb_h))
+    jobs = enumerate_blocks(len(planes), w, h, num_resolutions, cb_w, cb_h, windows)
+    nj = len(jobs)
     cap = 0
-    for b in enumerate_blocks(len(planes), w, h, num_resolutions, cb_w, cb_h):
+    for b in jobs:
         bw, bh = int(b["w"]), int(b["h"])
         cap += max(ht_bound(bw, bh), bw * bh * 2 + 16384)
     out = np.zeros(max(cap, 1), dtype=np.uint8)
     lens = np.zeros(max(nj, 1), dtype=np.uint32); nbps = np.zeros(max(nj, 1), dtype=np.uint8)
-    n = lib().orc_encode_tile_blocks(_plane_ptrs(planes), len(planes), int(w), int(h), int(num_resolutions),
-                                     int(cb_w), int(cb_h), int(coder), _u8(out), C.c_size_t(out.size),
-                                     lens.ctypes.data_as(C.POINTER(C.c_uint32)), _u8(nbps))
+    n = lib().orc_encode_tile_blocks2(_plane_ptrs(planes), len(planes), int(w), int(h), int(num_resolutions),
+                                      int(cb_w), int(cb_h), int(coder), int(windows), _u8(out), C.c_size_t(out.size),
+                                      lens.ctypes.data_as(C.POINTER(C.c_uint32)), _u8(nbps))
     if n < 0:
         raise ValueError("orc_encode_tile_blocks status %d" % n)
     return out[:n].copy(), lens[:nj].copy(), nbps[:nj].copy()
+
+
+def decode_tile_blocks(data, lens, numbps, ncomp, w, h, num_resolutions, cb_w, cb_h, coder, windows=1):
+    """The decode body decoder.decodeTile leaves out (decoder.go:375-411): tcd.DecodeCodeBlock (tcd.go:393-413) for every job
+    of the list, each block put back at its window of the zeroed component planes.  Returns the planes [(h, w) int32]."""
+    data = np.ascontiguousarray(np.frombuffer(bytes(data), np.uint8) if not isinstance(data, np.ndarray) else data, dtype=np.uint8)
+    lens = np.ascontiguousarray(lens, dtype=np.uint32); numbps = np.ascontiguousarray(numbps, dtype=np.uint8)
+    planes = [np.zeros(h * w, dtype=np.int32) for _ in range(ncomp)]
+    pad = np.concatenate([data, np.zeros(8, np.uint8)])
+    r = lib().orc_decode_tile_blocks(_u8(pad), lens.ctypes.data_as(C.POINTER(C.c_uint32)), _u8(numbps), int(ncomp), int(w), int(h),
+                                     int(num_resolutions), int(cb_w), int(cb_h), int(coder), int(windows), _plane_ptrs(planes))
+    if r != 0:
+        raise ValueError("orc_decode_tile_blocks status %d" % r)
+    return [p.reshape(h, w) for p in planes]
 
 
 def create_tile_header(tile_idx, tile_data):

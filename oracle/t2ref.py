@@ -11,7 +11,14 @@ Follows mrjoshuak/go-jpeg2000:
                                    SOP / EPH markers and bodies -- kept as is)
   internal/tcd/tcd.go:155-212      TagTree (shape only: the coder never walks it)
   internal/tcd/tcd.go:240-390      TileDecoder.InitTile / initResolution / initBand (the band rectangles as written)
-Parity of this file itself is pinned by the expectations the reference's own tests state (tests/test_t2_reference_tests.py)."""
+Parity of this file itself is pinned by the expectations the reference's own tests state (tests/test_t2_reference_tests.py).
+
+CLOSED-LOOP MODE (this library's, NOT the reference's; default off).  The reference's coder cannot read what it writes: the
+length-of-length field has three bits and wraps for blocks of 128 bytes or more (t2.go:408-437), and the decoder takes a
+packet's bodies from Position(), which its header reader never moves (t2.go:463-503).  PacketEncoder(len_bits=5) writes the
+field in five bits; PacketDecoder(len_bits=5, seated=True) reads the header FROM Position() and moves Position() past it;
+fresh() on either is a new coder object on the same buffer (one per tile: the writer's / reader's 0xFF flag starts clear).
+Everything else -- presence bit, unary values, pass code, stuffing, markers, body order -- is the reference's."""
 
 LRCP, RLCP, RPCL, PCRL, CPRL = 0, 1, 2, 3, 4   # codestream.ProgressionOrder (codestream.go)
 
@@ -217,8 +224,12 @@ class PacketIterator:                           # t2.go:18-238
 
 # ---- PacketEncoder -----------------------------------------------------------------------------------------------------
 class PacketEncoder:                            # t2.go:241-438
-    def __init__(self):
+    def __init__(self, len_bits=3):
         self.out = bytearray()
+        self.bio = ByteStuffingWriter(self.out)
+        self.len_bits = len_bits                # 3: the reference (t2.go:408-437); 5: closed-loop mode
+
+    def fresh(self):                            # NewPacketEncoder(w) on the same w
         self.bio = ByteStuffingWriter(self.out)
 
     def encode_packet(self, precinct, layer, sop, eph):
@@ -281,25 +292,33 @@ class PacketEncoder:                            # t2.go:241-438
 
     def encode_length(self, length):
         if length == 0:
-            return self.bio.write_bits(0, 3)
+            return self.bio.write_bits(0, self.len_bits)
         bits, temp = 0, length
         while temp > 0:
             bits += 1
             temp >>= 1
-        self.bio.write_bits(bits & 0xFFFFFFFF, 3)
+        self.bio.write_bits(bits & 0xFFFFFFFF, self.len_bits)
         self.bio.write_bits(length & 0xFFFFFFFF, bits)
 
 
 # ---- PacketDecoder -----------------------------------------------------------------------------------------------------
 class PacketDecoder:                            # t2.go:439-652
-    def __init__(self, data):
+    def __init__(self, data, len_bits=3, seated=False):
         self.buf, self.pos = bytes(data), 0
+        self.bio = ByteStuffingReader(self.buf)
+        self.len_bits, self.seated = len_bits, seated      # closed-loop mode: 5, True (see the module docstring)
+
+    def fresh(self):                            # a new decoder object that starts where this one stands
         self.bio = ByteStuffingReader(self.buf)
 
     def decode_packet(self, precinct, layer, sop, eph):
         if sop and self.pos + 6 <= len(self.buf) and self.buf[self.pos] == 0xFF and self.buf[self.pos + 1] == 0x91:
             self.pos += 6
+        if self.seated:                          # closed-loop mode: the header is read from Position() ...
+            self.bio.rpos, self.bio.cnt = self.pos, 0
         self.decode_packet_header(precinct, layer)
+        if self.seated:                          # ... and Position() moves past it
+            self.pos = self.bio.rpos
         if eph and self.pos + 2 <= len(self.buf) and self.buf[self.pos] == 0xFF and self.buf[self.pos + 1] == 0x92:
             self.pos += 2
         for band in precinct.code_blocks:
@@ -358,7 +377,7 @@ class PacketDecoder:                            # t2.go:439-652
         return r.read_bits(7) + 37
 
     def decode_length(self):
-        nb = self.bio.read_bits(3)
+        nb = self.bio.read_bits(self.len_bits)
         if nb == 0:
             return 0
         return self.bio.read_bits(nb)

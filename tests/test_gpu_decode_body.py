@@ -1,0 +1,422 @@
+"""GPU: the decode body.
+
+(i)   PacketDecoder.DecodePacket on a device buffer (csrc/t2dec.hip, j2k_t2_decode_packets_device) == the host call
+      (csrc/t2.cpp, j2k_t2_decode_packet) == the restatement of internal/tcd/t2.go:463-652 (oracle/t2ref.py), on the random runs
+      tests/test_gpu_t2.py draws for the encoder -- the reference's decoder AS IT IS (its header reader runs on its own,
+      Position() only moves over markers and bodies), so most of these runs end in its error return: packets done, every
+      decoded field, every body and Position() are compared up to that point.
+(ii)  closed-loop mode (j2k_params.closed_loop; this library's, not the reference's): 3840 x 2160 RGB8, MQ coder,
+      pixels -> tile-parts of packets -> pixels, bit-exact.
+(iii) every stage of (ii) against the oracle's composition of the reference's own functions (job list with windows that
+      partition the plane, T1.EncodeFast5, PacketEncoder / createTileHeader, PacketDecoder, T1.Decode, placement,
+      ReconstructMultiLevel53 + inverse RCT + DC shift) on a ragged multi-tile frame and on sampled tiles of the 4K frame."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "go-jpeg2000_amd"), os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from test_gpu_t2 import _rand_bands  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import t2ref
+    from j2kgfx import t2
+    from j2kgfx.context import Context
+    ctx = Context(0)
+    yield torch, t2ref, t2, ctx
+    ctx.close()
+
+
+def _dev(torch, a):
+    a = np.ascontiguousarray(a)
+    return torch.from_numpy(a.view(np.uint8).reshape(-1).copy()).cuda() if a.size else None
+
+
+def _decode_three_ways(env, data, shapes, layers, trees, sop, eph, flags=0, len_bits=3, seated=False, fresh_at=()):
+    """shapes[p] = code-blocks per band of packet p.  Returns (per decoder: packets done, fields, bodies, Position)."""
+    torch, t2ref, t2, ctx = env
+    from j2kgfx import J2KError
+    # restatement
+    dec = t2ref.PacketDecoder(data, len_bits=len_bits, seated=seated)
+    ref_done, ref_cbs, ref_err = 0, [], None
+    for p, shape in enumerate(shapes):
+        if p in fresh_at:
+            dec.fresh()
+        pr = t2ref.Precinct([[t2ref.CodeBlock(None, 0, 0, 0) for _ in range(n)] for n in shape], trees[p][0], trees[p][1])
+        try:
+            dec.decode_packet(pr, layers[p], sop, eph)
+        except (t2ref.EOF, t2ref.GoPanic) as e:
+            ref_err = type(e).__name__
+            break
+        ref_done += 1
+        ref_cbs.append([(cb.included_in_layers, cb.zero_bit_planes, cb.num_passes, bytes(cb.data) if cb.data is not None else b"")
+                        for band in pr.code_blocks for cb in band])
+    ref_pos = dec.pos
+    # device
+    pk = np.zeros(len(shapes), t2.DEV_PACKET_DTYPE)
+    k = 0
+    for p, shape in enumerate(shapes):
+        f = flags | (1 if p in fresh_at else 0)
+        pk[p] = (layers[p], trees[p][0], trees[p][1], f, k, sum(shape))
+        k += sum(shape)
+    cbs = torch.zeros(max(k, 1) * 24, dtype=torch.uint8, device="cuda")
+    d_data = _dev(torch, np.frombuffer(bytes(data), np.uint8)) if len(data) else torch.zeros(8, dtype=torch.uint8, device="cuda")[:0]
+    dd = t2.DevicePacketDecoder(ctx)
+    dev_err = None
+    try:
+        dd.decode(_dev(torch, pk), len(shapes), cbs, d_data if len(data) else None, sop, eph)
+    except J2KError as e:
+        dev_err = e.status
+    tab = cbs.cpu().numpy().view(t2.DEV_CB_DTYPE)
+    dev_cbs = []
+    k = 0
+    for p, shape in enumerate(shapes):
+        if p >= dd.done:
+            break
+        row = []
+        for _ in range(sum(shape)):
+            c = tab[k]
+            k += 1
+            body = bytes(data[int(c["data_off"]):int(c["data_off"]) + int(c["data_len"])]) if (int(c["included_in_layers"]) == layers[p] and int(c["data_len"])) else None
+            row.append((int(c["included_in_layers"]), int(c["zero_bit_planes"]), int(c["num_passes"]), int(c["data_len"]), body))
+        dev_cbs.append(row)
+    return (ref_done, ref_cbs, ref_err, ref_pos), (dd.done, dev_cbs, dev_err, dd.Position())
+
+
+def _same(ref, dev, layers):
+    ref_done, ref_cbs, ref_err, ref_pos = ref
+    dev_done, dev_cbs, dev_err, dev_pos = dev
+    assert dev_done == ref_done, (dev_done, ref_done, ref_err, dev_err)
+    assert (ref_err is None) == (dev_err is None), (ref_err, dev_err)
+    if ref_err == "GoPanic":
+        assert dev_err == -5
+    elif ref_err == "EOF":
+        assert dev_err == -1
+    for p in range(ref_done):
+        assert len(ref_cbs[p]) == len(dev_cbs[p])
+        for (ri, rz, rn, rd), (di, dz, dn, dl, body) in zip(ref_cbs[p], dev_cbs[p]):
+            assert (ri, rz, rn, len(rd)) == (di, dz, dn, dl), p
+            if ri == layers[p] and len(rd):
+                assert body == rd, p                      # the body the reference copies == the bytes at data_off
+    if ref_err is None:
+        assert dev_pos == ref_pos
+
+
+def test_device_packet_decoder_is_the_references_decoder_on_encoder_runs(env):
+    """(i): 300 random encoder runs (the ones test_gpu_t2 draws), decoded by the reference's own decoder semantics three ways"""
+    torch, t2ref, t2, ctx = env
+    from j2kgfx import J2KError
+    rng = np.random.default_rng(7)
+    full = 0
+    for it in range(300):
+        ff_heavy = it % 2 == 0
+        sop, eph = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        enc = t2ref.PacketEncoder()
+        shapes, layers, trees = [], [], []
+        for _ in range(int(rng.integers(1, 41))):
+            bands = _rand_bands(rng, ff_heavy)
+            if it % 5 == 0:                                     # runs the decoder can get through: one small block per packet, no SOP
+                bands = [[(bytes(rng.integers(0, 256, int(rng.integers(1, 100))).astype(np.uint8)), 0, int(rng.integers(0, 9)), int(rng.choice([1, 2, 3, 7, 40])))]]
+            layer = int(rng.integers(0, 3)) if it % 5 else 0
+            enc.encode_packet(t2ref.Precinct([[t2ref.CodeBlock(*cb) for cb in b] for b in bands], 1, 1), layer, sop, eph)
+            shapes.append([len(b) for b in bands]); layers.append(layer); trees.append((1, 1))
+        data = bytes(enc.out)
+        ref, dev = _decode_three_ways(env, data, shapes, layers, trees, sop, eph)
+        _same(ref, dev, layers)
+        full += ref[2] is None
+        # the host call, packet by packet, against the same restatement
+        hd = t2.PacketDecoder(data)
+        done = 0
+        for p, shape in enumerate(shapes):
+            pr = t2.Precinct([[t2.CodeBlock(None, 0, 0, 0) for _ in range(n)] for n in shape])
+            try:
+                hd.DecodePacket(pr, layers[p], sop, eph)
+            except J2KError:
+                break
+            done += 1
+            got = [(cb.IncludedInLayers, cb.ZeroBitPlanes, cb.Passes, cb.Data or b"") for band in pr.CodeBlocks for cb in band]
+            assert got == ref[1][p], (it, p)
+        assert done == ref[0]
+        if ref[2] is None:
+            assert hd.Position() == ref[3]
+    assert full >= 20                       # some runs do go through (a single small block per packet: body read from the header's own bytes)
+
+
+def test_device_packet_decoder_arbitrary_bytes_tree_widths_and_prefilled_tables(env):
+    """foreign input: random bytes as packets (long unary runs, lengths past the end), zero-width trees, layers > 0 on a
+    table an earlier run filled"""
+    torch, t2ref, t2, ctx = env
+    rng = np.random.default_rng(11)
+    for it in range(200):
+        n = int(rng.integers(0, 400))
+        kind = it % 4
+        raw = rng.integers(0, 256, n).astype(np.uint8)
+        if kind == 1:
+            raw[rng.random(n) < 0.5] = 0                         # zero runs: long unary values
+        elif kind == 2:
+            raw[rng.random(n) < 0.5] = 0xFF                      # stuffing everywhere
+        shapes = [[int(rng.integers(0, 5)) for _ in range(int(rng.integers(1, 4)))] for _ in range(int(rng.integers(1, 12)))]
+        layers = [0 for _ in shapes]
+        trees = [(int(rng.integers(0, 3)), int(rng.integers(0, 3))) for _ in shapes]
+        sop, eph = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        ref, dev = _decode_three_ways(env, bytes(raw), shapes, layers, trees, sop, eph)
+        _same(ref, dev, layers)
+
+
+def _cl_runs(rng, ntiles):
+    tiles = []
+    for _ in range(ntiles):
+        pk = []
+        for _ in range(int(rng.integers(1, 7))):
+            bands = []
+            for _ in range(int(rng.integers(1, 4))):
+                b = []
+                for _ in range(int(rng.integers(0, 80 if rng.random() < 0.1 else 9))):
+                    n = int(rng.choice([0, 1, 5, 127, 128, 300, 5000, 70000]))
+                    d = bytes(rng.integers(0, 256, n).astype(np.uint8)) if rng.random() < 0.7 else b"\xff" * n
+                    b.append((d, 1 if n == 0 else 0, int(rng.integers(0, 32)), int(rng.choice([1, 2, 4, 10, 40, 91]))))
+                bands.append(b)
+            pk.append(bands)
+        tiles.append(pk)
+    return tiles
+
+
+def test_closed_loop_packets_device_encoder_and_decoder_against_the_restatement(env):
+    """closed-loop flags (J2K_T2_FRESH / WIDE_LEN / SEATED): device encoder == t2ref.PacketEncoder(len_bits=5) with a new
+    encoder per tile; device decoder on those bytes == t2ref.PacketDecoder(len_bits=5, seated=True) == what went in"""
+    torch, t2ref, t2, ctx = env
+    from j2kgfx import _lib
+    rng = np.random.default_rng(21)
+    for it in range(60):
+        tiles = _cl_runs(rng, int(rng.integers(1, 5)))
+        sop, eph = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        enc = t2ref.PacketEncoder(len_bits=5)
+        run, flags, fresh_at, shapes = [], [], [], []
+        for pk in tiles:
+            enc.fresh()
+            fresh_at.append(len(run))
+            for bands in pk:
+                enc.encode_packet(t2ref.Precinct([[t2ref.CodeBlock(*cb) for cb in b] for b in bands]), 0, sop, eph)
+                flags.append(_lib.T2_WIDE_LEN | _lib.T2_SEATED | (_lib.T2_FRESH if len(run) == fresh_at[-1] else 0))
+                run.append((t2.Precinct([[t2.CodeBlock(*cb) for cb in b] for b in bands]), 0))
+                shapes.append([len(b) for b in bands])
+        want = bytes(enc.out)
+        dev_enc = t2.DevicePacketEncoder(ctx)
+        packets, cbs, data = dev_enc.tables(run, flags)
+        out = torch.zeros(len(want) + 64, dtype=torch.uint8, device="cuda")
+        offs = torch.zeros(len(run) + 1, dtype=torch.int64, device="cuda")
+        total = dev_enc.encode(_dev(torch, packets), len(run), _dev(torch, cbs), _dev(torch, data), sop, eph, out, offs)
+        assert total == len(want) and out.cpu().numpy()[:total].tobytes() == want, it
+        layers = [0] * len(run)
+        ref, dev = _decode_three_ways(env, want, shapes, layers, [(1, 1)] * len(run), sop, eph,
+                                      flags=_lib.T2_WIDE_LEN | _lib.T2_SEATED, len_bits=5, seated=True, fresh_at=set(fresh_at))
+        _same(ref, dev, layers)
+        assert ref[2] is None and ref[0] == len(run) and ref[3] == len(want)
+        flat = [cb for pk in tiles for bands in pk for b in bands for cb in b]
+        got = [c for row in dev[1] for c in row]
+        assert len(flat) == len(got)
+        for (d, incl, zbp, npass), (gi, gz, gn, gl, body) in zip(flat, got):
+            if len(d):
+                assert (gi, gz, gn, gl, body) == (0, zbp, npass, len(d), d)
+            else:
+                assert gl == 0 and body is None
+
+
+def _frame(W, H, seed, noise=16):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:H, 0:W]
+    f = np.stack([xx * 255 // W, yy * 255 // H, (xx + yy) * 127 // max(W, H)]) + rng.integers(-noise, noise + 1, (3, H, W))
+    return np.clip(f, 0, 255).astype(np.uint8)
+
+
+def _rgba(frame):
+    C, H, W = frame.shape
+    pix = np.full((H, W, 4), 255, np.uint8)
+    pix[..., :3] = frame.transpose(1, 2, 0)
+    return pix.reshape(H, W * 4)
+
+
+def test_closed_loop_4k_rgb8_mq_pixels_to_tile_parts_to_pixels_bit_exact(env):
+    """(ii): 3840 x 2160 RGB8, 512 x 512 tiles, 64 x 64 blocks, MQ coder: pixels -> SOT | SOD | packets -> pixels"""
+    torch, t2ref, t2, ctx = env
+    from j2kgfx import _lib
+    from j2kgfx.codec import FramePlan
+    W, H = 3840, 2160
+    pix = _rgba(_frame(W, H, 5))
+    plan = FramePlan(W, H, 3, precision=8, lossless=True, num_resolutions=6, cb=(64, 64), tile=(512, 512), coder=_lib.CODER_MQ, ctx=ctx, closed_loop=True)
+    d_pix = torch.from_numpy(pix).to(plan.device)
+    cs, toffs = plan.encode_frame_pixels(_lib.PIX_RGBA8, d_pix, sop=True, eph=True)
+    plan.frame_status()
+    total = int(toffs[-1].item())
+    assert 0 < total <= cs.numel()
+    h = cs[:14].cpu().numpy()
+    assert bytes(h[:4]) == b"\xff\x90\x00\x0a" and bytes(h[12:14]) == b"\xff\x93"
+    for given in (True, False):                                  # tile-part positions from the caller / found by walking the SOT segments
+        back = torch.zeros_like(d_pix)
+        plan.decode_frame_pixels(cs, total, back, tile_offs=toffs if given else None, sop=True, eph=True)
+        plan.frame_status()
+        got = back.cpu().numpy().reshape(H, W, 4)
+        assert np.array_equal(got[..., :3], pix.reshape(H, W, 4)[..., :3]), given
+        assert (got[..., 3] == 255).all()
+    # a smaller buffer: nothing written, the need reported, the status says so
+    from j2kgfx import J2KError
+    small = torch.full((total - 1,), 0xA5, dtype=torch.uint8, device=plan.device)
+    _, toffs2 = plan.encode_frame_pixels(_lib.PIX_RGBA8, d_pix, sop=True, eph=True, out=small)
+    with pytest.raises(J2KError) as e:
+        plan.frame_status()
+    assert e.value.status == _lib.ERR_CAPACITY and int(toffs2[-1].item()) == total and (small.cpu().numpy() == 0xA5).all()
+    # a truncated stream: malformed, reported, no fault
+    with pytest.raises(J2KError) as e:
+        plan.decode_frame_pixels(cs, total - 1000, torch.zeros_like(d_pix), tile_offs=None, sop=True, eph=True)
+        plan.frame_status()
+    assert e.value.status == _lib.ERR_INVALID_ARG
+    plan.close()
+
+
+def _oracle_frame(frame, W, H, tw, th, nres, cb, coder, sop, eph, orc, t2ref, tiles=None):
+    """The closed-loop frame by the oracle: per tile (the reference pipeline on the cropped sub-image) preprocess,
+    the job list with partitioning windows, the block coder, one packet per (component, resolution), createTileHeader.
+    Returns per tile: dict(coeff, bytes, lens, numbps, part)."""
+    out = {}
+    tx_n, ty_n = (W + tw - 1) // tw, (H + th - 1) // th
+    for t in range(tx_n * ty_n):
+        if tiles is not None and t not in tiles:
+            continue
+        tx, ty = t % tx_n, t // tx_n
+        x0, y0 = tx * tw, ty * th
+        w, h = min(tw, W - x0), min(th, H - y0)
+        sub = [np.ascontiguousarray(frame[c, y0:y0 + h, x0:x0 + w]).astype(np.int32) for c in range(frame.shape[0])]
+        coeff = orc.preprocess(sub, w, h, 8, True, nres)
+        by, lens, nb = orc.encode_tile_blocks(coeff, w, h, nres, cb, cb, coder, windows=1)
+        jobs = orc.enumerate_blocks(len(sub), w, h, nres, cb, cb, 1)
+        enc = t2ref.PacketEncoder(len_bits=5)
+        pos, j = 0, 0
+        while j < len(jobs):
+            k = j
+            blocks = []
+            while k < len(jobs) and jobs[k]["comp"] == jobs[j]["comp"] and jobs[k]["res"] == jobs[j]["res"]:
+                ln, n_b = int(lens[k]), int(nb[k])
+                blocks.append(t2ref.CodeBlock(bytes(by[pos:pos + ln]), 1 if ln == 0 else 0, max(31 - n_b, 0), 0 if n_b == 0 else (1 if coder == 1 else 3 * n_b - 2)))
+                pos += ln
+                k += 1
+            enc.encode_packet(t2ref.Precinct([blocks]), 0, sop, eph)
+            j = k
+        out[t] = dict(coeff=coeff, bytes=by, lens=lens, numbps=nb, part=orc.create_tile_header(t, bytes(enc.out)), w=w, h=h, x0=x0, y0=y0)
+    return out
+
+
+@pytest.mark.parametrize("coder", [0, 1])
+def test_closed_loop_every_stage_against_the_oracle_ragged_tiles(env, coder):
+    """(iii) on a frame with ragged edge tiles (odd sizes: bands of unequal widths, one-sample bands): job windows, block bytes,
+    tile-parts, parsed block tables, decoded + placed planes, pixels -- each against the oracle's composition"""
+    torch, t2ref, t2, ctx = env
+    import oracle as orc
+    from j2kgfx import _lib
+    from j2kgfx.codec import FramePlan
+    W, H, tw, th, nres, cb = 301, 211, 128, 96, 4, 32
+    frame = _frame(W, H, 3 + coder, noise=30 if coder == 0 else 3)
+    plan = FramePlan(W, H, 3, precision=8, lossless=True, num_resolutions=nres, cb=(cb, cb), tile=(tw, th), coder=coder, ctx=ctx, closed_loop=True)
+    want = _oracle_frame(frame, W, H, tw, th, nres, cb, coder, True, False, orc, t2ref)
+    # job windows
+    blocks = plan.blocks()
+    planes = plan.planes()
+    j = 0
+    for t in sorted(want):
+        jobs = orc.enumerate_blocks(3, want[t]["w"], want[t]["h"], nres, cb, cb, 1)
+        for b in jobs:
+            g = blocks[j]
+            assert (int(planes[g["plane"]][0]), int(planes[g["plane"]][1]), g["band"], g["x0"], g["y0"], g["w"], g["h"]) == \
+                (t, b["comp"], b["band"], b["x0"], b["y0"], b["w"], b["h"])
+            j += 1
+    assert j == len(blocks)
+    # forward + block coder
+    d_frame = torch.from_numpy(frame.astype(np.int32)).to(plan.device)
+    coeff = plan.forward(d_frame)
+    stream, offs, lens, numbps = plan.encode_stream(coeff)
+    cs, toffs = plan.encode_tile_parts(stream, offs, lens, numbps, sop=True, eph=False)
+    plan.frame_status()
+    h_lens, h_nb = lens.cpu().numpy(), numbps.cpu().numpy()
+    h_stream = stream.cpu().numpy()[:int(offs[-1].item())]
+    assert bytes(h_stream) == b"".join(bytes(want[t]["bytes"]) for t in sorted(want))
+    assert np.array_equal(h_lens[:len(blocks)].astype(np.uint32), np.concatenate([want[t]["lens"] for t in sorted(want)]))
+    h_toffs = toffs.cpu().numpy()
+    h_cs = cs.cpu().numpy()
+    for i, t in enumerate(sorted(want)):
+        assert bytes(h_cs[int(h_toffs[i]):int(h_toffs[i + 1])]) == want[t]["part"], t
+    total = int(h_toffs[-1])
+    # parse: the block tables point into the tile-parts
+    offs2, lens2, nb2 = plan.decode_tile_parts(cs, total, tile_offs=None, sop=True, eph=False)
+    plan.frame_status()
+    o2, l2, n2 = offs2.cpu().numpy(), lens2.cpu().numpy(), nb2.cpu().numpy()
+    assert np.array_equal(l2[:len(blocks)], h_lens[:len(blocks)])
+    pos = 0
+    for k in range(len(blocks)):
+        ln = int(l2[k])
+        if ln:
+            assert bytes(h_cs[int(o2[k]):int(o2[k]) + ln]) == bytes(h_stream[pos:pos + ln]), k
+            assert int(n2[k]) == int(h_nb[k])
+        else:
+            assert int(n2[k]) == 0
+        pos += ln
+    # block decode + placement against DecodeCodeBlock for every job of the oracle's list
+    decoded = plan.decode_blocks(cs, offs2, lens2, nb2)
+    placed = plan.place_blocks(decoded)
+    back = plan.inverse(placed)
+    ctx.sync()
+    hp = placed.cpu().numpy()
+    for t in sorted(want):
+        wt = want[t]
+        ref_planes = orc.decode_tile_blocks(wt["bytes"], wt["lens"], wt["numbps"], 3, wt["w"], wt["h"], nres, cb, cb, coder, 1)
+        for c in range(3):
+            row = [r for r in planes if int(r[0]) == t and int(r[1]) == c][0]
+            got = hp[int(row[6]):int(row[6]) + wt["w"] * wt["h"]].reshape(wt["h"], wt["w"])
+            assert np.array_equal(got, ref_planes[c]), (t, c)
+            if coder == 0:
+                assert np.array_equal(got, wt["coeff"][c])        # the MQ coder is lossless: the coefficients come back
+        sub = [orc.reconstruct53(ref_planes[c], wt["w"], wt["h"], nres - 1) for c in range(3)]
+        px = orc.postprocess(sub, 8, True)
+        for c in range(3):
+            assert np.array_equal(back.cpu().numpy()[c, wt["y0"]:wt["y0"] + wt["h"], wt["x0"]:wt["x0"] + wt["w"]], px[c]), (t, c)
+    if coder == 0:
+        assert np.array_equal(back.cpu().numpy(), frame.astype(np.int32))
+    plan.close()
+
+
+def test_closed_loop_4k_sampled_tiles_against_the_oracle(env):
+    """(iii) at full size: tile-parts 0 (full 512 x 512), 7 (256 wide) and 39 (256 x 112) of the 4K MQ frame == the oracle's"""
+    torch, t2ref, t2, ctx = env
+    import oracle as orc
+    from j2kgfx import _lib
+    from j2kgfx.codec import FramePlan
+    W, H = 3840, 2160
+    frame = _frame(W, H, 5)
+    plan = FramePlan(W, H, 3, precision=8, lossless=True, num_resolutions=6, cb=(64, 64), tile=(512, 512), coder=_lib.CODER_MQ, ctx=ctx, closed_loop=True)
+    d_pix = torch.from_numpy(_rgba(frame)).to(plan.device)
+    cs, toffs = plan.encode_frame_pixels(_lib.PIX_RGBA8, d_pix, sop=False, eph=True)
+    plan.frame_status()
+    h_cs, h_t = cs.cpu().numpy(), toffs.cpu().numpy()
+    want = _oracle_frame(frame, W, H, 512, 512, 6, 64, 0, False, True, orc, t2ref, tiles={0, 7, 39})
+    for t in (0, 7, 39):
+        assert bytes(h_cs[int(h_t[t]):int(h_t[t + 1])]) == want[t]["part"], t
+    plan.close()
+
+
+def test_closed_loop_calls_refuse_a_reference_mode_plan(env):
+    torch, t2ref, t2, ctx = env
+    from j2kgfx import J2KError, _lib
+    from j2kgfx.codec import FramePlan
+    plan = FramePlan(64, 64, 1, num_resolutions=3, cb=(32, 32), ctx=ctx)
+    assert plan.frame_bound() == 0
+    with pytest.raises(J2KError) as e:
+        plan.place_blocks(plan.empty(plan.info.decoded_elems, torch.int32))
+    assert e.value.status == _lib.ERR_UNSUPPORTED
+    plan.close()
