@@ -92,19 +92,6 @@ static int fail_hip(j2k_ctx *ctx, hipError_t e, const char *where) {
         if (e_ != hipSuccess) return fail_hip(ctx, e_, #call); \
     } while (0)
 
-extern "C" const char *j2k_status_string(int s) {
-    switch (s) {
-        case J2K_OK: return "ok";
-        case J2K_ERR_INVALID_ARG: return "invalid argument";
-        case J2K_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU fallback)";
-        case J2K_ERR_HIP: return "HIP runtime error";
-        case J2K_ERR_CAPACITY: return "output capacity too small";
-        case J2K_ERR_GO_PANIC: return "input on which the reference panics or never returns";
-        case J2K_ERR_UNSUPPORTED: return "unsupported";
-    }
-    return "unknown status";
-}
-extern "C" const char *j2k_version(void) { return "j2kgfx 0.1 (gfx950)"; }
 extern "C" const char *j2k_ctx_last_error(j2k_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
 
 // ------------------------------------------------------------------------------

@@ -82,46 +82,34 @@ def lib():
         # One HIP runtime per process: torch bundles its own libamdhip64 (same soname as
         # /opt/rocm's).  Importing torch FIRST makes libj2kgfx bind to that copy; loading ours
         # first would bring in a second runtime and torch would then see "No HIP GPUs".
-        try:
-            import torch  # noqa: F401
-        except ImportError:  # plain C-ABI use without torch is fine (single runtime from /opt/rocm)
-            pass
+        # J2K_LIB_HOST_ONLY=1 (tests/test_sanitized_host_build.py): J2K_LIB is the sanitised build of the host-only sources
+        # (t2.cpp, assemble.cpp) -- no HIP in it, so no torch first, and only the symbols it has are given their signatures.
+        partial = os.environ.get("J2K_LIB_HOST_ONLY") == "1"
+        if not partial:
+            try:
+                import torch  # noqa: F401
+            except ImportError:  # plain C-ABI use without torch is fine (single runtime from /opt/rocm)
+                pass
         L = C.CDLL(LIB_PATH)
-        L.j2k_status_string.restype = C.c_char_p
-        L.j2k_version.restype = C.c_char_p
-        L.j2k_ctx_last_error.restype = C.c_char_p
-        L.j2k_ctx_last_error.argtypes = [C.c_void_p]
-        L.j2k_ctx_stream.restype = C.c_void_p
-        L.j2k_ctx_stream.argtypes = [C.c_void_p]
-        L.j2k_block_bound.restype = C.c_size_t
-        L.j2k_block_bound.argtypes = [C.c_int, C.c_int, C.c_int]
-        L.j2k_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
-        L.j2k_ctx_destroy.argtypes = [C.c_void_p]
-        L.j2k_ctx_destroy.restype = None
-        L.j2k_ctx_sync.argtypes = [C.c_void_p]
-        L.j2k_ctx_profile_enable.argtypes = [C.c_void_p, C.c_int]
-        L.j2k_ctx_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
-        L.j2k_ctx_profile_read_tag.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
-        L.j2k_ctx_capture_begin.argtypes = [C.c_void_p]
-        L.j2k_ctx_capture_end.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
-        L.j2k_graph_launch.argtypes = [C.c_void_p]
-        L.j2k_graph_destroy.argtypes = [C.c_void_p]
-        L.j2k_graph_destroy.restype = None
-        L.j2k_plan_destroy.argtypes = [C.c_void_p]
-        L.j2k_comm_get_unique_id.argtypes = [C.c_void_p]
-        L.j2k_comm_load_error.restype = C.c_char_p
-        L.j2k_comm_load_error.argtypes = []
-        L.j2k_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
-        L.j2k_comm_destroy.argtypes = [C.c_void_p]
-        L.j2k_comm_destroy.restype = None
-        L.j2k_comm_last_error.argtypes = [C.c_void_p]
-        L.j2k_comm_last_error.restype = C.c_char_p
-        L.j2k_comm_stream.argtypes = [C.c_void_p]
-        L.j2k_comm_stream.restype = C.c_void_p
-        L.j2k_gather_streams.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
-        L.j2k_comm_wait.argtypes = [C.c_void_p, C.c_void_p]
-        L.j2k_plan_destroy.restype = None
-        L.j2k_plan_pack_bound.restype = C.c_size_t
-        L.j2k_plan_pack_bound.argtypes = [C.c_void_p]
+        V, I, S, I64P, DP = C.c_void_p, C.c_int, C.c_size_t, C.POINTER(C.c_int64), C.POINTER(C.c_double)
+        sigs = {
+            "j2k_status_string": (C.c_char_p, None), "j2k_version": (C.c_char_p, None), "j2k_ctx_last_error": (C.c_char_p, [V]),
+            "j2k_ctx_stream": (V, [V]), "j2k_block_bound": (S, [I, I, I]), "j2k_ctx_create": (I, [I, C.POINTER(V)]),
+            "j2k_ctx_destroy": (None, [V]), "j2k_ctx_sync": (I, [V]), "j2k_ctx_profile_enable": (I, [V, I]),
+            "j2k_ctx_profile_read": (I, [V, I64P, DP]), "j2k_ctx_profile_read_tag": (I, [V, I, I64P, DP]),
+            "j2k_ctx_capture_begin": (I, [V]), "j2k_ctx_capture_end": (I, [V, C.POINTER(V)]), "j2k_graph_launch": (I, [V]),
+            "j2k_graph_destroy": (None, [V]), "j2k_plan_destroy": (None, [V]), "j2k_comm_get_unique_id": (I, [V]),
+            "j2k_comm_load_error": (C.c_char_p, []), "j2k_comm_create": (I, [V, V, I, I, C.POINTER(V)]), "j2k_comm_destroy": (None, [V]),
+            "j2k_comm_last_error": (C.c_char_p, [V]), "j2k_comm_stream": (V, [V]),
+            "j2k_gather_streams": (I, [V, I, V, V, V, V, I, V, S, V, I]), "j2k_comm_wait": (I, [V, V]),
+            "j2k_plan_pack_bound": (S, [V]),
+        }
+        for name, (res, args) in sigs.items():
+            if partial and not hasattr(L, name):
+                continue
+            fn = getattr(L, name)
+            fn.restype = res
+            if args is not None:
+                fn.argtypes = args
         _lib = L
     return _lib

@@ -375,6 +375,13 @@ static double cs_srgb_gamma(double linear) {                         /* :302-307
     return 1.055 * pow(linear, 1.0 / 2.4) - 0.055;
 }
 
+static double cs_srgb_inverse_gamma(double encoded) {               /* :310-315 (only the reference's tests call it) */
+    if (encoded <= 0.04045) return encoded / 12.92;
+    return pow((encoded + 0.055) / 1.055, 2.4);
+}
+double orc_pin_srgb_gamma(double linear) { return cs_srgb_gamma(linear); }
+double orc_pin_srgb_inverse_gamma(double encoded) { return cs_srgb_inverse_gamma(encoded); }
+
 void orc_convert_colorspace(int cs, int32_t **planes, int ncomp, size_t n, int precision) {
     const int need4 = (cs == 5 || cs == 11);
     if (ncomp < (need4 ? 4 : 3)) return;

@@ -143,6 +143,10 @@ int orc_decode_tile_blocks(const uint8_t *bytes, const uint32_t *lens, const uin
 /* encoder.createTileHeader(tileIdx, tileData) (encoder.go:746-760): writes 14 + len bytes to out, returns that count */
 size_t orc_create_tile_header(int tile_idx, const uint8_t *tile_data, size_t len, uint8_t *out);
 
+/* srgbGamma / srgbInverseGamma (colorspace.go:302-315), probed by colorspace_spec_test.go:396-417 */
+double orc_pin_srgb_gamma(double linear);
+double orc_pin_srgb_inverse_gamma(double encoded);
+
 /* ---- pins: internals at the granularity of the reference's own unit tests ------------
  * (internal/entropy/coverage_test.go, t1_test.go; tests/test_oracle_reference_pins.py) */
 void orc_pin_mq_byte_out(uint8_t *buf, size_t buflen, long bp, uint32_t c,

@@ -20,7 +20,7 @@ def build():
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "libj2koracle.so")
+        path = os.environ.get("J2K_ORACLE_LIB") or os.path.join(_HERE, "libj2koracle.so")   # J2K_ORACLE_LIB: the sanitised build (tests/test_sanitized_host_build.py)
         if not os.path.exists(path):
             build()
         _LIB = C.CDLL(path)
