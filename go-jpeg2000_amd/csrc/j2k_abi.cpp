@@ -1747,6 +1747,10 @@ static bool pix_fusable(const j2k_plan *P, int bps, int channels, const void *d_
         else { if (!T1.pnjobs || T1.pwaves != 4) return false; io.triple = 4; }
     }
     if (inverse && channels == 4 && !T1.njobs && S.C != 4) return false;      // three components on their own leave alpha unwritten
+    // The single-plane inverse kernel writes one channel of a packed pixel by reading and rewriting the whole pixel (dwt53_plane_wg.inc,
+    // DST 3 / 4): safe only while at most ONE single-component plane per pixel is in the launch -- the alpha plane beside an MCT
+    // triple.  A four-channel frame whose components are all single planes (no colour transform) would lose updates.
+    if (inverse && channels == 4 && T0.njobs && !(T1.njobs && S.C - 3 <= 1)) return false;
     return true;
 }
 
@@ -1869,7 +1873,7 @@ extern "C" int j2k_plan_encode_blocks(j2k_plan *P, const int32_t *d_coeff, uint8
         if (r != J2K_OK) return r;
         uint8_t *ws = (uint8_t *)ctx->stage[2];
         // blocks of 65 ... 256 columns or rows: symbol lists for the two-kernel form (t1_big.inc) -- 16 symbols of room per sample
-        // (a 256 x 256 block of 8-bit noise makes 10; a block that needs more takes the fused kernel), n words of counts in front
+        // (a 256 x 256 block of 8-bit noise makes 10; a block that needs more is marked and takes the SERIAL t1_encode_kernel afterwards), n words of counts in front
         uint8_t *bigsym = nullptr;
         uint32_t *bignsyms = nullptr;
         // (one MQ context alone = one frame at a time: the fused kernel's latency is 7 % shorter; several = throughput: the lists)
@@ -1889,7 +1893,7 @@ extern "C" int j2k_plan_encode_blocks(j2k_plan *P, const int32_t *d_coeff, uint8
                 P->bigsym_total = (size_t)off[(size_t)n];
             }
             const size_t head = ((size_t)n * 4 + 255) & ~size_t(255);
-            if (P->bigsym_total && stage_reserve(ctx, 4, head + P->bigsym_total + 256) == J2K_OK) {      // (no room: the fused kernel)
+            if (P->bigsym_total && stage_reserve(ctx, 4, head + P->bigsym_total + 256) == J2K_OK) {      // (no room for the lists at all: the one-kernel form t1_encode_big_kernel<false>)
                 bignsyms = (uint32_t *)ctx->stage[4];
                 bigsym = (uint8_t *)ctx->stage[4] + head;
             }

@@ -235,7 +235,7 @@ class FramePlan:
         """the block coder's outputs -> SOT | SOD | packets per tile, end to end: (out uint8, tile_offs int64[tiles + 1])"""
         t = _torch()
         out = out if out is not None else self.empty(self.frame_bound(), t.uint8)
-        tile_offs = tile_offs if tile_offs is not None else self.empty(int(self.info.tiles) + 1, t.int64)
+        tile_offs = tile_offs if tile_offs is not None else self.empty(int(self.info.tiles) + 1, t.int64)[:int(self.info.tiles) + 1]
         self.ctx.check(self.ctx.L.j2k_plan_encode_tile_parts(self.h, self._p(stream), self._p(offs), self._p(lens), self._p(numbps), int(bool(sop)),
                                                              int(bool(eph)), self._p(out), C.c_size_t(int(out.numel())), self._p(tile_offs)))
         return out, tile_offs
@@ -268,7 +268,7 @@ class FramePlan:
         """pixels (a Go Pix layout, device uint8 [H, stride]) -> tile-parts: (out uint8, tile_offs int64[tiles + 1])"""
         t = _torch()
         out = out if out is not None else self.empty(self.frame_bound(), t.uint8)
-        tile_offs = tile_offs if tile_offs is not None else self.empty(int(self.info.tiles) + 1, t.int64)
+        tile_offs = tile_offs if tile_offs is not None else self.empty(int(self.info.tiles) + 1, t.int64)[:int(self.info.tiles) + 1]
         self.ctx.check(self.ctx.L.j2k_plan_encode_frame_pixels(self.h, int(fmt), self._p(pix), C.c_size_t(int(pix.shape[1])), int(bool(sop)), int(bool(eph)),
                                                                self._p(out), C.c_size_t(int(out.numel())), self._p(tile_offs)))
         return out, tile_offs

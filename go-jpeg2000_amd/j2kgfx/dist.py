@@ -23,10 +23,16 @@ def shard_range(n_units, rank, world):
     return first, base + (1 if rank < extra else 0)
 
 
-def num_tiles(width, height, tile_w, tile_h):
+def num_tiles(width, height, tile_w, tile_h, frame_rows=0):
+    """Tiles of a plan with these j2k_params, by build_plan's arithmetic (csrc/j2k_abi.cpp): with frame_rows > 0 the plan is a
+    BATCH of height / frame_rows frames and the tile grid starts again at every frame (a partial last tile row per frame;
+    tile_h = 0: one tile row per frame, not per batch)."""
+    fh = frame_rows if frame_rows > 0 else height
+    if fh <= 0 or height % fh:
+        raise ValueError("height is not a whole number of frames (frame_rows)")
     tw = tile_w if tile_w > 0 else width
-    th = tile_h if tile_h > 0 else height
-    return ((width + tw - 1) // tw) * ((height + th - 1) // th)
+    th = tile_h if tile_h > 0 else fh
+    return ((width + tw - 1) // tw) * ((fh + th - 1) // th) * (height // fh)
 
 
 def gather_streams(stream, nbytes, group=None, out=None):

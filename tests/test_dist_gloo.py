@@ -131,3 +131,10 @@ def test_shard_range_partitions_exactly():
     assert jd.num_tiles(3840, 2160, 512, 512) == 40                      # C2: 8 x 5
     assert jd.num_tiles(7680, 4320, 512, 512) == 135                     # C4: 15 x 9
     assert jd.num_tiles(512, 512, 0, 0) == 1
+    # batches (j2k_params.frame_rows): the tile grid starts again at every frame -- a partial last tile row PER FRAME, and
+    # tile_h = 0 is one tile per frame (the plan's arithmetic, not ceil(H_total / tile_h))
+    assert jd.num_tiles(1024, 4 * 600, 512, 512, frame_rows=600) == 4 * 2 * 2
+    assert jd.num_tiles(1024, 4 * 600, 0, 0, frame_rows=600) == 4
+    assert jd.num_tiles(2048, 4 * 2048, 0, 0, frame_rows=2048) == 4      # C5 batches in bench.py
+    with pytest.raises(ValueError):
+        jd.num_tiles(64, 100, 0, 0, frame_rows=30)

@@ -410,6 +410,42 @@ def test_closed_loop_4k_sampled_tiles_against_the_oracle(env):
     plan.close()
 
 
+@pytest.mark.parametrize("tw,th,W,H,nres,cb", [(1, 64, 3, 64, 4, 16), (2, 33, 5, 40, 3, 8), (3, 5, 7, 9, 6, 4), (64, 1, 130, 2, 5, 32), (5, 7, 5, 7, 1, 64)])
+def test_closed_loop_degenerate_tiles_round_trip_and_packets_per_resolution(env, tw, th, W, H, nres, cb):
+    """tiles one to three samples wide / one row high: bands without samples have no jobs, consecutive resolutions can hold
+    the SAME single band -- a packet is still the jobs of one resolution (j2k_plan_t2_packets used to merge them).
+    Closed loop: bit-exact round trip; both modes: every packet's jobs share one (tile-component, resolution)."""
+    torch, t2ref, t2, ctx = env
+    import oracle as orc
+    from j2kgfx.codec import FramePlan
+    rng = np.random.default_rng(W * 131 + H)
+    frame = rng.integers(0, 256, (3, H, W)).astype(np.int32)
+    for closed in (True, False):
+        plan = FramePlan(W, H, 3, precision=8, lossless=True, num_resolutions=nres, cb=(cb, cb), tile=(tw, th), ctx=ctx, closed_loop=closed)
+        blocks, planes, packets = plan.blocks(), plan.planes(), plan.t2_packets(0)
+        res = []
+        for t in range(int(plan.info.tiles)):
+            w, h = int(planes[t * 3][4]), int(planes[t * 3][5])
+            res += [int(b["res"]) for b in orc.enumerate_blocks(3, w, h, nres, cb, cb, 1 if closed else 0)]
+        assert len(res) == len(blocks) and int(packets["ncb"].sum()) == len(blocks)
+        for pk in packets:
+            j0, j1 = int(pk["cb0"]), int(pk["cb0"] + pk["ncb"])
+            assert len({(int(blocks[j]["plane"]), res[j]) for j in range(j0, j1)}) == 1
+        keys = [(int(blocks[int(pk["cb0"])]["plane"]), res[int(pk["cb0"])]) for pk in packets]
+        assert len(set(keys)) == len(keys)                       # and no (tile-component, resolution) is split over two packets
+        if closed:
+            coeff = plan.forward(torch.from_numpy(frame).to(plan.device))
+            stream, offs, lens, numbps = plan.encode_stream(coeff)
+            cs, toffs = plan.encode_tile_parts(stream, offs, lens, numbps, sop=True, eph=True)
+            plan.frame_status()
+            total = int(toffs[-1].item())
+            o2, l2, n2 = plan.decode_tile_parts(cs, total, tile_offs=None, sop=True, eph=True)
+            back = plan.inverse(plan.place_blocks(plan.decode_blocks(cs, o2, l2, n2)))
+            plan.frame_status()
+            assert np.array_equal(back.cpu().numpy(), frame)
+        plan.close()
+
+
 def test_closed_loop_calls_refuse_a_reference_mode_plan(env):
     torch, t2ref, t2, ctx = env
     from j2kgfx import J2KError, _lib
