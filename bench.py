@@ -29,11 +29,12 @@ sys.path.insert(0, os.path.join(ROOT, "go-jpeg2000_amd"))
 
 sys.path.insert(0, ROOT)
 import bench_extra  # noqa: E402  (workload definitions, CPU baseline, the C3 / C5 runner, the tile-sharded mode)
+import bench_host   # noqa: E402  (the pinned-host-memory boundary, the closed-loop codec)
 
 W, H, C, TILE, NRES, CB, PREC = 3840, 2160, 3, 512, 6, 64, 8
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 SEED = 0x4A324B30              # "J2K0" 
-MIN_TIMED_S = 0.1              # floor of the timed region, whatever --steps says
+MIN_TIMED_S = 1.0              # floor of the timed region, whatever --steps says (round 4: 0.1 s -- box-to-box spread of 5 % on 0.09 s of samples)
 # sha256 of the int32 `decoded` buffer (every code-block of frame 0 as HTDecoder.Decode returns it, job order) -- what the
 # block decoder must have produced in the timed region; tests/test_bench_digest.py recomputes it with the oracle on CPU
 DECODED_SHA256 = "76eab55b1f63e2eb3644d138c6d655d4b16975c46310378f3f9f1bc509de7d5e"
@@ -49,6 +50,11 @@ TRAFFIC = {   # frame_io -> (bytes per level-0 forward launch, source); tests/te
     "planes": _traffic(52495.8, 97200.0, "profiles/r01_bench_v3_inflight1_pmc_{FETCH,WRITE}_SIZE.csv"),
     "rgba8": _traffic(16431.7, 97269.2, "profiles/r04_bench_inflight1_pmc_summary.txt"),
 }
+# HBM bytes ALL kernels of one C2 frame move (same PMC passes, one frame in flight): sum over the nine kernels of a step of
+# 2 x FETCH_SIZE + WRITE_SIZE; tests/test_bench_traffic_constant.py re-adds them from the committed summary
+PIPELINE_KERNELS = ("dwt53_fwd_rgba8_wg_kernel", "dwt53_deep_fwd_kernel", "ht_encode_kernel", "gather_scan_kernel", "ht_vlcprep_kernel", "ht_walk_kernel",
+                    "ht_decode_kernel", "dwt53_deep_inv_kernel", "dwt53_inv_rgba8_wg_kernel")
+PIPELINE_TRAFFIC = (int(round(488482.5 * 1024)), "profiles/r04_bench_inflight1_pmc_summary.txt: sum of (2 x FETCH_SIZE + WRITE_SIZE) over %d kernels" % len(PIPELINE_KERNELS))
 COPY_PEAK_GUIDE_GBS = 6290.0   # MI355X_MICROARCH.md: the float4 device-to-device copy the guide measured (what a pure copy reaches)
 
 
@@ -81,7 +87,7 @@ def launch_ranks(n, argv):
     return subprocess.call(cmd, env=env)
 
 
-def other_configs_summary(budget_s=120.0):
+def other_configs_summary(budget_s=200.0):
     """One driver-visible record for the configurations the headline line does not cover: C3, C5 and C1-on-the-GPU
     each run as `bench.py --config X` in a FRESH CHILD PROCESS started before this process touches the GPU (C3 / c1gpu need their
     own GPU_MAX_HW_QUEUES, which the runtime reads when it initialises), short step counts, the CPU baseline's one-thread leg
@@ -95,7 +101,11 @@ def other_configs_summary(budget_s=120.0):
     except ImportError:
         pass
     t_all = time.perf_counter()
-    plan = [("c3", ["--steps", "5", "--warmup", "1"]), ("c5", ["--steps", "20", "--warmup", "3"]), ("c1gpu", ["--steps", "3", "--warmup", "1"])]
+    plan = [("c3", ["--config", "c3", "--steps", "5", "--warmup", "1"]), ("c5", ["--config", "c5", "--steps", "20", "--warmup", "3"]),
+            ("c1gpu", ["--config", "c1gpu", "--steps", "3", "--warmup", "1"]),
+            ("c4", ["--config", "c4", "--shard", "tiles", "--steps", "30", "--warmup", "3"]),
+            ("closed_loop", ["--config", "cl", "--steps", "3", "--warmup", "1"]),
+            ("host_boundary", ["--io", "host", "--steps", "50", "--warmup", "3"])]
     for name, extra in plan:
         left = budget_s - (time.perf_counter() - t_all)
         if left < 10:
@@ -104,7 +114,7 @@ def other_configs_summary(budget_s=120.0):
         env = dict(os.environ)
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
             env.pop(k, None)
-        cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--cpu-baseline-s", "2.5", "--cpu-baseline-1t"] + extra
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-s", "2.5", "--cpu-baseline-1t"] + extra
         t0 = time.perf_counter()
         try:
             r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=min(left, 60.0))
@@ -113,6 +123,16 @@ def other_configs_summary(budget_s=120.0):
                 out[name] = {"error": "exit %d: %s" % (r.returncode, r.stderr.strip()[-300:])}
                 continue
             d = json.loads(lines[-1])
+            if name == "host_boundary":
+                out[name] = dict(d["host_boundary"], wall_s=round(time.perf_counter() - t0, 1))
+                continue
+            if name in ("c4", "closed_loop"):
+                out[name] = {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+                             "n_gpus": d["n_gpus"], "scaling": d["scaling"], "wall_s": round(time.perf_counter() - t0, 1)}
+                for k in ("value_with_d2h", "codestream_bytes", "tiles", "parallelism", "frames_in_flight", "codestream_bytes_per_frame", "single_frame_ms", "round_trip"):
+                    if k in d["config"]:
+                        out[name][k] = d["config"][k]
+                continue
             out[name] = {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
                          "frames_in_flight": d["config"].get("frames_in_flight"), "contexts": d["config"].get("contexts"),
                          "frames_per_context": d["config"].get("frames_per_context"), "hw_queues": d["config"].get("hw_queues"),
@@ -141,10 +161,11 @@ def run(state):
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", type=int, default=-1, help="--config c3|c5: replay each frame's plan calls as one HIP graph (1), launch them one by one (0); -1: the configuration's default")
-    ap.add_argument("--io", choices=["planes", "rgba8"], default=os.environ.get("J2K_BENCH_IO", "rgba8"),
+    ap.add_argument("--io", choices=["planes", "rgba8", "host"], default=os.environ.get("J2K_BENCH_IO", "rgba8"),
                     help="frame format at the boundary: packed 8-bit RGBA pixels (image.RGBA.Pix) read / written directly by "
                          "the level-0 kernels (extractImageData / createImage fused, SURVEY 8f rank 2; the default), or "
-                         "int32 component planes (e.componentData, the boundary of SURVEY 8a-e)")
+                         "int32 component planes (e.componentData, the boundary of SURVEY 8a-e); 'host': the same step with pixels and "
+                         "tile-parts in PINNED HOST memory, copies overlapped with the kernels (bench_host.run_host_boundary)")
     ap.add_argument("--decode-rows", choices=["coded", "all"], default=os.environ.get("J2K_BENCH_DECODE_ROWS", "coded"),
                     help="HT block decode: 'coded' = j2k_plan_set_decode_coded_rows_only -- the rows the reference's decoder never "
                          "writes are left alone in a buffer zeroed once before the run (the pooled HTDecoder, ht.go:1393-1429); "
@@ -152,9 +173,10 @@ def run(state):
                          "same digest, either way")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("J2K_BENCH_INFLIGHT", "3")),
                     help="independent frames coded concurrently per step, each on its own context/stream")
-    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5", "c1gpu"], default="c2",
+    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5", "c1gpu", "cl"], default="c2",
                     help="BASELINE.json configuration: c2 (default, the headline: 4K RGB8 5-3 + HT), c3 (4K RGB 12-bit, 9-7 lossy + MQ), "
-                         "c5 (2048x2048 gray16 frames, 5-3 + HT); c4 only with --shard tiles")
+                         "c5 (2048x2048 gray16 frames, 5-3 + HT); c4 only with --shard tiles; cl = the closed-loop codec (4K RGB8, MQ coder, "
+                         "pixels -> tile-parts of packets -> pixels, bit-exact)")
     ap.add_argument("--batch", type=int, default=0, help="--config c1gpu: frames per context and call, coded as the tiles of one plan (0: the configuration's default)")
     ap.add_argument("--d2h", action="store_true", help="--shard tiles: copy the finished tile-parts to pinned host memory inside the timed step")
     ap.add_argument("--shard", choices=["frames", "tiles"], default="frames",
@@ -195,6 +217,20 @@ def run(state):
             args.config = "c4"
         args.inflight = 1
         return bench_extra.run_shard_tiles(args)
+    if args.config == "cl":
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+        if "--inflight" not in " ".join(sys.argv):
+            args.inflight = 0
+        if "--steps" not in " ".join(sys.argv):
+            args.steps, args.warmup = 3, 1
+        return bench_host.run_closed_loop(args)
+    if args.io == "host":
+        # two copy streams + the lanes' library streams, each on a hardware queue of its own (a copy stream that shares a queue with the
+        # other direction's, or with a lane's kernels, takes turns with it: 28.6 instead of 48.6 GB/s each way on these boxes)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+        if "--steps" not in " ".join(sys.argv):
+            args.steps, args.warmup = 50, 3
+        return bench_host.run_host_boundary(args)
     if args.config != "c2":
         if "--inflight" not in " ".join(sys.argv):
             args.inflight = 0           # the configuration's own default
@@ -293,6 +329,20 @@ def run(state):
             if world > 1 and rank == 0:
                 self.assembled = [(p.empty(i.bytes_cap, torch.uint8), p.empty(self.n + 1, torch.int64), p.empty(self.n, torch.int32),
                                    p.empty(self.n, torch.uint8)) for _ in range(world - 1)]
+
+        def code_set(self, S):
+            """the same step on another set of buffers (the rotating-footprint roofline pass, rank 0 after the timed region)"""
+            p = self.plan
+            p.forward_rgba8(S["pix"], S["coeff"])
+            p.encode_stream(S["coeff"], S["stream"], S["offs"], S["lens"], S["numbps"])
+            p.decode_blocks(S["stream"], S["offs"], S["lens"], S["numbps"], S["decoded"])
+            p.inverse_rgba8(S["coeff"], S["back_pix"])
+
+        def buffer_set(self):
+            p, i = self.plan, self.plan.info
+            return dict(pix=self.pix.clone(), coeff=p.alloc_coeff(), stream=p.empty(i.bytes_cap, torch.uint8), offs=p.empty(self.n + 1, torch.int64),
+                        lens=p.empty(self.n, torch.int32), numbps=p.empty(self.n, torch.uint8),
+                        decoded=torch.zeros(max(int(i.decoded_elems), 4), dtype=torch.int32, device=p.device), back_pix=torch.empty_like(self.pix))
 
         def encode_side(self, b=0):
             p = self.plan
@@ -644,6 +694,29 @@ def run(state):
         tags = [ctx.profile_read_tag(t) for t in range(4)]   # forward level 0 / deeper levels, inverse level 0 / deeper levels
         iso_launches, iso_ms = ctx.profile_read()
         ctx.profile_enable(False)
+        # ---- the same pass over FOUR buffer sets in rotation (> 1 GB touched between two uses of a line): one lane's ~250 MB fit
+        #      the 256 MB Infinity Cache, and FETCH / WRITE_SIZE count fabric requests whether or not the MALL serves them
+        #      (MI355X_MICROARCH.md) -- does the solo fraction hold at a footprint that rules the cache out?
+        rot_tags, rot_n = None, 0
+        if args.io == "rgba8" and world == 1 and os.environ.get("J2K_BENCH_ROTATE", "1") != "0":
+            try:
+                sets = [lanes[0].buffer_set() for _ in range(4)]
+                torch.cuda.synchronize()
+                for S_ in sets:
+                    lanes[0].code_set(S_)
+                ctx.sync()
+                ctx.profile_enable(2)
+                for k_ in range(32):
+                    lanes[0].code_set(sets[k_ % 4])
+                ctx.sync()
+                rot_tags = [ctx.profile_read_tag(t) for t in range(4)]
+                rot_n, _ = ctx.profile_read()
+                ctx.profile_enable(False)
+                for S_ in sets:
+                    assert torch.equal(S_["back_pix"], lanes[0].pix), "rotating-set round trip failed"
+                del sets
+            except torch.cuda.OutOfMemoryError:
+                rot_tags = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=plan.device if os.environ.get("J2K_BENCH_BACKEND", "nccl") == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -699,6 +772,15 @@ def run(state):
         us = [t[1] * 1e3 / nfr for t in tags]                 # per frame: fwd level 0, fwd deeper, inv level 0, inv deeper
         def frac(b, t_us):
             return round(b / (t_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if t_us > 0 else None
+        rot = None
+        if rot_tags and rot_n:
+            rus = [t[1] * 1e3 / rot_n for t in rot_tags]
+            rot = {"buffer_sets": 4, "frames": int(rot_n), "frac": frac(alg_bytes, rus[0]), "inv_level0_frac": frac(alg_bytes, rus[2]),
+                   "transform_fwd_frac": frac(tr_bytes, rus[0] + rus[1]), "transform_inv_frac": frac(tr_bytes, rus[2] + rus[3]),
+                   "us": [round(v, 2) for v in rus],
+                   "note": "the solo roofline pass repeated over four buffer sets in rotation (> 1 GB touched between two uses of any line): "
+                           "what the fractions are when the 256 MB Infinity Cache cannot hold a frame's buffers from one step to the next"}
+        frames_per_step = world * F - root_idle_all
         out = {
             "metric": "Mpixels/s encode+decode (4K sRGB, 5-3 lossless)",
             "value": round((world * F - root_idle_all) * px / (dt / args.steps) / 1e6, 1),
@@ -739,7 +821,14 @@ def run(state):
                          "avg_launch_us_in_timed_region": round(k_conc_s * 1e6, 2), "launches_in_timed_region": int(launches),
                          "traffic_source": TRAFFIC[args.io][1],
                          "copy_peak_guide_gbs": COPY_PEAK_GUIDE_GBS,
-                         "frac_of_guide_copy_peak": round(achieved / COPY_PEAK_GUIDE_GBS, 4)},
+                         "frac_of_guide_copy_peak": round(achieved / COPY_PEAK_GUIDE_GBS, 4),
+                         "rotating_buffers": rot},
+            # every kernel of the step, inside the timed region: the HBM bytes one frame's nine kernels move (PMC counters, committed)
+            # x the frames coded per second
+            "pipeline": {"hbm_bytes_per_frame": PIPELINE_TRAFFIC[0], "source": PIPELINE_TRAFFIC[1],
+                         "in_region_tbs": round(frames_per_step / max(world, 1) * PIPELINE_TRAFFIC[0] / (dt / args.steps) / 1e12, 3),
+                         "frac_of_hbm_peak": round(frames_per_step / max(world, 1) * PIPELINE_TRAFFIC[0] / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                         "note": "per GPU; all frames in flight, inside the timed region"} if args.io == "rgba8" else None,
         }
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base

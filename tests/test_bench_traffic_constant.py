@@ -41,3 +41,23 @@ def test_c3_traffic_constant_matches_committed_pmc_summary():
     assert abs(measured - nbytes) <= 0.001 * nbytes, (measured, nbytes)
     alg = 3840 * 2160 * 27                                  # 12 B in; 3/4 int32 + 1/4 float64 out per sample, three components
     assert 1.0 <= nbytes / alg < 1.03
+
+
+def test_pipeline_traffic_constant_is_the_sum_over_the_steps_kernels():
+    """bench.PIPELINE_TRAFFIC (the `pipeline` object of the JSON line): (2 x FETCH_SIZE + WRITE_SIZE) added over the nine
+    kernels of a C2 step, from the committed summary it cites"""
+    import bench
+    nbytes, src = bench.PIPELINE_TRAFFIC
+    path = os.path.join(ROOT, src.split(":")[0])
+    assert os.path.exists(path), path
+    vals = {}
+    for ln in open(path):
+        m = re.match(r"\s*(\S.*?)\s+(FETCH_SIZE|WRITE_SIZE) n=\d+ avg=([0-9.]+)", ln)
+        if not m:
+            continue
+        for k in bench.PIPELINE_KERNELS:
+            if k in m.group(1):
+                vals[(k, m.group(2))] = float(m.group(3))
+    assert len(vals) == 2 * len(bench.PIPELINE_KERNELS), sorted(vals)
+    measured = sum((2 if c == "FETCH_SIZE" else 1) * v for (_, c), v in vals.items()) * 1024
+    assert abs(measured - nbytes) <= 0.001 * nbytes, (measured, nbytes)
