@@ -26,6 +26,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "go-jpeg2000_amd"))
+os.environ.setdefault("J2K_TUNING", "1")     # bench.py is also the A/B harness: the library honours its J2K_* switches only with this set
 
 sys.path.insert(0, ROOT)
 import bench_extra  # noqa: E402  (workload definitions, CPU baseline, the C3 / C5 runner, the tile-sharded mode)

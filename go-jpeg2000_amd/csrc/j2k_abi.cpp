@@ -101,6 +101,51 @@ extern "C" const char *j2k_ctx_last_error(j2k_ctx *ctx) { return ctx ? ctx->last
 // throughput settings (t1.hip: blocks per wavefront of the encode chains, plane-stepped decoder), one = latency settings
 static std::atomic<int> g_mq_ctxs{0};
 static bool mq_throughput_mode() { return g_mq_ctxs.load(std::memory_order_relaxed) >= 2; }
+// ---- tuning options: which of the measured kernel forms a context takes.  The defaults (j2k_plan.h) are what the benchmarks
+// measured best; a host sets them through j2k_ctx_set_option BEFORE it creates plans on the context.
+struct CtxOption { const char *name; bool (*set)(j2k_ctx *, long); };
+static const std::vector<CtxOption> &ctx_options() {
+#define OPT(name, cond, stmt) CtxOption{name, [](j2k_ctx *c, long v) -> bool { (void)c; if (!(cond)) return false; stmt; return true; }}
+    static const std::vector<CtxOption> T = {
+        OPT("plane_wg3", v == 0 || v == 1, c->plane_wg3 = v != 0),
+        OPT("pix_fuse", v >= 0 && v <= 2, c->pix_fuse = (int)v),
+        OPT("plane_wg", v == 0 || v == 4 || v == 8, c->plane_wg = (int)v),
+        OPT("l0_fuse", v == 0 || v == 8 || v == 10 || v == 16, c->l0_fuse = (int)v),
+        OPT("l0_wg", v == 0 || v == 4 || v == 8, c->l0_wg = (int)v),
+        OPT("plane_wg97", v == 0 || v == 8, c->plane_wg97 = (int)v),
+        OPT("l0_wg97_inv", v == 0 || v == 6 || v == 8 || v == 10 || v == 12, c->l0_wg97_inv = (int)v),
+        OPT("l0_wg97", v == 0 || (v >= 6 && v <= 16 && v % 2 == 0), c->l0_wg97 = (int)v),
+        OPT("l0_xcd", v == 0 || v == 1, c->l0_xcd = v != 0),
+        OPT("l0_deal", v == 0 || v == 1, c->l0_deal = v != 0),
+        OPT("ht_alias", v == 0 || v == 1, c->ht_alias = v != 0),
+        OPT("l0_inv_wpe", v >= 5 && v <= 7, c->l0_inv_wpe = (int)v),
+        OPT("l0_wg_inv", v == 0 || v == 1, c->l0_wg_inv = v != 0),
+        OPT("l0_wg_invw", v == 0 || v == 4 || v == 8, c->l0_wg_invw = (int)v),
+        OPT("l0_xcd_group", v >= 0 && v <= 4096, c->l0_xcd_group = (int)v),
+        OPT("l0_store", v == 0 || v == 1 || v == 2 || v == 4, c->l0_store = (int)v),
+        OPT("fuse_compact", v == 0 || v == 1, c->fuse_compact = v != 0),
+        OPT("deep", v == 0 || v == 1, c->use_deep = v != 0),
+        OPT("deep_min_planes", v >= 0 && v <= 1000000, c->deep_min_planes = (int)v),
+        OPT("deep_mid", v == 0 || v == 1, c->deep_mid = v != 0),
+        OPT("deep_mid_inv", v >= 0 && v <= 2, c->deep_mid_inv = (int)v),
+        OPT("mega", v >= 0 && v <= 2, c->mega = (int)v),
+        OPT("t1_split", v == 0 || v == 1, c->t1_split = v != 0),
+        OPT("t1_sym_mb", v >= 0, c->t1_sym_mb = v),
+        OPT("t1_dec_general", v == 0 || v == 1, c->t1_dec_general = v != 0),
+        OPT("t1_dec_split", v >= -1, c->t1_dec_split = (int)v),
+        OPT("t1_dec_lanes", v >= 0 && v <= 2, c->t1_dec_lanes = (int)v),
+        OPT("t1_lanes", v >= 0 && v <= 64, c->t1_lanes = (int)v),
+    };
+#undef OPT
+    return T;
+}
+extern "C" int j2k_ctx_set_option(j2k_ctx *ctx, const char *name, long value) {
+    if (!ctx || !name) return J2K_ERR_INVALID_ARG;
+    for (const CtxOption &o : ctx_options())
+        if (!strcmp(o.name, name)) return o.set(ctx, value) ? J2K_OK : fail(ctx, J2K_ERR_INVALID_ARG, "j2k_ctx_set_option: value out of range");
+    return fail(ctx, J2K_ERR_INVALID_ARG, "j2k_ctx_set_option: no such option");
+}
+
 extern "C" int j2k_ctx_create(int device, j2k_ctx **out) {
     if (!out) return J2K_ERR_INVALID_ARG;
     *out = nullptr;
@@ -114,52 +159,19 @@ extern "C" int j2k_ctx_create(int device, j2k_ctx **out) {
         delete ctx;
         return J2K_ERR_HIP;
     }
-    if (const char *e = getenv("J2K_BAND_PROWS")) {
-        int v = atoi(e);
-        if (v >= 1 && v <= 4096) ctx->band_prows = v;
-    }
 #ifdef J2K_DEV
     if (const char *e = getenv("J2K_DEV_SKIP")) j2k::g_dev_skip = (int)strtol(e, nullptr, 0);
     if (const char *e = getenv("J2K_DEV_DUP")) j2k::g_dev_dup = (int)strtol(e, nullptr, 0);
 #endif
-    if (const char *e = getenv("J2K_PLANE_WG3")) ctx->plane_wg3 = atoi(e) != 0;
-    if (const char *e = getenv("J2K_PIX_FUSE")) ctx->pix_fuse = atoi(e);
-    if (const char *e = getenv("J2K_PLANE_WG")) { int v = atoi(e); if (v == 0 || v == 4 || v == 8) ctx->plane_wg = v; }
-    if (const char *e = getenv("J2K_L0_FUSE")) { int v = atoi(e); if (v == 0 || v == 8 || v == 10 || v == 16) ctx->l0_fuse = v; }
-    if (const char *e = getenv("J2K_L0_WG")) { int v = atoi(e); if (v == 0 || v == 4 || v == 8) ctx->l0_wg = v; }
-    if (const char *e = getenv("J2K_L0_WG_INVW")) { int v = atoi(e); if (v == 0 || v == 4 || v == 8) ctx->l0_wg_invw = v; }
-    if (const char *e = getenv("J2K_PLANE_WG97")) { int v = atoi(e); if (v == 0 || v == 8) ctx->plane_wg97 = v; }
-    if (const char *e = getenv("J2K_L0_WG97_INV")) { int v = atoi(e); if (v == 0 || v == 6 || v == 8 || v == 10 || v == 12) ctx->l0_wg97_inv = v; }
-    if (const char *e = getenv("J2K_L0_WG97")) { int v = atoi(e); if (v == 0 || (v >= 6 && v <= 16 && v % 2 == 0)) ctx->l0_wg97 = v; }
-    if (const char *e = getenv("J2K_L0_XCD")) ctx->l0_xcd = atoi(e) != 0;
-    if (const char *e = getenv("J2K_L0_DEAL")) ctx->l0_deal = atoi(e) != 0;
-    if (const char *e = getenv("J2K_HT_ALIAS")) ctx->ht_alias = atoi(e) != 0;
-    if (const char *e = getenv("J2K_L0_INV_WPE")) { int v = atoi(e); if (v >= 5 && v <= 7) ctx->l0_inv_wpe = v; }
-    if (const char *e = getenv("J2K_L0_WG_INV")) ctx->l0_wg_inv = atoi(e) != 0;
-    if (const char *e = getenv("J2K_L0_STORE")) { int v = atoi(e); if (v == 0 || v == 1 || v == 2 || v == 4) ctx->l0_store = v; }
-    if (const char *e = getenv("J2K_BAND_PROWS_PIX")) { int v = atoi(e); if (v >= 1 && v <= 4096) ctx->band_prows_pix = v; }
-    if (const char *e = getenv("J2K_BAND_PROWS_97")) { int v = atoi(e); if (v >= 2 && v <= 4096) ctx->band_prows_97 = v; }
-    if (const char *e = getenv("J2K_FORCE_NOVEC")) ctx->force_novec = atoi(e) != 0;
-    if (const char *e = getenv("J2K_FUSE_COMPACT")) ctx->fuse_compact = atoi(e) != 0;
-    if (const char *e = getenv("J2K_FWD_LINK")) ctx->fwd_link = atoi(e) != 0;
-    if (const char *e = getenv("J2K_INV_LINK")) ctx->inv_link = atoi(e) != 0;
-    if (const char *e = getenv("J2K_BAND_PROWS_INV")) { int v = atoi(e); if (v >= 1 && v <= 4096) ctx->band_prows_inv = v; }
-    if (const char *e = getenv("J2K_FWD_PF")) ctx->fwd_pf = atoi(e) != 0;
-    if (const char *e = getenv("J2K_TAIL")) ctx->use_tail = atoi(e) != 0;
-    if (const char *e = getenv("J2K_DEEP")) ctx->use_deep = atoi(e) != 0;
-    if (const char *e = getenv("J2K_L0_XCD_GROUP")) ctx->l0_xcd_group = std::max(0, atoi(e));     // (inverse table)
-    if (const char *e = getenv("J2K_DEEP_MIN_PLANES")) ctx->deep_min_planes = atoi(e);
-    if (const char *e = getenv("J2K_DEEP_MID")) ctx->deep_mid = atoi(e) != 0;
-    if (const char *e = getenv("J2K_DEEP_MID_INV")) { int v = atoi(e); if (v >= 0 && v <= 2) ctx->deep_mid_inv = v; }
-    if (const char *e = getenv("J2K_MEGA")) { int v = atoi(e); if (v >= 0 && v <= 2) ctx->mega = v; }
-    if (const char *e = getenv("J2K_XCD_MAP")) ctx->xcd_map = atoi(e) != 0;
-    if (const char *e = getenv("J2K_T1_SPLIT")) ctx->t1_split = atoi(e) != 0;
-    if (const char *e = getenv("J2K_T1_SYM_MB")) { long v = atol(e); if (v >= 0) ctx->t1_sym_mb = v; }
-    if (const char *e = getenv("J2K_T1_DEC_GENERAL")) ctx->t1_dec_general = atoi(e) != 0;
-    if (const char *e = getenv("J2K_T1_DEC_SPLIT")) { int v = atoi(e); if (v >= -1) ctx->t1_dec_split = v; }
-    if (const char *e = getenv("J2K_T1_DEC_LANES")) { int v = atoi(e); if (v >= 0 && v <= 2) ctx->t1_dec_lanes = v; }
-    if (const char *e = getenv("J2K_T1_LANES")) { int v = atoi(e); if (v >= 0 && v <= 64) ctx->t1_lanes = v; }
-    if (const char *e = getenv("J2K_CPL0")) { int v = atoi(e); if (v == 2 || v == 4 || v == 8) ctx->cpl0 = v; }
+    // The environment decides NOTHING unless J2K_TUNING=1 is set (tests, tools/ab.sh, bench.py's A/B modes): a host process does
+    // not inherit kernel choices from variables it never heard of.  With it, every option of
+    // j2k_ctx_set_option is read from J2K_<NAME IN UPPER CASE>; values out of range are ignored, as before.
+    if (j2k::tuning_env("J2K_TUNING"))
+        for (const CtxOption &o : ctx_options()) {
+            std::string var = "J2K_";
+            for (const char *c = o.name; *c; c++) var += (char)toupper((unsigned char)*c);
+            if (const char *e = getenv(var.c_str())) (void)o.set(ctx, atol(e));
+        }
     *out = ctx;
     return J2K_OK;
 }
@@ -695,7 +707,7 @@ static int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
                     if (ok && maxw < 512) {
                         int64_t prows = 0;
                         for (size_t i = 0; i < planes.size(); i++) prows += (ph[i] + 1) / 2;
-                        if (prows > 4096 && !getenv("J2K_PLANE_WG_ALWAYS")) ok = false;
+                        if (prows > 4096) ok = false;
                     }
                     if (ok) {
                         std::vector<DwtJob> pj;
@@ -1878,11 +1890,11 @@ extern "C" int j2k_plan_encode_blocks(j2k_plan *P, const int32_t *d_coeff, uint8
         uint32_t *bignsyms = nullptr;
         // (one MQ context alone = one frame at a time: the fused kernel's latency is 7 % shorter; several = throughput: the lists)
         // (while a graph is being captured nothing may be allocated or copied: the lists need their table from an earlier call)
-        if (max_dim > 64 && (mq_throughput_mode() || getenv("J2K_T1_BIG_SPLIT")) && !(ctx->capturing && !P->d_bigsym_off)) {
+        if (max_dim > 64 && (mq_throughput_mode() || j2k::tuning_env("J2K_T1_BIG_SPLIT")) && !(ctx->capturing && !P->d_bigsym_off)) {
             if (!P->d_bigsym_off) {
                 std::vector<uint64_t> off((size_t)n + 1, 0);
                 uint64_t room = 16;                                   // J2K_T1_BIG_SYM_ROOM: symbols of room per sample (testing the fall-back)
-                if (const char *en = getenv("J2K_T1_BIG_SYM_ROOM")) { const long v = atol(en); if (v >= 1 && v <= 64) room = (uint64_t)v; }
+                if (const char *en = j2k::tuning_env("J2K_T1_BIG_SYM_ROOM")) { const long v = atol(en); if (v >= 1 && v <= 64) room = (uint64_t)v; }
                 for (int j = 0; j < n; j++) {
                     const j2k_block &b = P->blocks[(size_t)j];
                     const bool big = (b.w > 64 || b.h > 64) && b.w <= 256 && b.h <= 256;

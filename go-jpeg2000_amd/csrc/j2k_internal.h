@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <algorithm>
 #include "../../include/j2kgfx.h"
 
@@ -117,6 +118,12 @@ hipError_t launch_t2_fill_cbs(hipStream_t s, long n, const uint64_t *offs, const
 size_t t2_dev_workspace(long npackets);
 hipError_t launch_t2_encode_packets(hipStream_t s, const j2k_t2_dev_packet *packets, long npackets, const j2k_t2_dev_cb *cbs, uint64_t ncbs, const uint8_t *data,
                                     int sop, int eph, int delay_in, uint8_t *out, uint64_t cap, uint64_t *offs, void *ws, uint64_t *result);
+
+// an environment variable of the tuning set: read only when J2K_TUNING=1 (see j2k_ctx_create)
+inline const char *tuning_env(const char *name) {
+    static const int on = [] { const char *t = getenv("J2K_TUNING"); return (t && t[0] == '1' && !t[1]) ? 1 : 0; }();
+    return on ? getenv(name) : nullptr;
+}
 
 // DEV BUILDS ONLY (make CXXFLAGS+=-DJ2K_DEV; env J2K_DEV_SKIP = bit mask): launches left out to measure what each kernel
 // costs with several frames in flight (`J2K_DEV_SKIP=<mask> bash tools/ab.sh ...` on a -DJ2K_DEV build).  Results are wrong with any bit set, so the shipped library

@@ -1704,7 +1704,7 @@ hipError_t launch_t1_encode(hipStream_t s, const BlockJob *jobs, int njobs, cons
                             uint8_t *sym, size_t sym_stride, uint32_t *nsyms, int lanes, uint8_t *bigsym, const uint64_t *bigsym_off, uint32_t *bignsyms) {
     if (njobs <= 0) return hipSuccess;
     static int serial_only = -1;   // J2K_T1_SERIAL=1: A/B against the serial kernel
-    if (serial_only < 0) { const char *en = getenv("J2K_T1_SERIAL"); serial_only = en ? atoi(en) : 0; }
+    if (serial_only < 0) serial_only = 0;          // (round 1's A/B switch J2K_T1_SERIAL: gone, the serial kernel only takes what the others leave)
     if (!serial_only) {
         if (sym && nsyms) {
             int planes = (int)((sym_stride - 1024) / 4096) - 2;
@@ -1720,7 +1720,7 @@ hipError_t launch_t1_encode(hipStream_t s, const BlockJob *jobs, int njobs, cons
             // With the lanes ordered by symbol count (t1_order_kernel; `lane_order`, J2K_T1_ENC_ORDER=0 turns it off) a wavefront's
             // chains end together, and the throughput setting fills all 64 lanes.
             static int lane_order = -1;
-            if (lane_order < 0) { const char *en = getenv("J2K_T1_ENC_ORDER"); lane_order = en ? atoi(en) : 1; }
+            if (lane_order < 0) lane_order = 1;            // (J2K_T1_ENC_ORDER: measured in round 3, ordered lanes kept)
             int K = lanes > 0 ? lanes : (lanes < 0 ? std::min(lane_order ? 64 : 32, (njobs + 255) / 256) : (njobs + 2047) / 2048);
             K = std::min(64, std::max(1, K));
             uint32_t *perm = lane_order ? nsyms + njobs : nullptr;       // njobs + 64 words behind nsyms (t1_workspace in j2k_abi.cpp)
@@ -1740,7 +1740,7 @@ hipError_t launch_t1_encode(hipStream_t s, const BlockJob *jobs, int njobs, cons
         // blocks above 64 x 64, up to 256 x 256 (the reference's default size): wave-parallel context formation (t1_big.inc)
         const uint32_t *marked = nullptr;      // the two-kernel form's overflow marks: those blocks take the serial kernel below (its workspace is global memory: no LDS to wait for)
         static int big_on = -1;        // J2K_T1_BIG=0: A/B against the serial kernel
-        if (big_on < 0) { const char *en = getenv("J2K_T1_BIG"); big_on = en ? atoi(en) : 1; }
+        if (big_on < 0) { const char *en = tuning_env("J2K_T1_BIG"); big_on = en ? atoi(en) : 1; }
         if (big_on) {
             static bool raised = false;
             if (!raised) {
@@ -1750,9 +1750,9 @@ hipError_t launch_t1_encode(hipStream_t s, const BlockJob *jobs, int njobs, cons
                 raised = true;
             }
             int rot = 1;               // J2K_T1_BIG_ROT=0: the chain stays on wave 0 (A/B)
-            { const char *en = getenv("J2K_T1_BIG_ROT"); if (en) rot = atoi(en); }
+            { const char *en = tuning_env("J2K_T1_BIG_ROT"); if (en) rot = atoi(en); }
             int split = 1;             // J2K_T1_BIG_SPLIT=0: context formation and MQ chain in one kernel (round 3's form; A/B)
-            { const char *en = getenv("J2K_T1_BIG_SPLIT"); if (en) split = atoi(en); }
+            { const char *en = tuning_env("J2K_T1_BIG_SPLIT"); if (en) split = atoi(en); }
             if (split && bigsym && bigsym_off && bignsyms) {
                 // two kernels through symbol lists in global memory, so that a block holds its LDS and four waves for the milliseconds of
                 // context formation only and its chain -- one wave, no LDS -- is resident beside thousands of others; a block whose
@@ -1831,17 +1831,17 @@ hipError_t launch_t1_decode(hipStream_t s, const BlockJob *jobs, int njobs, cons
     }
     // blocks above 64 x 64, up to 256 x 256 (the reference's default size): the wave-uniform decoder (t1_bigdec.inc)
     int big_dec = 1;                   // J2K_T1_BIG_DEC=0: A/B against the general kernel (read per call: only frames with such blocks get here)
-    { const char *en = getenv("J2K_T1_BIG_DEC"); if (en) big_dec = atoi(en); }
+    { const char *en = tuning_env("J2K_T1_BIG_DEC"); if (en) big_dec = atoi(en); }
     const bool use_big = big_dec && !general_only;
     if (use_big) {
         int rot = 1;                   // J2K_T1_BIG_ROT=0: one wave per block, wherever the dispatcher puts it (A/B)
-        { const char *en = getenv("J2K_T1_BIG_ROT"); if (en) rot = atoi(en); }
+        { const char *en = tuning_env("J2K_T1_BIG_ROT"); if (en) rot = atoi(en); }
         // two sizes of block state (t1_bigdec.inc): each launch takes the blocks of its size
         // throughput (several MQ contexts: frames in flight): two launches, so that the small blocks hold 10 KB of LDS instead of 41 --
         // one after the other on this stream, beside the other streams' launches; one context alone: one launch with the large state
         // for every block (the blocks of a frame decode side by side: latency)
         int classes = throughput;
-        { const char *en = getenv("J2K_T1_BIG_DEC_CLASSES"); if (en) classes = atoi(en); }
+        { const char *en = tuning_env("J2K_T1_BIG_DEC_CLASSES"); if (en) classes = atoi(en); }
         hipLaunchKernelGGL((t1_decode_big_kernel<4, 258>), dim3(njobs), dim3(rot ? 256 : 64), sizeof(T1BigDec<4, 258>), s, jobs, njobs, stream, offs, lens, numbps, decoded, rot, classes ? 0 : 1);
         if (classes) hipLaunchKernelGGL((t1_decode_big_kernel<2, 130>), dim3(njobs), dim3(rot ? 256 : 64), sizeof(T1BigDec<2, 130>), s, jobs, njobs, stream, offs, lens, numbps, decoded, rot, 0);
         hipError_t e = hipGetLastError();

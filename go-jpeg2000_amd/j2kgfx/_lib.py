@@ -40,7 +40,7 @@ class PlanInfo(C.Structure):
 # every symbol include/j2kgfx.h declares (tests/test_abi_symbols.py checks the header against this list)
 SYMBOLS = [
     "j2k_ctx_create", "j2k_ctx_destroy", "j2k_ctx_sync", "j2k_ctx_stream", "j2k_ctx_last_error",
-    "j2k_status_string", "j2k_version", "j2k_ctx_profile_enable", "j2k_ctx_profile_read", "j2k_ctx_profile_read_tag",
+    "j2k_status_string", "j2k_version", "j2k_ctx_set_option", "j2k_ctx_profile_enable", "j2k_ctx_profile_read", "j2k_ctx_profile_read_tag",
     "j2k_ctx_capture_begin", "j2k_ctx_capture_end", "j2k_graph_launch", "j2k_graph_destroy",
     "j2k_dc_level_shift_forward", "j2k_dc_level_shift_inverse", "j2k_forward_rct", "j2k_inverse_rct",
     "j2k_forward_ict", "j2k_inverse_ict",
@@ -102,7 +102,7 @@ def lib():
             "j2k_comm_load_error": (C.c_char_p, []), "j2k_comm_create": (I, [V, V, I, I, C.POINTER(V)]), "j2k_comm_destroy": (None, [V]),
             "j2k_comm_last_error": (C.c_char_p, [V]), "j2k_comm_stream": (V, [V]),
             "j2k_gather_streams": (I, [V, I, V, V, V, V, I, V, S, V, I]), "j2k_comm_wait": (I, [V, V]),
-            "j2k_plan_pack_bound": (S, [V]),
+            "j2k_plan_pack_bound": (S, [V]), "j2k_ctx_set_option": (I, [V, C.c_char_p, C.c_long]),
         }
         for name, (res, args) in sigs.items():
             if partial and not hasattr(L, name):

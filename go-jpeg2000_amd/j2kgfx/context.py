@@ -62,6 +62,10 @@ class Context:
             raise _lib.J2KError(st, "%s: %s" % (self.L.j2k_status_string(st).decode(),
                                                  self.L.j2k_ctx_last_error(self.h).decode()))
 
+    def set_option(self, name, value):
+        """j2k_ctx_set_option: a tuning option of this context (before its plans are made)"""
+        self.check(self.L.j2k_ctx_set_option(self.h, name.encode(), int(value)))
+
     def hold(self, t):
         """Keep `t` alive until the next sync(): kernels queued on the library stream may still read or write it."""
         self._held.append(t)

@@ -58,6 +58,14 @@ void *j2k_ctx_stream(j2k_ctx *ctx);             /* the hipStream_t, for event ti
 const char *j2k_ctx_last_error(j2k_ctx *ctx);   /* text of the last non-OK status */
 const char *j2k_status_string(int status);
 const char *j2k_version(void);
+/* Tuning options: which of its measured kernel forms a context takes (the defaults are what the benchmarks measured best; results
+ * are identical under every setting -- tests/test_gpu_knobs.py).  Set BEFORE plans are created on the context.  Names (csrc/j2k_abi.cpp,
+ * ctx_options): "t1_dec_split" (MQ decode plane by plane from this many blocks on; -1 automatic), "t1_lanes", "t1_dec_lanes",
+ * "t1_sym_mb" (cap of the MQ encoder's symbol workspace, MiB), "pix_fuse", "l0_wg", "l0_wg_inv", "l0_fuse", "plane_wg", "deep", "mega",
+ * ...  An unknown name or a value out of range is J2K_ERR_INVALID_ARG.  The ENVIRONMENT sets none of this unless J2K_TUNING=1 is in
+ * it (then J2K_<NAME> is read for every option at j2k_ctx_create: the tests' and tools' A/B switch); J2K_RCCL_LIB, the path of the
+ * RCCL library, is the one variable that is always read. */
+int j2k_ctx_set_option(j2k_ctx *ctx, const char *name, long value);
 /* Kernel timing for bench.py's roofline lines: while enabled, the dispatches of the 5-3 transform stamp a HIP event pair
  * with the kernel's own begin and end (hipExtLaunchKernelGGL start/stop events on the ctx stream).  on = 1: the level-0
  * dispatch of every j2k_plan_forward* only (tag 0; cheapest, used inside bench.py's timed region); on = 2: every

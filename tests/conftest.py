@@ -9,6 +9,11 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "go-jpeg2000_am
         sys.path.insert(0, p)
 
 
+# the tests' A/B switches (J2K_L0_WG, J2K_T1_DEC_SPLIT, ...) are environment variables of the TUNING set: the library reads them only
+# when J2K_TUNING=1 is there (a host process does not inherit kernel choices from its environment); set before the library loads
+os.environ.setdefault("J2K_TUNING", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
 

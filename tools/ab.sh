@@ -1,6 +1,6 @@
 # A/B on the GPU box: kernel stats of the default bench at one frame in flight under each setting of an environment knob.
 # usage: bash tools/ab.sh <kernel-substr> VAR=val1,val2,... [VAR2=...]   (cartesian product; "-" = unset)
-cd /tmp; export TMPDIR=/tmp
+cd /tmp; export TMPDIR=/tmp; export J2K_TUNING=1   # (the library reads its J2K_* switches only with this set)
 R=$GRAFT_REPO_ROOT
 SUB=$1; shift
 combos=("")

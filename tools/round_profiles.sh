@@ -1,7 +1,7 @@
 # Profiles committed under profiles/ (run on the GPU box: bash tools/round_profiles.sh): kernel stats for the default bench and for
 # one frame in flight, and the HBM traffic (FETCH_SIZE / WRITE_SIZE in separate passes) with one frame in flight; the same for C3;
 # kernel stats of c1gpu and c5.  python tools/collect_profiles.py <tag> copies the summaries.
-cd /tmp; export TMPDIR=/tmp
+cd /tmp; export TMPDIR=/tmp; export J2K_TUNING=1   # (the library reads its J2K_* switches only with this set)
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/round
 rm -rf $O; mkdir -p $O
