@@ -49,13 +49,13 @@ def _traffic(fetch_kib, write_kib, src):
 
 TRAFFIC = {   # frame_io -> (bytes per level-0 forward launch, source); tests/test_bench_traffic_constant.py re-reads the summary
     "planes": _traffic(52495.8, 97200.0, "profiles/r01_bench_v3_inflight1_pmc_{FETCH,WRITE}_SIZE.csv"),
-    "rgba8": _traffic(16431.7, 97269.2, "profiles/r04_bench_inflight1_pmc_summary.txt"),
+    "rgba8": _traffic(16430.1, 97259.8, "profiles/r05_bench_inflight1_pmc_summary.txt"),
 }
 # HBM bytes ALL kernels of one C2 frame move (same PMC passes, one frame in flight): sum over the nine kernels of a step of
 # 2 x FETCH_SIZE + WRITE_SIZE; tests/test_bench_traffic_constant.py re-adds them from the committed summary
 PIPELINE_KERNELS = ("dwt53_fwd_rgba8_wg_kernel", "dwt53_deep_fwd_kernel", "ht_encode_kernel", "gather_scan_kernel", "ht_vlcprep_kernel", "ht_walk_kernel",
                     "ht_decode_kernel", "dwt53_deep_inv_kernel", "dwt53_inv_rgba8_wg_kernel")
-PIPELINE_TRAFFIC = (int(round(488482.5 * 1024)), "profiles/r04_bench_inflight1_pmc_summary.txt: sum of (2 x FETCH_SIZE + WRITE_SIZE) over %d kernels" % len(PIPELINE_KERNELS))
+PIPELINE_TRAFFIC = (int(round(488239.0 * 1024)), "profiles/r05_bench_inflight1_pmc_summary.txt: sum of (2 x FETCH_SIZE + WRITE_SIZE) over %d kernels" % len(PIPELINE_KERNELS))
 COPY_PEAK_GUIDE_GBS = 6290.0   # MI355X_MICROARCH.md: the float4 device-to-device copy the guide measured (what a pure copy reaches)
 
 
@@ -801,7 +801,10 @@ def run(state):
                        "frames_in_flight": F, "frames_in_flight_rank0": F - root_idle_all, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "frame_io": args.io,
                        "decode_rows": args.decode_rows + (" (the rows the reference's HT decoder never writes are not re-zeroed on every call: the "
                                                           "buffer was zeroed once, as a pooled HTDecoder's slice is; digest unchanged)" if args.decode_rows == "coded" else ""),
-                       "parallelism": "frames/rank" if world > 1 else "single GPU", "gather": gather_path},
+                       "parallelism": "frames/rank" if world > 1 else "single GPU", "gather": gather_path,
+                       "ranks_seen": world,
+                       "gather_check": ("rank 0's rebuilt stream, offsets, lengths and bit-plane counts of rank 1's frame == that frame coded on rank 0, "
+                                        "byte for byte (asserted after the timed region)") if world > 1 else None},
             "roofline": {"bound": "hbm",
                          "kernel": ("dwt53_fwd_rgba8_wg_kernel (level 0: RGBA8 unpack + DC shift + RCT + 5-3 lifting, fused)" if args.io == "rgba8"
                                     else "dwt53_fwd_kernel<8,3,true,false,false> (level 0: DC shift + RCT + 5-3 lifting, fused)"),
@@ -835,7 +838,51 @@ def run(state):
             out["cpu_baseline"] = cpu_base
         if others is not None:
             out["other_configs"] = others
-        print(json.dumps(out))
+        state["line"] = out
+    # ---- N > 1: the same command also carries the tile-sharded C4 record and the frames-per-rank C5 record (a
+    #      SCALE file then answers "do tiles shard near-linearly?" without flags).  The headline's lanes are torn down first (the
+    #      process group stays), each record runs inside the same ranks, and a watchdog prints the headline alone if one of them hangs.
+    if world > 1 and not peer_rehearsal and not args.no_other_configs and os.environ.get("J2K_BENCH_SCALE_RECORDS", "1") != "0":
+        import copy
+        import threading
+        bench_extra.teardown(state.get("lanes", []), False, state.get("helper"), state.get("stop_helper"), ok=True, comm=state.get("comm"))
+        state["lanes"], state["helper"], state["comm"] = [], None, None
+        lanes.clear()
+        torch.cuda.empty_cache()
+        scale = {}
+
+        def bark():
+            if rank == 0 and state.get("line") is not None:
+                state["line"]["scale_records"] = dict(scale, error="timed out after %s s: the headline line is printed without the missing records" % os.environ.get("J2K_BENCH_SCALE_TIMEOUT", "240"))
+                print(json.dumps(state["line"]), flush=True)
+            os._exit(0)
+        dog = threading.Timer(float(os.environ.get("J2K_BENCH_SCALE_TIMEOUT", "240")), bark)
+        dog.daemon = True
+        dog.start()
+        for name, fn, kw in (("c4_tiles_sharded", bench_extra.run_shard_tiles, dict(config="c4", steps=20, warmup=3, inflight=1, d2h=False)),
+                             ("c5_frames_per_rank", bench_extra.run_config, dict(config="c5", steps=20, warmup=3, inflight=0))):
+            a2 = copy.copy(args)
+            for k_, v_ in kw.items():
+                setattr(a2, k_, v_)
+            a2.no_cpu_baseline = True
+            try:
+                rec = fn(a2, embedded=True) if fn is bench_extra.run_shard_tiles else fn(a2, "c5", embedded=True)
+                if rank == 0 and rec is not None:
+                    scale[name] = {k_: rec[k_] for k_ in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "scaling")}
+                    scale[name].update({k_: rec["config"][k_] for k_ in ("tiles", "codestream_bytes", "value_with_d2h", "parallelism", "gather", "assembly_check",
+                                                                         "frames_in_flight", "contexts", "frames_per_context") if k_ in rec["config"]})
+                    scale[name]["ranks_seen"] = world
+            except Exception as exc:                        # noqa: BLE001  (the headline does not depend on these)
+                scale[name] = {"error": repr(exc)[:300]}
+                try:
+                    dist.barrier()
+                except Exception:                           # noqa: BLE001
+                    pass
+        dog.cancel()
+        if rank == 0:
+            state["line"]["scale_records"] = scale
+    if rank == 0 and state.get("line") is not None:
+        print(json.dumps(state["line"]))
 
 
 def main():

@@ -10,7 +10,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 HBM_PEAK_GBS = 8000.0
 # HBM bytes of one launch of the configuration's roofline kernel from the PMC counters (cannot be collected from inside this
 # process: the committed measurement, checked against its source by tests/test_bench_traffic_constant.py)
-TRAFFIC = {"c3": (int(round((2 * 49692.0 + 121500.5) * 1024)), "profiles/r04_c3_pmc_summary.txt: dwt97_fwd_rgb_wg_kernel<8, 1, 7, 0>, (2 x 49692.0 + 121500.5) KiB")}
+# (C3 codes a BATCH of four frames per context and launch by default -- CONFIGS["c3"]["batch"] -- and so did the PMC pass: the figure is
+#  per launch of four stacked frames, like roofline.algorithmic_bytes_per_launch)
+TRAFFIC = {"c3": (int(round((2 * 198365.0 + 486000.9) * 1024)), "profiles/r05_c3_pmc_summary.txt: dwt97_fwd_rgb_wg_kernel<8, 1, 7, 0>, (2 x 198365.0 + 486000.9) KiB per launch of 4 frames")}
+TRAFFIC_BATCH = {"c3": 4}
 SEED = 0x4A324B30              # "J2K0" 
 
 # coder: 0 = MQ (T1.EncodeFast5 / T1.Decode), 1 = HT.  io: frame format at the boundary.
@@ -200,7 +203,9 @@ def cpu_baseline(cfgname, index=0, budget_s=10.0, decode=True, one_thread_only=F
 # ------------------------------------------------------------------------------------------------------------------
 # plain runner: F independent frames in flight per rank, no exchange (C3 on one GPU; C5 = frames sharded over ranks)
 # ------------------------------------------------------------------------------------------------------------------
-def run_config(args, cfgname):
+def run_config(args, cfgname, embedded=False):
+    """embedded: called by bench.py's default N > 1 run after its headline measurement -- the process group exists already and stays,
+    nothing is printed, rank 0 gets the record back"""
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -215,13 +220,14 @@ def run_config(args, cfgname):
     if backend != "nccl":
         local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 and not embedded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     W, H, C = cfg["W"], cfg["H"], cfg["C"]
+    record = [None]
     if os.environ.get("J2K_BENCH_H"):          # dev: another frame height (e.g. a whole number of tile rows, to try --batch on a tiled configuration)
         cfg = dict(cfg, H=int(os.environ["J2K_BENCH_H"])); H = cfg["H"]
     F = args.inflight if args.inflight > 0 else cfg["inflight"]
@@ -402,7 +408,7 @@ def run_config(args, cfgname):
                 alg = W * H * C * (4 + 3 + 2)
             k_s = (iso_ms / max(iso_n, 1)) * 1e-3
             # HBM bytes of that launch from the PMC counters: a committed measurement (bench.TRAFFIC), default kernel settings only
-            traffic, traffic_src = (TRAFFIC[cfgname] if cfgname in TRAFFIC and not os.environ.get("J2K_L0_WG97") else (None, None))
+            traffic, traffic_src = (TRAFFIC[cfgname] if cfgname in TRAFFIC and not os.environ.get("J2K_L0_WG97") and TRAFFIC_BATCH.get(cfgname, 1) == B else (None, None))
             ach = alg / k_s / 1e9 if iso_n else 0.0
             kern = {"c3": "dwt97_fwd_rgb_wg_kernel<8,1,7> (level 0: DC shift + ICT + rounding + 9-7 lifting + quantisation, fused; VALU-bound in float64)",
                     "c5": "dwt53_fwd_plane_wg_kernel<4,1,true,8> (level 0: Gray16 unpack + DC shift + 5-3 lifting, fused; four 512-column strips)"}.get(cfgname, "level-0 forward kernel")
@@ -431,10 +437,14 @@ def run_config(args, cfgname):
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(cfgname, budget_s=getattr(args, "cpu_baseline_s", 0) or 8.0,
                                                    one_thread_only=getattr(args, "cpu_baseline_1t", False))
-            print(json.dumps(out))
+            if embedded:
+                record[0] = out
+            else:
+                print(json.dumps(out))
         ok = True
     finally:
-        teardown(lanes, world > 1, ok=ok)
+        teardown(lanes, world > 1 and not embedded, ok=ok)
+    return record[0]
 
 
 def teardown(lanes, distributed, helper=None, stop_helper=None, ok=True, comm=None):
@@ -476,7 +486,8 @@ def teardown(lanes, distributed, helper=None, stop_helper=None, ok=True, comm=No
 # tile-sharded strong scaling (north_star / C4): ONE frame per step, rank r codes tiles shard_range(ntiles, r, N),
 # the packs are gathered to rank 0, rebuilt, and assembled into tile-parts (SOT ... SOD data per tile) there.
 # ------------------------------------------------------------------------------------------------------------------
-def run_shard_tiles(args):
+def run_shard_tiles(args, embedded=False):
+    """embedded: as run_config's"""
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -493,12 +504,13 @@ def run_shard_tiles(args):
     if backend != "nccl":
         local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 and not embedded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    record = [None]
     W, H, C, T = cfg["W"], cfg["H"], cfg["C"], cfg["tile"]
     ntiles = jdist.num_tiles(W, H, T, T)
     kw = dict(precision=cfg["prec"], lossless=cfg["lossless"], quality=cfg["quality"], num_resolutions=cfg["nres"], cb=(cfg["cb"], cfg["cb"]),
@@ -653,8 +665,14 @@ def run_shard_tiles(args):
                               "; synchronous step; the finished tile-parts %s" % (ntiles, "are copied to pinned host memory inside the timed region (--d2h)"
                                                                            if not other else "stay in HBM (value_with_d2h: the same step with "
                                                                            "one copy of them to pinned host memory inside)"),
-                              "tiles": ntiles, "codestream_bytes": int(assembled[0]), "value_with_d2h": round(W * H / dt2 / 1e6, 1), "parallelism": "tiles/rank" if world > 1 else "single GPU"}}
-            print(json.dumps(out))
+                              "tiles": ntiles, "codestream_bytes": int(assembled[0]), "value_with_d2h": round(W * H / dt2 / 1e6, 1), "parallelism": "tiles/rank" if world > 1 else "single GPU",
+                              "gather": "torch.distributed batch_isend_irecv peer->root (dist.gather_streams)" if world > 1 else None,
+                              "assembly_check": "tile-parts name tiles 0..%d in order and carry, byte for byte, the stream of an unsharded plan" % (ntiles - 1)}}
+            if embedded:
+                record[0] = out
+            else:
+                print(json.dumps(out))
         ok = True
     finally:
-        teardown(lanes, world > 1, ok=ok)
+        teardown(lanes, world > 1 and not embedded, ok=ok)
+    return record[0]

@@ -24,7 +24,7 @@ struct j2k_ctx {
     int l0_wg97 = 8;           // lossy level-0 forward of an RGB triple, workgroup form: waves per workgroup (J2K_L0_WG97: 0 off, 6..16 even; measured 4K: 8 -> 78 us, 16 -> 88 us, general kernel 160 us)
     int plane_wg97 = 8;        // deeper 9-7 levels (single float64 planes) in workgroup form: waves per workgroup (J2K_PLANE_WG97: 0 = general kernels, 8)
     int l0_wg97_inv = 8;       // lossy level-0 inverse of an RGB triple, workgroup form: waves per workgroup (J2K_L0_WG97_INV: 0 off, 6 8 10 12)
-    int l0_xcd_group = 8;      // J2K_L0_XCD_GROUP (inverse level-0 table): > 0 = bands go to the XCDs in groups of this many consecutive ones (0: one contiguous chunk of the table per XCD)
+    int l0_xcd_group = 16;     // J2K_L0_XCD_GROUP (inverse level-0 table): > 0 = bands go to the XCDs in groups of this many consecutive ones (0: one contiguous chunk of the table per XCD)
     bool l0_xcd = true;        // XCD-aware order of the workgroup jobs (J2K_L0_XCD=0: plane-major order)
     bool ht_alias = true;      // j2k_plan_encode_stream (HT): code each distinct block window once (J2K_HT_ALIAS=0: every job)
     int l0_inv_wpe = 5;        // its occupancy variant (J2K_L0_INV_WPE: 5 = all in registers, 26.4 us; 6 = odd row parked in LDS for 6 waves per SIMD, measured slower: 33.6 us)

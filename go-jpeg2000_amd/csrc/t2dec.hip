@@ -26,6 +26,7 @@ struct T2Rd {
     uint64_t end;                       // the decoder's buffer is data[0, end)
     uint64_t *win;                      // LDS, T2D_WIN / 8 words
     uint64_t wbase;                     // ADDRESS (8-byte aligned) of win[0]; ~0 = nothing loaded
+    uint64_t cw, cwa;                   // the window word the reader is in, and its address (~0: none): one LDS read per eight bytes
     uint64_t rpos;                      // next byte the reader takes
     uint64_t acc;                       // its low `have` bits are unread, oldest on top
     uint32_t have;                      // < 8 at every field boundary (bio's cnt)
@@ -45,9 +46,12 @@ struct T2Rd {
     }
     __device__ __forceinline__ uint32_t byte_at(uint64_t pos) {    // pos < end
         const uint64_t a = (uint64_t)(uintptr_t)data + pos;
-        if (a - wbase >= T2D_WIN) refill(a);                        // (also true for a < wbase: the difference wraps)
-        const uint64_t w = win[(a - wbase) >> 3];
-        return (uint32_t)(w >> (8u * ((uint32_t)a & 7u))) & 0xFFu;
+        if ((a & ~7ull) != cwa) {
+            if (a - wbase >= T2D_WIN) refill(a);                    // (also true for a < wbase: the difference wraps)
+            cwa = a & ~7ull;
+            cw = win[(a - wbase) >> 3];
+        }
+        return (uint32_t)(cw >> (8u * ((uint32_t)a & 7u))) & 0xFFu;
     }
     __device__ __forceinline__ bool need(uint32_t n) {              // n <= 32
         while (have < n) {
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(64) void t2_decode_kernel(T2Chain *__restrict__ cha
     if (Cn.skip) { if (lane == 0 && frame_status && Cn.status) atomicMin(frame_status, Cn.status); return; }
     const uint64_t base = Cn.start;
     T2Rd r;
-    r.data = data + base; r.end = Cn.end - base; r.win = win; r.wbase = ~0ull; r.lane = lane;
+    r.data = data + base; r.end = Cn.end - base; r.win = win; r.wbase = ~0ull; r.cwa = ~0ull; r.cw = 0; r.lane = lane;
     r.rpos = Cn.st.rpos; r.have = Cn.st.cnt; r.lastb = Cn.st.buf; r.acc = Cn.st.buf; r.saw_ff = Cn.st.saw_ff != 0; r.eof = false;
     uint64_t pos = Cn.st.pos;
     const uint64_t end = r.end;

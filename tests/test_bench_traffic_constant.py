@@ -39,7 +39,11 @@ def test_c3_traffic_constant_matches_committed_pmc_summary():
     assert set(vals) == {"FETCH_SIZE", "WRITE_SIZE"}
     measured = (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024
     assert abs(measured - nbytes) <= 0.001 * nbytes, (measured, nbytes)
-    alg = 3840 * 2160 * 27                                  # 12 B in; 3/4 int32 + 1/4 float64 out per sample, three components
+    # the PMC pass ran the configuration's default: a batch of four frames per launch (the constant and the launch it
+    # is quoted for must be the same launch)
+    assert bench_extra.TRAFFIC_BATCH["c3"] == bench_extra.CONFIGS["c3"]["batch"] == 4
+    assert "--batch" not in open(path).readline()           # (the summary's command line: no override of the batch)
+    alg = 3840 * 2160 * 27 * 4                              # 12 B in; 3/4 int32 + 1/4 float64 out per sample, three components, four frames
     assert 1.0 <= nbytes / alg < 1.03
 
 

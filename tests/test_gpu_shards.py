@@ -185,6 +185,13 @@ def test_bench_two_rank_control_flow_rehearsal():
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["frames_in_flight"] == 2 and d["value"] > 0
+    assert len([ln for ln in out.stdout.splitlines() if ln.startswith("{")]) == 1          # ONE line, whatever it carries
+    # ... and the same command carries the tile-sharded C4 record and the frames-per-rank C5 record
+    sr = d["scale_records"]
+    assert sr["c4_tiles_sharded"]["value"] > 0 and sr["c4_tiles_sharded"]["scaling"] == "strong" and sr["c4_tiles_sharded"]["tiles"] == 135
+    assert sr["c4_tiles_sharded"]["n_gpus"] == 2 and "byte for byte" in sr["c4_tiles_sharded"]["assembly_check"]
+    assert sr["c5_frames_per_rank"]["value"] > 0 and sr["c5_frames_per_rank"]["scaling"] == "weak" and sr["c5_frames_per_rank"]["n_gpus"] == 2
+    assert d["config"]["ranks_seen"] == 2 and "byte for byte" in d["config"]["gather_check"]
     # the same through bench.py's own launcher: `python bench.py --gpus 2` with no WORLD_SIZE starts the two ranks as a child
     # (before touching the GPU), relays rank 0's line and the status; n_gpus == --gpus
     env2 = dict(env)

@@ -39,3 +39,15 @@ if glob.glob(os.path.join(O, "stats_c3lanes/*/*kernel_stats.csv")):
 for name in ("c1gpu", "c5"):
     if glob.glob(os.path.join(O, "stats_%s/*/*kernel_stats.csv" % name)):
         shutil.copy(newest("stats_%s/*/*kernel_stats.csv" % name), os.path.join(P, "%s_%s_bench_kernel_stats.csv" % (tag, name)))
+if glob.glob(os.path.join(O, "stats_cl/*/*kernel_stats.csv")):
+    shutil.copy(newest("stats_cl/*/*kernel_stats.csv"), os.path.join(P, tag + "_closed_loop_bench_kernel_stats.csv"))
+if glob.glob(os.path.join(O, "pmc_invg16_FETCH/*/*counter_collection.csv")):
+    lines = ["# inverse level 0 (dwt53_inv_rgba8_wg_kernel<4, 5, false>), one frame in flight: FETCH_SIZE (rocprofv3 --pmc, KiB per launch; x2 on gfx950) and",
+             "# the kernel's average time (rocprofv3 --kernel-trace --stats) with 8 (default) and 16 consecutive bands per XCD (J2K_L0_XCD_GROUP):",
+             "# algorithmic read = 3840 x 2160 x 12 B = 97200 KiB"]
+    for g in (8, 16):
+        out = subprocess.run([sys.executable, os.path.join(R, "tools", "pmc_sum.py"), os.path.join(O, "pmc_invg%d_FETCH" % g), "dwt53_inv_rgba8"], capture_output=True, text=True).stdout
+        us = subprocess.run([sys.executable, os.path.join(R, "tools", "kstats.py"), "dwt53_inv_rgba8", os.path.join(O, "stats_invg%d" % g)], capture_output=True, text=True).stdout
+        lines += ["group %2d: %s  |  %s" % (g, out.strip().replace("\n", " ; "), us.strip())]
+    open(os.path.join(P, tag + "_inv_level0_xcd_group_ab.txt"), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))

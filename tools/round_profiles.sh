@@ -30,3 +30,16 @@ tail -1 $O/stats_c1gpu.log | cut -c1-200
 unset GPU_MAX_HW_QUEUES
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c5 -- python $R/bench.py --config c5 --steps 20 --warmup 3 --no-cpu-baseline > $O/stats_c5.log 2>&1
 tail -1 $O/stats_c5.log | cut -c1-200
+# round 5: the closed-loop codec (4K RGB8, MQ coder: pixels -> tile-parts of packets -> pixels) -- the kernels of the decode body
+export GPU_MAX_HW_QUEUES=32
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cl -- python $R/bench.py --config cl --steps 2 --warmup 1 --inflight 2 > $O/stats_cl.log 2>&1
+tail -1 $O/stats_cl.log | cut -c1-200
+unset GPU_MAX_HW_QUEUES
+# round 5: is the inverse level 0's read over-fetch what holds it back?  Groups of 16 bands per XCD instead of 8 halve the halo rows that
+# miss the L2: FETCH_SIZE and the kernel's time under both settings
+for g in 8 16; do
+  export J2K_L0_XCD_GROUP=$g
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_invg${g}_FETCH -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs --inflight 1 > $O/pmc_invg${g}.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_invg${g} -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-other-configs --inflight 1 > $O/stats_invg${g}.log 2>&1
+done
+unset J2K_L0_XCD_GROUP
