@@ -17,72 +17,179 @@
 
 namespace j2k {
 
-#define T2D_WIN 1024                    // bytes of the chain that the LDS window holds (a header of a C2 tile: 10 ... 250 bytes)
+#define T2D_RAW 4096                    // bytes of the buffer staged in LDS at a time (a tile's first packets -- a few blocks each -- lie within it)
+#define T2D_CHUNK 256                   // raw bytes un-stuffed at a time into the bit buffer (a header of a C2 tile: 10 ... 250 bytes)
 
-// bio.ByteStuffingReader (bio.go:105-155) over a window of the buffer: a byte is taken when a bit is asked for and none is left
-// -- never earlier, so that (rpos, cnt, buf, sawFF) are the reference's at every field boundary.  Wave-uniform.
+// bio.ByteStuffingReader (bio.go:105-155) in two stages.  (1) By the whole wavefront: T2D_CHUNK raw bytes -> their bits end to end in
+// an LDS bit buffer.  A byte holds 8 bits, or 7 behind a 0xFF byte (bio.go:127-131): the widths depend on the RAW bytes only, so four
+// bytes per lane, one scan over the lanes for the bit offsets, OR-deposits.  (2) The chain -- every lane the same state -- reads
+// fields from a 64-bit register window over that buffer: a field is a shift, a unary value a count of leading zeros; one LDS word per
+// 32 bits consumed.  The reader's position in the reference's terms (rpos, cnt, buf, sawFF) is recovered from the byte -> bit map
+// whenever it is asked for (a packet's end), so the two stages give exactly the reference's state at every field boundary.
 struct T2Rd {
-    const uint8_t *data;                // d_data; positions are offsets from it
-    uint64_t end;                       // the decoder's buffer is data[0, end)
-    uint64_t *win;                      // LDS, T2D_WIN / 8 words
-    uint64_t wbase;                     // ADDRESS (8-byte aligned) of win[0]; ~0 = nothing loaded
-    uint64_t cw, cwa;                   // the window word the reader is in, and its address (~0: none): one LDS read per eight bytes
-    uint64_t rpos;                      // next byte the reader takes
-    uint64_t acc;                       // its low `have` bits are unread, oldest on top
-    uint32_t have;                      // < 8 at every field boundary (bio's cnt)
-    uint32_t lastb;                     // the byte they come from (bio's buf)
-    bool saw_ff, eof;
+    const uint8_t *data;                // the decoder's buffer is data[0, end)
+    uint64_t end;
+    uint64_t *raw;                      // LDS: T2D_RAW / 8 words, data[...] from ADDRESS rwbase (8-byte aligned; ~0: nothing loaded)
+    uint64_t rwbase;
+    uint32_t *bits;                     // LDS: T2D_CHUNK * 8 / 32 + 4 words, most significant bit first
+    uint16_t *sbit;                     // LDS: T2D_CHUNK + 1: first bit of every raw byte of the chunk; [nbytes] = the chunk's bit count
+    uint64_t p0;                        // the chunk starts at data[p0] ...
+    uint32_t nbytes, nbits;             // ... holds this many raw bytes / bits (nbytes < T2D_CHUNK only at the end of the buffer)
+    uint32_t bitpos;                    // the reader's position in the chunk
+    uint64_t w;                         // the next `wav` bits of the chunk, from bit 63 down
+    uint32_t wav, wnext;                // wnext: index of the next buffer word to append
+    bool have_chunk, eof;
+    bool stale;                         // the register window does not match bitpos (the fast block path moved it): fetch() starts it again
+#ifdef J2K_T2D_STATS
+    uint64_t t_reload = 0, t_build = 0; uint32_t n_reload = 0, n_build = 0;
+#endif
+    uint64_t pend_pos; uint32_t pend_first; bool pend_sff;      // seat()
     int lane;
 
-    __device__ __forceinline__ void refill(uint64_t addr) {
-        __syncthreads();                                            // (one wavefront: everybody is done with the old window)
-        wbase = addr & ~7ull;
-        const uint64_t lim = ((uint64_t)(uintptr_t)data + end + 7) & ~7ull;      // words that overlap data[0, end) only
-        for (int k = lane; k < T2D_WIN / 8; k += 64) {
-            const uint64_t a = wbase + 8ull * (uint64_t)k;
-            win[k] = a < lim ? *reinterpret_cast<const uint64_t *>((uintptr_t)a) : 0ull;
+    __device__ __forceinline__ void raw_ensure(uint64_t a0, uint64_t a1) {       // addresses [a0, a1) (+ one byte before) staged
+        if (rwbase != ~0ull && a0 >= rwbase + 1 && a1 <= rwbase + T2D_RAW) return;
+#ifdef J2K_T2D_STATS
+        const uint64_t ts_ = wall_clock64(); n_reload++;
+#endif
+        __syncthreads();
+        rwbase = (a0 - 1) & ~7ull;                                               // (the byte before a0 decides a0's width)
+        const uint64_t lo = (uint64_t)(uintptr_t)data & ~7ull, lim = ((uint64_t)(uintptr_t)data + end + 7) & ~7ull;   // words that overlap data[0, end) only
+        for (int k = lane; k < T2D_RAW / 8; k += 64) {
+            const uint64_t a = rwbase + 8ull * (uint64_t)k;
+            raw[k] = (a >= lo && a < lim) ? *reinterpret_cast<const uint64_t *>(data + (int64_t)(a - (uint64_t)(uintptr_t)data)) : 0ull;   // (from `data`: a global load, not a flat one)
         }
         __syncthreads();
+#ifdef J2K_T2D_STATS
+        t_reload += wall_clock64() - ts_;
+#endif
     }
-    __device__ __forceinline__ uint32_t byte_at(uint64_t pos) {    // pos < end
+    __device__ __forceinline__ uint32_t raw_at(uint64_t addr) const { return reinterpret_cast<const uint8_t *>(raw)[addr - rwbase]; }
+    __device__ __forceinline__ uint32_t byte_at(uint64_t pos) {    // pos < end (the marker tests, t2.go:470-486)
         const uint64_t a = (uint64_t)(uintptr_t)data + pos;
-        if ((a & ~7ull) != cwa) {
-            if (a - wbase >= T2D_WIN) refill(a);                    // (also true for a < wbase: the difference wraps)
-            cwa = a & ~7ull;
-            cw = win[(a - wbase) >> 3];
-        }
-        return (uint32_t)(cw >> (8u * ((uint32_t)a & 7u))) & 0xFFu;
+        raw_ensure(a, a + 1);
+        return raw_at(a);
     }
-    __device__ __forceinline__ bool need(uint32_t n) {              // n <= 32
-        while (have < n) {
-            if (rpos >= end) { eof = true; return false; }
-            const uint32_t b = byte_at(rpos);
-            rpos++;
-            const uint32_t nb = saw_ff ? 7u : 8u;                   // bio.go:127-131: behind a 0xFF byte the next one holds seven bits
-            acc = (acc << nb) | (uint64_t)(b & (0xFFu >> (8u - nb)));
-            have += nb;
-            saw_ff = b == 0xFFu;
-            lastb = b;
+    // the chunk that starts at data[pos]: its first byte holds `first` bits (0: by the rule, from the byte before it or `sff` when pos == 0
+    // or the caller says so with force_sff >= 0)
+    __device__ __forceinline__ void build(uint64_t pos, uint32_t first, int force_sff) {
+        const uint64_t a0 = (uint64_t)(uintptr_t)data + pos;
+        const uint32_t nb = (uint32_t)(end - pos < T2D_CHUNK ? end - pos : T2D_CHUNK);
+#ifdef J2K_T2D_STATS
+        const uint64_t tb_ = wall_clock64(); n_build++;
+#endif
+        raw_ensure(a0, a0 + (nb ? nb : 1));
+        for (int k = lane; k < T2D_CHUNK * 8 / 32 + 4; k += 64) bits[k] = 0;
+        __syncthreads();
+        uint32_t wd[4], by[4], tot = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t i = 4u * (uint32_t)lane + (uint32_t)j;
+            by[j] = i < nb ? raw_at(a0 + i) : 0u;
+            uint32_t prev_ff;
+            if (i == 0) prev_ff = force_sff >= 0 ? (uint32_t)force_sff : (pos > 0 ? (uint32_t)(raw_at(a0 - 1) == 0xFFu) : 0u);
+            else prev_ff = (uint32_t)(raw_at(a0 + i - 1) == 0xFFu);
+            wd[j] = i < nb ? (prev_ff ? 7u : 8u) : 0u;
+            if (i == 0 && first) wd[j] = nb ? first : 0u;
+            tot += wd[j];
         }
-        return true;
+        uint32_t incl = tot;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(incl, d); if (lane >= d) incl += u; }
+        uint32_t off = incl - tot;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t i = 4u * (uint32_t)lane + (uint32_t)j;
+            if (i <= nb) sbit[i] = (uint16_t)off;
+            if (wd[j]) {
+                const uint32_t v = by[j] & (0xFFu >> (8u - wd[j])), wi = off >> 5, sh = off & 31u;
+                if (sh + wd[j] <= 32) atomicOr(&bits[wi], v << (32 - sh - wd[j]));
+                else { const uint32_t lo_ = sh + wd[j] - 32; atomicOr(&bits[wi], v >> lo_); atomicOr(&bits[wi + 1], v << (32 - lo_)); }
+            }
+            off += wd[j];
+        }
+        nbits = (uint32_t)__shfl(incl, 63);
+        if (lane == 63 && nb == T2D_CHUNK) sbit[T2D_CHUNK] = (uint16_t)nbits;    // (lanes cover i = 0 .. 255; the closing entry)
+        __syncthreads();
+        p0 = pos; nbytes = nb; bitpos = 0; w = 0; wav = 0; wnext = 0; have_chunk = true; stale = false;
+#ifdef J2K_T2D_STATS
+        t_build += wall_clock64() - tb_;
+#endif
     }
-    __device__ __forceinline__ uint32_t get(uint32_t n) {           // ReadBits(n), 0 <= n <= 32; 0 at the end of the buffer (eof set)
+    // the raw byte the reader is in, or would take next: bytes [0, j) of the chunk are used up entirely
+    __device__ __forceinline__ uint32_t byte_index() const {
+        // sbit[j] <= bitpos < sbit[j + 1]; bitpos == nbits -> nbytes
+        if (bitpos >= nbits) return nbytes;
+        uint32_t lo = bitpos >> 3, hi = bitpos / 7u + 3u;                        // a byte holds 7 or 8 bits (the chunk's first one: 1 ... 8)
+        if (hi > nbytes) hi = nbytes;
+        uint32_t j = lo;
+        for (uint32_t i = lo; i < hi; i++) if (sbit[i] <= bitpos) j = i;        // (a handful of entries; uniform)
+        return j;
+    }
+    // where the reader stands before its first chunk is made: at data[pos], `first` bits of that byte left (0: an untouched byte whose
+    // width the flag decides -- the reference's sawFF)
+    __device__ __forceinline__ void seat(uint64_t pos, uint32_t first, bool sff) { pend_pos = pos; pend_first = first; pend_sff = sff; have_chunk = false; }
+    __device__ __forceinline__ void fetch() {                       // keep more than 32 bits in the window while the chunk has them
+        if (stale) {
+            const uint32_t idx = bitpos >> 5, sh = bitpos & 31u;
+            w = idx * 32u < nbits ? (uint64_t)(bits[idx] << sh) << 32 : 0ull;
+            wav = 32u - sh; wnext = idx + 1;
+            stale = false;
+        }
+        while (wav <= 32 && wnext * 32u < nbits) { w |= (uint64_t)bits[wnext] << (32u - wav); wav += 32; wnext++; }
+    }
+    // THE place where chunks are made (one call site in the kernel: the chunk builder is inlined once): the first chunk after seat(),
+    // and a new one from the reader's position whenever fewer than 64 bits are left in a chunk that is not the buffer's last
+    __device__ __forceinline__ void ensure() {
+        uint64_t bp = 0; uint32_t bf = 0; int bs = -1; bool go = false;
+        if (!have_chunk) {
+            if (pend_pos < end) { bp = pend_pos; bf = pend_first; bs = pend_first ? -1 : (pend_sff ? 1 : 0); go = true; }
+        } else if (nbits - bitpos < 64 && p0 + nbytes < end) {
+            const uint32_t j = byte_index();
+            bp = p0 + j; bf = j < nbytes ? (uint32_t)sbit[j + 1] - bitpos : 0u; go = true;      // (the bits of byte j still unread; a fresh byte: by the rule)
+        }
+        if (go) build(bp, bf, bs);
+    }
+    __device__ __forceinline__ bool more_data() const { return have_chunk ? p0 + nbytes < end : pend_pos < end; }
+    __device__ __forceinline__ uint32_t get(uint32_t n) {           // ReadBits(n), 0 <= n <= 32, after ensure(); 0 at the end of the buffer (eof set)
         if (n == 0) return 0;
-        if (!need(n)) return 0;
-        have -= n;
-        return (uint32_t)(acc >> have) & (n < 32 ? (1u << n) - 1u : 0xFFFFFFFFu);
+        if (!have_chunk || nbits - bitpos < n) { eof = true; return 0; }
+        fetch();
+        const uint32_t v = (uint32_t)(w >> (64u - n));
+        w <<= n; wav -= n; bitpos += n;
+        return v;
     }
-    __device__ __forceinline__ uint32_t unary() {                   // decodeTagTreeValue (t2.go:574-590): zeros up to the first one
-        uint32_t v = 0;
+    // decodeTagTreeValue (t2.go:574-590), resumable: zeros are added to v up to the first one (true) or to the end of the chunk (false:
+    // ensure() and call again -- a value can be longer than any chunk)
+    __device__ __forceinline__ bool unary_some(uint32_t &v) {
         for (;;) {
-            if (!need(1)) return v;
-            const uint64_t w = acc & ((1ull << have) - 1ull);
-            if (w == 0) { v += have; have = 0; continue; }
-            const uint32_t top = 63u - (uint32_t)__builtin_clzll(w);        // position of the first one among the unread bits
-            v += have - 1u - top;
-            have = top;
-            return v;
+            if (!have_chunk || bitpos >= nbits) return false;
+            fetch();
+            const uint32_t left = nbits - bitpos, m = wav < left ? wav : left;      // real bits in the window
+            const uint32_t lz = w ? (uint32_t)__builtin_clzll(w) : 64u;
+            if (lz >= m) { v += m; w = m < 64 ? w << m : 0; wav -= m; bitpos += m; continue; }
+            v += lz;
+            w <<= lz + 1; wav -= lz + 1; bitpos += lz + 1;
+            return true;
         }
+    }
+    // the reference reader's state: bytes taken so far, bits left in the last one, that byte, whether it was 0xFF
+    __device__ __forceinline__ void state(uint64_t &rpos, uint32_t &cnt, uint32_t &buf, bool &sff) {
+        if (!have_chunk) {                                          // nothing read since seat()
+            rpos = pend_first ? pend_pos + 1 : pend_pos; cnt = pend_first; sff = pend_sff;
+            buf = sff ? 0xFFu : 0u;
+            if (pend_first && pend_pos < end) buf = byte_at(pend_pos);
+            return;
+        }
+        uint32_t j = byte_index();                                  // byte j is the one in progress (cnt > 0) or the next one (cnt == 0)
+        const bool partial = j < nbytes && (uint32_t)sbit[j] < bitpos;
+        const uint32_t taken = partial ? j + 1 : j;
+        rpos = p0 + taken;
+        cnt = partial ? (uint32_t)sbit[j + 1] - bitpos : 0u;
+        if (taken > 0 || p0 > 0) {
+            const uint64_t a = (uint64_t)(uintptr_t)data + rpos - 1;
+            raw_ensure(a, a + 1);
+            buf = raw_at(a);
+        } else buf = 0;
+        sff = buf == 0xFFu && rpos > 0;
     }
 };
 
@@ -93,19 +200,34 @@ struct T2Chain {
     j2k_t2_dec_state st;
     int32_t status, done;               // out: J2K_OK or the first failing packet's status; packets decoded before it
     int32_t skip, pad_;                 // != 0: the chain was found malformed before it started (status set): nothing to do
+#ifdef J2K_T2D_STATS
+    uint64_t t_total, t_reload, t_build; uint32_t n_reload, n_build, n_blocks, n_packets;   // dev: wall_clock64 ticks (100 MHz) per part
+#endif
 };
 
 __global__ __launch_bounds__(64) void t2_decode_kernel(T2Chain *__restrict__ chains, const j2k_t2_dev_packet *__restrict__ packets, long npackets_all,
                                                        j2k_t2_dev_cb *__restrict__ cbs, uint64_t ncbs, const uint8_t *__restrict__ data, int sop, int eph, int clean,
                                                        uint64_t *__restrict__ body_base, int *__restrict__ frame_status) {
-    __shared__ uint64_t win[T2D_WIN / 8];
+    __shared__ uint64_t raw[T2D_RAW / 8];
+    __shared__ uint32_t bits[T2D_CHUNK * 8 / 32 + 4];
+    __shared__ uint16_t sbit[T2D_CHUNK + 2];
     const int lane = threadIdx.x;
     T2Chain &Cn = chains[blockIdx.x];
+#ifdef J2K_T2D_STATS
+    const uint64_t t_start_ = wall_clock64(); uint32_t nblk_ = 0;
+#endif
     if (Cn.skip) { if (lane == 0 && frame_status && Cn.status) atomicMin(frame_status, Cn.status); return; }
     const uint64_t base = Cn.start;
     T2Rd r;
-    r.data = data + base; r.end = Cn.end - base; r.win = win; r.wbase = ~0ull; r.cwa = ~0ull; r.cw = 0; r.lane = lane;
-    r.rpos = Cn.st.rpos; r.have = Cn.st.cnt; r.lastb = Cn.st.buf; r.acc = Cn.st.buf; r.saw_ff = Cn.st.saw_ff != 0; r.eof = false;
+    r.data = data + base; r.end = Cn.end - base; r.raw = raw; r.rwbase = ~0ull; r.bits = bits; r.sbit = sbit; r.lane = lane; r.eof = false;
+    r.p0 = 0; r.nbytes = r.nbits = r.bitpos = r.wav = r.wnext = 0; r.w = 0; r.stale = false;
+    // the decoder object's header reader as it was left (a zeroed state: NewPacketDecoder): cnt bits of byte rpos - 1 still unread
+    {
+        const uint32_t cnt = Cn.st.cnt > 8 ? 8u : Cn.st.cnt;
+        if (cnt && Cn.st.rpos >= 1) r.seat(Cn.st.rpos - 1, cnt, Cn.st.saw_ff != 0);
+        else r.seat(Cn.st.rpos, 0, Cn.st.saw_ff != 0);
+    }
+    bool carried_ff = Cn.st.saw_ff != 0;                            // closed-loop mode: the last header byte of the previous packet was 0xFF
     uint64_t pos = Cn.st.pos;
     const uint64_t end = r.end;
     int status = J2K_OK;
@@ -117,29 +239,91 @@ __global__ __launch_bounds__(64) void t2_decode_kernel(T2Chain *__restrict__ cha
         if (P.ncb < 0 || P.cb0 < 0 || (uint64_t)P.cb0 + (uint64_t)P.ncb > ncbs) { status = J2K_ERR_INVALID_ARG; break; }
         const int layer = P.layer;
         const uint32_t lenbits = (P.flags & J2K_T2_WIDE_LEN) ? 5u : 3u;
-        if (P.flags & J2K_T2_FRESH) { r.saw_ff = false; r.have = 0; }                           // NewPacketDecoder
+        if (P.flags & J2K_T2_FRESH) { carried_ff = false; if (!(P.flags & J2K_T2_SEATED)) r.seat(0, 0, false); }   // NewPacketDecoder
         if (sop && pos + 6 <= end && r.byte_at(pos) == 0xFFu && r.byte_at(pos + 1) == 0x91u) pos += 6;     // t2.go:470-474
-        if (P.flags & J2K_T2_SEATED) { r.rpos = pos; r.have = 0; }                              // closed-loop mode: the header starts at Position()
+        if (P.flags & J2K_T2_SEATED) r.seat(pos, 0, carried_ff);                                // closed-loop mode: the header starts at Position()
         uint64_t body = 0;                                                                       // bytes of the bodies this packet carries
-        const uint32_t present = r.get(1);
-        if (r.eof) { status = J2K_ERR_INVALID_ARG; break; }
         j2k_t2_dev_cb *pc = cbs + P.cb0;
         // The body loop (t2.go:489-499) takes bytes for every block with IncludedInLayers == layer and data -- also one this
         // header did not touch but whose fields say so from before (a table the caller filled, or an earlier packet of the same
         // layer).  `clean`: the caller zeroed the table and decodes layer 0 only, so there is no such block and nothing is read.
         const bool old_matters = !clean || layer != 0;
-        if (present) {
-            for (int64_t i = 0; i < P.ncb; i++) {                                                // t2.go:516-571
-                j2k_t2_dev_cb old{};
-                if (old_matters) old = pc[i];
+        // decodePacketHeader (t2.go:506-571) as ONE loop over its reading steps -- presence bit, then per code-block inclusion,
+        // zero bit planes, pass count + length -- so that the chunk builder above has a single call site
+        enum { S_PRESENT, S_INCL, S_IMSB, S_REST, S_DONE };
+        int step = S_PRESENT;
+        int64_t i = 0;
+        uint32_t present = 0, uv = 0;
+        int incl_layers = 0;
+        j2k_t2_dev_cb old{};
+        const bool fast_ok = layer == 0 && !old_matters && P.incl_tree_w != 0 && P.imsb_tree_w != 0;
+        while (step != S_DONE) {
+            r.ensure();
+            if (step == S_INCL && fast_ok && r.have_chunk && r.nbits - r.bitpos >= 128) {
+                // The whole code-block straight from a 128-bit register window (four LDS words, one round trip): inclusion value, zero bit
+                // planes, pass count, length.  Anything that might not fit (long unary values) is left to the stepwise reader below --
+                // nothing is committed before the block is complete.
+                const uint32_t idx = r.bitpos >> 5, sh = r.bitpos & 31u;
+                uint64_t hi = (uint64_t)r.bits[idx] << 32 | r.bits[idx + 1], lo = (uint64_t)r.bits[idx + 2] << 32 | r.bits[idx + 3];
+                if (sh) { hi = hi << sh | lo >> (64u - sh); lo <<= sh; }                        // >= 97 bits from bit 63 of hi down
+                uint32_t used = 0;
+                auto take = [&](uint32_t n) -> uint32_t {                                        // 1 <= n <= 32
+                    const uint32_t v = (uint32_t)(hi >> (64u - n));
+                    hi = hi << n | lo >> (64u - n); lo <<= n; used += n;
+                    return v;
+                };
+                const uint32_t z1 = hi ? (uint32_t)__builtin_clzll(hi) : 64u;
+                if (z1 <= 30) {
+                    (void)take(z1 + 1);
+                    if (z1 != 0) {                                                               // not in this layer: only IncludedInLayers is written
+                        if (lane == 0) pc[i].included_in_layers = (int)z1;
+                        r.bitpos += used; r.stale = true;
+                        i++;
+                        if (i == P.ncb) step = S_DONE;
+                        continue;
+                    }
+                    const uint32_t z2 = hi ? (uint32_t)__builtin_clzll(hi) : 64u;
+                    if (z1 + z2 <= 40) {                                                         // (zero bit planes: 31 - numBPS in the frame calls)
+                        (void)take(z2 + 1);
+                        int np;                                                                  // t2.go:592-631
+                        if (take(1) == 0) np = 1;
+                        else if (take(1) == 0) np = 2;
+                        else {
+                            uint32_t v = take(2);
+                            if (v < 3) np = (int)v + 3;
+                            else {
+                                v = take(5);
+                                if (v < 31) np = (int)v + 6;
+                                else np = (int)take(7) + 37;
+                            }
+                        }
+                        const uint32_t nb = take(lenbits);
+                        const uint32_t length = nb ? take(nb) : 0u;                              // (nb <= 31; used <= 42 + 16 + 5 + 31 = 94 of the >= 97 bits)
+                        if (lane == 0) {
+                            *reinterpret_cast<int4 *>(&pc[i]) = int4{0, (int)z2, np, (int)length};
+                            pc[i].data_off = body;
+                        }
+                        body += length;
+                        r.bitpos += used; r.stale = true;
+                        i++;
+                        if (i == P.ncb) step = S_DONE;
+                        continue;
+                    }
+                }
+            }
+            if (step == S_PRESENT) {
+                present = r.get(1);
+                if (r.eof) { status = J2K_ERR_INVALID_ARG; break; }
+                step = (present && P.ncb > 0) ? S_INCL : S_DONE;
+                if (step == S_INCL && old_matters) old = pc[0];
+                uv = 0;
+            } else if (step == S_INCL) {                                                         // t2.go:516-540
                 bool inc;
-                int incl_layers;
                 if (layer == 0) {
                     if (P.incl_tree_w == 0) { status = J2K_ERR_GO_PANIC; break; }
-                    const uint32_t v = r.unary();
-                    if (r.eof) { status = J2K_ERR_INVALID_ARG; break; }
-                    inc = v == 0;
-                    incl_layers = (int)v;
+                    if (!r.unary_some(uv)) { if (!r.more_data()) { status = J2K_ERR_INVALID_ARG; break; } continue; }
+                    inc = uv == 0;
+                    incl_layers = (int)uv;
                     if (lane == 0) pc[i].included_in_layers = incl_layers;
                 } else {
                     inc = r.get(1) == 1;
@@ -147,17 +331,21 @@ __global__ __launch_bounds__(64) void t2_decode_kernel(T2Chain *__restrict__ cha
                     incl_layers = inc ? layer : old.included_in_layers;
                     if (inc && lane == 0) pc[i].included_in_layers = layer;
                 }
+                uv = 0;
                 if (!inc) {
                     if (incl_layers == layer && old.data_len > 0) { if (lane == 0) pc[i].data_off = body; body += old.data_len; }
-                    continue;
-                }
-                if (incl_layers == layer) {
-                    if (P.imsb_tree_w == 0) { status = J2K_ERR_GO_PANIC; break; }
-                    const uint32_t v = r.unary();
-                    if (r.eof) { status = J2K_ERR_INVALID_ARG; break; }
-                    if (lane == 0) pc[i].zero_bit_planes = (int)v;
-                }
-                int np;                                                                          // t2.go:592-631
+                    i++;
+                    if (i == P.ncb) step = S_DONE;
+                    else if (old_matters) old = pc[i];
+                } else step = incl_layers == layer ? S_IMSB : S_REST;
+            } else if (step == S_IMSB) {                                                         // t2.go:544-551
+                if (P.imsb_tree_w == 0) { status = J2K_ERR_GO_PANIC; break; }
+                if (!r.unary_some(uv)) { if (!r.more_data()) { status = J2K_ERR_INVALID_ARG; break; } continue; }
+                if (lane == 0) pc[i].zero_bit_planes = (int)uv;
+                uv = 0;
+                step = S_REST;
+            } else {                                                                             // t2.go:553-568, 592-648: at most 16 + 5 + 31 bits
+                int np;
                 if (r.get(1) == 0) np = 1;
                 else if (r.get(1) == 0) np = 2;
                 else {
@@ -170,30 +358,44 @@ __global__ __launch_bounds__(64) void t2_decode_kernel(T2Chain *__restrict__ cha
                     }
                 }
                 if (r.eof) { status = J2K_ERR_INVALID_ARG; break; }
-                const uint32_t nb = r.get(lenbits);                                              // t2.go:633-648
+                const uint32_t nb = r.get(lenbits);
                 const uint32_t length = r.get(nb);
                 if (r.eof) { status = J2K_ERR_INVALID_ARG; break; }
                 if (lane == 0) { pc[i].num_passes = np; pc[i].data_len = length; pc[i].data_off = body; }   // (offset within the packet's bodies; t2_bodies_kernel adds where they start)
                 body += length;
-            }
-            if (status != J2K_OK) break;
-        } else if (old_matters) {
-            for (int64_t i = 0; i < P.ncb; i++) {
-                const j2k_t2_dev_cb old = pc[i];
-                if (old.included_in_layers == layer && old.data_len > 0) { if (lane == 0) pc[i].data_off = body; body += old.data_len; }
+                i++;
+                if (i == P.ncb) step = S_DONE;
+                else { step = S_INCL; if (old_matters) old = pc[i]; }
             }
         }
-        if (P.flags & J2K_T2_SEATED) pos = r.rpos;                                               // ... and Position() moves past the header
+        if (status != J2K_OK) break;
+        if (!present && old_matters) {
+            for (int64_t q = 0; q < P.ncb; q++) {
+                const j2k_t2_dev_cb o = pc[q];
+                if (o.included_in_layers == layer && o.data_len > 0) { if (lane == 0) pc[q].data_off = body; body += o.data_len; }
+            }
+        }
+        if (P.flags & J2K_T2_SEATED) {                                                           // ... and Position() moves past the header
+            uint32_t cnt_, buf_;
+            r.state(pos, cnt_, buf_, carried_ff);
+        }
         if (eph && pos + 2 <= end && r.byte_at(pos) == 0xFFu && r.byte_at(pos + 1) == 0x92u) pos += 2;     // t2.go:481-486
         if (pos + body > end) { status = J2K_ERR_INVALID_ARG; break; }                           // "unexpected end of packet data"
         if (lane == 0) body_base[pk] = base + pos;
         pos += body;
         done = k + 1;
     }
+    uint64_t st_rpos; uint32_t st_cnt, st_buf; bool st_ff;
+    r.state(st_rpos, st_cnt, st_buf, st_ff);                       // (by every lane: it may restage the window)
     if (lane == 0) {
         for (int64_t k = done; k < Cn.npackets && Cn.packet0 + k < npackets_all && Cn.packet0 + k >= 0; k++) body_base[Cn.packet0 + k] = ~0ull;
-        Cn.st.pos = pos; Cn.st.rpos = r.rpos; Cn.st.buf = (uint8_t)r.lastb; Cn.st.cnt = (uint8_t)r.have; Cn.st.saw_ff = r.saw_ff ? 1 : 0;
+        Cn.st.pos = pos; Cn.st.rpos = st_rpos; Cn.st.buf = (uint8_t)st_buf; Cn.st.cnt = (uint8_t)st_cnt; Cn.st.saw_ff = st_ff ? 1 : 0;
         Cn.status = status; Cn.done = (int32_t)done;
+#ifdef J2K_T2D_STATS
+        Cn.t_total = wall_clock64() - t_start_; Cn.t_reload = r.t_reload; Cn.t_build = r.t_build; Cn.n_reload = r.n_reload; Cn.n_build = r.n_build; Cn.n_packets = (uint32_t)done;
+        if (blockIdx.x == 0 || blockIdx.x == 39) printf("chain %d: total %llu ticks, reload %llu (%u), build %llu (%u) incl. reloads, packets %u\n", (int)blockIdx.x, (unsigned long long)Cn.t_total,
+                                                        (unsigned long long)Cn.t_reload, Cn.n_reload, (unsigned long long)Cn.t_build, Cn.n_build, Cn.n_packets);
+#endif
         if (frame_status && status) atomicMin(frame_status, status);
     }
 }

@@ -410,7 +410,8 @@ def test_closed_loop_4k_sampled_tiles_against_the_oracle(env):
     plan.close()
 
 
-@pytest.mark.parametrize("tw,th,W,H,nres,cb", [(1, 64, 3, 64, 4, 16), (2, 33, 5, 40, 3, 8), (3, 5, 7, 9, 6, 4), (64, 1, 130, 2, 5, 32), (5, 7, 5, 7, 1, 64)])
+@pytest.mark.parametrize("tw,th,W,H,nres,cb", [(1, 64, 3, 64, 4, 16), (2, 33, 5, 40, 3, 8), (3, 5, 7, 9, 6, 4), (64, 1, 130, 2, 5, 32), (5, 7, 5, 7, 1, 64),
+                                                 (128, 64, 383, 64, 5, 8)])      # (8 x 8 blocks: packet headers longer than the parser's 256-byte chunk -- fuzz finding, round 5)
 def test_closed_loop_degenerate_tiles_round_trip_and_packets_per_resolution(env, tw, th, W, H, nres, cb):
     """tiles one to three samples wide / one row high: bands without samples have no jobs, consecutive resolutions can hold
     the SAME single band -- a packet is still the jobs of one resolution (j2k_plan_t2_packets used to merge them).
