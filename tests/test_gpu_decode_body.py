@@ -447,6 +447,35 @@ def test_closed_loop_degenerate_tiles_round_trip_and_packets_per_resolution(env,
         plan.close()
 
 
+@pytest.mark.parametrize("W,H,tile,cb,nres", [(512, 384, (256, 256), 64, 5), (512, 512, (0, 0), 256, 6)])
+def test_closed_loop_lossy_default_options_round_trip_of_the_quantised_coefficients(env, W, H, tile, cb, nres):
+    """the lossy path (9-7 + quantisation, Quality 75 -- the reference's DefaultOptions, second case with its default 256 x 256
+    code-blocks) through the closed loop: the MQ coder is lossless on the quantised coefficients, so what the decode body hands
+    the inverse transform is exactly what the forward transform made, and the pixels are the library's own inverse of those"""
+    torch, t2ref, t2, ctx = env
+    from j2kgfx import _lib
+    from j2kgfx.codec import FramePlan
+    pix = _rgba(_frame(W, H, 9, noise=12))
+    plan = FramePlan(W, H, 3, precision=8, lossless=False, quality=75, num_resolutions=nres, cb=(cb, cb), tile=tile, coder=_lib.CODER_MQ, ctx=ctx, closed_loop=True)
+    d_pix = torch.from_numpy(pix).to(plan.device)
+    cs, toffs = plan.encode_frame_pixels(_lib.PIX_RGBA8, d_pix, sop=True, eph=True)
+    back = torch.zeros_like(d_pix)
+    plan.decode_frame_pixels(cs, int(cs.numel()), back, tile_offs=toffs, sop=True, eph=True)
+    plan.frame_status()
+    coeff = plan.forward_pixels(_lib.PIX_RGBA8, d_pix)
+    want = plan.inverse_pixels(coeff, torch.zeros_like(d_pix))
+    # stage by stage as well: parsed blocks -> decoded -> placed == the forward transform's coefficients
+    total = int(toffs[-1].item())
+    o2, l2, n2 = plan.decode_tile_parts(cs, total, tile_offs=None, sop=True, eph=True)
+    placed = plan.place_blocks(plan.decode_blocks(cs, o2, l2, n2))
+    plan.frame_status()
+    assert torch.equal(placed[:int(plan.info.coeff_elems)], coeff[:int(plan.info.coeff_elems)])
+    assert torch.equal(back, want)
+    err = (back.cpu().numpy().astype(np.int32).reshape(H, W, 4)[..., :3] - pix.astype(np.int32).reshape(H, W, 4)[..., :3])
+    assert np.abs(err).max() <= 128            # (the reference's decode path never dequantises, SURVEY: this is not a reconstruction of the source; it is the same pixels either way)
+    plan.close()
+
+
 def test_closed_loop_calls_refuse_a_reference_mode_plan(env):
     torch, t2ref, t2, ctx = env
     from j2kgfx import J2KError, _lib
