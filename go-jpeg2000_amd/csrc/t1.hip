@@ -1723,7 +1723,7 @@ hipError_t launch_t1_encode(hipStream_t s, const BlockJob *jobs, int njobs, cons
             if (lane_order < 0) lane_order = 1;            // (J2K_T1_ENC_ORDER: measured in round 3, ordered lanes kept)
             int K = lanes > 0 ? lanes : (lanes < 0 ? std::min(lane_order ? 64 : 32, (njobs + 255) / 256) : (njobs + 2047) / 2048);
             K = std::min(64, std::max(1, K));
-            uint32_t *perm = lane_order ? nsyms + njobs : nullptr;       // njobs + 64 words behind nsyms (t1_workspace in j2k_abi.cpp)
+            uint32_t *perm = lane_order ? nsyms + njobs : nullptr;       // njobs + 64 words behind nsyms (t1_workspace in j2k_stages.cpp)
             if (perm) hipLaunchKernelGGL(t1_order_kernel, dim3(1), dim3(1024), 0, s, jobs, njobs, (const uint8_t *)nullptr, (const uint32_t *)nsyms, 1, perm,
                                          (uint32_t *)nullptr, njobs);
             hipLaunchKernelGGL(t1_mq_lanes_kernel, dim3(((njobs + K - 1) / K + T1_LANES_WPW - 1) / T1_LANES_WPW), dim3(64 * T1_LANES_WPW), 0, s, jobs, njobs, K, sym, sym_stride, nsyms,

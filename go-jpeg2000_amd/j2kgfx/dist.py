@@ -24,7 +24,7 @@ def shard_range(n_units, rank, world):
 
 
 def num_tiles(width, height, tile_w, tile_h, frame_rows=0):
-    """Tiles of a plan with these j2k_params, by build_plan's arithmetic (csrc/j2k_abi.cpp): with frame_rows > 0 the plan is a
+    """Tiles of a plan with these j2k_params, by build_plan's arithmetic (csrc/j2k_planbuild.cpp): with frame_rows > 0 the plan is a
     BATCH of height / frame_rows frames and the tile grid starts again at every frame (a partial last tile row per frame;
     tile_h = 0: one tile row per frame, not per batch)."""
     fh = frame_rows if frame_rows > 0 else height

@@ -59,7 +59,7 @@ const char *j2k_ctx_last_error(j2k_ctx *ctx);   /* text of the last non-OK statu
 const char *j2k_status_string(int status);
 const char *j2k_version(void);
 /* Tuning options: which of its measured kernel forms a context takes (the defaults are what the benchmarks measured best; results
- * are identical under every setting -- tests/test_gpu_knobs.py).  Set BEFORE plans are created on the context.  Names (csrc/j2k_abi.cpp,
+ * are identical under every setting -- tests/test_gpu_knobs.py).  Set BEFORE plans are created on the context.  Names (csrc/j2k_ctx.cpp,
  * ctx_options): "t1_dec_split" (MQ decode plane by plane from this many blocks on; -1 automatic), "t1_lanes", "t1_dec_lanes",
  * "t1_sym_mb" (cap of the MQ encoder's symbol workspace, MiB), "pix_fuse", "l0_wg", "l0_wg_inv", "l0_fuse", "plane_wg", "deep", "mega",
  * ...  An unknown name or a value out of range is J2K_ERR_INVALID_ARG.  The ENVIRONMENT sets none of this unless J2K_TUNING=1 is in
