@@ -173,7 +173,7 @@ extern "C" int j2k_plan_decode_tile_parts(j2k_plan *P, const uint8_t *d_cs, size
     HIPCHK(ctx, j2k::launch_t2_tile_chains(ctx->stream, d_cs, (uint64_t)len, d_tile_offs, P->tile_count, P->tile_first, P->d_tile_packet0, P->d_t2_chains));
     HIPCHK(ctx, j2k::launch_t2_decode_packets(ctx->stream, P->d_t2_chains, P->tile_count, P->d_t2_packets, P->t2_npackets, P->d_t2_cbs, (uint64_t)n, d_cs, sop, eph, 1,
                                               P->d_t2_body_base, P->d_frame_status));
-    HIPCHK(ctx, j2k::launch_t2_blocks(ctx->stream, n, P->d_t2_cbs, P->spec.coder == J2K_CODER_HT ? 1 : 0, 31, (uint64_t)len, d_offs, d_lens, d_numbps));
+    HIPCHK(ctx, j2k::launch_t2_blocks(ctx->stream, n, P->d_t2_cbs, P->spec.coder == J2K_CODER_HT ? 1 : 0, 31, (uint64_t)len, d_offs, d_lens, d_numbps, P->d_frame_status));
     return J2K_OK;
 }
 

@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void t2_bodies_kernel(const j2k_t2_dev_packet 
 // SOD (FF93), then the packets up to Psot bytes from the SOT marker (Psot = 0: to the end) -- ReadTilePartHeader,
 // parser.go:894-983.  With tile_offs the tile-parts are looked at side by side (a thread each); without, thread 0 walks them.
 __device__ int t2_tile_chain(const uint8_t *cs, uint64_t len, uint64_t at, int want_index, T2Chain &Cn, uint64_t &next) {
-    if (at + 12 > len || cs[at] != 0xFF || cs[at + 1] != 0x90) return J2K_ERR_INVALID_ARG;
+    if (at >= len || len - at < 14 || cs[at] != 0xFF || cs[at + 1] != 0x90) return J2K_ERR_INVALID_ARG;    // (`at` is the caller's: no sum of it may wrap)
     const uint32_t lsot = (uint32_t)cs[at + 2] << 8 | cs[at + 3], isot = (uint32_t)cs[at + 4] << 8 | cs[at + 5];
     const uint32_t psot = (uint32_t)cs[at + 6] << 24 | (uint32_t)cs[at + 7] << 16 | (uint32_t)cs[at + 8] << 8 | cs[at + 9];
     if (lsot != 10 || isot != ((uint32_t)want_index & 0xFFFFu)) return J2K_ERR_INVALID_ARG;
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(64) void t2_tile_chains_kernel(const uint8_t *__res
 // coder's pass count is 3 * numBPS - 2 (t1_fast5.go:66-70); an HT block carries one pass and the decoder does not use the count,
 // so it is mb - ZeroBitPlanes there (what j2k_plan_t2_fill_cbs wrote).
 __global__ __launch_bounds__(256) void t2_blocks_kernel(long n, const j2k_t2_dev_cb *__restrict__ cbs, int ht, int mb, uint64_t total, uint64_t *__restrict__ offs,
-                                                        uint32_t *__restrict__ lens, uint8_t *__restrict__ numbps) {
+                                                        uint32_t *__restrict__ lens, uint8_t *__restrict__ numbps, int *__restrict__ status) {
     const long j = (long)blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
     const j2k_t2_dev_cb cb = cbs[j];
@@ -474,9 +474,13 @@ __global__ __launch_bounds__(256) void t2_blocks_kernel(long n, const j2k_t2_dev
     const bool has = cb.included_in_layers == 0 && cb.data_len > 0 && cb.num_passes > 0 && cb.data_off <= total && cb.data_len <= total - cb.data_off;
     int nb = 0;
     if (has) nb = ht ? (mb > cb.zero_bit_planes ? mb - cb.zero_bit_planes : 0) : (cb.num_passes + 2) / 3;
-    offs[j] = has ? cb.data_off : 0;
-    lens[j] = has ? cb.data_len : 0u;
-    numbps[j] = (uint8_t)(nb > 255 ? 255 : nb);
+    // more bit planes than an int32 coefficient has: no encoder of this library writes that (numBPS <= 31) -- a foreign stream; the block is
+    // dropped and the frame's status says why
+    const bool bad = nb > 31;
+    if (bad && status) atomicMin(status, J2K_ERR_INVALID_ARG);
+    offs[j] = has && !bad ? cb.data_off : 0;
+    lens[j] = has && !bad ? cb.data_len : 0u;
+    numbps[j] = (uint8_t)(bad ? 0 : nb);
 }
 
 // decoded block j (dense w x h at D.out_off) -> its window of the coefficient planes (S.src_off, row stride S.stride); one
@@ -533,9 +537,9 @@ void t2_read_chain(const void *src, j2k_t2_dec_state &st, int &status, long &don
     __builtin_memcpy(&Cn, src, sizeof Cn);
     st = Cn.st; status = Cn.status; done = Cn.done;
 }
-hipError_t launch_t2_blocks(hipStream_t s, long n, const j2k_t2_dev_cb *cbs, int ht, int mb, uint64_t total, uint64_t *offs, uint32_t *lens, uint8_t *numbps) {
+hipError_t launch_t2_blocks(hipStream_t s, long n, const j2k_t2_dev_cb *cbs, int ht, int mb, uint64_t total, uint64_t *offs, uint32_t *lens, uint8_t *numbps, int *status) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(t2_blocks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, cbs, ht, mb, total, offs, lens, numbps);
+    hipLaunchKernelGGL(t2_blocks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, cbs, ht, mb, total, offs, lens, numbps, status);
     return hipGetLastError();
 }
 hipError_t launch_place_blocks(hipStream_t s, const BlockJob *src_jobs, const BlockJob *dec_jobs, int njobs, int max_h, const int32_t *decoded, int32_t *coeff) {

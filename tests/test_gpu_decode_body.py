@@ -476,6 +476,73 @@ def test_closed_loop_lossy_default_options_round_trip_of_the_quantised_coefficie
     plan.close()
 
 
+@pytest.mark.parametrize("coder", [0, 1])
+def test_closed_loop_corrupted_tile_parts_are_reported_not_followed(env, coder):
+    """foreign input: bytes of a valid frame overwritten at random (SOT fields, packet headers, bodies), truncations, garbage
+    tile-part positions -- the decode either succeeds (the damage hit a body) or reports J2K_ERR_INVALID_ARG; nothing is read
+    outside the buffer (the block tables are bounds-checked before the block decoder sees them) and nothing hangs"""
+    torch, t2ref, t2, ctx = env
+    from j2kgfx import J2KError, _lib
+    from j2kgfx.codec import FramePlan
+    W, H = 200, 150
+    rng = np.random.default_rng(31 + coder)
+    frame = _frame(W, H, 4, noise=25)
+    plan = FramePlan(W, H, 3, precision=8, lossless=True, num_resolutions=4, cb=(16, 16), tile=(64, 64), coder=coder, ctx=ctx, closed_loop=True)
+    coeff = plan.forward(torch.from_numpy(frame.astype(np.int32)).to(plan.device))
+    stream, offs, lens, numbps = plan.encode_stream(coeff)
+    cs, toffs = plan.encode_tile_parts(stream, offs, lens, numbps, sop=True, eph=True)
+    plan.frame_status()
+    total = int(toffs[-1].item())
+    good = cs[:total].cpu().numpy().copy()
+    h_toffs = toffs.cpu().numpy().copy()
+    guard = 4096
+    outcomes = {"ok": 0, "invalid": 0}
+    for it in range(120):
+        bad = good.copy()
+        kind = it % 6
+        n = total
+        t_offs = h_toffs.astype(np.uint64).copy()
+        if kind == 0:                                            # a few random bytes anywhere
+            for _ in range(int(rng.integers(1, 6))):
+                bad[int(rng.integers(0, total))] = int(rng.integers(0, 256))
+        elif kind == 1:                                          # the first 64 bytes of a tile-part: SOT, SOD, the first packet headers
+            t = int(rng.integers(0, len(h_toffs) - 1))
+            for _ in range(int(rng.integers(1, 8))):
+                bad[int(h_toffs[t]) + int(rng.integers(0, 64))] = int(rng.integers(0, 256))
+        elif kind == 2:                                          # truncation
+            n = int(rng.integers(0, total))
+        elif kind == 3:                                          # runs of zeros / 0xFF over headers (long unary values, stuffing everywhere)
+            a = int(rng.integers(0, total - 300))
+            bad[a:a + int(rng.integers(8, 300))] = 0 if it % 2 else 0xFF
+        elif kind == 4:                                          # tile-part positions from a hostile caller
+            t_offs[int(rng.integers(0, len(t_offs)))] = np.uint64([0, total, total + 12345, 2 ** 62, 2 ** 64 - 1 - int(rng.integers(0, 16))][int(rng.integers(0, 5))])
+        else:                                                    # everything random
+            bad = rng.integers(0, 256, total).astype(np.uint8)
+        buf = torch.zeros(total + 2 * guard, dtype=torch.uint8, device=plan.device)
+        buf[guard:guard + total] = torch.from_numpy(bad).to(plan.device)
+        d_t = torch.from_numpy(t_offs.view(np.int64).copy()).to(plan.device)
+        o2, l2, n2 = plan.decode_tile_parts(buf[guard:], n, tile_offs=d_t if (kind == 4 or it % 2) else None, sop=True, eph=True)
+        placed = plan.place_blocks(plan.decode_blocks(buf[guard:], o2, l2, n2))
+        try:
+            plan.frame_status()
+            outcomes["ok"] += 1
+        except J2KError as e:
+            assert e.status == _lib.ERR_INVALID_ARG
+            outcomes["invalid"] += 1
+        # whatever came out points inside the buffer the caller gave
+        o, l = o2.cpu().numpy()[:int(plan.info.blocks)].astype(np.uint64), l2.cpu().numpy()[:int(plan.info.blocks)].astype(np.uint64)
+        assert ((o + l) <= n).all()
+        assert int(n2.cpu().numpy()[:int(plan.info.blocks)].max()) <= 31
+    assert outcomes["invalid"] > 20 and outcomes["ok"] > 0, outcomes
+    # and the intact stream still decodes
+    o2, l2, n2 = plan.decode_tile_parts(cs, total, sop=True, eph=True)
+    back = plan.inverse(plan.place_blocks(plan.decode_blocks(cs, o2, l2, n2)))
+    plan.frame_status()
+    if coder == 0:
+        assert np.array_equal(back.cpu().numpy(), frame.astype(np.int32))
+    plan.close()
+
+
 def test_closed_loop_calls_refuse_a_reference_mode_plan(env):
     torch, t2ref, t2, ctx = env
     from j2kgfx import J2KError, _lib
