@@ -130,7 +130,7 @@ def other_configs_summary(budget_s=200.0):
             if name in ("c4", "closed_loop"):
                 out[name] = {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
                              "n_gpus": d["n_gpus"], "scaling": d["scaling"], "wall_s": round(time.perf_counter() - t0, 1)}
-                for k in ("value_with_d2h", "codestream_bytes", "tiles", "parallelism", "frames_in_flight", "codestream_bytes_per_frame", "single_frame_ms", "round_trip"):
+                for k in ("value_with_d2h", "codestream_bytes", "tiles", "parallelism", "frames_in_flight", "contexts", "frames_per_context", "codestream_bytes_per_frame", "single_frame_ms", "round_trip"):
                     if k in d["config"]:
                         out[name][k] = d["config"][k]
                 continue
