@@ -260,56 +260,58 @@ __global__ __launch_bounds__(64) void t2_decode_kernel(T2Chain *__restrict__ cha
         while (step != S_DONE) {
             r.ensure();
             if (step == S_INCL && fast_ok && r.have_chunk && r.nbits - r.bitpos >= 128) {
-                // The whole code-block straight from a 128-bit register window (four LDS words, one round trip): inclusion value, zero bit
-                // planes, pass count, length.  Anything that might not fit (long unary values) is left to the stepwise reader below --
-                // nothing is committed before the block is complete.
-                const uint32_t idx = r.bitpos >> 5, sh = r.bitpos & 31u;
-                uint64_t hi = (uint64_t)r.bits[idx] << 32 | r.bits[idx + 1], lo = (uint64_t)r.bits[idx + 2] << 32 | r.bits[idx + 3];
-                if (sh) { hi = hi << sh | lo >> (64u - sh); lo <<= sh; }                        // >= 97 bits from bit 63 of hi down
-                uint32_t used = 0;
-                auto take = [&](uint32_t n) -> uint32_t {                                        // 1 <= n <= 32
-                    const uint32_t v = (uint32_t)(hi >> (64u - n));
-                    hi = hi << n | lo >> (64u - n); lo <<= n; used += n;
-                    return v;
-                };
-                const uint32_t z1 = hi ? (uint32_t)__builtin_clzll(hi) : 64u;
-                if (z1 <= 30) {
+                // Whole code-blocks straight from a 128-bit register window (four LDS words, one round trip each): inclusion value, zero
+                // bit planes, pass count, length -- a tight loop over the blocks for as long as the chunk holds 128 bits more.  Anything
+                // that might not fit (long unary values) is left to the stepwise reader below: nothing is committed before a block is complete.
+                uint32_t bp = r.bitpos;
+                const uint32_t lim = r.nbits - 128u;
+                const uint32_t *bits_ = r.bits;
+                bool bail = false;
+                while (bp <= lim && i < P.ncb) {
+                    const uint32_t idx = bp >> 5, sh = bp & 31u;
+                    uint64_t hi = (uint64_t)bits_[idx] << 32 | bits_[idx + 1], lo = (uint64_t)bits_[idx + 2] << 32 | bits_[idx + 3];
+                    hi = (hi << sh) | ((lo >> 1) >> (63u - sh)); lo <<= sh;                      // >= 97 bits from bit 63 of hi down
+                    uint32_t used = 0;
+                    auto take = [&](uint32_t n) -> uint32_t {                                    // 1 <= n <= 32
+                        const uint32_t v = (uint32_t)(hi >> (64u - n));
+                        hi = hi << n | lo >> (64u - n); lo <<= n; used += n;
+                        return v;
+                    };
+                    const uint32_t z1 = hi ? (uint32_t)__builtin_clzll(hi) : 64u;
+                    if (z1 > 30) { bail = true; break; }
                     (void)take(z1 + 1);
                     if (z1 != 0) {                                                               // not in this layer: only IncludedInLayers is written
                         if (lane == 0) pc[i].included_in_layers = (int)z1;
-                        r.bitpos += used; r.stale = true;
-                        i++;
-                        if (i == P.ncb) step = S_DONE;
+                        bp += used; i++;
                         continue;
                     }
                     const uint32_t z2 = hi ? (uint32_t)__builtin_clzll(hi) : 64u;
-                    if (z1 + z2 <= 40) {                                                         // (zero bit planes: 31 - numBPS in the frame calls)
-                        (void)take(z2 + 1);
-                        int np;                                                                  // t2.go:592-631
-                        if (take(1) == 0) np = 1;
-                        else if (take(1) == 0) np = 2;
+                    if (z2 > 40) { bail = true; break; }                                         // (zero bit planes: 31 - numBPS in the frame calls)
+                    (void)take(z2 + 1);
+                    int np;                                                                      // t2.go:592-631
+                    if (take(1) == 0) np = 1;
+                    else if (take(1) == 0) np = 2;
+                    else {
+                        uint32_t v = take(2);
+                        if (v < 3) np = (int)v + 3;
                         else {
-                            uint32_t v = take(2);
-                            if (v < 3) np = (int)v + 3;
-                            else {
-                                v = take(5);
-                                if (v < 31) np = (int)v + 6;
-                                else np = (int)take(7) + 37;
-                            }
+                            v = take(5);
+                            if (v < 31) np = (int)v + 6;
+                            else np = (int)take(7) + 37;
                         }
-                        const uint32_t nb = take(lenbits);
-                        const uint32_t length = nb ? take(nb) : 0u;                              // (nb <= 31; used <= 42 + 16 + 5 + 31 = 94 of the >= 97 bits)
-                        if (lane == 0) {
-                            *reinterpret_cast<int4 *>(&pc[i]) = int4{0, (int)z2, np, (int)length};
-                            pc[i].data_off = body;
-                        }
-                        body += length;
-                        r.bitpos += used; r.stale = true;
-                        i++;
-                        if (i == P.ncb) step = S_DONE;
-                        continue;
                     }
+                    const uint32_t nb = take(lenbits);
+                    const uint32_t length = nb ? take(nb) : 0u;                                  // (nb <= 31; used <= 42 + 16 + 5 + 31 = 94 of the >= 97 bits)
+                    if (lane == 0) {
+                        *reinterpret_cast<int4 *>(&pc[i]) = int4{0, (int)z2, np, (int)length};
+                        pc[i].data_off = body;
+                    }
+                    body += length;
+                    bp += used; i++;
                 }
+                if (bp != r.bitpos) { r.bitpos = bp; r.stale = true; }
+                if (i == P.ncb) { step = S_DONE; continue; }
+                if (!bail) continue;                                                             // the chunk is nearly used up: ensure() makes the next
             }
             if (step == S_PRESENT) {
                 present = r.get(1);
