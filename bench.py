@@ -229,6 +229,10 @@ def run(state):
         # two copy streams + the lanes' library streams, each on a hardware queue of its own (a copy stream that shares a queue with the
         # other direction's, or with a lane's kernels, takes turns with it: 28.6 instead of 48.6 GB/s each way on these boxes)
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+        # ROCr's "recommended engine" choice per copy now and then puts the H2D and the D2H copy on ONE SDMA engine, and the two then share
+        # its 57 GB/s (28.6 each way) instead of running on an engine each (48.6 each way): with it off every segment of the run is in the
+        # fast mode (5.0-5.6 -> 6.0-6.15 Gpixel/s over a second).  Read when the HSA runtime initialises: set before torch is imported.
+        os.environ.setdefault("HSA_ENABLE_SDMA_RECOMMENDED_ENG", "0")
         if "--steps" not in " ".join(sys.argv):
             args.steps, args.warmup = 50, 3
         return bench_host.run_host_boundary(args)

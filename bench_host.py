@@ -68,7 +68,7 @@ def run_host_boundary(args):
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
     torch.cuda.set_device(0)
-    NL = args.inflight if args.inflight > 0 and "--inflight" in " ".join(sys.argv) else 3
+    NL = args.inflight if args.inflight > 0 and "--inflight" in " ".join(sys.argv) else 2      # (a lane holds two frames' device buffers: one to four lanes measure the same, 0.80-0.86)
     # the two copy streams are HIGH-PRIORITY streams: the runtime keeps a separate set of hardware queues per priority, so they never
     # share a queue with a lane's kernels (J2K_BENCH_HOST_PRIO=0: plain streams, dealt onto the same queues as everything else)
     prio = -1 if os.environ.get("J2K_BENCH_HOST_PRIO", "1") != "0" else 0
@@ -291,7 +291,7 @@ def run_host_boundary(args):
                           "H2D, forward transform + HT block coding + compaction + tile-part assembly on the device, the tile-parts D2H at their exact "
                           "length (+ per-block lengths and bit-plane counts); decode = the dense block stream and its tables H2D, HT block decode + inverse "
                           "transform, image.RGBA.Pix D2H; copies and kernels of frames_in_flight frames overlap (three streams per frame)",
-                          "frames_in_flight": NL, "frame_io": "pinned host", "copy_streams": "one per direction" if shared else "a pair per frame in flight", "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "h2d_bytes_per_frame": h2d, "d2h_bytes_per_frame": d2h,
+                          "frames_in_flight": NL, "frame_io": "pinned host", "hsa_enable_sdma_recommended_eng": os.environ.get("HSA_ENABLE_SDMA_RECOMMENDED_ENG", "(runtime default)"), "copy_streams": "one per direction" if shared else "a pair per frame in flight", "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "h2d_bytes_per_frame": h2d, "d2h_bytes_per_frame": d2h,
                           "tile_part_bytes": ln0["cs_bytes"]},
                "host_boundary": {"value": round(frames * W * H / dt / 1e6, 1), "unit": "Mpixels/s", "h2d_gbs": round(h2d_gbs, 2), "d2h_gbs": round(d2h_gbs, 2),
                                  "pinned_copy_peak_gbs": peak, "frac_of_pinned_copy_peak": round(max(h2d_gbs, d2h_gbs) / max(peak["both_each"], 1e-9), 4),
