@@ -309,3 +309,96 @@ extern "C" int j2k_encode_frame(j2k_plan *P, int32_t *const *planes, int32_t *co
     return J2K_OK;
 }
 
+
+// a plan-owned device buffer that grows with what the call needs (the stream is drained before it is replaced)
+static int ensure_sized(j2k_ctx *ctx, void **p, size_t *cur, size_t need) {
+    if (*p && *cur >= need) return J2K_OK;
+    if (*p) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(*p)); *p = nullptr; *cur = 0; }
+    HIPCHK(ctx, hipMalloc(p, std::max<size_t>(need, 64)));
+    *cur = std::max<size_t>(need, 64);
+    return J2K_OK;
+}
+
+// ---- pixels at native width from / to HOST memory: the one-call forms a cgo Encode() / Decode() binds ----------------------------
+// image.*.Pix (host) -> H2D at native width (4 x fewer bytes than int32 planes) -> forward transform -> block coder -> tile-parts
+// (reference-mode plan: SOT | SOD | the tile's concatenated block bytes, encoder.createTileHeader of encodeTile's output; closed-loop
+// plan: SOT | SOD | packets) -> D2H at the exact length.  Synchronous; bench.py --io host shows what pipelining adds on top.
+extern "C" int j2k_encode_pixels_host(j2k_plan *P, int format, const void *pix, size_t stride, int sop, int eph, uint8_t *out, size_t cap,
+                                      size_t *out_len, uint64_t *tile_offs, uint32_t *lens, uint8_t *numbps) {
+    if (!P || !pix || !out_len) return J2K_ERR_INVALID_ARG;
+    j2k_ctx *ctx = P->ctx;
+    if (ctx->capturing) return fail(ctx, J2K_ERR_INVALID_ARG, "a synchronising call while the context captures a graph");
+    const PlanSpec &S = P->spec;
+    const int pb = format == J2K_PIX_GRAY8 ? 1 : format == J2K_PIX_GRAY16 ? 2 : (format == J2K_PIX_RGBA8 || format == J2K_PIX_NRGBA8) ? 4 :
+                   (format == J2K_PIX_RGBA64 || format == J2K_PIX_NRGBA64) ? 8 : 0;
+    if (!pb || stride < (size_t)S.W * pb) return fail(ctx, J2K_ERR_INVALID_ARG, "pixel format / stride");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t nb = P->blocks.size(), nt = (size_t)P->tile_count;
+    const size_t bound = S.closed_loop ? j2k_plan_frame_bound(P) : j2k_plan_tile_parts_bound(P);
+    int r;
+    if ((r = ensure_sized(ctx, &P->d_host_pix, &P->host_pix_bytes, (size_t)S.H * stride)) != J2K_OK) return r;
+    if ((r = ensure(ctx, &P->d_coeff, (size_t)P->coeff_elems * 4)) != J2K_OK) return r;
+    if ((r = ensure(ctx, &P->d_stream, (size_t)P->bytes_cap)) != J2K_OK) return r;
+    const size_t toff_at = (bound + 64 + 15) & ~size_t(15);                                              // the tile-parts, and behind them their offsets / the length word
+    if ((r = ensure_sized(ctx, &P->d_host_io, &P->host_io_bytes, toff_at + (nt + 2) * 8)) != J2K_OK) return r;
+    if ((r = ensure(ctx, &P->d_lens, nb * 4 + 16)) != J2K_OK) return r;
+    if ((r = ensure(ctx, &P->d_numbps, nb + 16)) != J2K_OK) return r;
+    if ((r = ensure(ctx, &P->d_offs, (nb + 1) * 8)) != J2K_OK) return r;
+    uint64_t *d_toffs = reinterpret_cast<uint64_t *>((uint8_t *)P->d_host_io + toff_at);
+    HIPCHK(ctx, hipMemcpyAsync(P->d_host_pix, pix, (size_t)S.H * stride, hipMemcpyHostToDevice, ctx->stream));
+    if ((r = j2k_plan_forward_pixels(P, format, P->d_host_pix, stride, (int32_t *)P->d_coeff)) != J2K_OK) return r;
+    if ((r = j2k_plan_encode_stream(P, (int32_t *)P->d_coeff, (uint8_t *)P->d_stream, (uint64_t *)P->d_offs, (uint32_t *)P->d_lens, (uint8_t *)P->d_numbps)) != J2K_OK) return r;
+    std::vector<uint64_t> toffs(nt + 1, 0);
+    if (S.closed_loop) {
+        if ((r = j2k_plan_encode_tile_parts(P, (uint8_t *)P->d_stream, (uint64_t *)P->d_offs, (uint32_t *)P->d_lens, (uint8_t *)P->d_numbps, sop, eph,
+                                            (uint8_t *)P->d_host_io, bound, d_toffs)) != J2K_OK) return r;
+        HIPCHK(ctx, hipMemcpyAsync(toffs.data(), d_toffs, (nt + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        if ((r = j2k_plan_assemble_tiles_device(P, (uint8_t *)P->d_stream, (uint64_t *)P->d_offs, (uint8_t *)P->d_host_io, d_toffs + nt)) != J2K_OK) return r;
+        HIPCHK(ctx, hipMemcpyAsync(&toffs[nt], d_toffs + nt, 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (lens && nb) HIPCHK(ctx, hipMemcpyAsync(lens, P->d_lens, nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (numbps && nb) HIPCHK(ctx, hipMemcpyAsync(numbps, P->d_numbps, nb, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<uint64_t> boffs;
+    if (!S.closed_loop && tile_offs) { boffs.resize(nb + 1); if (nb) HIPCHK(ctx, hipMemcpyAsync(boffs.data(), P->d_offs, (nb + 1) * 8, hipMemcpyDeviceToHost, ctx->stream)); }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if ((r = check_fault(ctx)) != J2K_OK) return r;
+    if (S.closed_loop && (r = j2k_plan_frame_status(P)) != J2K_OK) return r;
+    const size_t total = (size_t)toffs[nt];
+    *out_len = total;
+    if (tile_offs) {
+        if (S.closed_loop) memcpy(tile_offs, toffs.data(), (nt + 1) * 8);
+        else {                                             // tile-part t starts 14 t bytes behind its tile's first block (SOT + SOD per tile before it)
+            size_t j = 0;
+            for (size_t t = 0; t < nt; t++) {
+                while (j < nb && (size_t)P->block_tile[j] < t) j++;
+                tile_offs[t] = (j < nb ? boffs[j] : boffs[nb]) + 14 * t;
+            }
+            tile_offs[nt] = total;
+        }
+    }
+    if (total > cap || (total && !out)) return fail(ctx, J2K_ERR_CAPACITY, "out too small (*out_len says what the tile-parts take)");
+    if (total) HIPCHK(ctx, hipMemcpy(out, P->d_host_io, total, hipMemcpyDeviceToHost));
+    return J2K_OK;
+}
+
+// closed-loop plans: tile-parts (host) -> H2D -> parse -> block decode -> placement -> inverse transform -> image.*.Pix (host), one
+// synchronous call.  The pixel format is the plan's: components 1 / 3 / 4, precision <= 8 -> Gray / RGBA, else Gray16 / RGBA64
+// (decoder.createImage, decoder.go:417-588).
+extern "C" int j2k_decode_pixels_host(j2k_plan *P, const uint8_t *cs, size_t len, int sop, int eph, void *pix, size_t stride) {
+    if (!P || !cs || !pix) return J2K_ERR_INVALID_ARG;
+    j2k_ctx *ctx = P->ctx;
+    if (ctx->capturing) return fail(ctx, J2K_ERR_INVALID_ARG, "a synchronising call while the context captures a graph");
+    const PlanSpec &S = P->spec;
+    if (!S.closed_loop) return fail(ctx, J2K_ERR_UNSUPPORTED, "the plan was not made with j2k_params.closed_loop: the reference has no decode body to mirror");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int r;
+    const size_t pixbytes = (size_t)S.H * stride;
+    if ((r = ensure_sized(ctx, &P->d_host_pix, &P->host_pix_bytes, pixbytes)) != J2K_OK) return r;
+    if ((r = ensure_sized(ctx, &P->d_host_io, &P->host_io_bytes, len + 64)) != J2K_OK) return r;
+    HIPCHK(ctx, hipMemcpyAsync(P->d_host_io, cs, len, hipMemcpyHostToDevice, ctx->stream));
+    if ((r = j2k_plan_decode_frame_pixels(P, (const uint8_t *)P->d_host_io, len, nullptr, sop, eph, P->d_host_pix, stride)) != J2K_OK) return r;
+    HIPCHK(ctx, hipMemcpyAsync(pix, P->d_host_pix, pixbytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return j2k_plan_frame_status(P);
+}

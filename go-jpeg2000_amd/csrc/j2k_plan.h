@@ -173,6 +173,8 @@ struct j2k_plan {
     int32_t *d_cl_decoded = nullptr, *d_cl_coeff = nullptr;   // j2k_plan_*_frame_pixels: decoded blocks, coefficient planes
     uint8_t *d_cl_stream = nullptr, *d_cl_numbps = nullptr; uint64_t *d_cl_offs = nullptr; uint32_t *d_cl_lens = nullptr;
     int max_block_h = 0;
+    void *d_host_io = nullptr, *d_host_pix = nullptr;          // j2k_encode_pixels_host / j2k_decode_pixels_host: tile-parts / pixels on the device
+    size_t host_io_bytes = 0, host_pix_bytes = 0;
     int *d_tile_job0 = nullptr;             // first job of each tile of the shard (+ the job count): j2k_plan_assemble_tiles_device
     uint64_t max_tile_bytes = 0;            // slot bytes of the largest tile (an upper bound of its stream bytes)
     std::vector<uint64_t> slot_off;         // byte offset of each job's worst-case slot

@@ -280,6 +280,32 @@ class FramePlan:
                                                                int(bool(sop)), int(bool(eph)), self._p(pix), C.c_size_t(int(pix.shape[1]))))
         return pix
 
+    # ---- host memory in, host memory out: the one-call forms (j2k_encode_pixels_host / j2k_decode_pixels_host) -------------------
+    def encode_pixels_host(self, fmt, pix, sop=False, eph=False, cap=None):
+        """pix: numpy uint8 [H, stride] (a Go Pix layout) -> dict(bytes, tile_offs, lens, numbps): every tile as a tile-part"""
+        L = self.ctx.L
+        n, nt = int(self.info.blocks), int(self.info.tiles)
+        L.j2k_plan_tile_parts_bound.restype = C.c_size_t
+        cap = int(cap) if cap is not None else max(self.frame_bound(), int(L.j2k_plan_tile_parts_bound(self.h))) + 64
+        pix = np.ascontiguousarray(pix, dtype=np.uint8)
+        out = np.zeros(max(cap, 1), np.uint8)
+        toffs = np.zeros(nt + 1, np.uint64); lens = np.zeros(max(n, 1), np.uint32); nbps = np.zeros(max(n, 1), np.uint8)
+        olen = C.c_size_t(0)
+        st = L.j2k_encode_pixels_host(self.h, int(fmt), pix.ctypes.data_as(C.c_void_p), C.c_size_t(int(pix.shape[1])), int(bool(sop)), int(bool(eph)),
+                                      out.ctypes.data_as(C.c_void_p), C.c_size_t(cap), C.byref(olen), toffs.ctypes.data_as(C.c_void_p),
+                                      lens.ctypes.data_as(C.c_void_p), nbps.ctypes.data_as(C.c_void_p))
+        self.encoded_len = olen.value
+        self.ctx.check(st)
+        return dict(bytes=out[:olen.value].copy(), tile_offs=toffs, lens=lens[:n].copy(), numbps=nbps[:n].copy())
+
+    def decode_pixels_host(self, cs, shape, sop=False, eph=False):
+        """closed-loop plans: tile-parts (bytes / numpy uint8) -> numpy uint8 pixels of `shape` = (H, stride)"""
+        cs = np.ascontiguousarray(np.frombuffer(bytes(cs), np.uint8) if not isinstance(cs, np.ndarray) else cs, dtype=np.uint8)
+        pix = np.zeros(shape, np.uint8)
+        self.ctx.check(self.ctx.L.j2k_decode_pixels_host(self.h, cs.ctypes.data_as(C.c_void_p), C.c_size_t(cs.size), int(bool(sop)), int(bool(eph)),
+                                                         pix.ctypes.data_as(C.c_void_p), C.c_size_t(int(shape[1]))))
+        return pix
+
     def pack_bound(self):
         return int(self.ctx.L.j2k_plan_pack_bound(self.h))
 

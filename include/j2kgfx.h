@@ -402,6 +402,17 @@ int j2k_convert_colorspace_device(j2k_ctx *ctx, int colorspace, int32_t *d_plane
 int j2k_encode_frame(j2k_plan *plan, int32_t *const *planes, int32_t *coeff, uint8_t *out, size_t cap,
                      size_t *out_len, uint64_t *tile_offs, uint32_t *lens, uint8_t *numbps);
 
+/* Pixels at native width from / to HOST memory, one synchronous call each: what a cgo jpeg2000.Encode / Decode binds when the image
+ * lives in Go memory (encoder.go:79-213 + 216-281 + 597-688 + 746-760; decoder.go:363-588).  j2k_encode_pixels_host: pix (a Go Pix
+ * layout, `stride` bytes per row) crosses PCIe at native width, out receives every tile of the shard as a tile-part -- reference-mode
+ * plan: SOT | SOD | the tile's concatenated block bytes (createTileHeader of encodeTile's output); closed-loop plan: SOT | SOD | packets
+ * (sop / eph used there only) -- *out_len the bytes (J2K_ERR_CAPACITY with *out_len set when cap is smaller), tile_offs[t] (tiles + 1, may
+ * be NULL) where tile-part t starts, lens / numbps per code-block (may be NULL).  j2k_decode_pixels_host (closed-loop plans): the
+ * tile-parts back to pixels of the plan's format (1 / 3 / 4 components, precision <= 8: Gray / RGBA, else Gray16 / RGBA64). */
+int j2k_encode_pixels_host(j2k_plan *plan, int format, const void *pix, size_t stride, int sop, int eph, uint8_t *out, size_t cap,
+                           size_t *out_len, uint64_t *tile_offs, uint32_t *lens, uint8_t *numbps);
+int j2k_decode_pixels_host(j2k_plan *plan, const uint8_t *cs, size_t len, int sop, int eph, void *pix, size_t stride);
+
 /* ---- multi-tile codestream assembly: host calls, no device needed ------------------------------
  * j2k_create_tile_header = encoder.createTileHeader(tileIdx, tileData) (encoder.go:746-760): SOT (0xFF90) Lsot = 10,
  * Isot = uint16(tileIdx), Psot = uint32(14 + len), TPsot = 0, TNsot = 1, SOD (0xFF93), then the tile data -- 14 + len bytes.

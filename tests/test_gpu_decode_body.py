@@ -553,3 +553,55 @@ def test_closed_loop_calls_refuse_a_reference_mode_plan(env):
         plan.place_blocks(plan.empty(plan.info.decoded_elems, torch.int32))
     assert e.value.status == _lib.ERR_UNSUPPORTED
     plan.close()
+
+
+@pytest.mark.parametrize("closed", [False, True])
+def test_host_pixels_one_call_forms(env, closed):
+    """j2k_encode_pixels_host / j2k_decode_pixels_host: image.RGBA.Pix in host memory -> tile-parts in host memory (and back, for a
+    closed-loop plan) == what the device-buffer calls produce from the same pixels; unaligned stride; capacity reported"""
+    torch, t2ref, t2, ctx = env
+    from j2kgfx import J2KError, _lib, codestream
+    from j2kgfx.codec import FramePlan
+    W, H = 600, 300
+    stride = W * 4 + 12                                          # a Go sub-image: rows not 16-byte multiples apart
+    frame = _frame(W, H, 13, noise=20)
+    pix = np.zeros((H, stride), np.uint8)
+    pix[:, :W * 4] = _rgba(frame)
+    plan = FramePlan(W, H, 3, precision=8, lossless=True, num_resolutions=5, cb=(32, 32), tile=(256, 128), coder=_lib.CODER_MQ, ctx=ctx, closed_loop=closed)
+    got = plan.encode_pixels_host(_lib.PIX_RGBA8, pix, sop=True, eph=False)
+    d_pix = torch.from_numpy(pix).to(plan.device)
+    coeff = plan.forward_pixels(_lib.PIX_RGBA8, d_pix)
+    stream, offs, lens, numbps = plan.encode_stream(coeff)
+    n = int(plan.info.blocks)
+    if closed:
+        cs, toffs = plan.encode_tile_parts(stream, offs, lens, numbps, sop=True, eph=False)
+        plan.frame_status()
+        want = cs[:int(toffs[-1].item())].cpu().numpy()
+        assert np.array_equal(got["tile_offs"].astype(np.int64), toffs.cpu().numpy())
+    else:
+        out, out_len = plan.assemble_tiles(stream, offs)
+        ctx.sync()
+        want = out[:int(out_len[0].item())].cpu().numpy()
+        parts = codestream.parse_tile_parts(got["bytes"].tobytes())
+        assert [p.TileIndex for p, _ in parts] == list(range(int(plan.info.tiles)))
+        # tile_offs[t] = where tile-part t starts
+        starts = [0]
+        for _, d in parts:
+            starts.append(starts[-1] + 14 + len(d))
+        assert [int(v) for v in got["tile_offs"]] == starts
+    ctx.sync()
+    assert np.array_equal(got["bytes"], want)
+    assert np.array_equal(got["lens"], lens.cpu().numpy()[:n].astype(np.uint32)) and np.array_equal(got["numbps"], numbps.cpu().numpy()[:n])
+    with pytest.raises(J2KError) as e:
+        plan.encode_pixels_host(_lib.PIX_RGBA8, pix, sop=True, eph=False, cap=got["bytes"].size - 1)
+    assert e.value.status == _lib.ERR_CAPACITY and plan.encoded_len == got["bytes"].size
+    if closed:
+        back = plan.decode_pixels_host(got["bytes"], (H, stride), sop=True, eph=False)
+        assert np.array_equal(back[:, :W * 4].reshape(H, W, 4)[..., :3], pix[:, :W * 4].reshape(H, W, 4)[..., :3])
+        with pytest.raises(J2KError):
+            plan.decode_pixels_host(got["bytes"][:-50], (H, stride), sop=True, eph=False)
+    else:
+        with pytest.raises(J2KError) as e:
+            plan.decode_pixels_host(got["bytes"], (H, stride))
+        assert e.value.status == _lib.ERR_UNSUPPORTED
+    plan.close()
