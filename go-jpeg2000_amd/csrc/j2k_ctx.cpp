@@ -60,6 +60,7 @@ static const std::vector<CtxOption> &ctx_options() {
         OPT("t1_dec_split", v >= -1, c->t1_dec_split = (int)v),
         OPT("t1_dec_lanes", v >= 0 && v <= 2, c->t1_dec_lanes = (int)v),
         OPT("t1_lanes", v >= 0 && v <= 64, c->t1_lanes = (int)v),
+        OPT("t2_parallel", v == 0 || v == 1, c->t2_parallel = v != 0),
     };
 #undef OPT
     return T;

@@ -127,6 +127,8 @@ static int cl_prepare(j2k_plan *P) {
     alloc(&P->d_t2_ws, ((j2k::t2_dev_workspace((long)np) + 15) & ~size_t(15)) + 64);
     alloc(&P->d_t2_chains, (size_t)P->tile_count * j2k::t2_chain_bytes());
     alloc((void **)&P->d_t2_body_base, np * 8);
+    alloc(&P->d_t2_par, j2k::t2_par_workspace((long)np, P->tile_count));
+    if (r == J2K_OK) { hipError_t e = hipMemsetAsync(P->d_t2_par, 0, j2k::t2_par_workspace((long)np, P->tile_count), ctx->stream); if (e != hipSuccess) r = fail_hip(ctx, e, "hipMemsetAsync"); }
     alloc((void **)&P->d_frame_status, 64);
     if (r == J2K_OK) { hipError_t e = hipMemsetAsync(P->d_frame_status, 0, 64, ctx->stream); if (e != hipSuccess) r = fail_hip(ctx, e, "hipMemsetAsync"); }
     P->t2_npackets = (int)np;
@@ -171,9 +173,25 @@ extern "C" int j2k_plan_decode_tile_parts(j2k_plan *P, const uint8_t *d_cs, size
     const long n = (long)P->blocks.size();
     HIPCHK(ctx, hipMemsetAsync(P->d_t2_cbs, 0, (size_t)n * sizeof(j2k_t2_dev_cb), ctx->stream));
     HIPCHK(ctx, j2k::launch_t2_tile_chains(ctx->stream, d_cs, (uint64_t)len, d_tile_offs, P->tile_count, P->tile_first, P->d_tile_packet0, P->d_t2_chains));
-    HIPCHK(ctx, j2k::launch_t2_decode_packets(ctx->stream, P->d_t2_chains, P->tile_count, P->d_t2_packets, P->t2_npackets, P->d_t2_cbs, (uint64_t)n, d_cs, sop, eph, 1,
-                                              P->d_t2_body_base, P->d_frame_status));
-    HIPCHK(ctx, j2k::launch_t2_blocks(ctx->stream, n, P->d_t2_cbs, P->spec.coder == J2K_CODER_HT ? 1 : 0, 31, (uint64_t)len, d_offs, d_lens, d_numbps, P->d_frame_status));
+    // (SOP + EPH streams: a tile's packets side by side, checked against the serial rule and redone by it where a guess was off -- t2dec.hip)
+    HIPCHK(ctx, j2k::launch_t2_decode_tiles(ctx->stream, P->d_t2_chains, P->tile_count, P->d_tile_packet0, P->d_t2_packets, P->t2_npackets, P->d_t2_cbs, (uint64_t)n, d_cs,
+                                            (uint64_t)len, sop, eph, P->d_t2_body_base, P->d_frame_status, ctx->t2_parallel ? P->d_t2_par : nullptr,
+                                            P->spec.coder == J2K_CODER_HT ? 1 : 0, 31, d_offs, d_lens, d_numbps));
+    return J2K_OK;
+}
+
+extern "C" int j2k_plan_frame_parallel_tiles(j2k_plan *P, long *tiles) {
+    if (!P || !tiles) return J2K_ERR_INVALID_ARG;
+    j2k_ctx *ctx = P->ctx;
+    if (ctx->capturing) return fail(ctx, J2K_ERR_INVALID_ARG, "a synchronising call while the context captures a graph");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    *tiles = 0;
+    if (!P->d_frame_status) return J2K_OK;
+    int n = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&n, P->d_frame_status + 1, sizeof n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(P->d_frame_status + 1, 0, sizeof n, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *tiles = n;
     return J2K_OK;
 }
 

@@ -58,6 +58,7 @@ struct j2k_ctx {
     bool capturing = false;    // between j2k_ctx_capture_begin / _end: the plan calls are recorded into a HIP graph, nothing may allocate or synchronise
     bool fault_armed_before_capture = false;
     bool counted_mq = false;   // this context has built an MQ-coder plan (counted in g_mq_ctxs)
+    bool t2_parallel = true;   // J2K_T2_PARALLEL: frame decode of SOP + EPH streams parses a tile's packets side by side from their markers (verified; 0 = the tile chain only)
     int t1_lanes = 0;          // J2K_T1_LANES: blocks per wavefront of the lane-parallel MQ kernel (0: blocks / 256, at most 32, while at least two contexts code with the MQ coder, else blocks / 2048)
     // cached single-plane plans for the host (unit) calls
     std::vector<j2k_plan *> cache;
@@ -169,6 +170,7 @@ struct j2k_plan {
     void *d_t2_ws = nullptr;                     // encode: the packet coder's workspace + its 3-word result
     void *d_t2_chains = nullptr;                 // decode: one chain per tile
     uint64_t *d_t2_body_base = nullptr;          // decode: where each packet's bodies start
+    void *d_t2_par = nullptr;                    // decode: one chain per PACKET, the marker lists and guesses (t2_par_workspace)
     int *d_frame_status = nullptr;               // sticky status word of the asynchronous frame calls (j2k_plan_frame_status)
     int32_t *d_cl_decoded = nullptr, *d_cl_coeff = nullptr;   // j2k_plan_*_frame_pixels: decoded blocks, coefficient planes
     uint8_t *d_cl_stream = nullptr, *d_cl_numbps = nullptr; uint64_t *d_cl_offs = nullptr; uint32_t *d_cl_lens = nullptr;

@@ -207,7 +207,9 @@ struct T2Chain {
 
 __global__ __launch_bounds__(64) void t2_decode_kernel(T2Chain *__restrict__ chains, const j2k_t2_dev_packet *__restrict__ packets, long npackets_all,
                                                        j2k_t2_dev_cb *__restrict__ cbs, uint64_t ncbs, const uint8_t *__restrict__ data, int sop, int eph, int clean,
-                                                       uint64_t *__restrict__ body_base, int *__restrict__ frame_status) {
+                                                       uint64_t *__restrict__ body_base, int *__restrict__ frame_status,
+                                                       const T2Chain *__restrict__ pchains, const uint64_t *__restrict__ seeds, const uint32_t *__restrict__ tile_par,
+                                                       const int *__restrict__ tile_packet0) {
     __shared__ uint64_t raw[T2D_RAW / 8];
     __shared__ uint32_t bits[T2D_CHUNK * 8 / 32 + 4];
     __shared__ uint16_t sbit[T2D_CHUNK + 2];
@@ -216,7 +218,39 @@ __global__ __launch_bounds__(64) void t2_decode_kernel(T2Chain *__restrict__ cha
 #ifdef J2K_T2D_STATS
     const uint64_t t_start_ = wall_clock64(); uint32_t nblk_ = 0;
 #endif
-    if (Cn.skip) { if (lane == 0 && frame_status && Cn.status) atomicMin(frame_status, Cn.status); return; }
+    if (Cn.skip) {
+        if (Cn.status) {                                            // a tile-part found malformed: its packets have no bodies (not a stale entry of the frame before)
+            for (int64_t k = lane; k < Cn.npackets && Cn.packet0 >= 0 && Cn.packet0 + k < npackets_all; k += 64) body_base[Cn.packet0 + k] = ~0ull;
+            if (lane == 0 && frame_status) atomicMin(frame_status, Cn.status);
+        }
+        return;
+    }
+    if (pchains && tile_par[blockIdx.x]) {
+        // The tile launch behind a packet-parallel one (see "the packets of a tile side by side" below): every packet of this tile was
+        // decoded on its own from a guessed state.  Kept if each packet ENDED in the state (position, carried flag) the next one was
+        // started from -- by induction the run this chain would make; otherwise the tile's fields are wiped and the chain runs.
+        const int p0 = tile_packet0[blockIdx.x], npk = tile_packet0[blockIdx.x + 1] - p0;
+        bool bad = false;
+        for (int p = lane; p < npk; p += 64) {
+            const T2Chain &Q = pchains[p0 + p];
+            if (Q.status != J2K_OK || Q.done != 1) bad = true;
+            else if (p + 1 < npk && (Q.st.pos << 1 | (uint64_t)(Q.st.saw_ff != 0)) != seeds[p0 + p + 1]) bad = true;
+        }
+        if (__ballot(bad) == 0) {
+            if (lane == 0) {
+                Cn.status = J2K_OK; Cn.done = npk; Cn.st = pchains[p0 + npk - 1].st;
+                if (frame_status) atomicAdd(&frame_status[1], 1);   // (a count for j2k_plan_frame_parallel_tiles)
+            }
+            return;
+        }
+        for (int p = 0; p < npk; p++) {                             // the serial decoder starts from a zeroed table
+            const j2k_t2_dev_packet P = packets[p0 + p];
+            if (P.ncb < 0 || P.cb0 < 0 || (uint64_t)P.cb0 + (uint64_t)P.ncb > ncbs) continue;
+            for (int64_t i = lane; i < P.ncb; i += 64) cbs[P.cb0 + i] = j2k_t2_dev_cb{};
+        }
+        __threadfence();
+        __syncthreads();
+    }
     const uint64_t base = Cn.start;
     T2Rd r;
     r.data = data + base; r.end = Cn.end - base; r.raw = raw; r.rwbase = ~0ull; r.bits = bits; r.sbit = sbit; r.lane = lane; r.eof = false;
@@ -419,14 +453,19 @@ __global__ __launch_bounds__(256) void t2_bodies_kernel(const j2k_t2_dev_packet 
 // SOD (FF93), then the packets up to Psot bytes from the SOT marker (Psot = 0: to the end) -- ReadTilePartHeader,
 // parser.go:894-983.  With tile_offs the tile-parts are looked at side by side (a thread each); without, thread 0 walks them.
 __device__ int t2_tile_chain(const uint8_t *cs, uint64_t len, uint64_t at, int want_index, T2Chain &Cn, uint64_t &next) {
-    if (at >= len || len - at < 14 || cs[at] != 0xFF || cs[at + 1] != 0x90) return J2K_ERR_INVALID_ARG;    // (`at` is the caller's: no sum of it may wrap)
-    const uint32_t lsot = (uint32_t)cs[at + 2] << 8 | cs[at + 3], isot = (uint32_t)cs[at + 4] << 8 | cs[at + 5];
-    const uint32_t psot = (uint32_t)cs[at + 6] << 24 | (uint32_t)cs[at + 7] << 16 | (uint32_t)cs[at + 8] << 8 | cs[at + 9];
+    if (at >= len || len - at < 14) return J2K_ERR_INVALID_ARG;      // (`at` is the caller's: no sum of it may wrap)
+    uint32_t b[14];                                                 // SOT and the marker behind it in one round trip (normally SOD)
+#pragma unroll
+    for (int k = 0; k < 14; k++) b[k] = cs[at + k];
+    if (b[0] != 0xFF || b[1] != 0x90) return J2K_ERR_INVALID_ARG;
+    const uint32_t lsot = b[2] << 8 | b[3], isot = b[4] << 8 | b[5];
+    const uint32_t psot = b[6] << 24 | b[7] << 16 | b[8] << 8 | b[9];
     if (lsot != 10 || isot != ((uint32_t)want_index & 0xFFFFu)) return J2K_ERR_INVALID_ARG;
     const uint64_t stop = psot ? at + psot : len;
     if (stop > len || stop < at + 14) return J2K_ERR_INVALID_ARG;
     uint64_t p = at + 12;
-    for (;;) {                                                      // parser.go:180-190: segments by length until SOD
+    if (b[12] == 0xFF && b[13] == 0x93) p += 2;
+    else for (;;) {                                                 // parser.go:180-190: segments by length until SOD
         if (p + 2 > stop || cs[p] != 0xFF) return J2K_ERR_INVALID_ARG;
         if (cs[p + 1] == 0x93) { p += 2; break; }
         if (p + 4 > stop) return J2K_ERR_INVALID_ARG;
@@ -463,17 +502,143 @@ __global__ __launch_bounds__(64) void t2_tile_chains_kernel(const uint8_t *__res
     }
 }
 
+// ---- the packets of a tile side by side (SOP + EPH streams) ------------------------------------------------------------------
+// A tile's packets are one chain: packet p + 1 starts where the lengths in packet p's header say.  With SOP and EPH markers in the
+// stream that place can be GUESSED without reading a header: neither FF91 nor FF92 can occur inside a header (a byte behind 0xFF keeps
+// its top bit clear, bio.go:127-131) or inside an MQ-coded body (behind 0xFF the coder emits at most 0x8F, mqc.go byteout).  So:
+//   t2_marks_kernel   every FF91 / FF92 of the tile-parts, found by all CUs (an unordered list per tile)
+//   t2_seed_kernel    per tile: the list sorted; if it reads SOP EPH SOP EPH ... with one pair per packet of the plan, packet p's guess is
+//                     (start = its SOP, carried flag = the byte before packet p - 1's EPH is 0xFF) -- one chain of ONE packet each
+//   t2_decode_kernel  the same decoder as ever, a wavefront per packet
+//   t2_decode_kernel  once more, a wavefront per TILE: first it checks that every packet was decoded and that the state packet p ENDED in
+//                     (position, flag) is the state packet p + 1 was started from.  By induction that is the serial decoder's run, field for field.  If anything is off -- a marker pair
+//                     inside an HT body (its bytes are not marker-free), a stream without the markers, a malformed header -- the
+//                     tile's fields are wiped and that wavefront runs the tile's chain as before: the guess decides speed, never the result.
+#define T2P_MAXM 1024                   // markers of one tile that the sort takes (2 per packet)
+__global__ __launch_bounds__(256) void t2_marks_kernel(const T2Chain *__restrict__ chains, const int *__restrict__ tile_packet0, const uint8_t *__restrict__ cs,
+                                                       uint64_t *__restrict__ marks, uint32_t *__restrict__ cnt) {
+    const int t = blockIdx.y;
+    if (chains[t].skip) return;
+    const uint64_t a0 = chains[t].start, a1 = chains[t].end;
+    const uint32_t cap = 2u * (uint32_t)(tile_packet0[t + 1] - tile_packet0[t]);
+    uint64_t *m = marks + 2 * (size_t)tile_packet0[t];
+    auto found = [&](uint64_t q, uint32_t nx) {
+        const uint32_t k = atomicAdd(&cnt[t], 1u);
+        if (k < cap) m[k] = q << 1 | (uint64_t)(nx == 0x92u);
+    };
+    const uint64_t base = (uint64_t)(uintptr_t)cs;
+    // positions [b0, b1): the 16-byte pieces (by ADDRESS) that lie inside the tile-part; [a0, b0) and [b1, a1) byte by byte
+    uint64_t b0 = ((base + a0 + 15) & ~15ull) - base, b1 = ((base + a1) & ~15ull) - base;
+    if (b1 < b0) b0 = b1 = a0;
+    if (blockIdx.x == 0 && threadIdx.x < 32) {
+        const uint64_t q = threadIdx.x < 16 ? a0 + threadIdx.x : (b1 > a0 ? b1 : a0) + (threadIdx.x - 16);
+        const bool in = (threadIdx.x < 16 ? q < b0 : q >= b1) && q + 1 < a1;
+        const uint32_t c0 = cs[in ? q : a0], c1 = cs[in ? q + 1 : a0];              // (a1 - a0 >= 1: the chain was checked)
+        if (in && c0 == 0xFFu && (c1 == 0x91u || c1 == 0x92u)) found(q, c1);
+    }
+    const uint64_t nvec = (b1 - b0) >> 4;
+    // 16 KiB per workgroup and trip: four pieces per thread and the byte behind each, every load unconditional (clamped) and in flight
+    // before the first is looked at
+    for (uint64_t c0 = (uint64_t)blockIdx.x * 1024; c0 < nvec; c0 += (uint64_t)gridDim.x * 1024) {
+        uint4 x[4]; uint32_t nx4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint64_t v = c0 + (uint64_t)(u * 256 + (int)threadIdx.x), vc = v < nvec ? v : nvec - 1;
+            const uint64_t p = b0 + 16 * vc;
+            x[u] = *reinterpret_cast<const uint4 *>(cs + (int64_t)p);
+            nx4[u] = cs[p + 16 < a1 ? p + 16 : p];                                   // (the byte behind the piece; none behind the buffer's last)
+        }
+        // any byte 0xFF with 0x91 / 0x92 behind it?  Four bytes a step: z has a zero byte exactly there (the usual zero-byte test is exact
+        // for "is there one").  Looking at every 0xFF byte instead (one piece in sixteen has one) made this kernel compute-bound.
+        uint32_t hit = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t d[5] = {x[u].x, x[u].y, x[u].z, x[u].w, nx4[u]};
+            uint32_t any = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t e = __builtin_amdgcn_alignbyte(d[j + 1], d[j], 1), nf = ~d[j];
+                const uint32_t z1 = nf | (e ^ 0x91919191u), z2 = nf | (e ^ 0x92929292u);
+                any |= ((z1 - 0x01010101u) & ~z1 & 0x80808080u) | ((z2 - 0x01010101u) & ~z2 & 0x80808080u);
+            }
+            if (any && c0 + (uint64_t)(u * 256 + (int)threadIdx.x) < nvec) hit |= 1u << u;
+        }
+        if (__ballot(hit != 0) == 0) continue;                      // (most wavefronts: a tile holds a few dozen markers)
+        // a wavefront with a marker (one in three on a 4K frame): the same words again with the EXACT zero-byte flags (bit 7 of every
+        // zero byte and of no other), a marker per set bit -- all in registers (reading the piece again byte by byte cost a round trip each)
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (!(hit >> u & 1)) continue;
+            const uint32_t d[5] = {x[u].x, x[u].y, x[u].z, x[u].w, nx4[u]};
+            const uint64_t p = b0 + 16 * (c0 + (uint64_t)(u * 256 + (int)threadIdx.x));
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t e = __builtin_amdgcn_alignbyte(d[j + 1], d[j], 1), nf = ~d[j];
+                const uint32_t z1 = nf | (e ^ 0x91919191u), z2 = nf | (e ^ 0x92929292u);
+                const uint32_t f1 = ~(((z1 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z1 | 0x7F7F7F7Fu), f2 = ~(((z2 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z2 | 0x7F7F7F7Fu);
+                uint32_t f = f1 | f2 >> 1;                          // bit 7: SOP at that byte, bit 6: EPH
+                while (f) {
+                    const int bit = __builtin_ctz(f);
+                    f &= f - 1;
+                    const uint64_t q = p + (uint64_t)(4 * j + (bit >> 3));
+                    if (q + 1 < a1) found(q, (bit & 7) == 7 ? 0x91u : 0x92u);
+                }
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void t2_seed_kernel(const T2Chain *__restrict__ chains, const int *__restrict__ tile_packet0, const uint8_t *__restrict__ cs,
+                                                      const uint64_t *__restrict__ marks, uint32_t *__restrict__ cnt, T2Chain *__restrict__ pchains,
+                                                      uint64_t *__restrict__ seeds, uint32_t *__restrict__ tile_par) {
+    __shared__ uint64_t in[T2P_MAXM], srt[T2P_MAXM];
+    __shared__ int bad;
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int p0 = tile_packet0[t], npk = tile_packet0[t + 1] - p0;
+    const uint64_t a0 = chains[t].start, a1 = chains[t].end;
+    const uint32_t n = cnt[t];
+    bool ok = !chains[t].skip && npk > 0 && n == 2u * (uint32_t)npk && n <= T2P_MAXM;
+    if (tid == 0) bad = 0;
+    if (ok) {
+        for (uint32_t j = tid; j < n; j += 256) in[j] = marks[2 * (size_t)p0 + j];
+        __syncthreads();
+        for (uint32_t j = tid; j < n; j += 256) {                   // positions are distinct: an entry's rank is its place
+            const uint64_t e = in[j];
+            uint32_t rk = 0;
+            for (uint32_t q = 0; q < n; q++) rk += in[q] < e;
+            srt[rk] = e;
+        }
+        __syncthreads();
+        for (uint32_t j = tid; j < n; j += 256) {
+            const uint64_t e = srt[j];
+            if ((e & 1) != (j & 1)) bad = 1;                        // SOP EPH SOP EPH ...
+            if ((j & 1) && (e >> 1) < (srt[j - 1] >> 1) + 7) bad = 1;   // ... with a header of a byte or more between them
+        }
+        if (tid == 0 && (srt[0] >> 1) != a0) bad = 1;
+    }
+    __syncthreads();
+    ok = ok && !bad;
+    if (tid == 0) cnt[t] = 0;                                       // (for the next frame: the workspace starts zeroed and every count is taken here)
+    for (int p = tid; p < npk; p += 256) {
+        T2Chain Q{};
+        Q.start = a0; Q.end = a1; Q.packet0 = p0 + p; Q.npackets = 1; Q.skip = !ok;
+        if (ok) {
+            const uint64_t s = (srt[2 * p] >> 1) - a0;
+            const uint32_t ff = p > 0 && cs[(srt[2 * p - 1] >> 1) - 1] == 0xFFu;
+            Q.st.pos = s; Q.st.saw_ff = (uint8_t)ff;
+            seeds[p0 + p] = s << 1 | ff;
+        }
+        pchains[p0 + p] = Q;
+    }
+    if (tid == 0) tile_par[t] = ok;
+}
 // Code-block fields -> what j2k_plan_decode_blocks takes.  A block the packets did not include (or a chain that failed before it)
 // has no data: length 0, no bit planes -- tcd.DecodeCodeBlock leaves its coefficients alone (tcd.go:394-396).  Bit planes: the MQ
 // coder's pass count is 3 * numBPS - 2 (t1_fast5.go:66-70); an HT block carries one pass and the decoder does not use the count,
 // so it is mb - ZeroBitPlanes there (what j2k_plan_t2_fill_cbs wrote).
-__global__ __launch_bounds__(256) void t2_blocks_kernel(long n, const j2k_t2_dev_cb *__restrict__ cbs, int ht, int mb, uint64_t total, uint64_t *__restrict__ offs,
-                                                        uint32_t *__restrict__ lens, uint8_t *__restrict__ numbps, int *__restrict__ status) {
-    const long j = (long)blockIdx.x * 256 + threadIdx.x;
-    if (j >= n) return;
-    const j2k_t2_dev_cb cb = cbs[j];
+__device__ __forceinline__ void t2_block_out(long j, const j2k_t2_dev_cb &cb, bool decoded, int ht, int mb, uint64_t total, uint64_t *__restrict__ offs,
+                                             uint32_t *__restrict__ lens, uint8_t *__restrict__ numbps, int *__restrict__ status) {
     // (a body outside the buffer can only come from a chain that failed half way -- the frame's status says so; nothing is read there)
-    const bool has = cb.included_in_layers == 0 && cb.data_len > 0 && cb.num_passes > 0 && cb.data_off <= total && cb.data_len <= total - cb.data_off;
+    const bool has = decoded && cb.included_in_layers == 0 && cb.data_len > 0 && cb.num_passes > 0 && cb.data_off <= total && cb.data_len <= total - cb.data_off;
     int nb = 0;
     if (has) nb = ht ? (mb > cb.zero_bit_planes ? mb - cb.zero_bit_planes : 0) : (cb.num_passes + 2) / 3;
     // more bit planes than an int32 coefficient has: no encoder of this library writes that (numBPS <= 31) -- a foreign stream; the block is
@@ -483,6 +648,26 @@ __global__ __launch_bounds__(256) void t2_blocks_kernel(long n, const j2k_t2_dev
     offs[j] = has && !bad ? cb.data_off : 0;
     lens[j] = has && !bad ? cb.data_len : 0u;
     numbps[j] = (uint8_t)(bad ? 0 : nb);
+}
+__global__ __launch_bounds__(256) void t2_blocks_kernel(long n, const j2k_t2_dev_cb *__restrict__ cbs, int ht, int mb, uint64_t total, uint64_t *__restrict__ offs,
+                                                        uint32_t *__restrict__ lens, uint8_t *__restrict__ numbps, int *__restrict__ status) {
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    t2_block_out(j, cbs[j], true, ht, mb, total, offs, lens, numbps, status);
+}
+// t2_bodies_kernel and t2_blocks_kernel in one pass for a plan's own packets (every block of the plan is in exactly one of them): one
+// workgroup per packet; a packet its chain did not reach (body_base = ~0) has no data
+__global__ __launch_bounds__(256) void t2_finish_kernel(const j2k_t2_dev_packet *__restrict__ packets, j2k_t2_dev_cb *__restrict__ cbs, uint64_t ncbs,
+                                                        const uint64_t *__restrict__ body_base, int ht, int mb, uint64_t total, uint64_t *__restrict__ offs,
+                                                        uint32_t *__restrict__ lens, uint8_t *__restrict__ numbps, int *__restrict__ status) {
+    const j2k_t2_dev_packet P = packets[blockIdx.x];
+    const uint64_t b = body_base[blockIdx.x];
+    if (P.ncb < 0 || P.cb0 < 0 || (uint64_t)P.cb0 + (uint64_t)P.ncb > ncbs) return;
+    for (int64_t i = threadIdx.x; i < P.ncb; i += 256) {
+        j2k_t2_dev_cb cb = cbs[P.cb0 + i];
+        if (b != ~0ull && cb.included_in_layers == P.layer && cb.data_len > 0) { cb.data_off += b; cbs[P.cb0 + i].data_off = cb.data_off; }
+        t2_block_out((long)(P.cb0 + i), cb, b != ~0ull, ht, mb, total, offs, lens, numbps, status);
+    }
 }
 
 // decoded block j (dense w x h at D.out_off) -> its window of the coefficient planes (S.src_off, row stride S.stride); one
@@ -524,8 +709,37 @@ hipError_t launch_t2_decode_packets(hipStream_t s, void *chains, int nchains, co
                                     const uint8_t *data, int sop, int eph, int clean, uint64_t *body_base, int *frame_status) {
     if (nchains <= 0 || npackets <= 0) return hipSuccess;
     hipLaunchKernelGGL(t2_decode_kernel, dim3((unsigned)nchains), dim3(64), 0, s, reinterpret_cast<T2Chain *>(chains), packets, npackets, cbs, ncbs, data, sop, eph,
-                       clean, body_base, frame_status);
+                       clean, body_base, frame_status, (const T2Chain *)nullptr, (const uint64_t *)nullptr, (const uint32_t *)nullptr, (const int *)nullptr);
     hipLaunchKernelGGL(t2_bodies_kernel, dim3((unsigned)npackets), dim3(256), 0, s, packets, cbs, ncbs, body_base);
+    return hipGetLastError();
+}
+// a frame's tile chains (launch_t2_tile_chains), each tile's packets side by side where its markers allow it; ws: t2_par_workspace() bytes
+size_t t2_par_workspace(long npackets, int ntiles) {
+    return (size_t)npackets * (sizeof(T2Chain) + 16 + 8) + (size_t)ntiles * 8 + 64;
+}
+hipError_t launch_t2_decode_tiles(hipStream_t s, void *chains, int ntiles, const int *tile_packet0, const j2k_t2_dev_packet *packets, long npackets,
+                                  j2k_t2_dev_cb *cbs, uint64_t ncbs, const uint8_t *data, uint64_t len, int sop, int eph, uint64_t *body_base, int *frame_status, void *ws,
+                                  int ht, int mb, uint64_t *offs, uint32_t *lens, uint8_t *numbps) {
+    if (ntiles <= 0 || npackets <= 0) return hipSuccess;
+    T2Chain *tc = reinterpret_cast<T2Chain *>(chains);
+    if (sop && eph && ws) {
+        T2Chain *pch = reinterpret_cast<T2Chain *>(ws);
+        uint64_t *marks = reinterpret_cast<uint64_t *>(pch + npackets), *seeds = marks + 2 * npackets;
+        uint32_t *cnt = reinterpret_cast<uint32_t *>(seeds + npackets), *tile_par = cnt + ntiles;
+        // pieces of 16 bytes, four per thread and trip: workgroups of 16 KiB of the average tile-part
+        // (`len` is the caller's buffer, often a bound well above the bytes in use: at most ~2048 workgroups -- one that finds nothing to
+        // do still waits for the tile's chain record)
+        const unsigned seg = (unsigned)std::min<uint64_t>(std::max(1, 2048 / ntiles), std::max<uint64_t>(1, len / (uint64_t)ntiles / 16384 + 1));
+        hipLaunchKernelGGL(t2_marks_kernel, dim3(seg, (unsigned)ntiles), dim3(256), 0, s, tc, tile_packet0, data, marks, cnt);
+        hipLaunchKernelGGL(t2_seed_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, tc, tile_packet0, data, marks, cnt, pch, seeds, tile_par);
+        hipLaunchKernelGGL(t2_decode_kernel, dim3((unsigned)npackets), dim3(64), 0, s, pch, packets, npackets, cbs, ncbs, data, sop, eph, 1, body_base, (int *)nullptr,
+                           (const T2Chain *)nullptr, (const uint64_t *)nullptr, (const uint32_t *)nullptr, (const int *)nullptr);
+        hipLaunchKernelGGL(t2_decode_kernel, dim3((unsigned)ntiles), dim3(64), 0, s, tc, packets, npackets, cbs, ncbs, data, sop, eph, 1, body_base, frame_status,
+                           (const T2Chain *)pch, (const uint64_t *)seeds, (const uint32_t *)tile_par, tile_packet0);
+    } else
+        hipLaunchKernelGGL(t2_decode_kernel, dim3((unsigned)ntiles), dim3(64), 0, s, tc, packets, npackets, cbs, ncbs, data, sop, eph, 1, body_base, frame_status,
+                           (const T2Chain *)nullptr, (const uint64_t *)nullptr, (const uint32_t *)nullptr, (const int *)nullptr);
+    hipLaunchKernelGGL(t2_finish_kernel, dim3((unsigned)npackets), dim3(256), 0, s, packets, cbs, ncbs, body_base, ht, mb, len, offs, lens, numbps, frame_status);
     return hipGetLastError();
 }
 // the generic call's one chain, made on the host

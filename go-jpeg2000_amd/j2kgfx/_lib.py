@@ -61,7 +61,7 @@ SYMBOLS = [
     "j2k_tile_part_bound", "j2k_create_tile_header", "j2k_assemble_tiles", "j2k_read_tile_part_header", "j2k_parse_tile_parts",
     "j2k_plan_tile_parts_bound", "j2k_plan_assemble_tiles_device",
     "j2k_t2_packet_sequence", "j2k_t2_packet_bound", "j2k_t2_encode_packet", "j2k_t2_decode_packet", "j2k_t2_encode_packets_device", "j2k_t2_decode_packets_device", "j2k_plan_t2_packets", "j2k_plan_t2_fill_cbs", "j2k_tagtree_shape", "j2k_tcd_init_tile",
-    "j2k_plan_frame_bound", "j2k_plan_encode_tile_parts", "j2k_plan_decode_tile_parts", "j2k_plan_place_blocks", "j2k_plan_frame_status",
+    "j2k_plan_frame_bound", "j2k_plan_encode_tile_parts", "j2k_plan_decode_tile_parts", "j2k_plan_place_blocks", "j2k_plan_frame_status", "j2k_plan_frame_parallel_tiles",
     "j2k_plan_encode_frame_pixels", "j2k_plan_decode_frame_pixels", "j2k_encode_pixels_host", "j2k_decode_pixels_host",
     "j2k_plan_pack_bound", "j2k_plan_pack_stream", "j2k_plan_unpack_stream", "j2k_plan_unpack_streams",
     "j2k_comm_load_error", "j2k_comm_get_unique_id", "j2k_comm_create", "j2k_comm_destroy", "j2k_comm_last_error", "j2k_comm_stream", "j2k_gather_streams", "j2k_comm_wait",

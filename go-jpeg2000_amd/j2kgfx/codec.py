@@ -263,6 +263,13 @@ class FramePlan:
         self.ctx.check(self.ctx.L.j2k_plan_frame_status(self.h))
         self.ctx.sync()
 
+    def frame_parallel_tiles(self):
+        """synchronises; tiles whose packets the decode calls since the last query parsed side by side (SOP + EPH streams)"""
+        import ctypes
+        n = ctypes.c_long(0)
+        self.ctx.check(self.ctx.L.j2k_plan_frame_parallel_tiles(self.h, ctypes.byref(n)))
+        return int(n.value)
+
     @_stage
     def encode_frame_pixels(self, fmt, pix, sop=False, eph=False, out=None, tile_offs=None):
         """pixels (a Go Pix layout, device uint8 [H, stride]) -> tile-parts: (out uint8, tile_offs int64[tiles + 1])"""

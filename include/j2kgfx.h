@@ -538,6 +538,13 @@ int j2k_t2_decode_packets_device(j2k_ctx *ctx, const j2k_t2_dev_packet *d_packet
  *                               (device, tiles + 1) where the caller knows the tile-parts' positions (the Go-side parser
  *                               has read the SOT segments, parser.go:894-983; or the encode call's own table), else NULL:
  *                               the call walks the SOT segments itself (Psot), one after the other.
+ *                               With sop != 0 and eph != 0 a tile's packets are parsed side by side: their starts are guessed from
+ *                               the FF91 / FF92 markers, every packet is decoded on its own, and the result is kept only if each
+ *                               packet ended in exactly the state the next one was started from -- otherwise (a marker pair inside
+ *                               a body, a damaged header) that tile is decoded again one packet after the other.  The output is
+ *                               the serial decoder's either way (j2k_ctx_set_option "t2_parallel" = 0: serial only).
+ *   j2k_plan_frame_parallel_tiles  diagnostic: synchronises; *tiles = tiles whose packets were parsed side by side in the
+ *                               decode calls since the last query
  *   j2k_plan_place_blocks       decoded blocks (j2k_plan_decode_blocks) -> each at its window of the coefficient planes
  *   j2k_plan_frame_status       synchronises and reports what the asynchronous calls above found since the last call:
  *                               J2K_OK, J2K_ERR_CAPACITY, or J2K_ERR_INVALID_ARG for a malformed tile-part / packet
@@ -551,6 +558,7 @@ int j2k_plan_decode_tile_parts(j2k_plan *plan, const uint8_t *d_cs, size_t len, 
                                uint64_t *d_offs, uint32_t *d_lens, uint8_t *d_numbps);
 int j2k_plan_place_blocks(j2k_plan *plan, const int32_t *d_decoded, int32_t *d_coeff);
 int j2k_plan_frame_status(j2k_plan *plan);
+int j2k_plan_frame_parallel_tiles(j2k_plan *plan, long *tiles);
 int j2k_plan_encode_frame_pixels(j2k_plan *plan, int format, const void *d_pix, size_t stride, int sop, int eph,
                                  uint8_t *d_out, size_t cap, uint64_t *d_tile_offs);
 int j2k_plan_decode_frame_pixels(j2k_plan *plan, const uint8_t *d_cs, size_t len, const uint64_t *d_tile_offs, int sop, int eph,

@@ -526,9 +526,23 @@ def test_closed_loop_corrupted_tile_parts_are_reported_not_followed(env, coder):
         try:
             plan.frame_status()
             outcomes["ok"] += 1
+            failed = False
         except J2KError as e:
             assert e.status == _lib.ERR_INVALID_ARG
             outcomes["invalid"] += 1
+            failed = True
+        # the packets of a tile side by side (the default for SOP + EPH streams) and one after the other: the same answer on damaged input too
+        ctx.set_option("t2_parallel", 0)
+        o3, l3, n3 = plan.decode_tile_parts(buf[guard:], n, tile_offs=d_t if (kind == 4 or it % 2) else None, sop=True, eph=True)
+        ctx.set_option("t2_parallel", 1)
+        try:
+            plan.frame_status()
+            assert not failed
+        except J2KError:
+            assert failed
+        if not failed:
+            nb = int(plan.info.blocks)
+            assert torch.equal(o2[:nb], o3[:nb]) and torch.equal(l2[:nb], l3[:nb]) and torch.equal(n2[:nb], n3[:nb]), (it, kind)
         # whatever came out points inside the buffer the caller gave
         o, l = o2.cpu().numpy()[:int(plan.info.blocks)].astype(np.uint64), l2.cpu().numpy()[:int(plan.info.blocks)].astype(np.uint64)
         assert ((o + l) <= n).all()
@@ -540,6 +554,126 @@ def test_closed_loop_corrupted_tile_parts_are_reported_not_followed(env, coder):
     plan.frame_status()
     if coder == 0:
         assert np.array_equal(back.cpu().numpy(), frame.astype(np.int32))
+    plan.close()
+
+
+@pytest.mark.parametrize("coder", [0, 1])
+def test_closed_loop_packets_of_a_tile_side_by_side_equal_the_tile_chain(env, coder):
+    """SOP + EPH streams: packet starts guessed from the markers, each packet decoded on its own, kept only when every packet ends where
+    (and how) the next was started -- the tile chain's result by induction.  Checked here against the tile chain itself (option
+    t2_parallel = 0): intact streams (every tile of an MQ frame goes the parallel way), a marker pair planted in a body (that tile falls
+    back; same bytes out), headers ending in 0xFF (the carried flag), streams without EPH (nothing to guess from)"""
+    torch, t2ref, t2, ctx = env
+    from j2kgfx.codec import FramePlan
+    rng = np.random.default_rng(77 + coder)
+    for (W, H, tile, cb, nres, noise) in [(640, 384, (128, 128), 32, 4, 30), (300, 200, (0, 0), 16, 5, 60), (1024, 512, (512, 512), 64, 6, 8), (96, 64, (32, 32), 8, 3, 90)]:
+        frame = _frame(W, H, 5, noise=noise).astype(np.int32)
+        plan = FramePlan(W, H, 3, precision=8, lossless=True, num_resolutions=nres, cb=(cb, cb), tile=tile, coder=coder, ctx=ctx, closed_loop=True)
+        tiles = int(plan.info.tiles)
+        coeff = plan.forward(torch.from_numpy(frame).to(plan.device))
+        stream, offs, lens, numbps = plan.encode_stream(coeff)
+
+        def both(cs, total, sop, eph, toffs):
+            plan.frame_parallel_tiles()
+            nb = int(plan.info.blocks)
+            a = plan.decode_tile_parts(cs, total, tile_offs=toffs, sop=sop, eph=eph)
+            par = plan.frame_parallel_tiles()
+            ctx.set_option("t2_parallel", 0)
+            b = plan.decode_tile_parts(cs, total, tile_offs=toffs, sop=sop, eph=eph)
+            ctx.set_option("t2_parallel", 1)
+            assert plan.frame_parallel_tiles() == 0
+            plan.frame_status()
+            a = [x[:nb] for x in a]
+            for x, y in zip(a, b):
+                assert torch.equal(x, y[:nb])
+            return a, par
+
+        cs, toffs = plan.encode_tile_parts(stream, offs, lens, numbps, sop=True, eph=True)
+        plan.frame_status()
+        total = int(toffs[-1].item())
+        (o2, l2, n2), par = both(cs, total, True, True, toffs)
+        if coder == 0:
+            assert par == tiles                                   # an MQ body holds no FF91 / FF92: every tile goes the parallel way
+        else:
+            assert par >= tiles - 2
+        back = plan.inverse(plan.place_blocks(plan.decode_blocks(cs, o2, l2, n2)))
+        plan.frame_status()
+        if coder == 0:
+            assert np.array_equal(back.cpu().numpy(), frame)
+        # a marker pair inside the largest body: the list of that tile no longer reads SOP EPH SOP EPH ... and the tile chain takes over
+        h_o, h_l = o2.cpu().numpy(), l2.cpu().numpy()
+        j = int(np.argmax(h_l))
+        if h_l[j] >= 8:
+            bad = cs.clone()
+            at = int(h_o[j]) + int(rng.integers(1, int(h_l[j]) - 4))
+            bad[at] = 0xFF
+            bad[at + 1] = 0x91 if rng.integers(0, 2) else 0x92
+            (o3, l3, n3), par3 = both(bad, total, True, True, None)
+            assert par3 == par - 1 or (coder == 1 and par3 <= par)
+            assert torch.equal(o3, o2) and torch.equal(l3, l2) and torch.equal(n3, n2)          # (a body's bytes do not move the packets)
+        # ... two of them, in order (a false packet in the middle of a body): the count is off
+        if h_l[j] >= 16:
+            bad = cs.clone()
+            at = int(h_o[j]) + 2
+            bad[at:at + 2] = torch.tensor([0xFF, 0x91], dtype=torch.uint8, device=bad.device)
+            bad[at + 9:at + 11] = torch.tensor([0xFF, 0x92], dtype=torch.uint8, device=bad.device)
+            (o3, l3, n3), par3 = both(bad, total, True, True, toffs)
+            assert par3 < tiles and torch.equal(o3, o2) and torch.equal(l3, l2)
+        # without EPH (or SOP) there is nothing to take the carried flag from: the tile chain as before
+        for sop, eph in [(True, False), (False, True), (False, False)]:
+            cs2, toffs2 = plan.encode_tile_parts(stream, offs, lens, numbps, sop=sop, eph=eph)
+            plan.frame_status()
+            (o4, l4, n4), par4 = both(cs2, int(toffs2[-1].item()), sop, eph, toffs2)
+            assert par4 == 0 and torch.equal(l4, l2) and torch.equal(n4, n2)
+        plan.close()
+
+
+def test_closed_loop_side_by_side_packets_with_headers_ending_in_0xff(env):
+    """the one thing a packet inherits from the one before it: whether that header's last byte was 0xFF (its own first byte then holds
+    7 bits).  Rare in real frames (the header has to end on a byte boundary in eight 1 bits), so block lengths and bit-plane counts
+    are drawn at random -- the packet parser reads headers only, a body's bytes are never looked at -- until headers end that way"""
+    torch, t2ref, t2, ctx = env
+    from j2kgfx.codec import FramePlan
+    W, H = 256, 192
+    frame = _frame(W, H, 100, noise=60).astype(np.int32)
+    plan = FramePlan(W, H, 3, precision=8, lossless=True, num_resolutions=3, cb=(16, 16), tile=(64, 64), coder=0, ctx=ctx, closed_loop=True)
+    nb, tiles = int(plan.info.blocks), int(plan.info.tiles)
+    coeff = plan.forward(torch.from_numpy(frame).to(plan.device))
+    stream, offs, lens, numbps = plan.encode_stream(coeff)
+    plan.frame_status()
+    h_lens = lens.cpu().numpy()[:nb].astype(np.int64)
+    rng = np.random.default_rng(5)
+    seen = 0
+    for trial in range(400):
+        rl = (h_lens * rng.random(nb)).astype(np.int64)             # 0 ... the real length: always inside the stream
+        ones = (1 << np.maximum(np.floor(np.log2(np.maximum(h_lens, 1) + 1)).astype(np.int64) - rng.integers(0, 2, nb), 0)) - 1    # 2^k - 1 <= the real length: a length field of 1 bits
+        l2 = torch.from_numpy(np.where(rng.random(nb) < 0.5, ones, rl).astype(np.int32)).to(plan.device)
+        n2 = torch.from_numpy(rng.integers(1, 17, nb).astype(np.uint8)).to(plan.device)
+        lens_t, nbp_t = lens.clone(), numbps.clone()
+        lens_t[:nb] = l2
+        nbp_t[:nb] = n2
+        cs, toffs = plan.encode_tile_parts(stream, offs, lens_t, nbp_t, sop=True, eph=True)
+        plan.frame_status()
+        total = int(toffs[-1].item())
+        h = cs[:total].cpu().numpy()
+        eph_at = np.nonzero((h[:-1] == 0xFF) & (h[1:] == 0x92))[0]
+        hits = int((h[eph_at - 1] == 0xFF).sum())
+        if not hits:
+            continue
+        seen += hits
+        plan.frame_parallel_tiles()
+        a = plan.decode_tile_parts(cs, total, tile_offs=toffs, sop=True, eph=True)
+        assert plan.frame_parallel_tiles() == tiles
+        ctx.set_option("t2_parallel", 0)
+        b = plan.decode_tile_parts(cs, total, tile_offs=toffs, sop=True, eph=True)
+        ctx.set_option("t2_parallel", 1)
+        plan.frame_status()
+        for x, y in zip(a, b):
+            assert torch.equal(x[:nb], y[:nb])
+        assert torch.equal(a[1][:nb], l2)                           # and the lengths that went in
+        if seen >= 4:
+            break
+    assert seen >= 1
     plan.close()
 
 

@@ -26,10 +26,14 @@ stream = plan.empty(plan.info.bytes_cap, torch.uint8); offs = plan.empty(n + 1, 
 cs = plan.empty(plan.frame_bound(), torch.uint8); toffs = plan.empty(int(plan.info.tiles) + 1, torch.int64)[:int(plan.info.tiles) + 1]
 o2 = plan.empty(n + 1, torch.int64); l2 = plan.empty(n, torch.int32); n2 = plan.empty(n, torch.uint8)
 decoded = plan.empty(plan.info.decoded_elems, torch.int32)
+cs2 = plan.empty(plan.frame_bound(), torch.uint8); toffs2 = plan.empty(int(plan.info.tiles) + 1, torch.int64)[:int(plan.info.tiles) + 1]
+plan.encode_tile_parts(plan.encode_stream(plan.forward_pixels(_lib.PIX_RGBA8, d_pix, coeff), stream, offs, lens, nb)[0], offs, lens, nb, True, True, cs2, toffs2)
 stages = [
     ("forward_pixels", lambda: plan.forward_pixels(_lib.PIX_RGBA8, d_pix, coeff)),
     ("encode_stream", lambda: plan.encode_stream(coeff, stream, offs, lens, nb)),
     ("encode_tile_parts", lambda: plan.encode_tile_parts(stream, offs, lens, nb, False, False, cs, toffs)),
+    ("decode_tile_parts (SOP + EPH: packets side by side)", lambda: plan.decode_tile_parts(cs2, cs2.numel(), toffs2, True, True, o2, l2, n2)),
+    ("decode_tile_parts (SOP + EPH, t2_parallel = 0)", lambda: (ctx.set_option("t2_parallel", 0), plan.decode_tile_parts(cs2, cs2.numel(), toffs2, True, True, o2, l2, n2), ctx.set_option("t2_parallel", 1))),
     ("decode_tile_parts", lambda: plan.decode_tile_parts(cs, cs.numel(), toffs, False, False, o2, l2, n2)),
     ("decode_tile_parts (SOT walk)", lambda: plan.decode_tile_parts(cs, cs.numel(), None, False, False, o2, l2, n2)),
     ("decode_blocks", lambda: plan.decode_blocks(cs, o2, l2, n2, decoded)),
@@ -52,4 +56,7 @@ if coder == 0:
     assert torch.equal(back, d_pix)
 print("closed-loop C2 frame, %s coder, %d blocks, %d bytes of tile-parts; us per stage (one frame alone, events around the call):" % ("MQ" if coder == 0 else "HT", n, int(toffs[-1].item())))
 for k, _ in stages:
-    print("  %-32s %9.1f" % (k, tot[k] / REP))
+    print("  %-52s %9.1f" % (k, tot[k] / REP))
+plan.frame_parallel_tiles()
+plan.decode_tile_parts(cs2, cs2.numel(), toffs2, True, True, o2, l2, n2)
+print("tiles parsed packet-parallel: %d of %d" % (plan.frame_parallel_tiles(), int(plan.info.tiles)))

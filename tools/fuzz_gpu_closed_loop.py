@@ -22,7 +22,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 t0 = time.time()
-n = npanic = 0
+n = npanic = npar_tiles = nser_tiles = 0
 t_say = t0
 while time.time() - t0 < budget:
     if time.time() - t_say > 60:
@@ -39,6 +39,8 @@ while time.time() - t0 < budget:
     coder = int(rng.integers(0, 2))
     prec = int(rng.choice([8, 12, 16]))
     sop, eph = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    if rng.integers(0, 3) == 0:
+        sop = eph = True                                        # (about half the frames: SOP + EPH, the packets of a tile parsed side by side)
     top = (1 << prec) - 1
     kind = int(rng.integers(0, 4))
     if kind == 0:
@@ -102,6 +104,7 @@ while time.time() - t0 < budget:
         ref.append((x0, y0, w, h, by, ln, nb))
     assert not panics, ("oracle panics where the product did not", desc)
     for given in (True, False):
+        plan.frame_parallel_tiles()
         offs2, lens2, nb2 = plan.decode_tile_parts(cs, total, tile_offs=toffs if given else None, sop=sop, eph=eph)
         decoded = plan.decode_blocks(cs, offs2, lens2, nb2)
         placed = plan.place_blocks(decoded)
@@ -110,6 +113,10 @@ while time.time() - t0 < budget:
             plan.frame_status()
         except J2KError as e:
             raise AssertionError(("decode status", e.status, desc, given, total, [int(x) for x in h_t[:6]]))
+        par = plan.frame_parallel_tiles()
+        npar_tiles += par
+        nser_tiles += ntiles - par if (sop and eph) else 0
+        assert par == 0 or (sop and eph), desc
         hp, hb = placed.cpu().numpy(), back.cpu().numpy().reshape(Cn, H, W)
         for tl, (x0, y0, w, h, by, ln, nb) in enumerate(ref):
             want_p = orc.decode_tile_blocks(by, ln, nb, Cn, w, h, nres_jobs, cb, cb, coder, 1)
@@ -121,4 +128,5 @@ while time.time() - t0 < budget:
             assert np.array_equal(hb, frame), ("round trip", desc, given)
     plan.close()
     n += 1
-print("closed-loop fuzz: %d frames clean (%d in the reference's HT panic domain) in %.0f s, seed %d" % (n, npanic, time.time() - t0, seed))
+print("closed-loop fuzz: %d frames clean (%d in the reference's HT panic domain; SOP + EPH frames: %d tiles parsed packet-parallel, %d fell back to the tile chain) in %.0f s, seed %d"
+      % (n, npanic, npar_tiles, nser_tiles, time.time() - t0, seed))
