@@ -171,7 +171,6 @@ extern "C" int j2k_plan_decode_tile_parts(j2k_plan *P, const uint8_t *d_cs, size
     int r = cl_prepare(P);
     if (r != J2K_OK) return r;
     const long n = (long)P->blocks.size();
-    HIPCHK(ctx, hipMemsetAsync(P->d_t2_cbs, 0, (size_t)n * sizeof(j2k_t2_dev_cb), ctx->stream));
     HIPCHK(ctx, j2k::launch_t2_tile_chains(ctx->stream, d_cs, (uint64_t)len, d_tile_offs, P->tile_count, P->tile_first, P->d_tile_packet0, P->d_t2_chains));
     // (SOP + EPH streams: a tile's packets side by side, checked against the serial rule and redone by it where a guess was off -- t2dec.hip)
     HIPCHK(ctx, j2k::launch_t2_decode_tiles(ctx->stream, P->d_t2_chains, P->tile_count, P->d_tile_packet0, P->d_t2_packets, P->t2_npackets, P->d_t2_cbs, (uint64_t)n, d_cs,

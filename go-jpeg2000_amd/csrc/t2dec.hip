@@ -26,6 +26,11 @@ namespace j2k {
 // fields from a 64-bit register window over that buffer: a field is a shift, a unary value a count of leading zeros; one LDS word per
 // 32 bits consumed.  The reader's position in the reference's terms (rpos, cnt, buf, sawFF) is recovered from the byte -> bit map
 // whenever it is asked for (a packet's end), so the two stages give exactly the reference's state at every field boundary.
+// every lane of the parsing wavefront holds the same reader state: a value read from LDS is taken through readfirstlane so that the compiler
+// KNOWS it is uniform and keeps the state in scalar registers, with scalar branches (left in vector registers the field loop was ~150
+// vector instructions a code-block under exec-mask control flow)
+__device__ __forceinline__ uint32_t t2_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
 struct T2Rd {
     const uint8_t *data;                // the decoder's buffer is data[0, end)
     uint64_t end;
@@ -67,7 +72,7 @@ struct T2Rd {
     __device__ __forceinline__ uint32_t byte_at(uint64_t pos) {    // pos < end (the marker tests, t2.go:470-486)
         const uint64_t a = (uint64_t)(uintptr_t)data + pos;
         raw_ensure(a, a + 1);
-        return raw_at(a);
+        return t2_uni(raw_at(a));
     }
     // the chunk that starts at data[pos]: its first byte holds `first` bits (0: by the rule, from the byte before it or `sff` when pos == 0
     // or the caller says so with force_sff >= 0)
@@ -106,7 +111,7 @@ struct T2Rd {
             }
             off += wd[j];
         }
-        nbits = (uint32_t)__shfl(incl, 63);
+        nbits = t2_uni((uint32_t)__shfl(incl, 63));
         if (lane == 63 && nb == T2D_CHUNK) sbit[T2D_CHUNK] = (uint16_t)nbits;    // (lanes cover i = 0 .. 255; the closing entry)
         __syncthreads();
         p0 = pos; nbytes = nb; bitpos = 0; w = 0; wav = 0; wnext = 0; have_chunk = true; stale = false;
@@ -121,7 +126,7 @@ struct T2Rd {
         uint32_t lo = bitpos >> 3, hi = bitpos / 7u + 3u;                        // a byte holds 7 or 8 bits (the chunk's first one: 1 ... 8)
         if (hi > nbytes) hi = nbytes;
         uint32_t j = lo;
-        for (uint32_t i = lo; i < hi; i++) if (sbit[i] <= bitpos) j = i;        // (a handful of entries; uniform)
+        for (uint32_t i = lo; i < hi; i++) if (t2_uni(sbit[i]) <= bitpos) j = i;    // (a handful of entries; uniform)
         return j;
     }
     // where the reader stands before its first chunk is made: at data[pos], `first` bits of that byte left (0: an untouched byte whose
@@ -130,11 +135,11 @@ struct T2Rd {
     __device__ __forceinline__ void fetch() {                       // keep more than 32 bits in the window while the chunk has them
         if (stale) {
             const uint32_t idx = bitpos >> 5, sh = bitpos & 31u;
-            w = idx * 32u < nbits ? (uint64_t)(bits[idx] << sh) << 32 : 0ull;
+            w = idx * 32u < nbits ? (uint64_t)(t2_uni(bits[idx]) << sh) << 32 : 0ull;
             wav = 32u - sh; wnext = idx + 1;
             stale = false;
         }
-        while (wav <= 32 && wnext * 32u < nbits) { w |= (uint64_t)bits[wnext] << (32u - wav); wav += 32; wnext++; }
+        while (wav <= 32 && wnext * 32u < nbits) { w |= (uint64_t)t2_uni(bits[wnext]) << (32u - wav); wav += 32; wnext++; }
     }
     // THE place where chunks are made (one call site in the kernel: the chunk builder is inlined once): the first chunk after seat(),
     // and a new one from the reader's position whenever fewer than 64 bits are left in a chunk that is not the buffer's last
@@ -144,7 +149,7 @@ struct T2Rd {
             if (pend_pos < end) { bp = pend_pos; bf = pend_first; bs = pend_first ? -1 : (pend_sff ? 1 : 0); go = true; }
         } else if (nbits - bitpos < 64 && p0 + nbytes < end) {
             const uint32_t j = byte_index();
-            bp = p0 + j; bf = j < nbytes ? (uint32_t)sbit[j + 1] - bitpos : 0u; go = true;      // (the bits of byte j still unread; a fresh byte: by the rule)
+            bp = p0 + j; bf = j < nbytes ? t2_uni(sbit[j + 1]) - bitpos : 0u; go = true;      // (the bits of byte j still unread; a fresh byte: by the rule)
         }
         if (go) build(bp, bf, bs);
     }
@@ -180,14 +185,14 @@ struct T2Rd {
             return;
         }
         uint32_t j = byte_index();                                  // byte j is the one in progress (cnt > 0) or the next one (cnt == 0)
-        const bool partial = j < nbytes && (uint32_t)sbit[j] < bitpos;
+        const bool partial = j < nbytes && t2_uni(sbit[j]) < bitpos;
         const uint32_t taken = partial ? j + 1 : j;
         rpos = p0 + taken;
-        cnt = partial ? (uint32_t)sbit[j + 1] - bitpos : 0u;
+        cnt = partial ? t2_uni(sbit[j + 1]) - bitpos : 0u;
         if (taken > 0 || p0 > 0) {
             const uint64_t a = (uint64_t)(uintptr_t)data + rpos - 1;
             raw_ensure(a, a + 1);
-            buf = raw_at(a);
+            buf = t2_uni(raw_at(a));
         } else buf = 0;
         sff = buf == 0xFFu && rpos > 0;
     }
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(64) void t2_decode_kernel(T2Chain *__restrict__ cha
     const int lane = threadIdx.x;
     T2Chain &Cn = chains[blockIdx.x];
 #ifdef J2K_T2D_STATS
-    const uint64_t t_start_ = wall_clock64(); uint32_t nblk_ = 0;
+    const uint64_t t_start_ = wall_clock64(); uint32_t nblk_ = 0; uint64_t t_fast_ = 0;
 #endif
     if (Cn.skip) {
         if (Cn.status) {                                            // a tile-part found malformed: its packets have no bodies (not a stale entry of the frame before)
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(64) void t2_decode_kernel(T2Chain *__restrict__ cha
     if (pchains && tile_par[blockIdx.x]) {
         // The tile launch behind a packet-parallel one (see "the packets of a tile side by side" below): every packet of this tile was
         // decoded on its own from a guessed state.  Kept if each packet ENDED in the state (position, carried flag) the next one was
-        // started from -- by induction the run this chain would make; otherwise the tile's fields are wiped and the chain runs.
+        // started from -- by induction the run this chain would make; otherwise the chain runs (and writes every field again).
         const int p0 = tile_packet0[blockIdx.x], npk = tile_packet0[blockIdx.x + 1] - p0;
         bool bad = false;
         for (int p = lane; p < npk; p += 64) {
@@ -243,14 +248,10 @@ __global__ __launch_bounds__(64) void t2_decode_kernel(T2Chain *__restrict__ cha
             }
             return;
         }
-        for (int p = 0; p < npk; p++) {                             // the serial decoder starts from a zeroed table
-            const j2k_t2_dev_packet P = packets[p0 + p];
-            if (P.ncb < 0 || P.cb0 < 0 || (uint64_t)P.cb0 + (uint64_t)P.ncb > ncbs) continue;
-            for (int64_t i = lane; i < P.ncb; i += 64) cbs[P.cb0 + i] = j2k_t2_dev_cb{};
-        }
-        __threadfence();
-        __syncthreads();
     }
+#ifdef J2K_T2D_STATS
+    const uint64_t t_a_ = wall_clock64(); uint64_t t_hdr_ = 0, t_pre_ = 0, t_post_ = 0;
+#endif
     const uint64_t base = Cn.start;
     T2Rd r;
     r.data = data + base; r.end = Cn.end - base; r.raw = raw; r.rwbase = ~0ull; r.bits = bits; r.sbit = sbit; r.lane = lane; r.eof = false;
@@ -268,6 +269,9 @@ __global__ __launch_bounds__(64) void t2_decode_kernel(T2Chain *__restrict__ cha
     int64_t done = 0;
     if (Cn.packet0 < 0 || Cn.npackets < 0 || Cn.packet0 + Cn.npackets > npackets_all) status = J2K_ERR_INVALID_ARG;
     for (int64_t k = 0; status == J2K_OK && k < Cn.npackets; k++) {
+#ifdef J2K_T2D_STATS
+        const uint64_t t_p0_ = wall_clock64();
+#endif
         const int64_t pk = Cn.packet0 + k;
         const j2k_t2_dev_packet P = packets[pk];
         if (P.ncb < 0 || P.cb0 < 0 || (uint64_t)P.cb0 + (uint64_t)P.ncb > ncbs) { status = J2K_ERR_INVALID_ARG; break; }
@@ -280,10 +284,15 @@ __global__ __launch_bounds__(64) void t2_decode_kernel(T2Chain *__restrict__ cha
         j2k_t2_dev_cb *pc = cbs + P.cb0;
         // The body loop (t2.go:489-499) takes bytes for every block with IncludedInLayers == layer and data -- also one this
         // header did not touch but whose fields say so from before (a table the caller filled, or an earlier packet of the same
-        // layer).  `clean`: the caller zeroed the table and decodes layer 0 only, so there is no such block and nothing is read.
+        // layer).  `clean`: layer 0 is decoded only and the table holds nothing from before -- 1: the caller zeroed it; 2 (frame calls): it
+        // may hold anything, this kernel writes EVERY field of every block of the packets it decodes (also of an empty packet) and flags
+        // the packets it did not reach (body_base = ~0), which is all t2_finish_kernel looks at.  No such block, nothing is read.
         const bool old_matters = !clean || layer != 0;
         // decodePacketHeader (t2.go:506-571) as ONE loop over its reading steps -- presence bit, then per code-block inclusion,
         // zero bit planes, pass count + length -- so that the chunk builder above has a single call site
+#ifdef J2K_T2D_STATS
+        const uint64_t t_b_ = wall_clock64(); t_pre_ += t_b_ - t_p0_;
+#endif
         enum { S_PRESENT, S_INCL, S_IMSB, S_REST, S_DONE };
         int step = S_PRESENT;
         int64_t i = 0;
@@ -297,13 +306,20 @@ __global__ __launch_bounds__(64) void t2_decode_kernel(T2Chain *__restrict__ cha
                 // Whole code-blocks straight from a 128-bit register window (four LDS words, one round trip each): inclusion value, zero
                 // bit planes, pass count, length -- a tight loop over the blocks for as long as the chunk holds 128 bits more.  Anything
                 // that might not fit (long unary values) is left to the stepwise reader below: nothing is committed before a block is complete.
+#ifdef J2K_T2D_STATS
+                const uint64_t tf_ = wall_clock64(); const int64_t i0_ = i;
+#endif
                 uint32_t bp = r.bitpos;
                 const uint32_t lim = r.nbits - 128u;
                 const uint32_t *bits_ = r.bits;
                 bool bail = false;
                 while (bp <= lim && i < P.ncb) {
+                    // (the loop-carried state through readfirstlane as well: the compiler cannot see that it is uniform across the trips)
+                    bp = t2_uni(bp);
+                    i = (int64_t)t2_uni((uint32_t)i);                                            // (i < ncb < 2^31)
+                    body = (uint64_t)t2_uni((uint32_t)(body >> 32)) << 32 | t2_uni((uint32_t)body);
                     const uint32_t idx = bp >> 5, sh = bp & 31u;
-                    uint64_t hi = (uint64_t)bits_[idx] << 32 | bits_[idx + 1], lo = (uint64_t)bits_[idx + 2] << 32 | bits_[idx + 3];
+                    uint64_t hi = (uint64_t)t2_uni(bits_[idx]) << 32 | t2_uni(bits_[idx + 1]), lo = (uint64_t)t2_uni(bits_[idx + 2]) << 32 | t2_uni(bits_[idx + 3]);
                     hi = (hi << sh) | ((lo >> 1) >> (63u - sh)); lo <<= sh;                      // >= 97 bits from bit 63 of hi down
                     uint32_t used = 0;
                     auto take = [&](uint32_t n) -> uint32_t {                                    // 1 <= n <= 32
@@ -315,7 +331,7 @@ __global__ __launch_bounds__(64) void t2_decode_kernel(T2Chain *__restrict__ cha
                     if (z1 > 30) { bail = true; break; }
                     (void)take(z1 + 1);
                     if (z1 != 0) {                                                               // not in this layer: only IncludedInLayers is written
-                        if (lane == 0) pc[i].included_in_layers = (int)z1;
+                        if (lane == 0) *reinterpret_cast<int4 *>(&pc[i]) = int4{(int)z1, 0, 0, 0};   // (every field: the table need not be zero before)
                         bp += used; i++;
                         continue;
                     }
@@ -343,6 +359,9 @@ __global__ __launch_bounds__(64) void t2_decode_kernel(T2Chain *__restrict__ cha
                     body += length;
                     bp += used; i++;
                 }
+#ifdef J2K_T2D_STATS
+                t_fast_ += wall_clock64() - tf_; nblk_ += (uint32_t)(i - i0_);
+#endif
                 if (bp != r.bitpos) { r.bitpos = bp; r.stale = true; }
                 if (i == P.ncb) { step = S_DONE; continue; }
                 if (!bail) continue;                                                             // the chunk is nearly used up: ensure() makes the next
@@ -360,7 +379,7 @@ __global__ __launch_bounds__(64) void t2_decode_kernel(T2Chain *__restrict__ cha
                     if (!r.unary_some(uv)) { if (!r.more_data()) { status = J2K_ERR_INVALID_ARG; break; } continue; }
                     inc = uv == 0;
                     incl_layers = (int)uv;
-                    if (lane == 0) pc[i].included_in_layers = incl_layers;
+                    if (lane == 0) { if (clean) *reinterpret_cast<int4 *>(&pc[i]) = int4{incl_layers, 0, 0, 0}; else pc[i].included_in_layers = incl_layers; }
                 } else {
                     inc = r.get(1) == 1;
                     if (r.eof) { status = J2K_ERR_INVALID_ARG; break; }
@@ -404,7 +423,12 @@ __global__ __launch_bounds__(64) void t2_decode_kernel(T2Chain *__restrict__ cha
                 else { step = S_INCL; if (old_matters) old = pc[i]; }
             }
         }
+#ifdef J2K_T2D_STATS
+        const uint64_t t_c_ = wall_clock64(); t_hdr_ += t_c_ - t_b_;
+#endif
         if (status != J2K_OK) break;
+        if (!present && clean == 2)                                                              // an empty packet: its blocks hold nothing
+            for (int64_t q = lane; q < P.ncb; q += 64) pc[q] = j2k_t2_dev_cb{};
         if (!present && old_matters) {
             for (int64_t q = 0; q < P.ncb; q++) {
                 const j2k_t2_dev_cb o = pc[q];
@@ -420,7 +444,13 @@ __global__ __launch_bounds__(64) void t2_decode_kernel(T2Chain *__restrict__ cha
         if (lane == 0) body_base[pk] = base + pos;
         pos += body;
         done = k + 1;
+#ifdef J2K_T2D_STATS
+        t_post_ += wall_clock64() - t_c_;
+#endif
     }
+#ifdef J2K_T2D_STATS
+    const uint64_t t_e_ = wall_clock64();
+#endif
     uint64_t st_rpos; uint32_t st_cnt, st_buf; bool st_ff;
     r.state(st_rpos, st_cnt, st_buf, st_ff);                       // (by every lane: it may restage the window)
     if (lane == 0) {
@@ -429,8 +459,8 @@ __global__ __launch_bounds__(64) void t2_decode_kernel(T2Chain *__restrict__ cha
         Cn.status = status; Cn.done = (int32_t)done;
 #ifdef J2K_T2D_STATS
         Cn.t_total = wall_clock64() - t_start_; Cn.t_reload = r.t_reload; Cn.t_build = r.t_build; Cn.n_reload = r.n_reload; Cn.n_build = r.n_build; Cn.n_packets = (uint32_t)done;
-        if (blockIdx.x == 0 || blockIdx.x == 39) printf("chain %d: total %llu ticks, reload %llu (%u), build %llu (%u) incl. reloads, packets %u\n", (int)blockIdx.x, (unsigned long long)Cn.t_total,
-                                                        (unsigned long long)Cn.t_reload, Cn.n_reload, (unsigned long long)Cn.t_build, Cn.n_build, Cn.n_packets);
+        if (blockIdx.x == 0 || blockIdx.x == 39 || blockIdx.x == 5) printf("chain %d of %d: total %llu ticks, reload %llu (%u), build %llu (%u) incl. reloads, packets %u, fast loop %llu ticks for %u blocks; prologue %llu, per packet: before header %llu, header %llu, after %llu; loop end at %llu\n", (int)blockIdx.x, (int)gridDim.x, (unsigned long long)Cn.t_total,
+                                                        (unsigned long long)Cn.t_reload, Cn.n_reload, (unsigned long long)Cn.t_build, Cn.n_build, Cn.n_packets, (unsigned long long)t_fast_, nblk_, (unsigned long long)(t_a_ - t_start_), (unsigned long long)t_pre_, (unsigned long long)t_hdr_, (unsigned long long)t_post_, (unsigned long long)(t_e_ - t_start_));
 #endif
         if (frame_status && status) atomicMin(frame_status, status);
     }
@@ -513,7 +543,7 @@ __global__ __launch_bounds__(64) void t2_tile_chains_kernel(const uint8_t *__res
 //   t2_decode_kernel  once more, a wavefront per TILE: first it checks that every packet was decoded and that the state packet p ENDED in
 //                     (position, flag) is the state packet p + 1 was started from.  By induction that is the serial decoder's run, field for field.  If anything is off -- a marker pair
 //                     inside an HT body (its bytes are not marker-free), a stream without the markers, a malformed header -- the
-//                     tile's fields are wiped and that wavefront runs the tile's chain as before: the guess decides speed, never the result.
+//                     wavefront runs the tile's chain as before, writing every field again: the guess decides speed, never the result.
 #define T2P_MAXM 1024                   // markers of one tile that the sort takes (2 per packet)
 __global__ __launch_bounds__(256) void t2_marks_kernel(const T2Chain *__restrict__ chains, const int *__restrict__ tile_packet0, const uint8_t *__restrict__ cs,
                                                        uint64_t *__restrict__ marks, uint32_t *__restrict__ cnt) {
@@ -732,12 +762,12 @@ hipError_t launch_t2_decode_tiles(hipStream_t s, void *chains, int ntiles, const
         const unsigned seg = (unsigned)std::min<uint64_t>(std::max(1, 2048 / ntiles), std::max<uint64_t>(1, len / (uint64_t)ntiles / 16384 + 1));
         hipLaunchKernelGGL(t2_marks_kernel, dim3(seg, (unsigned)ntiles), dim3(256), 0, s, tc, tile_packet0, data, marks, cnt);
         hipLaunchKernelGGL(t2_seed_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, tc, tile_packet0, data, marks, cnt, pch, seeds, tile_par);
-        hipLaunchKernelGGL(t2_decode_kernel, dim3((unsigned)npackets), dim3(64), 0, s, pch, packets, npackets, cbs, ncbs, data, sop, eph, 1, body_base, (int *)nullptr,
+        hipLaunchKernelGGL(t2_decode_kernel, dim3((unsigned)npackets), dim3(64), 0, s, pch, packets, npackets, cbs, ncbs, data, sop, eph, 2, body_base, (int *)nullptr,
                            (const T2Chain *)nullptr, (const uint64_t *)nullptr, (const uint32_t *)nullptr, (const int *)nullptr);
-        hipLaunchKernelGGL(t2_decode_kernel, dim3((unsigned)ntiles), dim3(64), 0, s, tc, packets, npackets, cbs, ncbs, data, sop, eph, 1, body_base, frame_status,
+        hipLaunchKernelGGL(t2_decode_kernel, dim3((unsigned)ntiles), dim3(64), 0, s, tc, packets, npackets, cbs, ncbs, data, sop, eph, 2, body_base, frame_status,
                            (const T2Chain *)pch, (const uint64_t *)seeds, (const uint32_t *)tile_par, tile_packet0);
     } else
-        hipLaunchKernelGGL(t2_decode_kernel, dim3((unsigned)ntiles), dim3(64), 0, s, tc, packets, npackets, cbs, ncbs, data, sop, eph, 1, body_base, frame_status,
+        hipLaunchKernelGGL(t2_decode_kernel, dim3((unsigned)ntiles), dim3(64), 0, s, tc, packets, npackets, cbs, ncbs, data, sop, eph, 2, body_base, frame_status,
                            (const T2Chain *)nullptr, (const uint64_t *)nullptr, (const uint32_t *)nullptr, (const int *)nullptr);
     hipLaunchKernelGGL(t2_finish_kernel, dim3((unsigned)npackets), dim3(256), 0, s, packets, cbs, ncbs, body_base, ht, mb, len, offs, lens, numbps, frame_status);
     return hipGetLastError();
