@@ -333,10 +333,11 @@ def run_closed_loop(args):
 
         def code(ln):
             p = ln["p"]
-            p.encode_frame_pixels(_lib.PIX_RGBA8, ln["pix"], sop=False, eph=False, out=ln["cs"], tile_offs=ln["toffs"])
+            p.encode_frame_pixels(_lib.PIX_RGBA8, ln["pix"], sop=True, eph=True, out=ln["cs"], tile_offs=ln["toffs"])
             # the decoder is handed the buffer at its capacity and the tile-part positions the encoder left on the device: no length
             # crosses to the host inside the step (a Go caller that holds the codestream passes its real length)
-            p.decode_frame_pixels(ln["cs"], ln["cs"].numel(), ln["back"], tile_offs=ln["toffs"], sop=False, eph=False)
+            # (SOP + EPH markers, 8 bytes a packet: the decoder parses a tile's packets side by side from them)
+            p.decode_frame_pixels(ln["cs"], ln["cs"].numel(), ln["back"], tile_offs=ln["toffs"], sop=True, eph=True)
 
         def barrier():
             for ln in lanes:
@@ -365,15 +366,18 @@ def run_closed_loop(args):
             ln["p"].frame_status()
             assert torch.equal(ln["back"], ln["pix"]), "closed-loop round trip is not bit-exact"
         total = int(lanes[0]["toffs"][-1].item())
+        lanes[0]["p"].frame_parallel_tiles()
+        code(lanes[0])
+        par_tiles = lanes[0]["p"].frame_parallel_tiles()
         out = {"metric": "Mpixels/s encode+decode, bit-exact round trip through tile-parts of packets (4K sRGB, 5-3 lossless, MQ coder, closed-loop mode)",
                "value": round(steps * F * B * W * H / dt / 1e6, 1), "unit": "Mpixels/s", "n_gpus": 1, "steps": steps, "warmup": args.warmup,
                "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
                "config": {"workload": "3840x2160 sRGB 8-bit, 512x512 tiles, 5-3 lossless + MQ block coder (T1.EncodeFast5 / T1.Decode), 64x64 code-blocks, "
                           "6 resolutions, j2k_params.closed_loop = 1 (this library's mode, outside reference parity: code-block windows that partition "
                           "the plane, packets the decoder can read); a step = image.RGBA.Pix -> forward transform -> block coder -> one packet per "
-                          "(tile, component, resolution) -> SOT | SOD | packets, then tile-part parse -> packet parse -> block decode -> placement -> "
+                          "(tile, component, resolution), SOP + EPH markers -> SOT | SOD | packets, then tile-part parse -> packet parse -> block decode -> placement -> "
                           "inverse transform -> image.RGBA.Pix, all on device buffers; the pixels that come back are compared with the pixels that went in",
-                          "frames_in_flight": F * B, "contexts": F, "frames_per_context": B, "codestream_bytes_per_frame": total // B, "single_frame_ms": round(single_ms / B, 2) if B > 1 else round(single_ms, 2),
+                          "frames_in_flight": F * B, "contexts": F, "frames_per_context": B, "codestream_bytes_per_frame": total // B, "tiles_parsed_packet_parallel": "%d of %d" % (par_tiles, int(lanes[0]["p"].info.tiles)), "single_frame_ms": round(single_ms / B, 2) if B > 1 else round(single_ms, 2),
                           "round_trip": "bit-exact (checked after the timed region, every frame in flight)"},
                "roofline": {"bound": "hbm", "kernel": "n/a (the MQ block coder bounds this configuration: serial chains, no bandwidth roofline)", "achieved": None,
                             "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None, "avg_launch_us": None}}

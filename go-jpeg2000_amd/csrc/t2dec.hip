@@ -3,13 +3,16 @@
 //                         wavefront) per chain -- the reference's decoder as it is written, or, with the J2K_T2_* flags of the
 //                         closed-loop mode (include/j2kgfx.h), one that can read what the encoder wrote
 //   t2_tile_chains_kernel the tile-parts of a frame (SOT ... SOD, codestream.Parser.ReadTilePartHeader, parser.go:894-983) as chains
-//   t2_blocks_kernel      the decoded code-block fields as the block decoder's inputs (offsets, lengths, bit-plane counts)
+//   t2_marks_kernel, t2_seed_kernel   SOP + EPH streams: every packet's start guessed from the markers, one chain per PACKET; the tile
+//                         launch of t2_decode_kernel verifies the guesses against the serial rule before it would run the tile's chain
+//   t2_blocks_kernel / t2_finish_kernel   the decoded code-block fields as the block decoder's inputs (offsets, lengths, bit-plane counts)
 //   place_blocks_kernel   decoded blocks -> their windows of the coefficient planes (the step decoder.decodeTile leaves out,
 //                         decoder.go:375-411)
 // What is serial and what is not.  A packet header is a prefix code: the place of every field depends on every field before it,
 // and the place of the NEXT packet on the lengths this header carries -- one chain per decoder object, i.e. per tile in the
 // closed-loop mode (a new PacketDecoder per tile, as the encoder side takes a new PacketEncoder) and per run in the reference's
-// mode (its header reader runs over the whole buffer on its own).  A chain is parsed by one wavefront with every lane holding the
+// mode (its header reader runs over the whole buffer on its own).  Where the stream carries SOP and EPH markers the second dependence
+// can be guessed away and checked afterwards ("the packets of a tile side by side", below).  A chain is parsed by one wavefront with every lane holding the
 // same state (wave-uniform: the instruction stream of one lane, and all 64 there for the refills of the LDS window the bytes are
 // read through); the chains of a frame run side by side.  Nothing is copied: a block's body stays where it is and the block
 // decoder reads it from there.
