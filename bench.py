@@ -106,6 +106,7 @@ def other_configs_summary(budget_s=200.0):
             ("c1gpu", ["--config", "c1gpu", "--steps", "3", "--warmup", "1"]),
             ("c4", ["--config", "c4", "--shard", "tiles", "--steps", "30", "--warmup", "3"]),
             ("closed_loop", ["--config", "cl", "--steps", "3", "--warmup", "1"]),
+            ("closed_loop_ht", ["--config", "clht", "--steps", "50", "--warmup", "5"]),
             ("host_boundary", ["--io", "host", "--steps", "50", "--warmup", "3"])]
     for name, extra in plan:
         left = budget_s - (time.perf_counter() - t_all)
@@ -127,10 +128,10 @@ def other_configs_summary(budget_s=200.0):
             if name == "host_boundary":
                 out[name] = dict(d["host_boundary"], wall_s=round(time.perf_counter() - t0, 1))
                 continue
-            if name in ("c4", "closed_loop"):
+            if name in ("c4", "closed_loop", "closed_loop_ht"):
                 out[name] = {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
                              "n_gpus": d["n_gpus"], "scaling": d["scaling"], "wall_s": round(time.perf_counter() - t0, 1)}
-                for k in ("value_with_d2h", "codestream_bytes", "tiles", "parallelism", "frames_in_flight", "contexts", "frames_per_context", "codestream_bytes_per_frame", "single_frame_ms", "round_trip"):
+                for k in ("value_with_d2h", "codestream_bytes", "tiles", "parallelism", "frames_in_flight", "contexts", "frames_per_context", "codestream_bytes_per_frame", "tiles_parsed_packet_parallel", "single_frame_ms", "round_trip"):
                     if k in d["config"]:
                         out[name][k] = d["config"][k]
                 continue
@@ -174,7 +175,7 @@ def run(state):
                          "same digest, either way")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("J2K_BENCH_INFLIGHT", "3")),
                     help="independent frames coded concurrently per step, each on its own context/stream")
-    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5", "c1gpu", "cl"], default="c2",
+    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5", "c1gpu", "cl", "clht"], default="c2",
                     help="BASELINE.json configuration: c2 (default, the headline: 4K RGB8 5-3 + HT), c3 (4K RGB 12-bit, 9-7 lossy + MQ), "
                          "c5 (2048x2048 gray16 frames, 5-3 + HT); c4 only with --shard tiles; cl = the closed-loop codec (4K RGB8, MQ coder, "
                          "pixels -> tile-parts of packets -> pixels, bit-exact)")
@@ -218,12 +219,12 @@ def run(state):
             args.config = "c4"
         args.inflight = 1
         return bench_extra.run_shard_tiles(args)
-    if args.config == "cl":
+    if args.config in ("cl", "clht"):
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
         if "--inflight" not in " ".join(sys.argv):
             args.inflight = 0
         if "--steps" not in " ".join(sys.argv):
-            args.steps, args.warmup = 3, 1
+            args.steps, args.warmup = (50, 5) if args.config == "clht" else (3, 1)
         return bench_host.run_closed_loop(args)
     if args.io == "host":
         # two copy streams + the lanes' library streams, each on a hardware queue of its own (a copy stream that shares a queue with the

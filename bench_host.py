@@ -308,22 +308,25 @@ def run_host_boundary(args):
 
 
 def run_closed_loop(args):
-    """4K RGB8, MQ coder, closed-loop mode: pixels -> tile-parts -> pixels on device buffers, F frames in flight"""
+    """4K RGB8, closed-loop mode: pixels -> tile-parts -> pixels on device buffers, F frames in flight.  MQ coder (--config cl: the
+    bit-exact round trip) or the reference's HT coder (--config clht: it codes one row in four, so what comes back is checked against the
+    same stream decoded with the serial packet parser, not against the source)"""
     import numpy as np
     import torch
-    from j2kgfx import CODER_MQ, Context, _lib
+    from j2kgfx import CODER_HT, CODER_MQ, Context, _lib
+    ht = getattr(args, "config", "cl") == "clht"
     from j2kgfx.codec import FramePlan
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
     torch.cuda.set_device(0)
-    F = args.inflight if args.inflight > 0 else 12
-    B = max(1, int(getattr(args, "batch", 0) or 4))            # frames per context and call: one plan over the frames stacked vertically (j2k_params.frame_rows)
+    F = args.inflight if args.inflight > 0 else (4 if ht else 12)
+    B = max(1, int(getattr(args, "batch", 0) or (1 if ht else 4)))   # frames per context and call: one plan over the frames stacked vertically (j2k_params.frame_rows)
     lanes = []
     ok = False
     try:
         for f in range(F):
             ctx = Context(0)
-            p = FramePlan(W, H * B, C, precision=PREC, lossless=True, num_resolutions=NRES, cb=(CB, CB), tile=(TILE, TILE), coder=CODER_MQ, ctx=ctx,
+            p = FramePlan(W, H * B, C, precision=PREC, lossless=True, num_resolutions=NRES, cb=(CB, CB), tile=(TILE, TILE), coder=CODER_HT if ht else CODER_MQ, ctx=ctx,
                           track_streams=False, closed_loop=True, frame_rows=H if B > 1 else 0)
             base = _rgba_host(np, f)
             pix = torch.from_numpy(np.concatenate([base if b == 0 else np.roll(base, (41 * b, 388 * b), axis=(0, 1)) for b in range(B)], axis=0)).to(p.device)
@@ -364,22 +367,32 @@ def run_closed_loop(args):
         single_ms = (time.perf_counter() - t1) * 1e3
         for ln in lanes:
             ln["p"].frame_status()
-            assert torch.equal(ln["back"], ln["pix"]), "closed-loop round trip is not bit-exact"
+            if not ht:
+                assert torch.equal(ln["back"], ln["pix"]), "closed-loop round trip is not bit-exact"
+            else:                                                   # the same tile-parts through the serial packet parser: the same pixels
+                got = ln["back"].clone()
+                ln["ctx"].set_option("t2_parallel", 0)
+                ln["p"].decode_frame_pixels(ln["cs"], ln["cs"].numel(), ln["back"], tile_offs=ln["toffs"], sop=True, eph=True)
+                ln["ctx"].set_option("t2_parallel", 1)
+                ln["p"].frame_status()
+                assert torch.equal(ln["back"], got), "closed-loop HT decode: packet-parallel and serial parses differ"
         total = int(lanes[0]["toffs"][-1].item())
         lanes[0]["p"].frame_parallel_tiles()
         code(lanes[0])
         par_tiles = lanes[0]["p"].frame_parallel_tiles()
-        out = {"metric": "Mpixels/s encode+decode, bit-exact round trip through tile-parts of packets (4K sRGB, 5-3 lossless, MQ coder, closed-loop mode)",
+        out = {"metric": ("Mpixels/s encode+decode through tile-parts of packets (4K sRGB, 5-3 lossless, the reference's HT coder, closed-loop mode)" if ht else
+                          "Mpixels/s encode+decode, bit-exact round trip through tile-parts of packets (4K sRGB, 5-3 lossless, MQ coder, closed-loop mode)"),
                "value": round(steps * F * B * W * H / dt / 1e6, 1), "unit": "Mpixels/s", "n_gpus": 1, "steps": steps, "warmup": args.warmup,
                "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-               "config": {"workload": "3840x2160 sRGB 8-bit, 512x512 tiles, 5-3 lossless + MQ block coder (T1.EncodeFast5 / T1.Decode), 64x64 code-blocks, "
+               "config": {"workload": "3840x2160 sRGB 8-bit, 512x512 tiles, 5-3 lossless + " + ("HT block coder (the reference's, bug for bug)" if ht else "MQ block coder (T1.EncodeFast5 / T1.Decode)") + ", 64x64 code-blocks, "
                           "6 resolutions, j2k_params.closed_loop = 1 (this library's mode, outside reference parity: code-block windows that partition "
                           "the plane, packets the decoder can read); a step = image.RGBA.Pix -> forward transform -> block coder -> one packet per "
                           "(tile, component, resolution), SOP + EPH markers -> SOT | SOD | packets, then tile-part parse -> packet parse -> block decode -> placement -> "
                           "inverse transform -> image.RGBA.Pix, all on device buffers; the pixels that come back are compared with the pixels that went in",
                           "frames_in_flight": F * B, "contexts": F, "frames_per_context": B, "codestream_bytes_per_frame": total // B, "tiles_parsed_packet_parallel": "%d of %d" % (par_tiles, int(lanes[0]["p"].info.tiles)), "single_frame_ms": round(single_ms / B, 2) if B > 1 else round(single_ms, 2),
-                          "round_trip": "bit-exact (checked after the timed region, every frame in flight)"},
-               "roofline": {"bound": "hbm", "kernel": "n/a (the MQ block coder bounds this configuration: serial chains, no bandwidth roofline)", "achieved": None,
+                          "round_trip": ("the reference's HT coder codes one row in four: pixels back == the same stream through the serial packet parser (checked after the timed region)" if ht
+                                         else "bit-exact (checked after the timed region, every frame in flight)")},
+               "roofline": {"bound": "hbm", "kernel": "n/a (see --config c2 for the kernels' rooflines)" if ht else "n/a (the MQ block coder bounds this configuration: serial chains, no bandwidth roofline)", "achieved": None,
                             "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None, "avg_launch_us": None}}
         print(json.dumps(out))
         ok = True

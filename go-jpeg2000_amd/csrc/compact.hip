@@ -68,46 +68,7 @@ __global__ __launch_bounds__(1024) void scan_lens_kernel(const uint32_t *__restr
     if (tid == 0) { offs[n] = carry; if (TWO) toffs[n] = carry2; }
 }
 
-// n bytes src -> dst, any alignment on both sides, one wavefront: bytes up to the destination's next 16-byte boundary,
-// then aligned 16-byte stores of (possibly unaligned) 16-byte loads, then the tail bytes
-__device__ __forceinline__ void copy_bytes(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, uint32_t n, int lane) {
-    const uint32_t head = min(n, (uint32_t)((16 - ((uintptr_t)dst & 15)) & 15));
-    if ((uint32_t)lane < head) dst[lane] = src[lane];
-    const uint32_t nv = (n - head) >> 4;
-    for (uint32_t i = lane; i < nv; i += 64) {
-        uint4 v;
-        __builtin_memcpy(&v, src + head + 16 * (size_t)i, 16);
-        *reinterpret_cast<uint4 *>(dst + head + 16 * (size_t)i) = v;
-    }
-    const uint32_t done = head + (nv << 4);
-    if (done + lane < n) dst[done + lane] = src[done + lane];
-}
-__device__ __forceinline__ void zero_run(uint8_t *__restrict__ dst, uint32_t n, int lane) {
-    const uint32_t head = min(n, (uint32_t)((16 - ((uintptr_t)dst & 15)) & 15));
-    if ((uint32_t)lane < head) dst[lane] = 0;
-    const uint32_t nv = (n - head) >> 4;
-    for (uint32_t i = lane; i < nv; i += 64) *reinterpret_cast<uint4 *>(dst + head + 16 * (size_t)i) = make_uint4(0, 0, 0, 0);
-    const uint32_t done = head + (nv << 4);
-    if (done + lane < n) dst[done + lane] = 0;
-}
-
-// one wavefront per job.  maglens != NULL (HT blocks coded by j2k_plan_encode_stream): the slot holds
-// MagSgn | <hole> | VLC | SCUP -- the MEL segment of max(64, 2wh)/4 zero bytes (ht.go:978, 1019) was never written to the
-// slot and is produced here as zeros, so two thirds of a 64x64 block's bytes are neither stored twice nor read back.
-__device__ __forceinline__ void gather_job(const BlockJob &J, const uint8_t *__restrict__ slots, uint8_t *__restrict__ dst, uint32_t len,
-                                           bool ht, uint32_t mag, int lane) {
-    const uint8_t *src = slots + J.out_off;
-    if (!ht) {
-        copy_bytes(dst, src, len, lane);
-        return;
-    }
-    const size_t nsamp = (size_t)J.w * J.h;
-    const uint32_t mel = (uint32_t)((nsamp * 2 < 64 ? 64 : nsamp * 2) / 4);
-    copy_bytes(dst, src, mag, lane);
-    zero_run(dst + mag, mel, lane);
-    copy_bytes(dst + mag + mel, src + mag + mel, len - mag - mel, lane);
-}
-
+// (copy_bytes / zero_run / gather_job: j2k_internal.h -- the packet coder gathers from slots too)
 __global__ __launch_bounds__(256) void gather_kernel(const BlockJob *__restrict__ jobs, int njobs, const uint8_t *__restrict__ slots,
                                                      const uint32_t *__restrict__ lens, const uint64_t *__restrict__ offs,
                                                      uint8_t *__restrict__ stream, const uint32_t *__restrict__ maglens) {

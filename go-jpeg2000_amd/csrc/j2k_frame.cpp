@@ -117,13 +117,16 @@ static int cl_prepare(j2k_plan *P) {
         max_tile = std::max(max_tile, b);
         total += b;
     }
-    P->t2_stream_cap = (size_t)total + 64;
+    (void)total;
     P->max_tile_bytes = std::max<uint64_t>(P->max_tile_bytes, max_tile);
+    std::vector<int32_t> ptile(np ? np : 1, 0);                     // packet -> its tile (packet p ends up 14 (ptile[p] + 1) bytes behind its place among the packets)
+    for (int t = 0; t < P->tile_count; t++)
+        for (int q = tp0[t]; q < tp0[t + 1]; q++) ptile[(size_t)q] = t;
     int r = upload(ctx, &P->d_tile_packet0, tp0);
+    if (r == J2K_OK) r = upload(ctx, &P->d_t2_ptile, ptile);
     auto alloc = [&](void **p, size_t bytes) { if (r == J2K_OK) { hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 64)); if (e != hipSuccess) r = fail_hip(ctx, e, "hipMalloc (frame codec)"); } };
     alloc((void **)&P->d_t2_cbs, n * sizeof(j2k_t2_dev_cb));
     alloc((void **)&P->d_t2_poffs, (np + 1) * 8);
-    alloc((void **)&P->d_t2_stream, P->t2_stream_cap);
     alloc(&P->d_t2_ws, ((j2k::t2_dev_workspace((long)np) + 15) & ~size_t(15)) + 64);
     alloc(&P->d_t2_chains, (size_t)P->tile_count * j2k::t2_chain_bytes());
     alloc((void **)&P->d_t2_body_base, np * 8);
@@ -143,6 +146,21 @@ extern "C" size_t j2k_plan_frame_bound(const j2k_plan *P) {
     return (size_t)P->bytes_cap + 16 * P->blocks.size() + 16 * pk.size() + 14 * (size_t)P->tile_count + 64;
 }
 
+// the packets of a frame written where they end up (t2dev.hip: launch_t2_encode_tile_parts).  d_stream + d_offs: the dense block stream, or
+// d_offs == NULL: d_stream is the plan's slot buffer as plan_encode_private_slots left it and every block is gathered from its slot
+static int encode_tile_parts_impl(j2k_plan *P, const uint8_t *d_data, const uint64_t *d_offs, const uint32_t *d_lens, const uint8_t *d_numbps,
+                                  int sop, int eph, uint8_t *d_out, size_t cap, uint64_t *d_tile_offs) {
+    j2k_ctx *ctx = P->ctx;
+    const long n = (long)P->blocks.size(), np = P->t2_npackets;
+    const int ht = P->spec.coder == J2K_CODER_HT ? 1 : 0;
+    uint64_t *d_res = reinterpret_cast<uint64_t *>((uint8_t *)P->d_t2_ws + ((j2k::t2_dev_workspace(np) + 15) & ~size_t(15)));
+    HIPCHK(ctx, j2k::launch_t2_fill_cbs(ctx->stream, n, d_offs, d_lens, d_numbps, 31, ht | 2, P->d_t2_cbs, d_res));
+    HIPCHK(ctx, j2k::launch_t2_encode_tile_parts(ctx->stream, P->d_t2_packets, np, P->d_t2_cbs, (uint64_t)n, d_data, sop, eph, d_out, (uint64_t)cap, P->d_t2_poffs,
+                                                 P->d_t2_ws, d_res, P->d_t2_ptile, P->d_tile_packet0, P->tile_count, P->tile_first, d_tile_offs, P->d_frame_status,
+                                                 d_offs ? nullptr : (P->d_bjobs_alias ? P->d_bjobs_alias : P->d_bjobs), d_offs ? nullptr : (ht ? P->d_maglens : nullptr), ht));
+    return J2K_OK;
+}
+
 extern "C" int j2k_plan_encode_tile_parts(j2k_plan *P, const uint8_t *d_stream, const uint64_t *d_offs, const uint32_t *d_lens, const uint8_t *d_numbps,
                                           int sop, int eph, uint8_t *d_out, size_t cap, uint64_t *d_tile_offs) {
     if (!P) return J2K_ERR_INVALID_ARG;
@@ -151,15 +169,7 @@ extern "C" int j2k_plan_encode_tile_parts(j2k_plan *P, const uint8_t *d_stream, 
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int r = cl_prepare(P);
     if (r != J2K_OK) return r;
-    const long n = (long)P->blocks.size(), np = P->t2_npackets;
-    HIPCHK(ctx, j2k::launch_t2_fill_cbs(ctx->stream, n, d_offs, d_lens, d_numbps, 31, (P->spec.coder == J2K_CODER_HT ? 1 : 0) | 2, P->d_t2_cbs));
-    uint64_t *d_res = reinterpret_cast<uint64_t *>((uint8_t *)P->d_t2_ws + ((j2k::t2_dev_workspace(np) + 15) & ~size_t(15)));
-    HIPCHK(ctx, hipMemsetAsync(d_res, 0, 3 * sizeof(uint64_t), ctx->stream));
-    HIPCHK(ctx, j2k::launch_t2_encode_packets(ctx->stream, P->d_t2_packets, np, P->d_t2_cbs, (uint64_t)n, d_stream, sop, eph, 0, P->d_t2_stream,
-                                              (uint64_t)P->t2_stream_cap, P->d_t2_poffs, P->d_t2_ws, d_res));
-    HIPCHK(ctx, launch_assemble_tiles(ctx->stream, P->d_t2_stream, P->d_t2_poffs, P->d_tile_packet0, P->tile_count, P->tile_first, P->max_tile_bytes,
-                                      d_out, nullptr, (uint64_t)cap, d_tile_offs, P->d_frame_status));
-    return J2K_OK;
+    return encode_tile_parts_impl(P, d_stream, d_offs, d_lens, d_numbps, sop, eph, d_out, cap, d_tile_offs);
 }
 
 extern "C" int j2k_plan_decode_tile_parts(j2k_plan *P, const uint8_t *d_cs, size_t len, const uint64_t *d_tile_offs, int sop, int eph,
@@ -227,7 +237,6 @@ static int cl_workspaces(j2k_plan *P) {
     const size_t n = P->blocks.size();
     auto alloc = [&](void **p, size_t bytes) { if (r == J2K_OK) { hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 64)); if (e != hipSuccess) r = fail_hip(ctx, e, "hipMalloc (frame codec)"); } };
     alloc((void **)&P->d_cl_decoded, (size_t)P->decoded_elems * 4);
-    alloc((void **)&P->d_cl_stream, (size_t)P->bytes_cap);
     alloc((void **)&P->d_cl_offs, (n + 1) * 8);
     alloc((void **)&P->d_cl_lens, n * 4 + 16);
     alloc((void **)&P->d_cl_numbps, n + 16);
@@ -238,11 +247,14 @@ static int cl_workspaces(j2k_plan *P) {
 extern "C" int j2k_plan_encode_frame_pixels(j2k_plan *P, int format, const void *d_pix, size_t stride, int sop, int eph, uint8_t *d_out, size_t cap,
                                             uint64_t *d_tile_offs) {
     if (!P) return J2K_ERR_INVALID_ARG;
+    if (!d_out || !d_tile_offs) return fail(P->ctx, J2K_ERR_INVALID_ARG, "null device pointer");
     int r = cl_prepare(P);
     if (r == J2K_OK) r = cl_workspaces(P);
     if (r == J2K_OK) r = j2k_plan_forward_pixels(P, format, d_pix, stride, P->d_cl_coeff);
-    if (r == J2K_OK) r = j2k_plan_encode_stream(P, P->d_cl_coeff, P->d_cl_stream, P->d_cl_offs, P->d_cl_lens, P->d_cl_numbps);
-    if (r == J2K_OK) r = j2k_plan_encode_tile_parts(P, P->d_cl_stream, P->d_cl_offs, P->d_cl_lens, P->d_cl_numbps, sop, eph, d_out, cap, d_tile_offs);
+    // block coding into the plan's slots, then every block's bytes ONCE: from its slot to its place in its packet in its tile-part (the stage
+    // calls j2k_plan_encode_stream + j2k_plan_encode_tile_parts copy them three times: dense stream, packets, tile-parts)
+    if (r == J2K_OK) r = plan_encode_private_slots(P, P->d_cl_coeff, P->d_cl_lens, P->d_cl_numbps);
+    if (r == J2K_OK) r = encode_tile_parts_impl(P, (const uint8_t *)P->d_slots, nullptr, P->d_cl_lens, P->d_cl_numbps, sop, eph, d_out, cap, d_tile_offs);
     return r;
 }
 

@@ -114,10 +114,54 @@ hipError_t launch_colorspace(hipStream_t s, int cs, int32_t *planes, int ncomp, 
 hipError_t launch_pack_pixels(hipStream_t s, const int32_t *planes, int ncomp, int precision, int w, int h, uint8_t *pix, size_t stride);
 
 // Tier-2 packets on device buffers (t2dev.hip)
-hipError_t launch_t2_fill_cbs(hipStream_t s, long n, const uint64_t *offs, const uint32_t *lens, const uint8_t *numbps, int mb, int ht, j2k_t2_dev_cb *cbs);
+hipError_t launch_t2_fill_cbs(hipStream_t s, long n, const uint64_t *offs, const uint32_t *lens, const uint8_t *numbps, int mb, int ht, j2k_t2_dev_cb *cbs, uint64_t *reset = nullptr);
+hipError_t launch_t2_encode_tile_parts(hipStream_t s, const j2k_t2_dev_packet *packets, long npackets, const j2k_t2_dev_cb *cbs, uint64_t ncbs, const uint8_t *data,
+                                       int sop, int eph, uint8_t *out, uint64_t cap, uint64_t *offs, void *ws, uint64_t *result, const int32_t *ptile,
+                                       const int *tile_packet0, int ntiles, int tile_first, uint64_t *tile_offs, int *status, const BlockJob *slot_jobs,
+                                       const uint32_t *maglens, int ht);
 size_t t2_dev_workspace(long npackets);
 hipError_t launch_t2_encode_packets(hipStream_t s, const j2k_t2_dev_packet *packets, long npackets, const j2k_t2_dev_cb *cbs, uint64_t ncbs, const uint8_t *data,
                                     int sop, int eph, int delay_in, uint8_t *out, uint64_t cap, uint64_t *offs, void *ws, uint64_t *result);
+
+// n bytes src -> dst, any alignment on both sides, one wavefront: bytes up to the destination's next 16-byte boundary,
+// then aligned 16-byte stores of (possibly unaligned) 16-byte loads, then the tail bytes
+__device__ __forceinline__ void copy_bytes(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, uint32_t n, int lane) {
+    const uint32_t head = min(n, (uint32_t)((16 - ((uintptr_t)dst & 15)) & 15));
+    if ((uint32_t)lane < head) dst[lane] = src[lane];
+    const uint32_t nv = (n - head) >> 4;
+    for (uint32_t i = lane; i < nv; i += 64) {
+        uint4 v;
+        __builtin_memcpy(&v, src + head + 16 * (size_t)i, 16);
+        *reinterpret_cast<uint4 *>(dst + head + 16 * (size_t)i) = v;
+    }
+    const uint32_t done = head + (nv << 4);
+    if (done + lane < n) dst[done + lane] = src[done + lane];
+}
+__device__ __forceinline__ void zero_run(uint8_t *__restrict__ dst, uint32_t n, int lane) {
+    const uint32_t head = min(n, (uint32_t)((16 - ((uintptr_t)dst & 15)) & 15));
+    if ((uint32_t)lane < head) dst[lane] = 0;
+    const uint32_t nv = (n - head) >> 4;
+    for (uint32_t i = lane; i < nv; i += 64) *reinterpret_cast<uint4 *>(dst + head + 16 * (size_t)i) = make_uint4(0, 0, 0, 0);
+    const uint32_t done = head + (nv << 4);
+    if (done + lane < n) dst[done + lane] = 0;
+}
+
+// one wavefront per job.  maglens != NULL (HT blocks coded by j2k_plan_encode_stream): the slot holds
+// MagSgn | <hole> | VLC | SCUP -- the MEL segment of max(64, 2wh)/4 zero bytes (ht.go:978, 1019) was never written to the
+// slot and is produced here as zeros, so two thirds of a 64x64 block's bytes are neither stored twice nor read back.
+__device__ __forceinline__ void gather_job(const BlockJob &J, const uint8_t *__restrict__ slots, uint8_t *__restrict__ dst, uint32_t len,
+                                           bool ht, uint32_t mag, int lane) {
+    const uint8_t *src = slots + J.out_off;
+    if (!ht) {
+        copy_bytes(dst, src, len, lane);
+        return;
+    }
+    const size_t nsamp = (size_t)J.w * J.h;
+    const uint32_t mel = (uint32_t)((nsamp * 2 < 64 ? 64 : nsamp * 2) / 4);
+    copy_bytes(dst, src, mag, lane);
+    zero_run(dst + mag, mel, lane);
+    copy_bytes(dst + mag + mel, src + mag + mel, len - mag - mel, lane);
+}
 
 // an environment variable of the tuning set: read only when J2K_TUNING=1 (see j2k_ctx_create)
 inline const char *tuning_env(const char *name) {

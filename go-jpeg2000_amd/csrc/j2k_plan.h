@@ -164,16 +164,15 @@ struct j2k_plan {
     int *d_tile_packet0 = nullptr;               // first packet of every tile of the shard (+ the packet count)
     int t2_npackets = 0;
     j2k_t2_dev_cb *d_t2_cbs = nullptr;           // code-block table of the packet coder / decoder (one entry per job)
-    uint64_t *d_t2_poffs = nullptr;              // encode: where each packet starts in d_t2_stream (+ the total)
-    uint8_t *d_t2_stream = nullptr;              // encode: the packets end to end, before the tile-part headers go in between
-    size_t t2_stream_cap = 0;
+    uint64_t *d_t2_poffs = nullptr;              // encode: where each packet starts among the packets (+ their total)
+    int32_t *d_t2_ptile = nullptr;               // encode: packet -> tile (its place in the tile-parts is 14 (tile + 1) bytes further)
     void *d_t2_ws = nullptr;                     // encode: the packet coder's workspace + its 3-word result
     void *d_t2_chains = nullptr;                 // decode: one chain per tile
     uint64_t *d_t2_body_base = nullptr;          // decode: where each packet's bodies start
     void *d_t2_par = nullptr;                    // decode: one chain per PACKET, the marker lists and guesses (t2_par_workspace)
     int *d_frame_status = nullptr;               // sticky status word of the asynchronous frame calls (j2k_plan_frame_status)
     int32_t *d_cl_decoded = nullptr, *d_cl_coeff = nullptr;   // j2k_plan_*_frame_pixels: decoded blocks, coefficient planes
-    uint8_t *d_cl_stream = nullptr, *d_cl_numbps = nullptr; uint64_t *d_cl_offs = nullptr; uint32_t *d_cl_lens = nullptr;
+    uint8_t *d_cl_numbps = nullptr; uint64_t *d_cl_offs = nullptr; uint32_t *d_cl_lens = nullptr;
     int max_block_h = 0;
     void *d_host_io = nullptr, *d_host_pix = nullptr;          // j2k_encode_pixels_host / j2k_decode_pixels_host: tile-parts / pixels on the device
     size_t host_io_bytes = 0, host_pix_bytes = 0;

@@ -553,6 +553,33 @@ extern "C" int j2k_plan_encode_blocks(j2k_plan *P, const int32_t *d_coeff, uint8
     return J2K_OK;
 }
 
+// Block coding into the PLAN's slot buffer, no compaction (j2k_plan_encode_stream gathers it into the dense stream; the closed-loop frame
+// encoder gathers it straight into the tile-parts).  HT: the slot buffer is private, so the MEL zero bytes are not written into it -- whoever
+// gathers emits them (gather_job, j2k_internal.h; P->d_maglens says where).
+int plan_encode_private_slots(j2k_plan *P, const int32_t *d_coeff, uint32_t *d_lens, uint8_t *d_numbps) {
+    j2k_ctx *ctx = P->ctx;
+    const int n = (int)P->blocks.size();
+    if (!P->d_slots) {
+        if (ctx->capturing) return fail(ctx, J2K_ERR_INVALID_ARG, "capture: run the same calls once before j2k_ctx_capture_begin");
+        HIPCHK(ctx, hipMalloc(&P->d_slots, (size_t)P->bytes_cap + 64));
+    }
+    if (P->spec.coder != J2K_CODER_HT) return j2k_plan_encode_blocks(P, d_coeff, (uint8_t *)P->d_slots, d_lens, d_numbps);
+    if (!P->d_maglens) {
+        if (ctx->capturing) return fail(ctx, J2K_ERR_INVALID_ARG, "capture: run the same calls once before j2k_ctx_capture_begin");
+        HIPCHK(ctx, hipMalloc((void **)&P->d_maglens, (size_t)n * 4));
+        HIPCHK(ctx, hipMalloc((void **)&P->d_mels, (size_t)n * 4));
+        HIPCHK(ctx, hipMalloc((void **)&P->d_toffs, ((size_t)n + 1) * 8));
+        HIPCHK(ctx, launch_mel_table(ctx->stream, P->d_bjobs, n, P->d_mels));
+    }
+    int r = stage_reserve(ctx, 3, 256);
+    if (r != J2K_OK) return r;
+    ctx->fault_armed = true;
+    for (int rep_ = 0; rep_ < dev_reps(8); rep_++)
+    HIPCHK(ctx, launch_ht_encode(ctx->stream, P->d_bjobs, n, d_coeff, (uint8_t *)P->d_slots, d_lens, d_numbps, (int *)ctx->stage[3],
+                                 P->d_maglens, P->d_ht_ujobs, P->ht_nunique, P->d_ht_alias_next));
+    return J2K_OK;
+}
+
 // encode_blocks + compact in one launch when every block is on the parallel HT path; otherwise the two steps through a
 // slot buffer owned by the context
 extern "C" int j2k_plan_encode_stream(j2k_plan *P, const int32_t *d_coeff, uint8_t *d_stream, uint64_t *d_offs, uint32_t *d_lens,
@@ -589,25 +616,9 @@ extern "C" int j2k_plan_encode_stream(j2k_plan *P, const int32_t *d_coeff, uint8
                                             P->epoch, (int *)ctx->stage[3]));
         return J2K_OK;
     }
-    if (!P->d_slots) {
-        if (ctx->capturing) return fail(ctx, J2K_ERR_INVALID_ARG, "capture: run the same calls once before j2k_ctx_capture_begin");
-        HIPCHK(ctx, hipMalloc(&P->d_slots, (size_t)P->bytes_cap + 64));
-    }
+    int r = plan_encode_private_slots(P, d_coeff, d_lens, d_numbps);
+    if (r != J2K_OK) return r;
     if (P->spec.coder == J2K_CODER_HT) {
-        // the slot buffer is private here: the MEL zero bytes are not written into it, the gather emits them (compact.hip)
-        if (!P->d_maglens) {
-            if (ctx->capturing) return fail(ctx, J2K_ERR_INVALID_ARG, "capture: run the same calls once before j2k_ctx_capture_begin");
-            HIPCHK(ctx, hipMalloc((void **)&P->d_maglens, (size_t)n * 4));
-            HIPCHK(ctx, hipMalloc((void **)&P->d_mels, (size_t)n * 4));
-            HIPCHK(ctx, hipMalloc((void **)&P->d_toffs, ((size_t)n + 1) * 8));
-            HIPCHK(ctx, launch_mel_table(ctx->stream, P->d_bjobs, n, P->d_mels));
-        }
-        int r = stage_reserve(ctx, 3, 256);
-        if (r != J2K_OK) return r;
-        ctx->fault_armed = true;
-        for (int rep_ = 0; rep_ < dev_reps(8); rep_++)
-        HIPCHK(ctx, launch_ht_encode(ctx->stream, P->d_bjobs, n, d_coeff, (uint8_t *)P->d_slots, d_lens, d_numbps, (int *)ctx->stage[3],
-                                     P->d_maglens, P->d_ht_ujobs, P->ht_nunique, P->d_ht_alias_next));
         for (int rep_ = 0; rep_ < dev_reps(16); rep_++)
         // the transport offsets (a second running sum in the scan, +4 us) only once j2k_plan_pack_stream has asked for them
         HIPCHK(ctx, launch_compact(ctx->stream, P->d_bjobs_alias ? P->d_bjobs_alias : P->d_bjobs, n, (const uint8_t *)P->d_slots, d_lens, d_offs, d_stream, P->d_maglens,
@@ -616,8 +627,6 @@ extern "C" int j2k_plan_encode_stream(j2k_plan *P, const int32_t *d_coeff, uint8
         P->last_stream = d_stream; P->last_lens = d_lens;
         return J2K_OK;
     }
-    int r = j2k_plan_encode_blocks(P, d_coeff, (uint8_t *)P->d_slots, d_lens, d_numbps);
-    if (r != J2K_OK) return r;
     return j2k_plan_compact(P, (const uint8_t *)P->d_slots, d_lens, d_offs, d_stream);
 }
 

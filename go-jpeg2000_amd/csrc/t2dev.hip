@@ -303,15 +303,17 @@ __global__ __launch_bounds__(256) void t2_scan_kernel(const T2Size *__restrict__
 // markers + header of packet p at its final place, the writer's entry state known (t2.go:257-276)
 __global__ __launch_bounds__(64) void t2_header_kernel(const j2k_t2_dev_packet *__restrict__ packets, long npackets, const j2k_t2_dev_cb *__restrict__ cbs,
                                                        const T2Size *__restrict__ sizes, const uint64_t *__restrict__ offs, const uint8_t *__restrict__ var,
-                                                       int sop, int eph, uint8_t *__restrict__ out, uint64_t cap, const uint64_t *__restrict__ result) {
+                                                       int sop, int eph, uint8_t *__restrict__ out, uint64_t cap, const uint64_t *__restrict__ result,
+                                                       const int32_t *__restrict__ ptile, uint64_t extra) {
     __shared__ T2Fields fld[64];
     __shared__ uint32_t bits[T2_FAST_WORDS + 2];
     const long p = blockIdx.x;
     const int lane = threadIdx.x;
-    if (result[2] != 0 || offs[npackets] > cap) return;      // (a fault or too little room: nothing is written, the host reports it)
+    if (result[2] != 0 || offs[npackets] + extra > cap) return;      // (a fault or too little room: nothing is written, the host reports it)
     const j2k_t2_dev_packet P = packets[p];
     const int v = (P.flags & J2K_T2_FRESH) ? 0 : var[p];
-    uint8_t *o = out + offs[p];
+    // (frame calls: straight into the tile-parts -- packet p of tile t lies 14 (t + 1) bytes further, behind t + 1 SOT | SOD heads)
+    uint8_t *o = out + offs[p] + (ptile ? 14ull * (uint64_t)(ptile[p] + 1) : 0ull);
     if (lane == 0 && sop) { o[0] = 0xFF; o[1] = 0x91; o[2] = 0x00; o[3] = 0x04; o[4] = (uint8_t)((unsigned)P.layer >> 8); o[5] = (uint8_t)P.layer; }
     {
         bool any = false;
@@ -335,12 +337,13 @@ typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 __global__ __launch_bounds__(64) void t2_body_kernel(const j2k_t2_dev_packet *__restrict__ packets, long npackets, const j2k_t2_dev_cb *__restrict__ cbs,
                                                      const uint8_t *__restrict__ data, const T2Size *__restrict__ sizes, const uint64_t *__restrict__ offs,
                                                      const uint8_t *__restrict__ var, int fixed, uint8_t *__restrict__ out, uint64_t cap,
-                                                     const uint64_t *__restrict__ result) {
+                                                     const uint64_t *__restrict__ result, const int32_t *__restrict__ ptile, uint64_t extra,
+                                                     const BlockJob *__restrict__ slot_jobs, const uint32_t *__restrict__ maglens, int ht) {
     const long p = blockIdx.x;
     const int slice = blockIdx.y, lane = threadIdx.x;
-    if (result[2] != 0 || offs[npackets] > cap) return;
+    if (result[2] != 0 || offs[npackets] + extra > cap) return;
     const j2k_t2_dev_packet P = packets[p];
-    uint8_t *o = out + offs[p];
+    uint8_t *o = out + offs[p] + (ptile ? 14ull * (uint64_t)(ptile[p] + 1) : 0ull);
     uint64_t pos = (uint64_t)fixed + sizes[p].hlen[var[p]];
     for (int64_t i0 = 0; i0 < P.ncb; i0 += 64) {
         const int64_t i = i0 + lane;
@@ -355,8 +358,13 @@ __global__ __launch_bounds__(64) void t2_body_kernel(const j2k_t2_dev_packet *__
             const uint32_t len = __shfl(mylen, j);
             if (!len) continue;
             const uint64_t dof = __shfl(myoff, j), sof = __shfl(cb.data_off, j);
-            const uint8_t *s = data + sof;
             uint8_t *d = o + dof;
+            if (slot_jobs) {                                         // frame encoder: block P.cb0 + i0 + j of the plan, from its coding slot (no dense stream in between)
+                const int64_t jb = P.cb0 + i0 + j;
+                gather_job(slot_jobs[jb], data, d, len, ht != 0, maglens ? maglens[jb] : 0u, lane);
+                continue;
+            }
+            const uint8_t *s = data + sof;
             const uint32_t words = len >> 2;
             for (uint32_t k = lane; k < words; k += 64) *reinterpret_cast<u32_unaligned *>(d + 4 * k) = *reinterpret_cast<const u32_unaligned *>(s + 4 * k);
             if (lane < (int)(len & 3)) d[4 * words + lane] = s[4 * words + lane];
@@ -369,8 +377,10 @@ __global__ __launch_bounds__(64) void t2_body_kernel(const j2k_t2_dev_packet *__
 // block column: encoder.go:616-673) with the bytes lens[j] at offs[j] of the compacted stream.  IncludedInLayers 0, Passes = the
 // 3 * numBPS - 2 coding passes EncodeFast5 ran (t1_fast5.go:66-70; HT: one), ZeroBitPlanes = max(mb - numBPS, 0).
 __global__ __launch_bounds__(256) void t2_fill_cbs_kernel(long n, const uint64_t *__restrict__ offs, const uint32_t *__restrict__ lens,
-                                                          const uint8_t *__restrict__ numbps, int mb, int ht, j2k_t2_dev_cb *__restrict__ cbs) {
+                                                          const uint8_t *__restrict__ numbps, int mb, int ht, j2k_t2_dev_cb *__restrict__ cbs,
+                                                          uint64_t *__restrict__ reset) {
     const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j == 0 && reset) { reset[0] = 0; reset[1] = 0; reset[2] = 0; }   // (the packet coder's result words, for the launches behind this one)
     if (j >= n) return;
     const int nb = numbps[j];
     j2k_t2_dev_cb cb{};
@@ -378,13 +388,13 @@ __global__ __launch_bounds__(256) void t2_fill_cbs_kernel(long n, const uint64_t
     cb.zero_bit_planes = mb > nb ? mb - nb : 0;
     cb.num_passes = nb == 0 ? 0 : ((ht & 1) ? 1 : 3 * nb - 2);
     cb.data_len = lens[j];
-    cb.data_off = offs[j];
+    cb.data_off = offs ? offs[j] : 0;                              // (no stream: the bytes are gathered from the coding slots)
     cbs[j] = cb;
 }
 
-hipError_t launch_t2_fill_cbs(hipStream_t s, long n, const uint64_t *offs, const uint32_t *lens, const uint8_t *numbps, int mb, int ht, j2k_t2_dev_cb *cbs) {
+hipError_t launch_t2_fill_cbs(hipStream_t s, long n, const uint64_t *offs, const uint32_t *lens, const uint8_t *numbps, int mb, int ht, j2k_t2_dev_cb *cbs, uint64_t *reset) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(t2_fill_cbs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, offs, lens, numbps, mb, ht, cbs);
+    hipLaunchKernelGGL(t2_fill_cbs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, offs, lens, numbps, mb, ht, cbs, reset);
     return hipGetLastError();
 }
 
@@ -399,9 +409,55 @@ hipError_t launch_t2_encode_packets(hipStream_t s, const j2k_t2_dev_packet *pack
     if (npackets > 0) hipLaunchKernelGGL(t2_size_kernel, dim3((unsigned)npackets), dim3(64), 0, s, packets, npackets, cbs, ncbs, sizes, result);
     hipLaunchKernelGGL(t2_scan_kernel, dim3(1), dim3(256), 0, s, sizes, npackets, fixed, delay_in, offs, var, result);
     if (npackets > 0) {
-        hipLaunchKernelGGL(t2_header_kernel, dim3((unsigned)npackets), dim3(64), 0, s, packets, npackets, cbs, sizes, offs, var, sop, eph, out, cap, result);
-        hipLaunchKernelGGL(t2_body_kernel, dim3((unsigned)npackets, T2_BODY_SLICES), dim3(64), 0, s, packets, npackets, cbs, data, sizes, offs, var, fixed, out, cap, result);
+        hipLaunchKernelGGL(t2_header_kernel, dim3((unsigned)npackets), dim3(64), 0, s, packets, npackets, cbs, sizes, offs, var, sop, eph, out, cap, result,
+                           (const int32_t *)nullptr, (uint64_t)0);
+        hipLaunchKernelGGL(t2_body_kernel, dim3((unsigned)npackets, T2_BODY_SLICES), dim3(64), 0, s, packets, npackets, cbs, data, sizes, offs, var, fixed, out, cap, result,
+                           (const int32_t *)nullptr, (uint64_t)0, (const BlockJob *)nullptr, (const uint32_t *)nullptr, 0);
     }
+    return hipGetLastError();
+}
+
+// SOT | SOD of every tile-part in front of its packets (tcd CreateTileHeader: FF90 000A Isot Psot TPsot = 0 TNsot = 1, FF93), where each
+// starts, the total -- and the capacity verdict (nothing is written by anyone when the caller's buffer is too small)
+__global__ __launch_bounds__(64) void t2_tile_heads_kernel(const uint64_t *__restrict__ offs, long npackets, const int *__restrict__ tile_packet0, int ntiles, int tile_first,
+                                                           uint8_t *__restrict__ out, uint64_t cap, uint64_t *__restrict__ tile_offs, int *__restrict__ status,
+                                                           const uint64_t *__restrict__ result) {
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    const uint64_t total = offs[npackets] + 14ull * (uint64_t)ntiles;
+    if (t == 0) {
+        tile_offs[ntiles] = total;
+        if (status && result[2] != 0) atomicMin(status, J2K_ERR_GO_PANIC);       // (a tree width of 0: no plan makes one)
+        else if (status && total > cap) atomicMin(status, J2K_ERR_CAPACITY);
+    }
+    if (t >= ntiles) return;
+    const uint64_t o0 = offs[tile_packet0[t]], o1 = offs[tile_packet0[t + 1]];
+    tile_offs[t] = o0 + 14ull * (uint64_t)t;
+    if (result[2] != 0 || total > cap) return;
+    uint8_t *dst = out + o0 + 14ull * (uint64_t)t;
+    const uint32_t idx = (uint32_t)(tile_first + t) & 0xFFFFu, psot = (uint32_t)(14 + (o1 - o0));
+    const uint8_t hdr[14] = {0xFF, 0x90, 0x00, 0x0A, (uint8_t)(idx >> 8), (uint8_t)idx, (uint8_t)(psot >> 24), (uint8_t)(psot >> 16),
+                             (uint8_t)(psot >> 8), (uint8_t)psot, 0x00, 0x01, 0xFF, 0x93};
+#pragma unroll
+    for (int k = 0; k < 14; k++) dst[k] = hdr[k];
+}
+// The packets of a frame written where they end up: tile-parts in `out` (SOT | SOD | packets per tile), no packet stream and no dense
+// block stream in between.  data + cbs[].data_off: the blocks' bytes (the compacted stream of j2k_plan_encode_stream), or, with
+// slot_jobs, data = the plan's coding slots and block j is gathered from slot_jobs[j] (HT: MagSgn | MEL zeros made here | VLC, maglens).
+hipError_t launch_t2_encode_tile_parts(hipStream_t s, const j2k_t2_dev_packet *packets, long npackets, const j2k_t2_dev_cb *cbs, uint64_t ncbs, const uint8_t *data,
+                                       int sop, int eph, uint8_t *out, uint64_t cap, uint64_t *offs, void *ws, uint64_t *result, const int32_t *ptile,
+                                       const int *tile_packet0, int ntiles, int tile_first, uint64_t *tile_offs, int *status, const BlockJob *slot_jobs,
+                                       const uint32_t *maglens, int ht) {
+    if (npackets <= 0 || ntiles <= 0) return hipSuccess;
+    T2Size *sizes = reinterpret_cast<T2Size *>(ws);
+    uint8_t *var = reinterpret_cast<uint8_t *>(sizes + npackets);
+    const int fixed = (sop ? 6 : 0) + (eph ? 2 : 0);
+    const uint64_t extra = 14ull * (uint64_t)ntiles;
+    hipLaunchKernelGGL(t2_size_kernel, dim3((unsigned)npackets), dim3(64), 0, s, packets, npackets, cbs, ncbs, sizes, result);
+    hipLaunchKernelGGL(t2_scan_kernel, dim3(1), dim3(256), 0, s, sizes, npackets, fixed, 0, offs, var, result);
+    hipLaunchKernelGGL(t2_tile_heads_kernel, dim3((unsigned)((ntiles + 63) / 64)), dim3(64), 0, s, offs, npackets, tile_packet0, ntiles, tile_first, out, cap, tile_offs, status, result);
+    hipLaunchKernelGGL(t2_header_kernel, dim3((unsigned)npackets), dim3(64), 0, s, packets, npackets, cbs, sizes, offs, var, sop, eph, out, cap, result, ptile, extra);
+    hipLaunchKernelGGL(t2_body_kernel, dim3((unsigned)npackets, T2_BODY_SLICES), dim3(64), 0, s, packets, npackets, cbs, data, sizes, offs, var, fixed, out, cap, result,
+                       ptile, extra, slot_jobs, maglens, ht);
     return hipGetLastError();
 }
 

@@ -677,6 +677,37 @@ def test_closed_loop_side_by_side_packets_with_headers_ending_in_0xff(env):
     plan.close()
 
 
+@pytest.mark.parametrize("coder", [0, 1])
+@pytest.mark.parametrize("W,H,tile,cb,nres", [(301, 211, (128, 96), 32, 4), (640, 360, (0, 0), 64, 6), (97, 130, (32, 64), 8, 3), (1024, 768, (512, 512), 64, 6)])
+def test_closed_loop_frame_encoder_gathers_from_the_slots_what_the_stage_calls_copy(env, coder, W, H, tile, cb, nres):
+    """j2k_plan_encode_frame_pixels writes every block's bytes once -- from its coding slot (HT: MagSgn | the MEL zero run made on the way |
+    VLC) straight to its place in its packet in its tile-part; the stage calls go through the dense block stream and the same packet coder.
+    Same bytes, same tile-part positions, with and without the markers"""
+    torch, t2ref, t2, ctx = env
+    from j2kgfx import _lib
+    from j2kgfx.codec import FramePlan
+    frame = _frame(W, H, 21 + coder, noise=25)
+    plan = FramePlan(W, H, 3, precision=8, lossless=True, num_resolutions=nres, cb=(cb, cb), tile=tile, coder=coder, ctx=ctx, closed_loop=True)
+    d_pix = torch.from_numpy(_rgba(frame)).to(plan.device)
+    for sop, eph in [(True, True), (False, False), (True, False)]:
+        coeff = plan.forward_pixels(_lib.PIX_RGBA8, d_pix)
+        stream, offs, lens, numbps = plan.encode_stream(coeff)
+        cs1, t1 = plan.encode_tile_parts(stream, offs, lens, numbps, sop=sop, eph=eph)
+        plan.frame_status()
+        cs2, t2_ = plan.encode_frame_pixels(_lib.PIX_RGBA8, d_pix, sop=sop, eph=eph)
+        plan.frame_status()
+        total = int(t1[-1].item())
+        assert torch.equal(t1, t2_)
+        assert torch.equal(cs1[:total], cs2[:total])
+        # and it decodes (MQ: to the source)
+        back = torch.zeros_like(d_pix)
+        plan.decode_frame_pixels(cs2, total, back, tile_offs=None, sop=sop, eph=eph)
+        plan.frame_status()
+        if coder == 0:
+            assert torch.equal(back, d_pix)
+    plan.close()
+
+
 def test_closed_loop_calls_refuse_a_reference_mode_plan(env):
     torch, t2ref, t2, ctx = env
     from j2kgfx import J2KError, _lib

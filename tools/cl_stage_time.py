@@ -28,7 +28,10 @@ o2 = plan.empty(n + 1, torch.int64); l2 = plan.empty(n, torch.int32); n2 = plan.
 decoded = plan.empty(plan.info.decoded_elems, torch.int32)
 cs2 = plan.empty(plan.frame_bound(), torch.uint8); toffs2 = plan.empty(int(plan.info.tiles) + 1, torch.int64)[:int(plan.info.tiles) + 1]
 plan.encode_tile_parts(plan.encode_stream(plan.forward_pixels(_lib.PIX_RGBA8, d_pix, coeff), stream, offs, lens, nb)[0], offs, lens, nb, True, True, cs2, toffs2)
+cs3 = plan.empty(plan.frame_bound(), torch.uint8); toffs3 = plan.empty(int(plan.info.tiles) + 1, torch.int64)[:int(plan.info.tiles) + 1]
 stages = [
+    ("encode_frame_pixels (whole: slots -> tile-parts direct)", lambda: plan.encode_frame_pixels(_lib.PIX_RGBA8, d_pix, True, True, cs3, toffs3)),
+    ("decode_frame_pixels (whole)", lambda: plan.decode_frame_pixels(cs3, cs3.numel(), back, toffs3, True, True)),
     ("forward_pixels", lambda: plan.forward_pixels(_lib.PIX_RGBA8, d_pix, coeff)),
     ("encode_stream", lambda: plan.encode_stream(coeff, stream, offs, lens, nb)),
     ("encode_tile_parts", lambda: plan.encode_tile_parts(stream, offs, lens, nb, False, False, cs, toffs)),

@@ -15,14 +15,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "go-jpeg2000_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import oracle as orc                                     # noqa: E402
 import t2ref                                             # noqa: E402
-from j2kgfx import J2KError                              # noqa: E402
+from j2kgfx import J2KError, _lib                        # noqa: E402
 from j2kgfx.codec import FramePlan                       # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 t0 = time.time()
-n = npanic = npar_tiles = nser_tiles = 0
+n = npanic = npar_tiles = nser_tiles = nframe_enc = 0
 t_say = t0
 while time.time() - t0 < budget:
     if time.time() - t_say > 60:
@@ -103,6 +103,14 @@ while time.time() - t0 < budget:
         assert bytes(h_cs[int(h_t[tl]):int(h_t[tl + 1])]) == part, ("tile-part", desc, tl)
         ref.append((x0, y0, w, h, by, ln, nb))
     assert not panics, ("oracle panics where the product did not", desc)
+    if Cn == 3 and prec == 8:
+        # the one-call frame encoder (blocks gathered from their coding slots straight into the tile-parts) == the stage calls
+        pix = np.full((H, W, 4), 255, np.uint8)
+        pix[..., :3] = frame.transpose(1, 2, 0)
+        cs_f, toffs_f = plan.encode_frame_pixels(_lib.PIX_RGBA8, torch.from_numpy(pix.reshape(H, W * 4)).to(plan.device), sop=sop, eph=eph)
+        plan.frame_status()
+        assert np.array_equal(toffs_f.cpu().numpy(), h_t) and np.array_equal(cs_f.cpu().numpy()[:total], h_cs[:total]), ("frame encoder", desc)
+        nframe_enc += 1
     for given in (True, False):
         plan.frame_parallel_tiles()
         offs2, lens2, nb2 = plan.decode_tile_parts(cs, total, tile_offs=toffs if given else None, sop=sop, eph=eph)
@@ -128,5 +136,5 @@ while time.time() - t0 < budget:
             assert np.array_equal(hb, frame), ("round trip", desc, given)
     plan.close()
     n += 1
-print("closed-loop fuzz: %d frames clean (%d in the reference's HT panic domain; SOP + EPH frames: %d tiles parsed packet-parallel, %d fell back to the tile chain) in %.0f s, seed %d"
-      % (n, npanic, npar_tiles, nser_tiles, time.time() - t0, seed))
+print("closed-loop fuzz: %d frames clean (%d in the reference's HT panic domain; SOP + EPH frames: %d tiles parsed packet-parallel, %d fell back to the tile chain; %d frames also through the one-call frame encoder) in %.0f s, seed %d"
+      % (n, npanic, npar_tiles, nser_tiles, nframe_enc, time.time() - t0, seed))
