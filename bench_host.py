@@ -319,7 +319,7 @@ def run_closed_loop(args):
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
     torch.cuda.set_device(0)
-    F = args.inflight if args.inflight > 0 else (4 if ht else 12)
+    F = args.inflight if args.inflight > 0 else (2 if ht else 12)
     B = max(1, int(getattr(args, "batch", 0) or (1 if ht else 4)))   # frames per context and call: one plan over the frames stacked vertically (j2k_params.frame_rows)
     lanes = []
     ok = False
@@ -388,7 +388,7 @@ def run_closed_loop(args):
                           "6 resolutions, j2k_params.closed_loop = 1 (this library's mode, outside reference parity: code-block windows that partition "
                           "the plane, packets the decoder can read); a step = image.RGBA.Pix -> forward transform -> block coder -> one packet per "
                           "(tile, component, resolution), SOP + EPH markers -> SOT | SOD | packets, then tile-part parse -> packet parse -> block decode -> placement -> "
-                          "inverse transform -> image.RGBA.Pix, all on device buffers; the pixels that come back are compared with the pixels that went in",
+                          "inverse transform -> image.RGBA.Pix, all on device buffers (j2k_plan_encode_frame_pixels / j2k_plan_decode_frame_pixels)" + ("" if ht else "; the pixels that come back are compared with the pixels that went in"),
                           "frames_in_flight": F * B, "contexts": F, "frames_per_context": B, "codestream_bytes_per_frame": total // B, "tiles_parsed_packet_parallel": "%d of %d" % (par_tiles, int(lanes[0]["p"].info.tiles)), "single_frame_ms": round(single_ms / B, 2) if B > 1 else round(single_ms, 2),
                           "round_trip": ("the reference's HT coder codes one row in four: pixels back == the same stream through the serial packet parser (checked after the timed region)" if ht
                                          else "bit-exact (checked after the timed region, every frame in flight)")},

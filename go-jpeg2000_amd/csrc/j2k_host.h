@@ -67,7 +67,7 @@ hipError_t launch_t2_decode_tiles(hipStream_t s, void *chains, int ntiles, const
                                   uint64_t ncbs, const uint8_t *data, uint64_t len, int sop, int eph, uint64_t *body_base, int *frame_status, void *ws,
                                   int ht, int mb, uint64_t *offs, uint32_t *lens, uint8_t *numbps);
 hipError_t launch_t2_blocks(hipStream_t s, long n, const j2k_t2_dev_cb *cbs, int ht, int mb, uint64_t total, uint64_t *offs, uint32_t *lens, uint8_t *numbps, int *status);
-hipError_t launch_place_blocks(hipStream_t s, const BlockJob *src_jobs, const BlockJob *dec_jobs, int njobs, int max_h, const int32_t *decoded, int32_t *coeff);
+hipError_t launch_place_blocks(hipStream_t s, const BlockJob *src_jobs, const BlockJob *dec_jobs, int njobs, int max_h, const int32_t *decoded, int32_t *coeff, int ystep = 1);
 hipError_t launch_scan(hipStream_t s, const uint32_t *lens, int njobs, uint64_t *offs, const uint32_t *mels, uint64_t *toffs);
 size_t pack_header_bytes(size_t n);
 hipError_t launch_pack(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs, const uint64_t *toffs,

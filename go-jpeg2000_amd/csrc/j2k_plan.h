@@ -172,6 +172,7 @@ struct j2k_plan {
     void *d_t2_par = nullptr;                    // decode: one chain per PACKET, the marker lists and guesses (t2_par_workspace)
     int *d_frame_status = nullptr;               // sticky status word of the asynchronous frame calls (j2k_plan_frame_status)
     int32_t *d_cl_decoded = nullptr, *d_cl_coeff = nullptr;   // j2k_plan_*_frame_pixels: decoded blocks, coefficient planes
+    int32_t *d_cl_coeff_dec = nullptr;           // HT plans: the frame DECODER's coefficient planes (zeroed once, only the coded rows ever written)
     uint8_t *d_cl_numbps = nullptr; uint64_t *d_cl_offs = nullptr; uint32_t *d_cl_lens = nullptr;
     int max_block_h = 0;
     void *d_host_io = nullptr, *d_host_pix = nullptr;          // j2k_encode_pixels_host / j2k_decode_pixels_host: tile-parts / pixels on the device

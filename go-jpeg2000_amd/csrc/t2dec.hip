@@ -704,25 +704,27 @@ __global__ __launch_bounds__(256) void t2_finish_kernel(const j2k_t2_dev_packet 
 }
 
 // decoded block j (dense w x h at D.out_off) -> its window of the coefficient planes (S.src_off, row stride S.stride); one
-// workgroup per block and 64 rows
+// workgroup per block and 64 rows.  ystep = 4: only the rows y % 4 == 0 -- all the reference's HT decoder ever writes; the
+// frame decoder keeps both buffers for itself, zeroed once, so the other rows are zero on both sides already
 __global__ __launch_bounds__(256) void place_blocks_kernel(const BlockJob *__restrict__ src_jobs, const BlockJob *__restrict__ dec_jobs,
-                                                           const int32_t *__restrict__ decoded, int32_t *__restrict__ coeff) {
+                                                           const int32_t *__restrict__ decoded, int32_t *__restrict__ coeff, int ystep) {
     const BlockJob S = src_jobs[blockIdx.x];
     const int64_t doff = dec_jobs[blockIdx.x].out_off;
     const int w = S.w, h = S.h;
     const int y0 = blockIdx.y * 64, y1 = min(h, y0 + 64);
     if (y0 >= h) return;
+    const int nrows = (y1 - y0 + ystep - 1) / ystep;                // rows y0, y0 + ystep, ... (y0 is a multiple of 64)
     const int32_t *src = decoded + doff;
     int32_t *dst = coeff + S.src_off;
     if (!(w & 3) && !(doff & 3) && !(S.src_off & 3) && !(S.stride & 3)) {
         const int wq = w >> 2;
-        for (int i = threadIdx.x; i < (y1 - y0) * wq; i += 256) {
-            const int y = y0 + i / wq, x = (i - (i / wq) * wq) << 2;
+        for (int i = threadIdx.x; i < nrows * wq; i += 256) {
+            const int y = y0 + (i / wq) * ystep, x = (i - (i / wq) * wq) << 2;
             *reinterpret_cast<int4 *>(dst + (int64_t)y * S.stride + x) = *reinterpret_cast<const int4 *>(src + (int64_t)y * w + x);
         }
     } else {
-        for (int i = threadIdx.x; i < (y1 - y0) * w; i += 256) {
-            const int y = y0 + i / w, x = i - (i / w) * w;
+        for (int i = threadIdx.x; i < nrows * w; i += 256) {
+            const int y = y0 + (i / w) * ystep, x = i - (i / w) * w;
             dst[(int64_t)y * S.stride + x] = src[(int64_t)y * w + x];
         }
     }
@@ -791,9 +793,9 @@ hipError_t launch_t2_blocks(hipStream_t s, long n, const j2k_t2_dev_cb *cbs, int
     hipLaunchKernelGGL(t2_blocks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, cbs, ht, mb, total, offs, lens, numbps, status);
     return hipGetLastError();
 }
-hipError_t launch_place_blocks(hipStream_t s, const BlockJob *src_jobs, const BlockJob *dec_jobs, int njobs, int max_h, const int32_t *decoded, int32_t *coeff) {
+hipError_t launch_place_blocks(hipStream_t s, const BlockJob *src_jobs, const BlockJob *dec_jobs, int njobs, int max_h, const int32_t *decoded, int32_t *coeff, int ystep) {
     if (njobs <= 0) return hipSuccess;
-    hipLaunchKernelGGL(place_blocks_kernel, dim3((unsigned)njobs, (unsigned)((max_h + 63) / 64)), dim3(256), 0, s, src_jobs, dec_jobs, decoded, coeff);
+    hipLaunchKernelGGL(place_blocks_kernel, dim3((unsigned)njobs, (unsigned)((max_h + 63) / 64)), dim3(256), 0, s, src_jobs, dec_jobs, decoded, coeff, ystep == 4 ? 4 : 1);
     return hipGetLastError();
 }
 

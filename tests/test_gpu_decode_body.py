@@ -708,6 +708,32 @@ def test_closed_loop_frame_encoder_gathers_from_the_slots_what_the_stage_calls_c
     plan.close()
 
 
+@pytest.mark.parametrize("W,H,tile,cb,nres", [(640, 360, (256, 256), 64, 5), (301, 211, (128, 96), 32, 4), (130, 70, (0, 0), 16, 3)])
+def test_closed_loop_ht_frame_decoder_touches_the_coded_rows_only_and_stays_equal_to_the_stage_calls(env, W, H, tile, cb, nres):
+    """j2k_plan_decode_frame_pixels on an HT plan decodes and places only the rows the reference's HT decoder writes (y % 4 == 0) into
+    workspaces it zeroed once.  Frame after frame on ONE plan -- busy, flat (empty blocks where there were bytes a frame ago), busy again --
+    the pixels equal those of the stage calls, which zero, decode and copy every row every time"""
+    torch, t2ref, t2, ctx = env
+    from j2kgfx import _lib
+    from j2kgfx.codec import FramePlan
+    plan = FramePlan(W, H, 3, precision=8, lossless=True, num_resolutions=nres, cb=(cb, cb), tile=tile, coder=_lib.CODER_HT, ctx=ctx, closed_loop=True)
+    frames = [_frame(W, H, 40, noise=40), np.full((3, H, W), 128, np.uint8), _frame(W, H, 41, noise=3), _frame(W, H, 42, noise=90)]
+    frames[1][:, H // 2, W // 3] = 255
+    for k, frame in enumerate(frames):
+        d_pix = torch.from_numpy(_rgba(frame)).to(plan.device)
+        cs, toffs = plan.encode_frame_pixels(_lib.PIX_RGBA8, d_pix, sop=True, eph=True)
+        plan.frame_status()
+        total = int(toffs[-1].item())
+        got = torch.zeros_like(d_pix)
+        plan.decode_frame_pixels(cs, total, got, tile_offs=toffs, sop=True, eph=True)
+        plan.frame_status()
+        o2, l2, n2 = plan.decode_tile_parts(cs, total, tile_offs=toffs, sop=True, eph=True)
+        want = plan.inverse_pixels(plan.place_blocks(plan.decode_blocks(cs, o2, l2, n2)), torch.zeros_like(d_pix))
+        plan.frame_status()
+        assert torch.equal(got, want), k
+    plan.close()
+
+
 def test_closed_loop_calls_refuse_a_reference_mode_plan(env):
     torch, t2ref, t2, ctx = env
     from j2kgfx import J2KError, _lib
