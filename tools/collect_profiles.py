@@ -41,6 +41,8 @@ for name in ("c1gpu", "c5"):
         shutil.copy(newest("stats_%s/*/*kernel_stats.csv" % name), os.path.join(P, "%s_%s_bench_kernel_stats.csv" % (tag, name)))
 if glob.glob(os.path.join(O, "stats_cl/*/*kernel_stats.csv")):
     shutil.copy(newest("stats_cl/*/*kernel_stats.csv"), os.path.join(P, tag + "_closed_loop_bench_kernel_stats.csv"))
+    if glob.glob(os.path.join(O, "stats_clht/*/*kernel_stats.csv")):
+        shutil.copy(newest("stats_clht/*/*kernel_stats.csv"), os.path.join(P, tag + "_closed_loop_ht_inflight1_kernel_stats.csv"))
 if glob.glob(os.path.join(O, "pmc_invg16_FETCH/*/*counter_collection.csv")):
     lines = ["# inverse level 0 (dwt53_inv_rgba8_wg_kernel<4, 5, false>), one frame in flight: FETCH_SIZE (rocprofv3 --pmc, KiB per launch; x2 on gfx950) and",
              "# the kernel's average time (rocprofv3 --kernel-trace --stats) with 8 (default) and 16 consecutive bands per XCD (J2K_L0_XCD_GROUP):",

@@ -34,6 +34,9 @@ tail -1 $O/stats_c5.log | cut -c1-200
 export GPU_MAX_HW_QUEUES=32
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cl -- python $R/bench.py --config cl --steps 2 --warmup 1 --inflight 2 > $O/stats_cl.log 2>&1
 tail -1 $O/stats_cl.log | cut -c1-200
+# ... and with the reference's HT coder, one frame in flight: every kernel of pixels -> tile-parts -> pixels at its solo duration
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_clht -- python $R/bench.py --config clht --steps 30 --warmup 3 --inflight 1 > $O/stats_clht.log 2>&1
+tail -1 $O/stats_clht.log | cut -c1-200
 unset GPU_MAX_HW_QUEUES
 # round 5: is the inverse level 0's read over-fetch what holds it back?  Groups of 16 bands per XCD instead of 8 halve the halo rows that
 # miss the L2: FETCH_SIZE and the kernel's time under both settings
