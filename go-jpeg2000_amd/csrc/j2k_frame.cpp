@@ -251,6 +251,17 @@ static int cl_workspaces(j2k_plan *P) {
     return r;
 }
 
+// coefficients -> tile-parts with one copy of every block's bytes (the closed-loop one-call forms; d_lens / d_numbps: the caller's tables, filled)
+int plan_encode_frame_from_coeff(j2k_plan *P, const int32_t *d_coeff, uint32_t *d_lens, uint8_t *d_numbps, int sop, int eph, uint8_t *d_out, size_t cap,
+                                 uint64_t *d_tile_offs) {
+    int r = cl_prepare(P);
+    // block coding into the plan's slots, then every block's bytes ONCE: from its slot to its place in its packet in its tile-part (the stage
+    // calls j2k_plan_encode_stream + j2k_plan_encode_tile_parts copy them twice: dense stream, tile-parts)
+    if (r == J2K_OK) r = plan_encode_private_slots(P, d_coeff, d_lens, d_numbps);
+    if (r == J2K_OK) r = encode_tile_parts_impl(P, (const uint8_t *)P->d_slots, nullptr, d_lens, d_numbps, sop, eph, d_out, cap, d_tile_offs);
+    return r;
+}
+
 extern "C" int j2k_plan_encode_frame_pixels(j2k_plan *P, int format, const void *d_pix, size_t stride, int sop, int eph, uint8_t *d_out, size_t cap,
                                             uint64_t *d_tile_offs) {
     if (!P) return J2K_ERR_INVALID_ARG;
@@ -258,10 +269,7 @@ extern "C" int j2k_plan_encode_frame_pixels(j2k_plan *P, int format, const void 
     int r = cl_prepare(P);
     if (r == J2K_OK) r = cl_workspaces(P);
     if (r == J2K_OK) r = j2k_plan_forward_pixels(P, format, d_pix, stride, P->d_cl_coeff);
-    // block coding into the plan's slots, then every block's bytes ONCE: from its slot to its place in its packet in its tile-part (the stage
-    // calls j2k_plan_encode_stream + j2k_plan_encode_tile_parts copy them three times: dense stream, packets, tile-parts)
-    if (r == J2K_OK) r = plan_encode_private_slots(P, P->d_cl_coeff, P->d_cl_lens, P->d_cl_numbps);
-    if (r == J2K_OK) r = encode_tile_parts_impl(P, (const uint8_t *)P->d_slots, nullptr, P->d_cl_lens, P->d_cl_numbps, sop, eph, d_out, cap, d_tile_offs);
+    if (r == J2K_OK) r = plan_encode_frame_from_coeff(P, P->d_cl_coeff, P->d_cl_lens, P->d_cl_numbps, sop, eph, d_out, cap, d_tile_offs);
     return r;
 }
 

@@ -112,4 +112,6 @@ int ensure(j2k_ctx *ctx, void **p, size_t bytes);
 struct PixIO { int stride = 0, single = 0, triple = 0; };
 int plan_forward_impl(j2k_plan *P, const void *d_frame, void *d_coeff, PixIO pix = PixIO());
 int plan_encode_private_slots(j2k_plan *P, const int32_t *d_coeff, uint32_t *d_lens, uint8_t *d_numbps);
+int plan_encode_frame_from_coeff(j2k_plan *P, const int32_t *d_coeff, uint32_t *d_lens, uint8_t *d_numbps, int sop, int eph, uint8_t *d_out, size_t cap,
+                                 uint64_t *d_tile_offs);
 int plan_inverse_impl(j2k_plan *P, const void *d_coeff, void *d_frame, PixIO pix = PixIO());

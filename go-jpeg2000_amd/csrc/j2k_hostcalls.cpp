@@ -338,22 +338,21 @@ extern "C" int j2k_encode_pixels_host(j2k_plan *P, int format, const void *pix, 
     int r;
     if ((r = ensure_sized(ctx, &P->d_host_pix, &P->host_pix_bytes, (size_t)S.H * stride)) != J2K_OK) return r;
     if ((r = ensure(ctx, &P->d_coeff, (size_t)P->coeff_elems * 4)) != J2K_OK) return r;
-    if ((r = ensure(ctx, &P->d_stream, (size_t)P->bytes_cap)) != J2K_OK) return r;
+    if (!S.closed_loop && (r = ensure(ctx, &P->d_stream, (size_t)P->bytes_cap)) != J2K_OK) return r;
     const size_t toff_at = (bound + 64 + 15) & ~size_t(15);                                              // the tile-parts, and behind them their offsets / the length word
     if ((r = ensure_sized(ctx, &P->d_host_io, &P->host_io_bytes, toff_at + (nt + 2) * 8)) != J2K_OK) return r;
     if ((r = ensure(ctx, &P->d_lens, nb * 4 + 16)) != J2K_OK) return r;
     if ((r = ensure(ctx, &P->d_numbps, nb + 16)) != J2K_OK) return r;
-    if ((r = ensure(ctx, &P->d_offs, (nb + 1) * 8)) != J2K_OK) return r;
+    if (!S.closed_loop && (r = ensure(ctx, &P->d_offs, (nb + 1) * 8)) != J2K_OK) return r;
     uint64_t *d_toffs = reinterpret_cast<uint64_t *>((uint8_t *)P->d_host_io + toff_at);
     HIPCHK(ctx, hipMemcpyAsync(P->d_host_pix, pix, (size_t)S.H * stride, hipMemcpyHostToDevice, ctx->stream));
     if ((r = j2k_plan_forward_pixels(P, format, P->d_host_pix, stride, (int32_t *)P->d_coeff)) != J2K_OK) return r;
-    if ((r = j2k_plan_encode_stream(P, (int32_t *)P->d_coeff, (uint8_t *)P->d_stream, (uint64_t *)P->d_offs, (uint32_t *)P->d_lens, (uint8_t *)P->d_numbps)) != J2K_OK) return r;
     std::vector<uint64_t> toffs(nt + 1, 0);
-    if (S.closed_loop) {
-        if ((r = j2k_plan_encode_tile_parts(P, (uint8_t *)P->d_stream, (uint64_t *)P->d_offs, (uint32_t *)P->d_lens, (uint8_t *)P->d_numbps, sop, eph,
-                                            (uint8_t *)P->d_host_io, bound, d_toffs)) != J2K_OK) return r;
+    if (S.closed_loop) {                                     // (blocks gathered from their coding slots straight into the tile-parts: no dense stream)
+        if ((r = plan_encode_frame_from_coeff(P, (int32_t *)P->d_coeff, (uint32_t *)P->d_lens, (uint8_t *)P->d_numbps, sop, eph, (uint8_t *)P->d_host_io, bound, d_toffs)) != J2K_OK) return r;
         HIPCHK(ctx, hipMemcpyAsync(toffs.data(), d_toffs, (nt + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
     } else {
+        if ((r = j2k_plan_encode_stream(P, (int32_t *)P->d_coeff, (uint8_t *)P->d_stream, (uint64_t *)P->d_offs, (uint32_t *)P->d_lens, (uint8_t *)P->d_numbps)) != J2K_OK) return r;
         if ((r = j2k_plan_assemble_tiles_device(P, (uint8_t *)P->d_stream, (uint64_t *)P->d_offs, (uint8_t *)P->d_host_io, d_toffs + nt)) != J2K_OK) return r;
         HIPCHK(ctx, hipMemcpyAsync(&toffs[nt], d_toffs + nt, 8, hipMemcpyDeviceToHost, ctx->stream));
     }

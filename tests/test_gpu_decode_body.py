@@ -734,6 +734,43 @@ def test_closed_loop_ht_frame_decoder_touches_the_coded_rows_only_and_stays_equa
     plan.close()
 
 
+@pytest.mark.parametrize("coder", [0, 1])
+def test_closed_loop_frame_calls_replay_from_a_hip_graph(env, coder):
+    """the frame calls are asynchronous launches on the context's stream with workspaces made at their first call: after one warm-up they can be
+    captured (j2k_ctx_capture_begin / _end) and a whole frame -- pixels -> tile-parts -> pixels, some thirty kernels -- replayed as ONE graph launch,
+    on new pixel contents in the same buffers"""
+    torch, t2ref, t2, ctx = env
+    from j2kgfx import _lib
+    from j2kgfx.codec import FramePlan
+    W, H = 400, 300
+    plan = FramePlan(W, H, 3, precision=8, lossless=True, num_resolutions=4, cb=(32, 32), tile=(128, 128), coder=coder, ctx=ctx, closed_loop=True)
+    d_pix = torch.from_numpy(_rgba(_frame(W, H, 60, noise=20))).to(plan.device)
+    back = torch.zeros_like(d_pix)
+    cs = plan.empty(plan.frame_bound(), torch.uint8)
+    toffs = plan.empty(int(plan.info.tiles) + 1, torch.int64)[:int(plan.info.tiles) + 1]
+
+    def code():
+        plan.encode_frame_pixels(_lib.PIX_RGBA8, d_pix, True, True, cs, toffs)
+        plan.decode_frame_pixels(cs, cs.numel(), back, toffs, True, True)
+    code()
+    plan.frame_status()
+    with ctx.capture() as g:
+        code()
+    for seed in (61, 62):
+        d_pix.copy_(torch.from_numpy(_rgba(_frame(W, H, seed, noise=5 * (seed - 58)))).to(plan.device))
+        torch.cuda.synchronize()
+        back.zero_()
+        g.launch()
+        plan.frame_status()
+        got, cs_g = back.clone(), cs.clone()
+        code()
+        plan.frame_status()
+        assert torch.equal(back, got) and torch.equal(cs, cs_g)
+        if coder == 0:
+            assert torch.equal(got, d_pix)
+    plan.close()
+
+
 def test_closed_loop_calls_refuse_a_reference_mode_plan(env):
     torch, t2ref, t2, ctx = env
     from j2kgfx import J2KError, _lib

@@ -5,10 +5,10 @@ cd /tmp; export TMPDIR=/tmp; export J2K_TUNING=1   # (the library reads its J2K_
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/round
 rm -rf $O; mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_default -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $O/stats_default.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_inflight1 -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --inflight 1 > $O/stats_inflight1.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_default -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-other-configs > $O/stats_default.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_inflight1 -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-other-configs --inflight 1 > $O/stats_inflight1.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --inflight 1 > $O/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs --inflight 1 > $O/pmc_$c.log 2>&1
 done
 tail -1 $O/stats_default.log | cut -c1-200; tail -1 $O/stats_inflight1.log | cut -c1-200
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c3 -- python $R/tools/bench_c3.py 0 0 > $O/stats_c3.log 2>&1
