@@ -354,7 +354,7 @@ __global__ __launch_bounds__(64) void t2_body_kernel(const j2k_t2_dev_packet *__
         for (int d = 1; d < 64; d <<= 1) { const uint64_t u = __shfl_up(incl, d); if (lane >= d) incl += u; }
         const uint64_t myoff = pos + incl - mylen;
         const int cnt = (int)(P.ncb - i0 < 64 ? P.ncb - i0 : 64);
-        for (int j = slice; j < cnt; j += T2_BODY_SLICES) {
+        for (int j = slice; j < cnt; j += (int)gridDim.y) {
             const uint32_t len = __shfl(mylen, j);
             if (!len) continue;
             const uint64_t dof = __shfl(myoff, j), sof = __shfl(cb.data_off, j);
@@ -398,6 +398,10 @@ hipError_t launch_t2_fill_cbs(hipStream_t s, long n, const uint64_t *offs, const
     return hipGetLastError();
 }
 
+static unsigned t2_body_slices() {                                  // J2K_T2_BODY_SLICES (tuning): wavefronts that share a packet's bodies
+    static const unsigned n = [] { const char *e = tuning_env("J2K_T2_BODY_SLICES"); const long v = e ? atol(e) : 0; return (unsigned)(v >= 1 && v <= 64 ? v : T2_BODY_SLICES); }();
+    return n;
+}
 size_t t2_dev_workspace(long npackets) { return (size_t)npackets * sizeof(T2Size) + (size_t)npackets + 64; }
 
 // ws: t2_dev_workspace(npackets) bytes; result: 3 x uint64 {total, flag out, fault}, zeroed by the caller on this stream
@@ -411,7 +415,7 @@ hipError_t launch_t2_encode_packets(hipStream_t s, const j2k_t2_dev_packet *pack
     if (npackets > 0) {
         hipLaunchKernelGGL(t2_header_kernel, dim3((unsigned)npackets), dim3(64), 0, s, packets, npackets, cbs, sizes, offs, var, sop, eph, out, cap, result,
                            (const int32_t *)nullptr, (uint64_t)0);
-        hipLaunchKernelGGL(t2_body_kernel, dim3((unsigned)npackets, T2_BODY_SLICES), dim3(64), 0, s, packets, npackets, cbs, data, sizes, offs, var, fixed, out, cap, result,
+        hipLaunchKernelGGL(t2_body_kernel, dim3((unsigned)npackets, t2_body_slices()), dim3(64), 0, s, packets, npackets, cbs, data, sizes, offs, var, fixed, out, cap, result,
                            (const int32_t *)nullptr, (uint64_t)0, (const BlockJob *)nullptr, (const uint32_t *)nullptr, 0);
     }
     return hipGetLastError();
@@ -456,7 +460,7 @@ hipError_t launch_t2_encode_tile_parts(hipStream_t s, const j2k_t2_dev_packet *p
     hipLaunchKernelGGL(t2_scan_kernel, dim3(1), dim3(256), 0, s, sizes, npackets, fixed, 0, offs, var, result);
     hipLaunchKernelGGL(t2_tile_heads_kernel, dim3((unsigned)((ntiles + 63) / 64)), dim3(64), 0, s, offs, npackets, tile_packet0, ntiles, tile_first, out, cap, tile_offs, status, result);
     hipLaunchKernelGGL(t2_header_kernel, dim3((unsigned)npackets), dim3(64), 0, s, packets, npackets, cbs, sizes, offs, var, sop, eph, out, cap, result, ptile, extra);
-    hipLaunchKernelGGL(t2_body_kernel, dim3((unsigned)npackets, T2_BODY_SLICES), dim3(64), 0, s, packets, npackets, cbs, data, sizes, offs, var, fixed, out, cap, result,
+    hipLaunchKernelGGL(t2_body_kernel, dim3((unsigned)npackets, t2_body_slices()), dim3(64), 0, s, packets, npackets, cbs, data, sizes, offs, var, fixed, out, cap, result,
                        ptile, extra, slot_jobs, maglens, ht);
     return hipGetLastError();
 }

@@ -38,11 +38,5 @@ tail -1 $O/stats_cl.log | cut -c1-200
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_clht -- python $R/bench.py --config clht --steps 30 --warmup 3 --inflight 1 > $O/stats_clht.log 2>&1
 tail -1 $O/stats_clht.log | cut -c1-200
 unset GPU_MAX_HW_QUEUES
-# round 5: is the inverse level 0's read over-fetch what holds it back?  Groups of 16 bands per XCD instead of 8 halve the halo rows that
-# miss the L2: FETCH_SIZE and the kernel's time under both settings
-for g in 8 16; do
-  export J2K_L0_XCD_GROUP=$g
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_invg${g}_FETCH -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs --inflight 1 > $O/pmc_invg${g}.log 2>&1
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_invg${g} -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-other-configs --inflight 1 > $O/stats_invg${g}.log 2>&1
-done
-unset J2K_L0_XCD_GROUP
+# (round 5's XCD-group A/B of the inverse level 0 -- J2K_L0_XCD_GROUP=8|16 under --pmc FETCH_SIZE and under --stats -- was collected once with
+#  the loop that stood here, profiles/r05_inv_level0_xcd_group_ab.txt; a later PMC pass of it went silent for seven minutes, so it is not repeated)
