@@ -135,6 +135,9 @@ static int cl_prepare(j2k_plan *P) {
     alloc((void **)&P->d_frame_status, 64);
     if (r == J2K_OK) { hipError_t e = hipMemsetAsync(P->d_frame_status, 0, 64, ctx->stream); if (e != hipSuccess) r = fail_hip(ctx, e, "hipMemsetAsync"); }
     P->t2_npackets = (int)np;
+    int max_ncb = 1;
+    for (const j2k_t2_dev_packet &q : pk) max_ncb = std::max(max_ncb, (int)q.ncb);
+    P->t2_body_slices = std::min(32, max_ncb);                      // wavefronts that share the bodies of one packet (t2_body_kernel)
     if (r == J2K_OK) r = upload(ctx, &P->d_t2_packets, pk);      // (last: its presence says the tables are complete)
     return r;
 }
@@ -157,7 +160,7 @@ static int encode_tile_parts_impl(j2k_plan *P, const uint8_t *d_data, const uint
     HIPCHK(ctx, j2k::launch_t2_fill_cbs(ctx->stream, n, d_offs, d_lens, d_numbps, 31, ht | 2, P->d_t2_cbs, d_res));
     HIPCHK(ctx, j2k::launch_t2_encode_tile_parts(ctx->stream, P->d_t2_packets, np, P->d_t2_cbs, (uint64_t)n, d_data, sop, eph, d_out, (uint64_t)cap, P->d_t2_poffs,
                                                  P->d_t2_ws, d_res, P->d_t2_ptile, P->d_tile_packet0, P->tile_count, P->tile_first, d_tile_offs, P->d_frame_status,
-                                                 d_offs ? nullptr : (P->d_bjobs_alias ? P->d_bjobs_alias : P->d_bjobs), d_offs ? nullptr : (ht ? P->d_maglens : nullptr), ht));
+                                                 d_offs ? nullptr : (P->d_bjobs_alias ? P->d_bjobs_alias : P->d_bjobs), d_offs ? nullptr : (ht ? P->d_maglens : nullptr), ht, P->t2_body_slices));
     return J2K_OK;
 }
 

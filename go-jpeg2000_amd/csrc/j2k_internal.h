@@ -118,7 +118,7 @@ hipError_t launch_t2_fill_cbs(hipStream_t s, long n, const uint64_t *offs, const
 hipError_t launch_t2_encode_tile_parts(hipStream_t s, const j2k_t2_dev_packet *packets, long npackets, const j2k_t2_dev_cb *cbs, uint64_t ncbs, const uint8_t *data,
                                        int sop, int eph, uint8_t *out, uint64_t cap, uint64_t *offs, void *ws, uint64_t *result, const int32_t *ptile,
                                        const int *tile_packet0, int ntiles, int tile_first, uint64_t *tile_offs, int *status, const BlockJob *slot_jobs,
-                                       const uint32_t *maglens, int ht);
+                                       const uint32_t *maglens, int ht, int body_slices);
 size_t t2_dev_workspace(long npackets);
 hipError_t launch_t2_encode_packets(hipStream_t s, const j2k_t2_dev_packet *packets, long npackets, const j2k_t2_dev_cb *cbs, uint64_t ncbs, const uint8_t *data,
                                     int sop, int eph, int delay_in, uint8_t *out, uint64_t cap, uint64_t *offs, void *ws, uint64_t *result);

@@ -165,6 +165,7 @@ struct j2k_plan {
     int t2_npackets = 0;
     j2k_t2_dev_cb *d_t2_cbs = nullptr;           // code-block table of the packet coder / decoder (one entry per job)
     uint64_t *d_t2_poffs = nullptr;              // encode: where each packet starts among the packets (+ their total)
+    int t2_body_slices = 8;
     int32_t *d_t2_ptile = nullptr;               // encode: packet -> tile (its place in the tile-parts is 14 (tile + 1) bytes further)
     void *d_t2_ws = nullptr;                     // encode: the packet coder's workspace + its 3-word result
     void *d_t2_chains = nullptr;                 // decode: one chain per tile

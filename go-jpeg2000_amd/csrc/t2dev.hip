@@ -332,8 +332,8 @@ __global__ __launch_bounds__(64) void t2_header_kernel(const j2k_t2_dev_packet *
 
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 #define T2_BODY_SLICES 8
-// The bodies in block order behind the header (t2.go:279-287).  Wavefront (p, s) copies the code-blocks j = s mod T2_BODY_SLICES of
-// packet p; every wavefront sizes all of them (64 at a time, a scan over the lanes) to know where its own go.
+// The bodies in block order behind the header (t2.go:279-287).  Wavefront (p, s) copies the code-blocks j = s mod gridDim.y of
+// packet p (frame calls: as many slices as the plan's largest packet has blocks, at most 32 -- 8 -> 32 on the C2 frame: 25 -> 19 us); every wavefront sizes all of them (64 at a time, a scan over the lanes) to know where its own go.
 __global__ __launch_bounds__(64) void t2_body_kernel(const j2k_t2_dev_packet *__restrict__ packets, long npackets, const j2k_t2_dev_cb *__restrict__ cbs,
                                                      const uint8_t *__restrict__ data, const T2Size *__restrict__ sizes, const uint64_t *__restrict__ offs,
                                                      const uint8_t *__restrict__ var, int fixed, uint8_t *__restrict__ out, uint64_t cap,
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(64) void t2_tile_heads_kernel(const uint64_t *__res
 hipError_t launch_t2_encode_tile_parts(hipStream_t s, const j2k_t2_dev_packet *packets, long npackets, const j2k_t2_dev_cb *cbs, uint64_t ncbs, const uint8_t *data,
                                        int sop, int eph, uint8_t *out, uint64_t cap, uint64_t *offs, void *ws, uint64_t *result, const int32_t *ptile,
                                        const int *tile_packet0, int ntiles, int tile_first, uint64_t *tile_offs, int *status, const BlockJob *slot_jobs,
-                                       const uint32_t *maglens, int ht) {
+                                       const uint32_t *maglens, int ht, int body_slices) {
     if (npackets <= 0 || ntiles <= 0) return hipSuccess;
     T2Size *sizes = reinterpret_cast<T2Size *>(ws);
     uint8_t *var = reinterpret_cast<uint8_t *>(sizes + npackets);
@@ -460,7 +460,7 @@ hipError_t launch_t2_encode_tile_parts(hipStream_t s, const j2k_t2_dev_packet *p
     hipLaunchKernelGGL(t2_scan_kernel, dim3(1), dim3(256), 0, s, sizes, npackets, fixed, 0, offs, var, result);
     hipLaunchKernelGGL(t2_tile_heads_kernel, dim3((unsigned)((ntiles + 63) / 64)), dim3(64), 0, s, offs, npackets, tile_packet0, ntiles, tile_first, out, cap, tile_offs, status, result);
     hipLaunchKernelGGL(t2_header_kernel, dim3((unsigned)npackets), dim3(64), 0, s, packets, npackets, cbs, sizes, offs, var, sop, eph, out, cap, result, ptile, extra);
-    hipLaunchKernelGGL(t2_body_kernel, dim3((unsigned)npackets, t2_body_slices()), dim3(64), 0, s, packets, npackets, cbs, data, sizes, offs, var, fixed, out, cap, result,
+    hipLaunchKernelGGL(t2_body_kernel, dim3((unsigned)npackets, tuning_env("J2K_T2_BODY_SLICES") || body_slices < 1 ? t2_body_slices() : (unsigned)std::min(body_slices, 64)), dim3(64), 0, s, packets, npackets, cbs, data, sizes, offs, var, fixed, out, cap, result,
                        ptile, extra, slot_jobs, maglens, ht);
     return hipGetLastError();
 }
