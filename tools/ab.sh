@@ -14,7 +14,7 @@ i=0
 for c in "${combos[@]}"; do
   i=$((i+1)); O=$R/gpurun_out/ab/$i; rm -rf $O; mkdir -p $O
   envs=""; for kv in $c; do if [ "${kv#*=}" != "-" ]; then export $kv; envs="$envs $kv"; else unset ${kv%%=*}; fi; done
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --inflight 1 > $O.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-other-configs --inflight 1 > $O.log 2>&1
   echo "$c :: $(python $R/tools/kstats.py "$SUB" $O | cut -d' ' -f2- )"
   for kv in $c; do unset ${kv%%=*}; done
 done
