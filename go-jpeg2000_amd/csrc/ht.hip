@@ -1281,9 +1281,12 @@ __device__ uint32_t ht_loaded_bits(const HtDecShared &S, uint32_t nff, long segL
 // returns false when the block needs the bit-serial decoder (never on encoder output)
 // mpos2[t] = bit position of pair lane + 64 t in the MagSgn bit string, total_bits = the bits all pairs consume (both from the
 // caller, which has the records in registers): the LDS string is prepared only as far as it will be read.
+// STRIDED (the closed-loop frame decoder): row y of the block lies at out + y * os_ -- its window of a coefficient plane -- instead of out + y * w
+template <bool STRIDED>
 __device__ bool ht_extract_fast(HtDecShared &S, const uint8_t *__restrict__ data, long len, long scup, int w, int h,
                                 int32_t *__restrict__ out, int lane, bool bigu, const uint32_t (&mpos2)[2], uint32_t total_bits,
-                                const uint32_t (&raw0)[4]) {
+                                const uint32_t (&raw0)[4], int os_) {
+    const size_t os64 = STRIDED ? (size_t)os_ : (size_t)64, osw = STRIDED ? (size_t)os_ : (size_t)w;
     const int quadCols = (w + 3) / 4, P = (quadCols + 1) / 2, R = (h + 3) / 4, N = R * P;
     const long lcup = len;
     {
@@ -1459,7 +1462,7 @@ __device__ bool ht_extract_fast(HtDecShared &S, const uint8_t *__restrict__ data
         }
         // the pair's 8 columns of the coded row are written exactly once (zeros included): the zero fill
         // of the kernel skips coded rows, so no store ever has to be ordered behind another
-        if (w == 64 && (((uintptr_t)out) & 15) == 0) {
+        if (w == 64 && (((uintptr_t)out) & 15) == 0 && (!STRIDED || (os_ & 3) == 0)) {
             // 64-wide blocks: lane = (row of this round, pair) holds 32 bytes of a 256-byte row, and storing them as they lie
             // makes every store instruction write 16-byte pieces 32 bytes apart -- half-written 128-byte lines, which the
             // memory system turns into partial writes (measured: the kernel's 102 MB left at 3.2 TB/s against 5.4 TB/s for
@@ -1478,11 +1481,11 @@ __device__ bool ht_extract_fast(HtDecShared &S, const uint8_t *__restrict__ data
 #ifdef J2K_DEC_NO_CODED_STORES
                 if (o[0] == 0x7fffffff)            // DEV experiment: everything but the coded rows' stores
 #endif
-                if (rg < R) st_decoded(out + (size_t)(4 * rg) * 64 + 4 * q, o[0], o[1], o[2], o[3]);
+                if (rg < R) st_decoded(out + (size_t)(4 * rg) * os64 + 4 * q, o[0], o[1], o[2], o[3]);
             }
         } else if (it < N) {
             const int xb = pi * 8;
-            int32_t *orow = out + (size_t)(4 * r) * w + xb;
+            int32_t *orow = out + (size_t)(4 * r) * osw + xb;
             if (xb + 8 <= w && (((uintptr_t)orow) & 15) == 0) {
                 st_decoded(orow, vals[0], vals[1], vals[2], vals[3]);
                 st_decoded(orow + 4, vals[4], vals[5], vals[6], vals[7]);
@@ -1497,10 +1500,14 @@ __device__ bool ht_extract_fast(HtDecShared &S, const uint8_t *__restrict__ data
 }
 
 // four independent wavefronts per workgroup, one block each (no workgroup barrier anywhere on the fast path)
+// STRIDED: J.out_off / J.stride are the block's window of a coefficient plane (closed-loop plans: the windows partition the plane) and only the
+// coded rows are ever written -- the caller's planes were zeroed once (j2k_plan_decode_frame_pixels); no dense block, no placement copy
+template <bool STRIDED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void ht_decode_kernel(const BlockJob *__restrict__ jobs, int njobs,
                                                         const uint8_t *__restrict__ stream, const uint64_t *__restrict__ offs,
                                                         const uint32_t *__restrict__ lens, int32_t *__restrict__ decoded,
-                                                        const uint32_t *__restrict__ pairs, int coded_rows_only) {
+                                                        const uint32_t *__restrict__ pairs, int coded_rows_only_) {
+    const int coded_rows_only = STRIDED ? 1 : coded_rows_only_;
     __shared__ HtDecShared S4[4];
     HtDecShared &S = S4[threadIdx.x >> 6];
     const int jid = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1511,6 +1518,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
 #endif
     const BlockJob J = jobs[jid];
     const int w = J.w, h = J.h;
+    const int os_ = STRIDED ? J.stride : w;                       // row stride of the output
     int32_t *out = decoded + J.out_off;
     const size_t n = (size_t)w * h;
     // records first (their latency hides behind the zero fill)
@@ -1535,7 +1543,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
             if (skip_coded) return;                              // fast path: nothing but the coded rows, which the extraction writes
             // other paths: zero the coded rows, which the serial decoder (or nobody: invalid stream) then writes
             const uint32_t uw = (uint32_t)w, nrow = (uint32_t)(h + 3) >> 2;
-            for (uint32_t i = lane; i < uw * nrow; i += 64) out[(size_t)(i / uw) * 4 * uw + i % uw] = 0;
+            for (uint32_t i = lane; i < uw * nrow; i += 64) out[(size_t)(i / uw) * 4 * (STRIDED ? (uint32_t)os_ : uw) + i % uw] = 0;
             return;
         }
         if (w == 64 && (J.out_off & 3) == 0) {
@@ -1644,7 +1652,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
         const uint8_t *fdata = stream + my_off;
         const long flen = (long)my_len;
         const long fscup = (long)my_scup;                              // validated by ht_vlcprep_kernel
-        if (ht_extract_fast(S, fdata, flen, fscup, w, h, out, lane, bigu, mpos2, total_bits, raw0)) {
+        if (ht_extract_fast<STRIDED>(S, fdata, flen, fscup, w, h, out, lane, bigu, mpos2, total_bits, raw0, os_)) {
 #ifdef J2K_DEC_STAMP
             if ((jid % 700) == 13 && lane == 0) printf("dec job %d: start %lld | job+records %lld | prefetch+zero issue %lld | uvlc+pos %lld | unstuff %lld | extract %lld | end %lld (x10 ns)\n", jid, d0 % 100000, d_a - d0, d_b - d_a, d_c - d_b, g_dbg_unstuff - d_c, wall_clock64() - g_dbg_unstuff, wall_clock64() % 100000);
 #endif
@@ -1727,7 +1735,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
                     fwd_advance(ms, emb);
                     const uint32_t sign = fwd_fetch(ms) & 1;
                     fwd_advance(ms, 1);
-                    out[(size_t)y * w + base + i] = sign ? (int32_t)(0u - mag) : (int32_t)mag;
+                    out[(size_t)y * (STRIDED ? (size_t)os_ : (size_t)w) + base + i] = sign ? (int32_t)(0u - mag) : (int32_t)mag;
                 }
             }
         }
@@ -1781,8 +1789,9 @@ int ht_fast_max_samples() { return HT_FAST_MAX_SAMPLES; }
 // words of device scratch launch_ht_decode needs for njobs blocks: per-pair records + unstuffed VLC bit strings
 size_t ht_decode_scratch_words(int njobs) { return (size_t)njobs * (HT_WALK_REC + HT_VBITS_WORDS); }
 
+// placed_jobs != NULL: the blocks are written straight into their windows of the coefficient planes `decoded` (ht_decode_kernel<true>)
 hipError_t launch_ht_decode(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs,
-                            const uint32_t *lens, int32_t *decoded, uint32_t *scratch, int coded_rows_only) {
+                            const uint32_t *lens, int32_t *decoded, uint32_t *scratch, int coded_rows_only, const BlockJob *placed_jobs) {
     if (njobs <= 0) return hipSuccess;
     hipError_t e;
     if ((e = ht_tables_ready(s)) != hipSuccess) return e;
@@ -1794,7 +1803,9 @@ hipError_t launch_ht_decode(hipStream_t s, const BlockJob *jobs, int njobs, cons
     hipLaunchKernelGGL(ht_walk_kernel, dim3((njobs + HT_WALK_BLOCKS - 1) / HT_WALK_BLOCKS), dim3(256), sizeof(HtWalkShared), s, jobs, njobs, vbits, pairs);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     for (int rep_ = 0; rep_ < dev_reps(128); rep_++)
-    hipLaunchKernelGGL(ht_decode_kernel, dim3((njobs + 3) / 4), dim3(256), 0, s, jobs, njobs, stream, offs, lens, decoded, pairs, coded_rows_only);
+    if (placed_jobs) hipLaunchKernelGGL(ht_decode_kernel<true>, dim3((njobs + 3) / 4), dim3(256), 0, s, placed_jobs, njobs, stream, offs, lens, decoded, pairs, 1);
+    else
+    hipLaunchKernelGGL(ht_decode_kernel<false>, dim3((njobs + 3) / 4), dim3(256), 0, s, jobs, njobs, stream, offs, lens, decoded, pairs, coded_rows_only);
     return hipGetLastError();
 }
 

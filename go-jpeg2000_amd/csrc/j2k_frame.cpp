@@ -239,15 +239,14 @@ static int cl_workspaces(j2k_plan *P) {
     int r = J2K_OK;
     const size_t n = P->blocks.size();
     auto alloc = [&](void **p, size_t bytes) { if (r == J2K_OK) { hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 64)); if (e != hipSuccess) r = fail_hip(ctx, e, "hipMalloc (frame codec)"); } };
-    alloc((void **)&P->d_cl_decoded, (size_t)P->decoded_elems * 4);
+    if (P->spec.coder != J2K_CODER_HT) alloc((void **)&P->d_cl_decoded, (size_t)P->decoded_elems * 4);     // (HT: decoded in place, below)
     alloc((void **)&P->d_cl_offs, (n + 1) * 8);
     alloc((void **)&P->d_cl_lens, n * 4 + 16);
     alloc((void **)&P->d_cl_numbps, n + 16);
-    // HT plans: the decoder's two workspaces zeroed once, the coefficient planes its own (the encoder's forward transform writes d_cl_coeff) --
+    // HT plans: the decoder's coefficient planes, its own (the encoder's forward transform writes d_cl_coeff) and zeroed once --
     // j2k_plan_decode_frame_pixels relies on it
     if (P->spec.coder == J2K_CODER_HT) {
         alloc((void **)&P->d_cl_coeff_dec, (size_t)P->coeff_elems * 4);
-        if (r == J2K_OK) { hipError_t e = hipMemsetAsync(P->d_cl_decoded, 0, std::max<size_t>((size_t)P->decoded_elems * 4, 64), ctx->stream); if (e != hipSuccess) r = fail_hip(ctx, e, "hipMemsetAsync"); }
         if (r == J2K_OK) { hipError_t e = hipMemsetAsync(P->d_cl_coeff_dec, 0, std::max<size_t>((size_t)P->coeff_elems * 4, 64), ctx->stream); if (e != hipSuccess) r = fail_hip(ctx, e, "hipMemsetAsync"); }
     }
     alloc((void **)&P->d_cl_coeff, (size_t)P->coeff_elems * 4);     // (last: its presence says the workspaces are complete)
@@ -284,16 +283,16 @@ extern "C" int j2k_plan_decode_frame_pixels(j2k_plan *P, const uint8_t *d_cs, si
     if (r == J2K_OK) r = j2k_plan_decode_tile_parts(P, d_cs, len, d_tile_offs, sop, eph, P->d_cl_offs, P->d_cl_lens, P->d_cl_numbps);
     if (r != J2K_OK) return r;
     if (P->spec.coder == J2K_CODER_HT) {
-        // The reference's HT decoder writes one row in four and the other rows of a fresh decoder's block are zero.  Both
-        // workspaces here are the plan's own, zeroed when they were made, and nothing else writes them (the inverse transform reads
-        // its input only): the block decoder and the placement touch the coded rows alone -- a quarter of the stores and of the copy.
-        const bool was = P->dec_coded_rows_only;
-        P->dec_coded_rows_only = true;
-        r = j2k_plan_decode_blocks(P, d_cs, P->d_cl_offs, P->d_cl_lens, P->d_cl_numbps, P->d_cl_decoded);
-        P->dec_coded_rows_only = was;
-        if (r == J2K_OK) { j2k_ctx *ctx = P->ctx; HIPCHK(ctx, j2k::launch_place_blocks(ctx->stream, P->d_bjobs, P->d_djobs, (int)P->blocks.size(), P->max_block_h, P->d_cl_decoded, P->d_cl_coeff_dec, 4)); }
-        if (r == J2K_OK) r = j2k_plan_inverse_pixels(P, P->d_cl_coeff_dec, d_pix, stride);
-        return r;
+        // The reference's HT decoder writes one row in four and the other rows of a fresh decoder's block are zero.  The
+        // coefficient planes here are the plan's own, zeroed when they were made, and nothing else writes them (the inverse transform reads
+        // its input only; the encoder's forward transform has planes of its own): the block decoder writes the coded rows straight into each
+        // block's window (closed-loop windows partition the plane) -- a quarter of the stores, no dense blocks, no placement copy.
+        j2k_ctx *ctx = P->ctx;
+        const int n = (int)P->blocks.size();
+        r = stage_reserve(ctx, 2, ht_decode_scratch_words(n) * 4 + 256);
+        if (r != J2K_OK) return r;
+        HIPCHK(ctx, launch_ht_decode(ctx->stream, P->d_djobs, n, d_cs, P->d_cl_offs, P->d_cl_lens, P->d_cl_coeff_dec, (uint32_t *)ctx->stage[2], 1, P->d_djobs_placed));
+        return j2k_plan_inverse_pixels(P, P->d_cl_coeff_dec, d_pix, stride);
     } else {
         r = j2k_plan_decode_blocks(P, d_cs, P->d_cl_offs, P->d_cl_lens, P->d_cl_numbps, P->d_cl_decoded);
         if (r == J2K_OK) r = j2k_plan_place_blocks(P, P->d_cl_decoded, P->d_cl_coeff);

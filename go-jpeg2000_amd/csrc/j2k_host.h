@@ -28,7 +28,7 @@ hipError_t launch_ht_encode(hipStream_t s, const BlockJob *jobs, int njobs, cons
                             uint32_t *lens, uint8_t *numbps, int *fault, uint32_t *maglens = nullptr, const HtUJob *utab = nullptr, int nunique = 0,
                             const int *alias_ids = nullptr);
 hipError_t launch_ht_decode(hipStream_t s, const BlockJob *jobs, int njobs, const uint8_t *stream, const uint64_t *offs,
-                            const uint32_t *lens, int32_t *decoded, uint32_t *scratch, int coded_rows_only = 0);
+                            const uint32_t *lens, int32_t *decoded, uint32_t *scratch, int coded_rows_only = 0, const BlockJob *placed_jobs = nullptr);
 size_t ht_decode_scratch_words(int njobs);
 hipError_t launch_ht_encode_stream(hipStream_t s, const BlockJob *jobs, int njobs, const int32_t *coef, uint8_t *stream,
                                    uint64_t *offs, uint32_t *lens, uint8_t *numbps, uint64_t *status, uint32_t epoch, int *fault);

@@ -184,6 +184,7 @@ struct j2k_plan {
     std::vector<uint64_t> dec_off;          // element offset of each job's decoded block
     j2k::BlockJob *d_bjobs = nullptr;       // out_off = slot byte offset (encode)
     j2k::BlockJob *d_djobs = nullptr;       // out_off = decoded element offset (decode)
+    j2k::BlockJob *d_djobs_placed = nullptr; // closed-loop HT plans: out_off = the block's window in the coefficient planes, stride = the plane's
     int64_t bytes_cap = 0, decoded_elems = 0, block_samples = 0;
     int64_t dwt_bytes = 0, dwt_level0_bytes = 0;
     // device workspaces owned by the plan for j2k_encode_frame

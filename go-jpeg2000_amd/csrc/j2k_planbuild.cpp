@@ -689,6 +689,11 @@ int build_plan(j2k_ctx *ctx, const PlanSpec &S, j2k_plan **out) {
         }
         for (size_t i = 0; i < bj.size(); i++) bj[i].out_off = (int64_t)P->dec_off[i];   // decode table: dense decoded blocks
         if (r == J2K_OK) r = upload(ctx, &P->d_djobs, bj);
+        if (r == J2K_OK && P->spec.closed_loop && P->spec.coder == J2K_CODER_HT) {
+            // closed-loop HT plans: the frame decoder writes every block straight into its window of the coefficient planes (ht_decode_kernel<true>)
+            for (size_t i = 0; i < bj.size(); i++) bj[i].out_off = bj[i].src_off;
+            r = upload(ctx, &P->d_djobs_placed, bj);
+        }
         if (r != J2K_OK) { j2k_plan_destroy(P); return r; }
     }
     *out = P;
@@ -703,7 +708,7 @@ extern "C" void j2k_plan_destroy(j2k_plan *P) {
         if (cls == 0 && P->d_bigsym_off) { (void)hipFree(P->d_bigsym_off); P->d_bigsym_off = nullptr; }
         for (auto &T : P->inv[cls]) { if (T.d_planes) (void)hipFree(T.d_planes); if (T.d_jobs) (void)hipFree(T.d_jobs); if (T.d_pjobs) (void)hipFree(T.d_pjobs); }
     }
-    void *ptrs[] = {P->d_deep_jobs_inv, P->d_mega_fwd_jobs, P->d_mega_inv_jobs, P->d_fwd_top_jobs, P->d_inv_top_jobs, P->d_inv_wg_jobs, P->d_deep_planes, P->d_deep_jobs, P->d_tile_job0, P->d_scrA, P->d_scrB, P->d_tail, P->d_bjobs, P->d_djobs, P->d_frame, P->d_coeff, P->d_slots, P->d_stream, P->d_lens, P->d_numbps, P->d_offs, P->d_status, P->d_fwd_pix_jobs, P->d_fwd_wg2_jobs, P->d_fwd_wg_rest_jobs, P->d_fwd_wg_jobs, P->d_fwd97_wg_jobs, P->d_inv97_wg_jobs, P->d_ht_ujobs, P->d_ht_alias_next, P->d_bjobs_alias, P->d_maglens, P->d_mels, P->d_toffs,
+    void *ptrs[] = {P->d_deep_jobs_inv, P->d_mega_fwd_jobs, P->d_mega_inv_jobs, P->d_fwd_top_jobs, P->d_inv_top_jobs, P->d_inv_wg_jobs, P->d_deep_planes, P->d_deep_jobs, P->d_tile_job0, P->d_scrA, P->d_scrB, P->d_tail, P->d_bjobs, P->d_djobs, P->d_djobs_placed, P->d_frame, P->d_coeff, P->d_slots, P->d_stream, P->d_lens, P->d_numbps, P->d_offs, P->d_status, P->d_fwd_pix_jobs, P->d_fwd_wg2_jobs, P->d_fwd_wg_rest_jobs, P->d_fwd_wg_jobs, P->d_fwd97_wg_jobs, P->d_inv97_wg_jobs, P->d_ht_ujobs, P->d_ht_alias_next, P->d_bjobs_alias, P->d_maglens, P->d_mels, P->d_toffs,
                     P->d_t2_packets, P->d_tile_packet0, P->d_t2_cbs, P->d_t2_poffs, P->d_t2_ptile, P->d_t2_ws, P->d_t2_chains, P->d_t2_body_base, P->d_t2_par, P->d_frame_status,
                     P->d_cl_decoded, P->d_cl_coeff, P->d_cl_coeff_dec, P->d_cl_numbps, P->d_cl_offs, P->d_cl_lens, P->d_host_io, P->d_host_pix};
     for (void *p : ptrs) if (p) (void)hipFree(p);

@@ -552,8 +552,8 @@ int j2k_t2_decode_packets_device(j2k_ctx *ctx, const j2k_t2_dev_packet *d_packet
  *                               pixels (any format, as j2k_plan_forward_pixels) -> tile-parts, and tile-parts -> pixels.  Same bytes
  *                               and pixels as the stage calls, with less copying: the encoder gathers every block once from its
  *                               coding slot into its packet in its tile-part (no dense stream in between); on an HT plan the
- *                               decoder writes and places only the rows the reference's HT decoder writes (one in four) into
- *                               workspaces it zeroed once.
+ *                               block decoder writes only the rows the reference's HT decoder writes (one in four), straight
+ *                               into each block's window of coefficient planes the plan zeroed once.
  * All of them return J2K_ERR_UNSUPPORTED on a plan without closed_loop. */
 size_t j2k_plan_frame_bound(const j2k_plan *plan);
 int j2k_plan_encode_tile_parts(j2k_plan *plan, const uint8_t *d_stream, const uint64_t *d_offs, const uint32_t *d_lens, const uint8_t *d_numbps,
