@@ -710,8 +710,8 @@ def test_closed_loop_frame_encoder_gathers_from_the_slots_what_the_stage_calls_c
 
 @pytest.mark.parametrize("W,H,tile,cb,nres", [(640, 360, (256, 256), 64, 5), (301, 211, (128, 96), 32, 4), (130, 70, (0, 0), 16, 3)])
 def test_closed_loop_ht_frame_decoder_touches_the_coded_rows_only_and_stays_equal_to_the_stage_calls(env, W, H, tile, cb, nres):
-    """j2k_plan_decode_frame_pixels on an HT plan decodes and places only the rows the reference's HT decoder writes (y % 4 == 0) into
-    workspaces it zeroed once.  Frame after frame on ONE plan -- busy, flat (empty blocks where there were bytes a frame ago), busy again --
+    """j2k_plan_decode_frame_pixels on an HT plan writes only the rows the reference's HT decoder writes (y % 4 == 0), straight into the blocks'
+    windows of coefficient planes it zeroed once (no dense blocks, no placement).  Frame after frame on ONE plan -- busy, flat (empty blocks where there were bytes a frame ago), busy again --
     the pixels equal those of the stage calls, which zero, decode and copy every row every time"""
     torch, t2ref, t2, ctx = env
     from j2kgfx import _lib

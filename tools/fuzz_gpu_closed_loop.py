@@ -134,6 +134,14 @@ while time.time() - t0 < budget:
                 assert np.array_equal(got, want_p[c]), ("placed", desc, tl, c, given)
         if coder == 0:
             assert np.array_equal(hb, frame), ("round trip", desc, given)
+        if Cn == 3 and prec == 8 and given:
+            # the one-call frame decoder (HT: coded rows straight into the planes' windows, planes zeroed once) == the stage calls, frame after frame
+            want_px = plan.inverse_pixels(placed, torch.zeros(H, W * 4, dtype=torch.uint8, device=plan.device))
+            got_px = torch.zeros_like(want_px)
+            for _ in range(2):
+                plan.decode_frame_pixels(cs, total, got_px, tile_offs=toffs, sop=sop, eph=eph)
+                plan.frame_status()
+                assert torch.equal(got_px, want_px), ("frame decoder", desc)
     plan.close()
     n += 1
 print("closed-loop fuzz: %d frames clean (%d in the reference's HT panic domain; SOP + EPH frames: %d tiles parsed packet-parallel, %d fell back to the tile chain; %d frames also through the one-call frame encoder) in %.0f s, seed %d"
