@@ -291,22 +291,11 @@ hipError_t launch_unpack(hipStream_t s, const BlockJob *jobs, int njobs, int cou
 // D2H copy carry the finished tile-parts.)
 __global__ __launch_bounds__(256) void assemble_tiles_kernel(const uint8_t *__restrict__ stream, const uint64_t *__restrict__ offs,
                                                               const int *__restrict__ job0, int ntiles, int tile_first,
-                                                              uint8_t *__restrict__ out, uint64_t *__restrict__ out_len,
-                                                              uint64_t cap, uint64_t *__restrict__ tile_offs, int *__restrict__ status) {
+                                                              uint8_t *__restrict__ out, uint64_t *__restrict__ out_len) {
     const int t = blockIdx.x;
     const uint64_t base = offs[job0[0]], o0 = offs[job0[t]], o1 = offs[job0[t + 1]];
     const uint64_t len = o1 - o0;
     uint8_t *dst = out + (o0 - base) + 14ull * (uint64_t)t;
-    // the closed-loop frame call (j2k_plan_encode_tile_parts): where every tile-part starts (+ the total), and nothing written
-    // when the caller's buffer is too small -- the total then says what it takes
-    if (tile_offs) {
-        const uint64_t total = (offs[job0[ntiles]] - base) + 14ull * (uint64_t)ntiles;
-        if (blockIdx.y == 0 && threadIdx.x == 0) {
-            tile_offs[t] = (o0 - base) + 14ull * (uint64_t)t;
-            if (t == 0) { tile_offs[ntiles] = total; if (total > cap && status) atomicMin(status, J2K_ERR_CAPACITY); }
-        }
-        if (total > cap) return;
-    }
     if (blockIdx.y == 0 && threadIdx.x < 14) {
         const uint32_t idx = (uint32_t)(tile_first + t) & 0xFFFFu, psot = (uint32_t)(14 + len);
         const uint8_t hdr[14] = {0xFF, 0x90, 0x00, 0x0A, (uint8_t)(idx >> 8), (uint8_t)idx, (uint8_t)(psot >> 24), (uint8_t)(psot >> 16),
@@ -332,10 +321,10 @@ __global__ __launch_bounds__(256) void assemble_tiles_kernel(const uint8_t *__re
     if (done + threadIdx.x < n) d[done + threadIdx.x] = src[done + threadIdx.x];
 }
 hipError_t launch_assemble_tiles(hipStream_t s, const uint8_t *stream, const uint64_t *offs, const int *job0, int ntiles, int tile_first,
-                                 uint64_t max_tile_bytes, uint8_t *out, uint64_t *out_len, uint64_t cap, uint64_t *tile_offs, int *status) {
+                                 uint64_t max_tile_bytes, uint8_t *out, uint64_t *out_len) {
     if (ntiles <= 0) return hipSuccess;
     const unsigned chunks = (unsigned)std::max<uint64_t>(1, (max_tile_bytes + 65535) >> 16);
-    hipLaunchKernelGGL(assemble_tiles_kernel, dim3(ntiles, chunks), dim3(256), 0, s, stream, offs, job0, ntiles, tile_first, out, out_len, cap, tile_offs, status);
+    hipLaunchKernelGGL(assemble_tiles_kernel, dim3(ntiles, chunks), dim3(256), 0, s, stream, offs, job0, ntiles, tile_first, out, out_len);
     return hipGetLastError();
 }
 

@@ -106,19 +106,6 @@ static int cl_prepare(j2k_plan *P) {
     std::vector<int> tp0;
     plan_t2_packets(P, 0, pk, &tp0);
     const size_t n = P->blocks.size(), np = pk.size();
-    // per tile: its slots + what the headers can take (inclusion 2 bits, zero bit planes 32, passes 16, length 5 + 32: 11 bytes, 13
-    // with every byte stuffed; a packet: presence bit + padding, SOP, EPH)
-    uint64_t max_tile = 0, total = 0;
-    for (int t = 0; t < P->tile_count; t++) {
-        uint64_t b = 0;
-        for (int q = tp0[t]; q < tp0[t + 1]; q++)
-            for (int64_t j = pk[q].cb0; j < pk[q].cb0 + pk[q].ncb; j++) b += ((j2k_block_bound(P->spec.coder, P->blocks[(size_t)j].w, P->blocks[(size_t)j].h) + 15) & ~size_t(15)) + 16;
-        b += 16ull * (uint64_t)(tp0[t + 1] - tp0[t]);
-        max_tile = std::max(max_tile, b);
-        total += b;
-    }
-    (void)total;
-    P->max_tile_bytes = std::max<uint64_t>(P->max_tile_bytes, max_tile);
     std::vector<int32_t> ptile(np ? np : 1, 0);                     // packet -> its tile (packet p ends up 14 (ptile[p] + 1) bytes behind its place among the packets)
     for (int t = 0; t < P->tile_count; t++)
         for (int q = tp0[t]; q < tp0[t + 1]; q++) ptile[(size_t)q] = t;

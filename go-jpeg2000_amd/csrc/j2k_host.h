@@ -52,8 +52,7 @@ hipError_t launch_compact(hipStream_t s, const BlockJob *jobs, int njobs, const 
                           uint64_t *offs, uint8_t *stream, const uint32_t *maglens, const uint32_t *mels = nullptr, uint64_t *toffs = nullptr);
 hipError_t launch_mel_table(hipStream_t s, const BlockJob *jobs, int njobs, uint32_t *mels);
 hipError_t launch_assemble_tiles(hipStream_t s, const uint8_t *stream, const uint64_t *offs, const int *job0, int ntiles, int tile_first,
-                                 uint64_t max_tile_bytes, uint8_t *out, uint64_t *out_len, uint64_t cap = 0, uint64_t *tile_offs = nullptr,
-                                 int *status = nullptr);
+                                 uint64_t max_tile_bytes, uint8_t *out, uint64_t *out_len);
 // t2dec.hip
 size_t t2_chain_bytes();
 hipError_t launch_t2_tile_chains(hipStream_t s, const uint8_t *cs, uint64_t len, const uint64_t *tile_offs, int ntiles, int tile_first,
