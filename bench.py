@@ -49,13 +49,13 @@ def _traffic(fetch_kib, write_kib, src):
 
 TRAFFIC = {   # frame_io -> (bytes per level-0 forward launch, source); tests/test_bench_traffic_constant.py re-reads the summary
     "planes": _traffic(52495.8, 97200.0, "profiles/r01_bench_v3_inflight1_pmc_{FETCH,WRITE}_SIZE.csv"),
-    "rgba8": _traffic(16430.1, 97259.8, "profiles/r05_bench_inflight1_pmc_summary.txt"),
+    "rgba8": _traffic(16433.0, 97281.6, "profiles/r05_bench_inflight1_pmc_summary.txt"),
 }
 # HBM bytes ALL kernels of one C2 frame move (same PMC passes, one frame in flight): sum over the nine kernels of a step of
 # 2 x FETCH_SIZE + WRITE_SIZE; tests/test_bench_traffic_constant.py re-adds them from the committed summary
 PIPELINE_KERNELS = ("dwt53_fwd_rgba8_wg_kernel", "dwt53_deep_fwd_kernel", "ht_encode_kernel", "gather_scan_kernel", "ht_vlcprep_kernel", "ht_walk_kernel",
                     "ht_decode_kernel", "dwt53_deep_inv_kernel", "dwt53_inv_rgba8_wg_kernel")
-PIPELINE_TRAFFIC = (int(round(488239.0 * 1024)), "profiles/r05_bench_inflight1_pmc_summary.txt: sum of (2 x FETCH_SIZE + WRITE_SIZE) over %d kernels" % len(PIPELINE_KERNELS))
+PIPELINE_TRAFFIC = (int(round(485558.8 * 1024)), "profiles/r05_bench_inflight1_pmc_summary.txt: sum of (2 x FETCH_SIZE + WRITE_SIZE) over %d kernels" % len(PIPELINE_KERNELS))
 COPY_PEAK_GUIDE_GBS = 6290.0   # MI355X_MICROARCH.md: the float4 device-to-device copy the guide measured (what a pure copy reaches)
 
 
