@@ -231,11 +231,7 @@ def test_closed_loop_packets_device_encoder_and_decoder_against_the_restatement(
                 assert gl == 0 and body is None
 
 
-def _frame(W, H, seed, noise=16):
-    rng = np.random.default_rng(seed)
-    yy, xx = np.mgrid[0:H, 0:W]
-    f = np.stack([xx * 255 // W, yy * 255 // H, (xx + yy) * 127 // max(W, H)]) + rng.integers(-noise, noise + 1, (3, H, W))
-    return np.clip(f, 0, 255).astype(np.uint8)
+from closed_loop_ref import frame as _frame, oracle_frame as _oracle_frame  # noqa: E402  (shared with the golden digests)
 
 
 def _rgba(frame):
@@ -280,38 +276,6 @@ def test_closed_loop_4k_rgb8_mq_pixels_to_tile_parts_to_pixels_bit_exact(env):
         plan.frame_status()
     assert e.value.status == _lib.ERR_INVALID_ARG
     plan.close()
-
-
-def _oracle_frame(frame, W, H, tw, th, nres, cb, coder, sop, eph, orc, t2ref, tiles=None):
-    """The closed-loop frame by the oracle: per tile (the reference pipeline on the cropped sub-image) preprocess,
-    the job list with partitioning windows, the block coder, one packet per (component, resolution), createTileHeader.
-    Returns per tile: dict(coeff, bytes, lens, numbps, part)."""
-    out = {}
-    tx_n, ty_n = (W + tw - 1) // tw, (H + th - 1) // th
-    for t in range(tx_n * ty_n):
-        if tiles is not None and t not in tiles:
-            continue
-        tx, ty = t % tx_n, t // tx_n
-        x0, y0 = tx * tw, ty * th
-        w, h = min(tw, W - x0), min(th, H - y0)
-        sub = [np.ascontiguousarray(frame[c, y0:y0 + h, x0:x0 + w]).astype(np.int32) for c in range(frame.shape[0])]
-        coeff = orc.preprocess(sub, w, h, 8, True, nres)
-        by, lens, nb = orc.encode_tile_blocks(coeff, w, h, nres, cb, cb, coder, windows=1)
-        jobs = orc.enumerate_blocks(len(sub), w, h, nres, cb, cb, 1)
-        enc = t2ref.PacketEncoder(len_bits=5)
-        pos, j = 0, 0
-        while j < len(jobs):
-            k = j
-            blocks = []
-            while k < len(jobs) and jobs[k]["comp"] == jobs[j]["comp"] and jobs[k]["res"] == jobs[j]["res"]:
-                ln, n_b = int(lens[k]), int(nb[k])
-                blocks.append(t2ref.CodeBlock(bytes(by[pos:pos + ln]), 1 if ln == 0 else 0, max(31 - n_b, 0), 0 if n_b == 0 else (1 if coder == 1 else 3 * n_b - 2)))
-                pos += ln
-                k += 1
-            enc.encode_packet(t2ref.Precinct([blocks]), 0, sop, eph)
-            j = k
-        out[t] = dict(coeff=coeff, bytes=by, lens=lens, numbps=nb, part=orc.create_tile_header(t, bytes(enc.out)), w=w, h=h, x0=x0, y0=y0)
-    return out
 
 
 @pytest.mark.parametrize("coder", [0, 1])
