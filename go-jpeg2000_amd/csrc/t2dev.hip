@@ -256,8 +256,12 @@ __global__ __launch_bounds__(64) void t2_size_kernel(const j2k_t2_dev_packet *__
 }
 
 // offs[p] = where packet p starts, var[p] = the writer's flag on entry; result = {total bytes, flag after the last packet, fault}
+struct T2Heads {                        // frame calls: the tile-part heads written by the scan's own workgroup once the offsets stand (ntiles == 0: none)
+    const int *tile_packet0; int ntiles, tile_first; uint8_t *out; uint64_t cap; uint64_t *tile_offs; int *status;
+};
+__device__ void t2_tile_heads(const uint64_t *__restrict__ offs, long npackets, const T2Heads &Hd, const uint64_t *__restrict__ result, int t0, int tstep);
 __global__ __launch_bounds__(256) void t2_scan_kernel(const T2Size *__restrict__ sizes, long npackets, int fixed, int delay_in, uint64_t *__restrict__ offs,
-                                                      uint8_t *__restrict__ var, uint64_t *__restrict__ result) {
+                                                      uint8_t *__restrict__ var, uint64_t *__restrict__ result, T2Heads Hd) {
     __shared__ uint64_t len_s[256][2], base_s[256];
     __shared__ uint8_t st_s[256][2], in_s[256];
     const int t = threadIdx.x;
@@ -297,6 +301,11 @@ __global__ __launch_bounds__(256) void t2_scan_kernel(const T2Size *__restrict__
         offs[p] = off; var[p] = (uint8_t)st;
         off += (uint64_t)fixed + S.hlen[st] + S.body;
         st = (S.ff_out >> st) & 1;
+    }
+    if (Hd.ntiles > 0) {                                            // (one workgroup wrote every offset: visible to all of it behind the barrier)
+        __threadfence();
+        __syncthreads();
+        t2_tile_heads(offs, npackets, Hd, result, t, 256);
     }
 }
 
@@ -411,7 +420,7 @@ hipError_t launch_t2_encode_packets(hipStream_t s, const j2k_t2_dev_packet *pack
     uint8_t *var = reinterpret_cast<uint8_t *>(sizes + npackets);
     const int fixed = (sop ? 6 : 0) + (eph ? 2 : 0);
     if (npackets > 0) hipLaunchKernelGGL(t2_size_kernel, dim3((unsigned)npackets), dim3(64), 0, s, packets, npackets, cbs, ncbs, sizes, result);
-    hipLaunchKernelGGL(t2_scan_kernel, dim3(1), dim3(256), 0, s, sizes, npackets, fixed, delay_in, offs, var, result);
+    hipLaunchKernelGGL(t2_scan_kernel, dim3(1), dim3(256), 0, s, sizes, npackets, fixed, delay_in, offs, var, result, T2Heads{});
     if (npackets > 0) {
         hipLaunchKernelGGL(t2_header_kernel, dim3((unsigned)npackets), dim3(64), 0, s, packets, npackets, cbs, sizes, offs, var, sop, eph, out, cap, result,
                            (const int32_t *)nullptr, (uint64_t)0);
@@ -422,27 +431,27 @@ hipError_t launch_t2_encode_packets(hipStream_t s, const j2k_t2_dev_packet *pack
 }
 
 // SOT | SOD of every tile-part in front of its packets (tcd CreateTileHeader: FF90 000A Isot Psot TPsot = 0 TNsot = 1, FF93), where each
-// starts, the total -- and the capacity verdict (nothing is written by anyone when the caller's buffer is too small)
-__global__ __launch_bounds__(64) void t2_tile_heads_kernel(const uint64_t *__restrict__ offs, long npackets, const int *__restrict__ tile_packet0, int ntiles, int tile_first,
-                                                           uint8_t *__restrict__ out, uint64_t cap, uint64_t *__restrict__ tile_offs, int *__restrict__ status,
-                                                           const uint64_t *__restrict__ result) {
-    const int t = blockIdx.x * 64 + threadIdx.x;
+// starts, the total -- and the capacity verdict (nothing is written by anyone when the caller's buffer is too small).  Runs at the end of
+// t2_scan_kernel (a launch of its own cost 4.6 us of a frame's 130)
+__device__ void t2_tile_heads(const uint64_t *__restrict__ offs, long npackets, const T2Heads &Hd, const uint64_t *__restrict__ result, int t0, int tstep) {
+    const int ntiles = Hd.ntiles;
     const uint64_t total = offs[npackets] + 14ull * (uint64_t)ntiles;
-    if (t == 0) {
-        tile_offs[ntiles] = total;
-        if (status && result[2] != 0) atomicMin(status, J2K_ERR_GO_PANIC);       // (a tree width of 0: no plan makes one)
-        else if (status && total > cap) atomicMin(status, J2K_ERR_CAPACITY);
+    if (t0 == 0) {
+        Hd.tile_offs[ntiles] = total;
+        if (Hd.status && result[2] != 0) atomicMin(Hd.status, J2K_ERR_GO_PANIC);       // (a tree width of 0: no plan makes one)
+        else if (Hd.status && total > Hd.cap) atomicMin(Hd.status, J2K_ERR_CAPACITY);
     }
-    if (t >= ntiles) return;
-    const uint64_t o0 = offs[tile_packet0[t]], o1 = offs[tile_packet0[t + 1]];
-    tile_offs[t] = o0 + 14ull * (uint64_t)t;
-    if (result[2] != 0 || total > cap) return;
-    uint8_t *dst = out + o0 + 14ull * (uint64_t)t;
-    const uint32_t idx = (uint32_t)(tile_first + t) & 0xFFFFu, psot = (uint32_t)(14 + (o1 - o0));
-    const uint8_t hdr[14] = {0xFF, 0x90, 0x00, 0x0A, (uint8_t)(idx >> 8), (uint8_t)idx, (uint8_t)(psot >> 24), (uint8_t)(psot >> 16),
-                             (uint8_t)(psot >> 8), (uint8_t)psot, 0x00, 0x01, 0xFF, 0x93};
+    for (int t = t0; t < ntiles; t += tstep) {
+        const uint64_t o0 = offs[Hd.tile_packet0[t]], o1 = offs[Hd.tile_packet0[t + 1]];
+        Hd.tile_offs[t] = o0 + 14ull * (uint64_t)t;
+        if (result[2] != 0 || total > Hd.cap) continue;
+        uint8_t *dst = Hd.out + o0 + 14ull * (uint64_t)t;
+        const uint32_t idx = (uint32_t)(Hd.tile_first + t) & 0xFFFFu, psot = (uint32_t)(14 + (o1 - o0));
+        const uint8_t hdr[14] = {0xFF, 0x90, 0x00, 0x0A, (uint8_t)(idx >> 8), (uint8_t)idx, (uint8_t)(psot >> 24), (uint8_t)(psot >> 16),
+                                 (uint8_t)(psot >> 8), (uint8_t)psot, 0x00, 0x01, 0xFF, 0x93};
 #pragma unroll
-    for (int k = 0; k < 14; k++) dst[k] = hdr[k];
+        for (int k = 0; k < 14; k++) dst[k] = hdr[k];
+    }
 }
 // The packets of a frame written where they end up: tile-parts in `out` (SOT | SOD | packets per tile), no packet stream and no dense
 // block stream in between.  data + cbs[].data_off: the blocks' bytes (the compacted stream of j2k_plan_encode_stream), or, with
@@ -457,8 +466,7 @@ hipError_t launch_t2_encode_tile_parts(hipStream_t s, const j2k_t2_dev_packet *p
     const int fixed = (sop ? 6 : 0) + (eph ? 2 : 0);
     const uint64_t extra = 14ull * (uint64_t)ntiles;
     hipLaunchKernelGGL(t2_size_kernel, dim3((unsigned)npackets), dim3(64), 0, s, packets, npackets, cbs, ncbs, sizes, result);
-    hipLaunchKernelGGL(t2_scan_kernel, dim3(1), dim3(256), 0, s, sizes, npackets, fixed, 0, offs, var, result);
-    hipLaunchKernelGGL(t2_tile_heads_kernel, dim3((unsigned)((ntiles + 63) / 64)), dim3(64), 0, s, offs, npackets, tile_packet0, ntiles, tile_first, out, cap, tile_offs, status, result);
+    hipLaunchKernelGGL(t2_scan_kernel, dim3(1), dim3(256), 0, s, sizes, npackets, fixed, 0, offs, var, result, T2Heads{tile_packet0, ntiles, tile_first, out, cap, tile_offs, status});
     hipLaunchKernelGGL(t2_header_kernel, dim3((unsigned)npackets), dim3(64), 0, s, packets, npackets, cbs, sizes, offs, var, sop, eph, out, cap, result, ptile, extra);
     hipLaunchKernelGGL(t2_body_kernel, dim3((unsigned)npackets, tuning_env("J2K_T2_BODY_SLICES") || body_slices < 1 ? t2_body_slices() : (unsigned)std::min(body_slices, 64)), dim3(64), 0, s, packets, npackets, cbs, data, sizes, offs, var, fixed, out, cap, result,
                        ptile, extra, slot_jobs, maglens, ht);
