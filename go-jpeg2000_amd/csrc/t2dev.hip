@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void t2_scan_kernel(const T2Size *__restrict__
         st = (S.ff_out >> st) & 1;
     }
     if (Hd.ntiles > 0) {                                            // (one workgroup wrote every offset: visible to all of it behind the barrier)
-        __threadfence();
+        __threadfence_block();                                    // (workgroup scope is all it takes -- a device-scope release writes the L2 back, docs/KERNEL_NOTES.md 4p)
         __syncthreads();
         t2_tile_heads(offs, npackets, Hd, result, t, 256);
     }
