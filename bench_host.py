@@ -298,8 +298,10 @@ def run_host_boundary(args):
                                  "frames_in_flight": NL, "h2d_bytes_per_frame": h2d, "d2h_bytes_per_frame": d2h,
                                  "host_issue_ms_per_frame": round((t_issue - host_wait[0]) / frames * 1e3, 4), "host_wait_ms_per_frame": round(host_wait[0] / frames * 1e3, 4),
                                  "ms_per_frame": round(dt / frames * 1e3, 4), "copy_stream_pairs_tried_ms_per_round": [round(v * 1e3, 3) for v in tried],
-                                 "segments_mpixels_s": segs, "best_segment_frac": round(max(segs) * 1e6 / (W * H) * max(h2d, d2h) / 1e9 / max(peak["both_each"], 1e-9), 4),
-                                 "note": "fraction = the busier direction's bytes per second / what each direction reaches when two large pinned "
+                                 "segments_mpixels_s": segs, "median_segment_mpixels_s": round(float(np.median(segs)), 1),
+                                 "median_segment_frac": round(float(np.median(segs)) * 1e6 / (W * H) * max(h2d, d2h) / 1e9 / max(peak["both_each"], 1e-9), 4), "best_segment_frac": round(max(segs) * 1e6 / (W * H) * max(h2d, d2h) / 1e9 / max(peak["both_each"], 1e-9), 4),
+                                 "note": "value and frac_of_pinned_copy_peak are over the WHOLE timed region (every segment counted, a stalled one too -- the host is shared); the median segment is given beside them. "
+                                         "fraction = the busier direction's bytes per second / what each direction reaches when two large pinned "
                                          "copies run at once on this box (both_each); never the headline `value`, which has its inputs resident in HBM"}}
         print(json.dumps(out))
         ok = True
