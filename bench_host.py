@@ -247,12 +247,12 @@ def run_host_boundary(args):
             for ln in lanes:
                 issue(ln)
         drain()
-        steps = max(args.steps, int(np.ceil(1.0 / max((time.perf_counter() - tc) / 3, 1e-6))))
+        steps = max(args.steps, int(np.ceil(2.0 / max((time.perf_counter() - tc) / 3, 1e-6))))   # (2 s: one stalled moment of a shared host weighs less)
         steps = min(steps, 5000)
         # The timed region is NSEG segments of steps / NSEG rounds each (the pipeline drained in between), all of them counted: on
         # these boxes the link runs in one of two modes at a time -- both directions at once (48.6 GB/s each way) or taking turns
         # (28.6; the same two figures two plain pinned copies give, see pinned_copy_peak) -- and a segment is in one or the other
-        NSEG = 8
+        NSEG = 16
         per = max(steps // NSEG, 1)
         steps = per * NSEG
         segs = []
