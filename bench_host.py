@@ -68,7 +68,7 @@ def run_host_boundary(args):
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
     torch.cuda.set_device(0)
-    NL = args.inflight if args.inflight > 0 and "--inflight" in " ".join(sys.argv) else 2      # (a lane holds two frames' device buffers: one to four lanes measure the same, 0.80-0.86)
+    NL = args.inflight if args.inflight > 0 and "--inflight" in " ".join(sys.argv) else 1      # (a lane holds two frames' device buffers and keeps both copy directions and the kernels busy; more lanes put several PCIe-writing kernels on the link at once: 0.92 / 0.80 / 0.70 / 0.65 with 1 / 2 / 3 / 4)
     # the two copy streams are HIGH-PRIORITY streams: the runtime keeps a separate set of hardware queues per priority, so they never
     # share a queue with a lane's kernels (J2K_BENCH_HOST_PRIO=0: plain streams, dealt onto the same queues as everything else)
     prio = -1 if os.environ.get("J2K_BENCH_HOST_PRIO", "1") != "0" else 0
@@ -80,6 +80,13 @@ def run_host_boundary(args):
     # link anyway, and a dozen copy streams dealt onto the runtime's hardware queues end up sharing queues with each other and with the
     # kernels' streams at random
     shared = os.environ.get("J2K_BENCH_HOST_STREAMS", "shared") == "shared"
+    # The inverse level-0 kernel stores the pixels STRAIGHT into the pinned host frame (pinned memory is device-addressable) instead of into a
+    # device frame that a D2H copy then moves: the larger half of the D2H bytes leaves the copy engines, and with it the moments when the two
+    # directions' copies took turns on one engine.  One lane: 0.91-0.92 of the pinned-copy peak, every segment within 5 % (device frame + copy:
+    # 0.86 with segments from 0.80 to 0.97, and 0.65-0.84 as two lanes).  J2K_BENCH_HOST_DIRECT=0: the copy; =2: the forward kernel READS the
+    # pinned pixels as well (no H2D copy of them: 0.63 -- loads over the link are not posted)
+    direct = os.environ.get("J2K_BENCH_HOST_DIRECT", "1") in ("1", "2")
+    direct_in = os.environ.get("J2K_BENCH_HOST_DIRECT", "1") == "2"     # (experiment: the forward kernel READS the pinned pixels too -- no H2D copy of them)
     try:
         for f in range(NL):
             ctx = Context(0)
@@ -108,6 +115,7 @@ def run_host_boundary(args):
                       d_stream2=[p.empty(int(i.bytes_cap) + 8 * (n + 1) + 5 * n + 64, torch.uint8) for _ in range(2)],
                       decoded=torch.zeros(max(int(i.decoded_elems), 4), dtype=torch.int32, device=p.device),
                       d_back=[torch.empty((H, W * 4), dtype=torch.uint8, device=p.device) for _ in range(2)], h_back=torch.empty((H, W * 4), dtype=torch.uint8).pin_memory(),
+                      h_back2=[torch.empty((H, W * 4), dtype=torch.uint8).pin_memory() for _ in range(2)],
                       k=0)
             for name in ("e_pix", "e_fwd", "e_enc", "e_len", "e_tabs", "e_str", "e_dec", "e_inv", "e_back", "e_cs_free"):
                 ln[name] = [torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()]
@@ -157,7 +165,8 @@ def run_host_boundary(args):
                 ln["e_len"][b].record(s_out)
                 ln["e_tabs"][b].record(s_out)
                 s_out.wait_event(ln["e_inv"][b])
-                ln["h_back"].copy_(ln["d_back"][b], non_blocking=True)
+                if not direct:
+                    ln["h_back"].copy_(ln["d_back"][b], non_blocking=True)
                 ln["e_back"][b].record(s_out)
 
         def issue(ln):
@@ -171,14 +180,15 @@ def run_host_boundary(args):
             # ---- in: pinned pixels and pinned block stream + tables -> device set b (last used by frame k - 2)
             with torch.cuda.stream(s_in):
                 s_in.wait_event(ln["e_fwd"][b])
-                ln["d_pix"][b].copy_(ln["h_pix"], non_blocking=True)
+                if not direct_in:
+                    ln["d_pix"][b].copy_(ln["h_pix"], non_blocking=True)
                 ln["e_pix"][b].record(s_in)
                 s_in.wait_event(ln["e_dec"][b])
                 ln["d_stream2"][b][:ln["h_in2"].numel()].copy_(ln["h_in2"], non_blocking=True)
                 ln["e_str"][b].record(s_in)
             # ---- kernels: encode (pixels -> tile-parts) and decode (block stream -> pixels) of frame k
             lib.wait_event(ln["e_pix"][b])
-            p.forward_rgba8(ln["d_pix"][b], ln["coeff"])
+            p.forward_rgba8(ln["h_pix"] if direct_in else ln["d_pix"][b], ln["coeff"])
             ln["e_fwd"][b].record(lib)
             lib.wait_event(ln["e_tabs"][b])
             p.encode_stream(ln["coeff"], ln["stream"], ln["offs"], ln["lens"][b], ln["nb"][b])
@@ -189,7 +199,7 @@ def run_host_boundary(args):
             p.decode_blocks(ln["d_stream2"][b], ln["d_offs2"][b], ln["d_lens2"][b], ln["d_nb2"][b], ln["decoded"])
             ln["e_dec"][b].record(lib)
             lib.wait_event(ln["e_back"][b])
-            p.inverse_rgba8(ln["coeff"], ln["d_back"][b])
+            p.inverse_rgba8(ln["coeff"], ln["h_back2"][b] if direct else ln["d_back"][b])
             ln["e_inv"][b].record(lib)
             # ---- out: the PREVIOUS frame's results (their kernels were queued a round ago)
             if k >= 1:
@@ -270,7 +280,8 @@ def run_host_boundary(args):
         dt = time.perf_counter() - t0
         # ---- what came back is right ----
         for ln in lanes:
-            assert torch.equal(ln["h_back"], ln["h_pix"]), "pixels back in host memory differ from the pixels in"
+            for hb in (ln["h_back2"] if direct else [ln["h_back"]]):
+                assert torch.equal(hb, ln["h_pix"]), "pixels back in host memory differ from the pixels in"
             from j2kgfx import codestream
             parts = codestream.parse_tile_parts(ln["h_cs"][:ln["cs_bytes"]].numpy().tobytes())
             assert [pt.TileIndex for pt, _ in parts] == list(range(int(ln["p"].info.tiles)))
@@ -290,7 +301,8 @@ def run_host_boundary(args):
                "config": {"workload": bench_extra.CONFIGS["c2"]["workload"] + "; the C2 step with its inputs and outputs in PINNED HOST memory: encode = image.RGBA.Pix "
                           "H2D, forward transform + HT block coding + compaction + tile-part assembly on the device, the tile-parts D2H at their exact "
                           "length (+ per-block lengths and bit-plane counts); decode = the dense block stream and its tables H2D, HT block decode + inverse "
-                          "transform, image.RGBA.Pix D2H; copies and kernels of frames_in_flight frames overlap (three streams per frame)",
+                          "transform, image.RGBA.Pix back in pinned host memory" + (" -- stored there by the inverse level-0 kernel itself (pinned memory is device-addressable: no device frame, no D2H copy of the pixels)" if direct else " by a D2H copy") + "; copies and kernels of consecutive frames overlap (a copy stream per direction + the library stream)",
+                          "pixels_out": "kernel stores into the pinned frame" if direct else "device frame + D2H copy", "lanes": NL,
                           "frames_in_flight": NL, "frame_io": "pinned host", "hsa_enable_sdma_recommended_eng": os.environ.get("HSA_ENABLE_SDMA_RECOMMENDED_ENG", "(runtime default)"), "copy_streams": "one per direction" if shared else "a pair per frame in flight", "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "h2d_bytes_per_frame": h2d, "d2h_bytes_per_frame": d2h,
                           "tile_part_bytes": ln0["cs_bytes"]},
                "host_boundary": {"value": round(frames * W * H / dt / 1e6, 1), "unit": "Mpixels/s", "h2d_gbs": round(h2d_gbs, 2), "d2h_gbs": round(d2h_gbs, 2),
